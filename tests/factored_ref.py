@@ -1,0 +1,150 @@
+"""Torch restatement of the FACTORED algorithm the HIP kernels implement (test helper).
+
+The reference ships every per-sample weight gradient to the host and sums it there
+(PW_NNAL.py:773-807 + NNAL_tools.py:784-796).  The kernels never materialise those gradients;
+they use, per parameterised layer t with input a and pre-activation cotangent d:
+
+  conv            sum(dW)+sum(db) = sum_x dsum[x] * (box_k(asum)[x] + 1)
+  conv_transpose  sum(dW)+sum(db) = sum_q asum[q] * sum_t dsum[s*q + t - lo] + sum_p dsum[p]
+  fc              sum(dW)+sum(db) = (sum_i d_i) * (sum_j a_j + 1)
+
+with asum/dsum the channel sums, and ONE backward pass with the unit cotangent (+1,-1) on the
+two logits, because d log p_j / dz = e_j - p makes the class-0 / class-1 cotangents
+p1*(+1,-1) and p0*(-1,+1).  This file states that algorithm with torch ops so that the
+identity can be checked against the oracle in fp64 on the CPU, and so that GPU intermediates
+can be compared layer by layer.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import tfops
+
+
+def _box_same(field, k):
+    """zero-padded k-window sum of a [N,*sp] field, SAME geometry, stride 1."""
+    nd = field.dim() - 1
+    x = field.unsqueeze(1)
+    pads = []
+    for d in reversed(range(nd)):
+        _, lo, hi = tfops.same_pads(field.shape[1 + d], k[d], 1)
+        pads += [lo, hi]
+    x = F.pad(x, pads)
+    w = torch.ones((1, 1) + tuple(k), dtype=field.dtype)
+    fn = F.conv2d if nd == 2 else F.conv3d
+    return fn(x, w)[:, 0]
+
+
+def _strided_box(dsum, k, s, in_sp):
+    """B[q] = sum_t dsum[s*q + t - lo] over in-range positions, q on the INPUT grid."""
+    nd = dsum.dim() - 1
+    x = dsum.unsqueeze(1)
+    pads = []
+    for d in reversed(range(nd)):
+        _, lo, hi = tfops.same_pads(dsum.shape[1 + d], k[d], s[d])
+        pads += [lo, hi]
+    x = F.pad(x, pads)
+    w = torch.ones((1, 1) + tuple(k), dtype=dsum.dtype)
+    fn = F.conv2d if nd == 2 else F.conv3d
+    y = fn(x, w, stride=tuple(s))[:, 0]
+    assert tuple(y.shape[1:]) == tuple(in_sp)
+    return y
+
+
+def factored_unit_scores(model, x):
+    """Returns (p [2,N], S [N,L], sizes [L]): S_t = sum of ALL entries of d(z0-z1)/d(theta_t).
+
+    `model` is an oracle.model.OracleModel (its graph is re-walked here with hooks on every
+    parameterised layer's input and pre-activation output)."""
+    xt = model._as_input(x)
+    N = xt.shape[0]
+    recs = []
+
+    # re-implementation of the walk with explicit pre-activation capture
+    names = model.names
+    out = xt
+    sources = {}
+    src_idx = [s[0] for s in model.skips]
+    for i, name in enumerate(names):
+        spec = model.layer_dict[name]
+        ltype = model._ltype(name)
+        last = (i == len(names) - 1)
+        nxt = None if last else model._ltype(names[i + 1])
+        for (src, dsts, kind) in model.skips:
+            if i in dsts:
+                out = out + sources[src] if kind == 'sum' else torch.cat((sources[src], out), out.dim() - 1)
+        if ltype in ('conv', 'conv_transpose', 'fc'):
+            W, b = [p.detach() for p in model.params[name]]
+            a_in = out
+            if ltype == 'conv':
+                strides = None
+                if model.ext and len(spec[1]) > 2:
+                    strides = spec[1][2]
+                pre = tfops.conv_same(out, W, b, strides)
+                relu = ('A' in spec[2]) if model.ext else True
+            elif ltype == 'conv_transpose':
+                pre = tfops.conv_transpose_same(out, W, b, spec[1][2])
+                relu = 'A' in spec[2]
+            else:
+                pre = W @ out + b
+                relu = (('A' in spec[2]) if len(spec) > 2 else False) if model.ext else (not last)
+            pre.requires_grad_(True)
+            pre.retain_grad()
+            recs.append(dict(name=name, type=ltype, a=a_in.detach(), pre=pre, W=W, b=b, spec=spec))
+            out = torch.relu(pre) if relu else pre
+        elif ltype == 'pool':
+            if model.ext:
+                out = tfops.max_pool_same(out, spec[1], spec[1])
+            else:
+                nd = out.dim() - 2
+                out = tfops.max_pool_same(out, [spec[0][0]] * nd, [spec[0][1]] * nd)
+        if i in src_idx:
+            sources[i] = out
+        if (not last) and ltype in ('conv', 'pool') and nxt == 'fc':
+            out = tfops.flatten_tf(out)
+    z = out                                     # [2, N]
+    p = tfops.softmax_cols(z.detach())
+    (z[0] - z[1]).sum().backward()
+    S = torch.zeros((N, len(recs)), dtype=xt.dtype)
+    sizes = []
+    for t, r in enumerate(recs):
+        d = r['pre'].grad
+        W, b = r['W'], r['b']
+        sizes.append(int(W.numel() + b.shape[0]))
+        if r['type'] == 'fc':
+            S[:, t] = d.sum(0) * (r['a'].sum(0) + 1.)
+        elif r['type'] == 'conv':
+            nd = d.dim() - 2
+            k = list(W.shape[:nd])
+            dsum = d.sum(-1)
+            asum = r['a'].sum(-1)
+            S[:, t] = (dsum * (_box_same(asum, k) + 1.)).reshape(N, -1).sum(1)
+        else:
+            nd = d.dim() - 2
+            k = list(W.shape[:nd])
+            s = list(r['spec'][1][2])
+            dsum = d.sum(-1)
+            asum = r['a'].sum(-1)
+            B = _strided_box(dsum, k, s, asum.shape[1:])
+            S[:, t] = (asum * B).reshape(N, -1).sum(1) + dsum.reshape(N, -1).sum(1)
+    return p.numpy(), S.numpy(), np.array(sizes)
+
+
+def fisher_from_unit(p1, S, sizes, diag_load):
+    """g0, g1, A exactly as gen_A_matrices would form them from the unit-cotangent sums."""
+    p1 = np.asarray(p1, np.float64)
+    g = np.asarray(S, np.float64) / sizes[None, :]
+    p0 = 1. - p1
+    g0 = p1[:, None] * g
+    g1 = -p0[:, None] * g
+    N, L = g.shape
+    A = np.zeros((N, L, L))
+    for i in range(N):
+        p = p1[i]
+        a0, a1 = g0[i], g1[i]
+        if p < 1e-6:
+            p, a1 = 0., np.zeros(L)
+        elif p > 1 - 1e-6:
+            p, a0 = 1., np.zeros(L)
+        A[i] = (1. - p) * np.outer(a0, a0) + p * np.outer(a1, a1) + np.eye(L) * diag_load
+    return g0, g1, A

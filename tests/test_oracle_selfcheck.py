@@ -1,0 +1,110 @@
+"""Pins the part of the oracle the reference cannot pin (the TensorFlow op semantics): torch
+calls vs loop-level numpy twins, fp64 finite differences of the log-posterior gradients, and
+the factored identity the HIP kernels rely on.  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import alpath, netspec, tfops
+from oracle.model import OracleModel, OracleSession
+from tests import factored_ref
+
+
+@pytest.mark.parametrize('shape,k,s', [((2, 7, 6, 3), (3, 3), None), ((1, 5, 5, 2), (5, 5), None),
+                                       ((1, 4, 5, 3, 2), (3, 3, 3), None), ((1, 7, 6, 2), (3, 3), (2, 2))])
+def test_conv_same_vs_naive(shape, k, s):
+    rs = np.random.RandomState(0)
+    x = rs.randn(*shape)
+    W = rs.randn(*(k + (shape[-1], 4)))
+    b = rs.randn(4)
+    y = tfops.conv_same(torch.tensor(x), torch.tensor(W), torch.tensor(b), s).numpy()
+    np.testing.assert_allclose(y, tfops.naive_conv_same(x, W, b, s), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize('shape,w', [((2, 7, 5, 3), (2, 2)), ((1, 5, 4, 3, 2), (2, 2, 2)), ((1, 25, 25, 1), (2, 2))])
+def test_max_pool_same_vs_naive(shape, w):
+    x = np.random.RandomState(1).randn(*shape)
+    y = tfops.max_pool_same(torch.tensor(x), w, w).numpy()
+    np.testing.assert_array_equal(y, tfops.naive_max_pool_same(x, w, w))
+    assert y.shape[1] == -(-shape[1] // 2)      # 25 -> 13: the odd unit of padding goes to the end
+
+
+@pytest.mark.parametrize('shape,k,s', [((2, 4, 3, 3), (3, 3), (2, 2)), ((1, 3, 2, 4, 2), (3, 3, 3), (2, 2, 2)),
+                                       ((1, 4, 4, 2), (2, 2), (2, 2))])
+def test_conv_transpose_same_vs_naive(shape, k, s):
+    rs = np.random.RandomState(2)
+    x = rs.randn(*shape)
+    W = rs.randn(*(k + (5, shape[-1])))
+    b = rs.randn(5)
+    y = tfops.conv_transpose_same(torch.tensor(x), torch.tensor(W), torch.tensor(b), s).numpy()
+    assert y.shape[1] == shape[1] * s[0]
+    np.testing.assert_allclose(y, tfops.naive_conv_transpose_same(x, W, b, s), rtol=1e-12, atol=1e-12)
+
+
+def test_conv_transpose_is_gradient_of_same_conv():
+    """tf.nn.conv*_transpose is DEFINED as the input-gradient of the SAME conv (no flip)."""
+    rs = np.random.RandomState(3)
+    x = torch.tensor(rs.randn(1, 3, 4, 2))                     # small map
+    W = torch.tensor(rs.randn(3, 3, 5, 2))                     # [k,k,out,in] of the transpose
+    big = torch.zeros(1, 6, 8, 5, dtype=torch.float64, requires_grad=True)
+    y = tfops.conv_same(big, W, torch.zeros(2, dtype=torch.float64), (2, 2))   # filter [k,k,in=5,out=2]
+    (y * x).sum().backward()
+    np.testing.assert_allclose(tfops.conv_transpose_same(x, W, torch.zeros(5, dtype=torch.float64), (2, 2)).numpy(),
+                               big.grad.numpy(), rtol=1e-12, atol=1e-12)
+
+
+def test_flatten_order():
+    x = torch.arange(2 * 3 * 4 * 5, dtype=torch.float64).reshape(2, 3, 4, 5)    # N,H,W,C
+    f = tfops.flatten_tf(x).numpy()
+    for (h, w, c) in [(0, 0, 0), (2, 1, 3), (1, 3, 4)]:
+        assert f[c * (4 * 3) + w * 3 + h, 1] == x[1, h, w, c]                  # f = c*(W*H) + w*H + h
+
+
+def _models():
+    out = []
+    ld = netspec.net_a()
+    out.append(('neta', ld, (12, 12, 2), ()))
+    out.append(('netb', netspec.net_b_small(width=16), (9, 9, 2), ()))
+    lc, sk = netspec.net_c_2d()
+    out.append(('netc2d', lc, (8, 8, 1), sk))
+    lc, sk = netspec.net_c()
+    out.append(('netc', lc, (4, 4, 4, 1), sk))
+    return out
+
+
+@pytest.mark.parametrize('name,ld,in_shape,skips', _models())
+def test_grad_finite_difference_fp64(name, ld, in_shape, skips):
+    pars = netspec.he_init(ld, in_shape, seed=5, skips=skips, bias_std=0.1, dtype=np.float64)
+    x = np.random.RandomState(6).randn(1, *in_shape)
+    model = OracleModel(ld, in_shape, pars, skips=skips, dtype=torch.float64)
+    for j in (0, 1):
+        grads = model.grad_log_post(j, x)
+        rs = np.random.RandomState(7)
+        for t, (lname, (W, b)) in enumerate(pars.items()):
+            for arr, gr in ((W, grads[2 * t]), (b, grads[2 * t + 1])):
+                idx = tuple(rs.randint(0, s) for s in arr.shape)
+                eps = 1e-6
+                vals = []
+                for sgn in (+1, -1):
+                    p2 = {k: [v[0].copy(), v[1].copy()] for k, v in pars.items()}
+                    tgt = p2[lname][0] if arr is W else p2[lname][1]
+                    tgt[idx] += sgn * eps
+                    m2 = OracleModel(ld, in_shape, p2, skips=skips, dtype=torch.float64)
+                    vals.append(np.log(m2.forward(x)['posteriors'][j, 0]))
+                fd = (vals[0] - vals[1]) / (2 * eps)
+                assert abs(fd - gr[idx]) <= 1e-6 * max(1., abs(fd)), (name, lname, idx)
+
+
+@pytest.mark.parametrize('name,ld,in_shape,skips', _models())
+def test_factored_identity_fp64(name, ld, in_shape, skips):
+    """One unit-cotangent backward + channel-sum/box-sum reductions == summed full gradients."""
+    pars = netspec.he_init(ld, in_shape, seed=8, skips=skips, bias_std=0.1, dtype=np.float64)
+    model = OracleModel(ld, in_shape, pars, skips=skips, dtype=torch.float64)
+    sess = OracleSession(model)
+    x = np.random.RandomState(9).randn(3, *in_shape)
+    p, S, sizes = factored_ref.factored_unit_scores(model, x)
+    g0f, g1f, _ = factored_ref.fisher_from_unit(p[1], S, sizes, 1e-5)
+    for i in range(3):
+        g0, g1 = alpath.shrunk_grads(model, sess, x[i])
+        np.testing.assert_allclose(g0f[i], g0, rtol=1e-9, atol=1e-14)
+        np.testing.assert_allclose(g1f[i], g1, rtol=1e-9, atol=1e-14)

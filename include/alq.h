@@ -1,0 +1,157 @@
+/*
+ * alq.h - C ABI of the MI355X-native active-learning query-scoring library (libalq.so).
+ *
+ * The reference (jsourati/nn-active-learning) has no FFI: its device boundary is
+ * `sess.run(...)` on a TensorFlow-1.x graph.  Each entry point below names the reference
+ * call site(s) whose device work it replaces (file:line under /root/reference).
+ *
+ * Conventions
+ *   - plain C, no torch / C++ types in any signature;
+ *   - every function returns an int status: 0 = ok, negative = error
+ *     (alq_last_error() gives the text); nothing throws, nothing exits;
+ *   - pointers named `d_*` are DEVICE pointers owned by the caller (e.g. torch-ROCm
+ *     tensors); pointers named `h_*` are HOST pointers; the library never frees caller memory;
+ *   - all work is enqueued on the stream given to alq_ctx_create (a hipStream_t passed as
+ *     void*; NULL = the null stream) and is stream-ordered; the calls do not synchronise
+ *     unless documented;
+ *   - tensors are channels-last fp32: patches [N, D, H, W, C] (D = 1 for the 2-D nets,
+ *     i.e. the reference's [N, H, W, C] placeholder, NN.py:1338-1344).
+ */
+#ifndef ALQ_H
+#define ALQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct alq_ctx alq_ctx;
+typedef struct alq_model alq_model;
+
+enum { ALQ_OK = 0, ALQ_EINVAL = -1, ALQ_EHIP = -2, ALQ_ENOMEM = -3, ALQ_EUNSUPPORTED = -4 };
+
+enum { ALQ_CONV = 0, ALQ_CONVT = 1, ALQ_POOL = 2, ALQ_FC = 3 };
+
+/* One layer of the reference's layer dicts (NN.py:96-110; NN_extended.py:103-124). */
+typedef struct {
+    int32_t type;      /* ALQ_CONV / ALQ_CONVT / ALQ_POOL / ALQ_FC                               */
+    int32_t cout;      /* output channels (conv, conv_transpose) or units (fc); unused for pool  */
+    int32_t k[3];      /* kernel (conv / conv_transpose) or window (pool), order D,H,W; 1 = n/a  */
+    int32_t s[3];      /* strides, order D,H,W                                                   */
+    int32_t relu;      /* 1: ReLU after the main op (NN.py:290,326-327; 'A' in NN_extended.py:352-355) */
+    int32_t skip_src;  /* index of the earlier layer whose OUTPUT is concatenated IN FRONT of this
+                          layer's input ('con' skip, NN_extended.py:1207-1214), or -1            */
+} alq_layer_t;
+
+const char *alq_last_error(void);
+int alq_version(void);
+
+/* ---- context ---------------------------------------------------------------------------- */
+/* Replaces: tf.Session creation (PW_AL.py:363-377).  `stream` is a hipStream_t or NULL.       */
+int alq_ctx_create(int device, void *stream, alq_ctx **out);
+int alq_ctx_destroy(alq_ctx *ctx);
+int alq_ctx_set_stream(alq_ctx *ctx, void *stream);
+int alq_ctx_synchronize(alq_ctx *ctx);
+
+/* ---- model ------------------------------------------------------------------------------ */
+/* Replaces: graph construction NN.CNN.__init__ (NN.py:147-188) / NN_extended.CNN.__init__
+ * (NN_extended.py:187-295) + get_gradients (NN.py:621-645).  in_dims = {D, H, W, C}.
+ * max_batch = largest N any later call will pass (activation workspace is sized for it).     */
+int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers,
+                     const int32_t in_dims[4], int max_batch, alq_model **out);
+int alq_model_destroy(alq_model *m);
+/* Number of parameterised layers L ( = len(grad_posts['1'])/2, PW_NNAL.py:751 ).             */
+int alq_model_num_param_layers(const alq_model *m);
+/* W/b element counts of parameterised layer t (creation order), i.e. prod(W.shape), len(b).  */
+int alq_model_param_sizes(const alq_model *m, int t, int64_t *w_elems, int64_t *b_elems);
+/* Length of the feature vector of layer `layer_idx`'s output (feature_layer, NN.py:172-175). */
+int alq_model_layer_out_elems(const alq_model *m, int layer_idx, int64_t *elems);
+/* Replaces: CNN.load_weights / perform_assign_ops (NN.py:396-419, :462-519).  HOST pointers,
+ * TF layouts: conv [k...,Ci,Co], conv_transpose [k...,Co,Ci], fc [out,in] with `in` in the
+ * reference's flatten order (full axis reversal, NN.py:296-301); bias [Co] / [out,1].
+ * Synchronises the stream before returning (the host buffers may be reused at once).         */
+int alq_model_set_weights(alq_model *m, int t, const float *h_W, const float *h_b);
+
+/* ---- patch gather + normalisation ------------------------------------------------------- */
+/* Replaces: patch_utils.get_patches (patch_utils.py:1087-1173) + the normalisation loops of
+ * PW_NN.batch_eval (PW_NN.py:503-506) / PW_NNAL.CNN_query (PW_NNAL.py:125-129) [quirk = 1:
+ * channel j < m is normalised with stats[j]] or of patch_utils.get_patches_multimg
+ * (patch_utils.py:1203-1207) [quirk = 0: depth slab j*d3..(j+1)*d3 with stats[j]].
+ * d_vols: m device pointers (host array of device pointers) to zero-padded volumes, C order,
+ * element type double (vol_is_f64 = 1) or float; pad_dims = padded shape; d_inds: int64
+ * raveled indices in UN-padded coordinates; h_stats: m pairs (mu, sigma), double.
+ * quirk = 2: no normalisation (plain get_patches).  d_out: [n, d1, d2, m*d3], float
+ * (out_is_f64 = 0) or double (out_is_f64 = 1, bit-identical to the reference's float64
+ * patches).  Arithmetic is fp64, rounded once to fp32 for the float output, like the
+ * reference's float64 patches fed to a float32 placeholder.                                  */
+int alq_gather_normalize(alq_ctx *ctx, const void *const *d_vols, int m, int vol_is_f64,
+                         const int64_t pad_dims[3], const int64_t *d_inds, int64_t n,
+                         const int32_t patch_shape[3], const double *h_stats, int quirk,
+                         int out_is_f64, void *d_out);
+
+/* ---- forward ---------------------------------------------------------------------------- */
+/* Replaces: sess.run(model.posteriors / prediction / feature_layer) in PW_NN.batch_eval
+ * (PW_NN.py:522-524).  d_x: [N, D,H,W,C]; d_post: [2... c, N] row-major like the reference's
+ * [c, N] posteriors (NN.py:184-188); d_pred: int64 [N] or NULL; d_feat: [N, F] of layer
+ * feature_layer_idx (or NULL / -1).  N <= max_batch.                                         */
+int alq_forward(alq_model *m, const float *d_x, int N, float *d_post, int64_t *d_pred,
+                float *d_feat, int feature_layer_idx);
+
+/* ---- uncertainty scores ----------------------------------------------------------------- */
+/* Replaces: np.abs(posts - .5) (PW_NNAL.py:64,109,728) and NNAL_tools.compute_entropy
+ * (NNAL_tools.py:71-85).  d_p1: float [n] (row 1 of the posteriors); d_absdev: double [n]
+ * = |double(p1) - 0.5| (exact); d_H: float [n] Shannon entropy of (1-p1, p1) with the
+ * reference's +10e-8 guard on exact zeros, or NULL.                                          */
+int alq_score_entropy(alq_ctx *ctx, const float *d_p1, int64_t n, double *d_absdev, float *d_H);
+
+/* Replaces: np.argsort(np.abs(posts - .5))[:B] (PW_NNAL.py:64,109-110,671-681,730).
+ * Ascending keys, ties -> lower index first (the reference's tie order is unspecified).
+ * d_out_idx: int64 [B].  d_work: device scratch of alq_topk_work_bytes(n) bytes.             */
+size_t alq_topk_work_bytes(int64_t n);
+int alq_topk_uncertain(alq_ctx *ctx, const double *d_keys, int64_t n, int64_t B,
+                       int64_t *d_out_idx, void *d_work);
+
+/* ---- Fisher scoring --------------------------------------------------------------------- */
+/* Replaces: the per-sample loop of PW_NNAL.gen_A_matrices (PW_NNAL.py:757-814): up to two
+ * sess.run(model.grad_posts[j]) at batch 1, NNAL_tools.shrink_gradient(...,'sum')
+ * (NNAL_tools.py:784-796) and the outer products.  d_x: [N, D,H,W,C] normalised patches.
+ * d_p1_in: float [N] posteriors to branch on (what batch_eval returned, PW_NNAL.py:767) or
+ * NULL to use the posteriors of this forward pass.  Outputs (any may be NULL):
+ *   d_p1_out float [N]; d_g0, d_g1 double [N, L] (shrunk class-0 / class-1 gradients, zero
+ *   where the reference's saturation branch skips them); d_A double [N, L, L];
+ *   d_trace double [N]; d_Asum double [L, L] = sum_i A_i (overwritten, deterministic order). */
+int alq_fisher(alq_model *m, const float *d_x, int N, const float *d_p1_in, double diag_load,
+               float *d_p1_out, double *d_g0, double *d_g1, double *d_A, double *d_trace,
+               double *d_Asum);
+
+/* ---- measurement hooks (bench.py only) -------------------------------------------------- */
+/* Per-kernel-class HIP-event timing on the context's stream.  alq_prof_enable(ctx, 1) makes
+ * every launch of an instrumented kernel class record start/stop events;
+ * alq_prof_read returns, for class `cls`, the accumulated milliseconds, launch count and
+ * algorithmic FLOPs since the last alq_prof_reset (synchronises the stream).                 */
+int alq_prof_enable(alq_ctx *ctx, int on);
+int alq_prof_reset(alq_ctx *ctx);
+int alq_prof_num_classes(void);
+const char *alq_prof_class_name(int cls);
+int alq_prof_read(alq_ctx *ctx, int cls, double *ms, int64_t *launches, double *flops);
+
+/* Debug / test hook: copies an internal tensor of the last alq_forward / alq_fisher call into a
+ * dense device buffer.  what: 0 = activation of layer `layer_idx` [N, vox, C], 1 = its cotangent
+ * (after the ReLU mask), 2 = channel-sum field of the layer's INPUT [N, vox_in], 3 = channel-sum
+ * field of its masked cotangent [N, vox_out], 4 = the unit-cotangent layer sums S [N, L] (as
+ * float; layer_idx ignored).  *elems_out receives the element count.  Tests only.             */
+int alq_model_debug_copy(alq_model *m, int layer_idx, int what, int N, float *d_out,
+                         int64_t *elems_out);
+
+/* Synthetic patch generator: counter-based RNG keyed (seed, patch_id, element), standard
+ * normal, written to d_out [n, elems_per_patch] for patch ids first_id .. first_id+n-1
+ * (shards are reproducible whatever the sharding).                    */
+int alq_synth_patches(alq_ctx *ctx, uint64_t seed, int64_t first_id, int64_t n,
+                      int64_t elems_per_patch, float *d_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALQ_H */

@@ -1,0 +1,53 @@
+"""`NN.CNN`-schema models on the device (reference: NN.py:56-188 class CNN, :1217-1245
+create_model, :1319-1359 create_PW1)."""
+from collections import OrderedDict
+
+from .device import DeviceModel, default_session
+
+
+class CNN(DeviceModel):
+    """NN.CNN(x, layer_dict, name, feature_layer, dropout, probes): same layer-dict schema
+    ``{name: [depth,'conv',[kh,kw]] | [depth,'fc'] | [[window,stride],'pool']}``; `x` is replaced
+    by the placeholder SHAPE (H, W, C)."""
+
+    def __init__(self, in_shape, layer_dict, name, feature_layer=None, dropout=None, probes=(),
+                 sess=None, max_batch=256):
+        super(CNN, self).__init__(sess or default_session(), layer_dict, in_shape, (), feature_layer,
+                                  dropout, max_batch, name)
+        self.probes = list(probes)
+
+    def get_optimizer(self, *a, **k):
+        raise NotImplementedError('training (get_optimizer, NN.py:557-619) is outside the scored path')
+
+    def get_gradients(self, grad_layers=[]):
+        """NN.py:621-645.  Gradients of the log-posteriors w.r.t. ALL layers are what the device
+        Fisher pass reduces; a layer subset would change L and is not supported."""
+        if len(grad_layers) not in (0, self.L):
+            raise NotImplementedError('grad_layers subsets are outside the scored path')
+        self.grad_layers = grad_layers
+
+
+def pw1_layer_dict(nclass):
+    """The layer dict of create_PW1 (NN.py:1328-1336)."""
+    return OrderedDict([
+        ('conv1', [24, 'conv', [5, 5]]), ('conv2', [32, 'conv', [5, 5]]), ('max1', [[2, 2], 'pool']),
+        ('conv3', [48, 'conv', [3, 3]]), ('conv4', [96, 'conv', [3, 3]]), ('max2', [[2, 2], 'pool']),
+        ('fc1', [4096, 'fc']), ('fc2', [4096, 'fc']), ('fc3', [nclass, 'fc'])])
+
+
+def create_PW1(nclass, dropout_rate, learning_rate, optimizer_name, patch_shape, sess=None,
+               max_batch=256):
+    """NN.create_PW1 (NN.py:1319-1359): the patch-wise net of PW_AL; feature layer = fc2
+    (index len-2, :1346); dropout on layers 6-8 is identity at keep_prob = 1."""
+    d = pw1_layer_dict(nclass)
+    model = CNN(tuple(patch_shape), d, 'PatchWise', len(d) - 2, [[6, 7, 8], dropout_rate], [5], sess, max_batch)
+    model.get_gradients()
+    return model
+
+
+def create_model(model_name, dropout_rate, nclass, learning_rate, grad_layers=[], train_layers=[],
+                 optimizer_name='SGD', patch_shape=None, sess=None, max_batch=256):
+    """NN.create_model (NN.py:1217-1245), 'PW' only."""
+    if model_name != 'PW':
+        raise NotImplementedError("model %r: only the patch-wise 'PW' net is on the scored path" % model_name)
+    return create_PW1(nclass, dropout_rate, learning_rate, optimizer_name, patch_shape, sess, max_batch)

@@ -1,0 +1,57 @@
+"""Batched patch evaluation (reference: PW_NN.py:357-539) on the device."""
+import numpy as np
+
+from . import patch_utils
+
+_CHUNK = 8192   # indices gathered per device pass (results do not depend on it)
+
+
+def batch_eval(model, sess, img_dat, inds, patch_shape, batch_size, stats, varnames,
+               mask=None, x_feed_dict={}):
+    """PW_NN.batch_eval: evaluates `varnames` ('posteriors', 'prediction', 'feature_layer')
+    of `model` on patches around voxels `inds` of the m padded modalities `img_dat`.
+
+    Returns a list of float64 arrays: 'posteriors' -> [n] probability of class 1
+    (PW_NN.py:526-529), 'prediction' -> [n], 'feature_layer' -> [fdim, n].  Patches are
+    normalised with the channel-index rule of PW_NN.py:503-506 (channel j < m with stats[j]).
+    `batch_size` only bounds the reference's feed size; samples are independent, so the device
+    path walks the same index order in larger chunks.
+    """
+    if not isinstance(varnames, list):
+        varnames = [varnames]
+    for v in varnames:
+        if v not in ('posteriors', 'prediction', 'feature_layer'):
+            raise NotImplementedError("batch_eval variable %r (training-time graph) is outside the scored path" % v)
+    for k, val in x_feed_dict.items():
+        if k is getattr(model, 'keep_prob', None) and float(val) != 1.:
+            raise NotImplementedError('dropout at keep_prob < 1 is outside the scored path')
+    if not isinstance(img_dat[0], np.ndarray):
+        raise NotImplementedError('volume paths need pynrrd (absent): pass the padded arrays (PW_NN.py:429-444)')
+    if int(batch_size) < 1:
+        raise ValueError('batch_size must be positive')
+    m = len(img_dat)
+    inds = np.asarray(inds)
+    n = len(inds)
+    vols = patch_utils.DeviceVolumes(sess, img_dat)
+    want_pred = 'prediction' in varnames
+    want_feat = 'feature_layer' in varnames
+    posts = np.zeros(n)
+    preds = np.zeros(n)
+    feats = np.zeros((model.feature_dim, n)) if want_feat else None
+    st = np.asarray(stats, dtype=np.float64)[:m]
+    for a in range(0, n, _CHUNK):
+        b = min(n, a + _CHUNK)
+        t = vols.gather(inds[a:b], patch_shape, st, quirk=1)
+        post, pred, feat = model.forward_device(t, b - a, want_pred, want_feat)
+        posts[a:b] = post[1].cpu().numpy()
+        if want_pred:
+            preds[a:b] = pred.cpu().numpy()
+        if want_feat:
+            f = feat.cpu().numpy()
+            if model._feature_perm is not None:
+                f = f[:, model._feature_perm]
+            feats[:, a:b] = f.T
+    out = []
+    for v in varnames:
+        out.append({'posteriors': posts, 'prediction': preds, 'feature_layer': feats}[v])
+    return out

@@ -1,0 +1,147 @@
+"""Patch-wise query strategies of the scored path (reference: PW_NNAL.py): `entropy` and `fi`
+branches of CNN_query / query_multimg, the uncertainty filters and gen_A_matrices, with the
+reference's signatures.  `sess` is a device.DeviceSession, `model` a device.DeviceModel."""
+import numpy as np
+
+from . import NNAL_tools, PW_NN, patch_utils
+
+
+def binary_uncertainty_filter(posts, B):
+    """PW_NNAL.py:671-681: the B posteriors closest to 0.5 (ties: lower index first)."""
+    return np.argsort(np.abs(np.array(posts) - 0.5), kind='stable')[:B]
+
+
+def device_uncertainty_filter(sess, posts, B):
+    """Same selection on the device (alq_score_entropy + alq_topk_uncertain) for posteriors that
+    are already resident: `posts` float32 device tensor [n] -> int64 device tensor [B]."""
+    import ctypes as C
+    from ._lib import check
+    torch = sess.torch
+    n = int(posts.numel())
+    B = min(int(B), n)
+    keys = sess.empty((n,), torch.float64)
+    check(sess.lib.alq_score_entropy(sess.ctx, C.c_void_p(posts.data_ptr()), n, C.c_void_p(keys.data_ptr()), None))
+    work = sess.empty((sess.lib.alq_topk_work_bytes(n),), torch.uint8)
+    out = sess.empty((B,), torch.int64)
+    check(sess.lib.alq_topk_uncertain(sess.ctx, C.c_void_p(keys.data_ptr()), n, B, C.c_void_p(out.data_ptr()),
+                                      C.c_void_p(work.data_ptr())))
+    return out
+
+
+def bin_uncertainty_filter_multimg(expr, model, sess, all_padded_imgs, pool_inds, B, x_feed_dict={}):
+    """PW_NNAL.py:684-736: posteriors of every subject's pool voxels (per-subject stats from
+    expr.train_stats), then the B most uncertain over the concatenation, split back per subject."""
+    s = len(pool_inds)
+    sizes = [len(p) for p in pool_inds]
+    m = len(all_padded_imgs[0]) - 1
+    per_img = [[] for _ in range(s)]
+    for i in range(s):
+        if sizes[i] == 0:
+            continue
+        stats = [[expr.train_stats[i, 2 * j], expr.train_stats[i, 2 * j + 1]] for j in range(m)]
+        per_img[i] = list(PW_NN.batch_eval(model, sess, all_padded_imgs[i][:-1], pool_inds[i],
+                                           expr.pars['patch_shape'], expr.pars['ntb'], stats,
+                                           'posteriors', None, x_feed_dict)[0])
+    allp = np.concatenate(per_img)
+    if len(x_feed_dict) > 0:
+        return allp
+    order = binary_uncertainty_filter(allp, B)
+    sel_inds = patch_utils.global2local_inds(order, sizes)
+    sel_posts = [np.array(per_img[i])[sel_inds[i]] for i in range(s)]
+    return sel_inds, sel_posts
+
+
+def gen_A_matrices(expr, model, sess, sel_patches, sel_posts, diag_load=1e-5):
+    """PW_NNAL.py:738-816: conditional Fisher matrices A_i = (1-p) g0 g0^T + p g1 g1^T + diag_load I
+    of the (already normalised) patches, with the reference's saturation branches on `sel_posts`.
+    Returns a list of float64 [L, L] arrays.  One batched device pass replaces the per-sample
+    `sess.run(model.grad_posts[j])` + `shrink_gradient` loop."""
+    sel_posts = np.asarray(sel_posts, dtype=np.float64)
+    n = len(sel_posts)
+    if n == 0:
+        return []
+    x = np.asarray(sel_patches)
+    res = model.fisher(x.reshape((n,) + model.in_shape), p1=sel_posts, diag_load=diag_load)
+    return [res['A'][i] for i in range(n)]
+
+
+def _entropy_query_single(expr, model, sess, padded_imgs, pool_inds):
+    posts = PW_NN.batch_eval(model, sess, padded_imgs, pool_inds, expr.pars['patch_shape'],
+                             expr.pars['ntb'], expr.pars['stats'], 'posteriors')[0]
+    return binary_uncertainty_filter(posts, expr.pars['k'])
+
+
+def fisher_candidates(expr, model, sess, padded_imgs, pool_inds):
+    """The device part of CNN_query(...,'fi') (PW_NNAL.py:89-136): posteriors, uncertainty filter
+    to B candidates, their patches (channel-index normalisation of :125-129) and A-matrices.
+    Returns (sel_inds, sel_posts, A list)."""
+    B = expr.pars['B']
+    posts = PW_NN.batch_eval(model, sess, padded_imgs, pool_inds, expr.pars['patch_shape'],
+                             expr.pars['ntb'], expr.pars['stats'], 'posteriors')[0]
+    if B < len(pool_inds):
+        sel_inds = binary_uncertainty_filter(posts, B)
+    else:
+        # the reference's `posts.shape[1]` raises here; the evident intent is "all"
+        sel_inds = np.arange(len(pool_inds))
+    sel_posts = posts[sel_inds]
+    m = len(padded_imgs)
+    vols = patch_utils.DeviceVolumes(sess, padded_imgs)
+    t = vols.gather(np.asarray(pool_inds)[sel_inds], expr.pars['patch_shape'],
+                    np.asarray(expr.pars['stats'], dtype=np.float64)[:m], quirk=1)
+    p1_in = sess.to_device(sel_posts.astype(np.float32), sess.torch.float32)
+    out = model.fisher_device(t, len(sel_inds), p1_in, 1e-5, want=('A',))
+    A = out['A'].cpu().numpy()
+    return sel_inds, sel_posts, [A[i] for i in range(len(sel_inds))]
+
+
+def CNN_query(expr, model, sess, padded_imgs, pool_inds, tr_inds, method_name):
+    """PW_NNAL.CNN_query (PW_NNAL.py:18-166), branches `entropy` and `fi`.  Returns positions into
+    `pool_inds` (the caller maps them, PW_AL.py:405-408)."""
+    pool_inds = np.asarray(pool_inds)
+    if method_name == 'random':
+        return np.random.permutation(len(pool_inds))[:expr.pars['k']]
+    if method_name == 'entropy':
+        return _entropy_query_single(expr, model, sess, padded_imgs, pool_inds)
+    if method_name == 'fi':
+        sel_inds, sel_posts, A = fisher_candidates(expr, model, sess, padded_imgs, pool_inds)
+        F = PW_NN.batch_eval(model, sess, padded_imgs, pool_inds[sel_inds], expr.pars['patch_shape'],
+                             expr.pars['ntb'], expr.pars['stats'], 'feature_layer')[0]
+        soln = NNAL_tools.SDP_query_distribution(A, expr.pars['lambda_'], F, expr.pars['k'])
+        q_opt = np.array(soln['x'][:len(sel_inds)]).ravel()
+        Q_inds = NNAL_tools.sample_query_dstr(q_opt, expr.pars['k'], replacement=True)
+        return sel_inds[Q_inds]
+    raise NotImplementedError("query method %r is outside the scored path (entropy, fi)" % (method_name,))
+
+
+def query_multimg(expr, model, sess, all_padded_imgs, pool_inds, labeled_inds, method_name):
+    """PW_NNAL.query_multimg (PW_NNAL.py:169-629), branches `entropy` (:226-230) and `fi`
+    (:547-627).  Returns, per subject, positions into that subject's pool_inds."""
+    k = expr.pars['k']
+    B = expr.pars['B']
+    sizes = [len(p) for p in pool_inds]
+    if method_name == 'random':
+        inds = np.random.permutation(int(np.sum(sizes)))[:k]
+        return patch_utils.global2local_inds(inds, sizes)
+    if method_name == 'entropy':
+        return bin_uncertainty_filter_multimg(expr, model, sess, all_padded_imgs, pool_inds, k)[0]
+    if method_name == 'fi':
+        sel_inds, sel_posts = bin_uncertainty_filter_multimg(expr, model, sess, all_padded_imgs, pool_inds, B)
+        m = len(all_padded_imgs[0]) - 1
+        A = []
+        stats = np.asarray(expr.train_stats, dtype=np.float64)
+        for i in range(len(pool_inds)):
+            if len(sel_inds[i]) == 0:
+                continue
+            vols = patch_utils.DeviceVolumes(sess, all_padded_imgs[i][:m])
+            t = vols.gather(np.asarray(pool_inds[i])[sel_inds[i]], expr.pars['patch_shape'],
+                            stats[i, :2 * m], quirk=0)                 # slab rule, patch_utils.py:1203-1207
+            p1_in = sess.to_device(np.asarray(sel_posts[i], dtype=np.float32), sess.torch.float32)
+            out = model.fisher_device(t, len(sel_inds[i]), p1_in, 1e-3, want=('A',))   # diag_load 1e-3, :578
+            Ai = out['A'].cpu().numpy()
+            A += [Ai[j] for j in range(Ai.shape[0])]
+        soln = NNAL_tools.SDP_query_distribution(A, expr.pars['lambda_'], [], k)
+        q_opt = np.array(soln['x'][:len(A)]).ravel()
+        draws = NNAL_tools.sample_query_dstr(q_opt, k, replacement=True)
+        local = patch_utils.global2local_inds(draws, [len(s) for s in sel_inds])
+        return [np.array(sel_inds[i])[local[i]] for i in range(len(sel_inds))]
+    raise NotImplementedError("query method %r is outside the scored path (entropy, fi)" % (method_name,))

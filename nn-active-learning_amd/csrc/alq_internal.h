@@ -1,0 +1,174 @@
+// Internal declarations shared by the translation units of libalq.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "alq.h"
+
+namespace alq {
+
+void set_error(const char *fmt, ...);
+
+#define ALQ_HIP(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            ::alq::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,               \
+                             hipGetErrorString(e_));                                      \
+            return ALQ_EHIP;                                                              \
+        }                                                                                 \
+    } while (0)
+
+#define ALQ_REQUIRE(cond, code, ...)                                                      \
+    do {                                                                                  \
+        if (!(cond)) {                                                                    \
+            ::alq::set_error(__VA_ARGS__);                                                \
+            return (code);                                                                \
+        }                                                                                 \
+    } while (0)
+
+#define ALQ_TRY(expr)                                                                     \
+    do {                                                                                  \
+        int rc_ = (expr);                                                                 \
+        if (rc_ != ALQ_OK) return rc_;                                                    \
+    } while (0)
+
+// A channels-last activation tensor [N, D, H, W, cs] of which channels c0 .. c0+C-1 are "ours"
+// (concat skips are realised by two producers writing disjoint channel slices of one buffer).
+struct View {
+    float *p = nullptr;
+    int D = 1, H = 1, W = 1;
+    int cs = 0, c0 = 0, C = 0;
+    int64_t vox() const { return (int64_t)D * H * W; }
+    int64_t elems() const { return vox() * C; }
+};
+
+enum ProfClass { PROF_IGEMM_FWD = 0, PROF_IGEMM_BWD = 1, PROF_ELEMWISE = 2, PROF_REDUCE = 3,
+                 PROF_FC_SMALL = 4, PROF_NUM = 5 };
+
+struct ProfSlot {
+    double ms = 0;
+    int64_t launches = 0;
+    double flops = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<hipEvent_t> pool;
+};
+
+}  // namespace alq
+
+#define ALQ_PARAM_BLOCK_BYTES 512
+
+struct alq_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool prof_on = false;
+    void *param_block = nullptr;   // small device buffer for per-call parameters (gather)
+    alq::ProfSlot prof[alq::PROF_NUM];
+    int prof_begin(int cls, hipEvent_t *e0, hipEvent_t *e1);
+    void prof_end(int cls, hipEvent_t e0, hipEvent_t e1, double flops);
+    int prof_collect();
+};
+
+namespace alq {
+
+struct ProfScope {
+    alq_ctx *ctx;
+    int cls;
+    double flops;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool active = false;
+    ProfScope(alq_ctx *c, int k, double f) : ctx(c), cls(k), flops(f) {
+        if (ctx->prof_on) active = (ctx->prof_begin(cls, &e0, &e1) == ALQ_OK);
+    }
+    ~ProfScope() {
+        if (active) ctx->prof_end(cls, e0, e1, flops);
+    }
+};
+
+// ------------------------------------------------------------------ implicit-GEMM engine
+// C[m, n] = sum_k A(m, k) * B[k, n] on v_mfma_f32_16x16x4_f32, where
+//   m  = (patch, point of an "M grid" MD x MH x MW),
+//   k  = (tap, input channel): A(m, k) = in[patch, m*sm + tapoff(tap), ci]  (0 outside the tensor),
+//   n  = output channel, written at out[patch, m*so + ooff, n].
+// conv fwd, conv bwd-data, conv_transpose fwd (one launch per output parity class),
+// conv_transpose bwd-data and fc are all this GEMM with different tap tables.
+constexpr int IG_MAXTAPS = 28;
+constexpr int IG_MAXK_SMALL = 1024;
+
+struct IgemmArgs {
+    const float *in;
+    float *out;
+    const float *W;     // packed [chunk][nblock][NTW][KC][16]
+    const float *bias;  // [Co] or null
+    int in_cs, in_c0, Ci, ID, IH, IW;
+    int out_cs, out_c0, Co, OD, OH, OW;
+    int MD, MH, MW;
+    int sm, so, ooffz, ooffy, ooffx;
+    int PT, TZ, TY, TX, HZ, HY, HX;
+    int minz, miny, minx;
+    int ntaps, nchunks, NB;
+    int tilesZ, tilesY, tilesX;
+    int N, relu, accumulate;
+    int K;                        // SMALLC: ntaps * Ci
+    int tapoff[IG_MAXTAPS];       // LDS float offset of each tap's shifted window (non-SMALLC)
+    const int *koff;              // SMALLC: device table, LDS float offset of flattened (tap, ci)
+};
+
+struct IgemmPlan {
+    IgemmArgs a;
+    int CB = 8, NTW = 1;
+    bool smallc = false;
+    size_t lds_bytes = 0;
+    dim3 grid;
+    double flops_per_patch = 0;  // 2 * MACs of the GEMM actually described (no padding waste)
+    std::vector<float> h_W;      // packed weights (host), uploaded to d_W
+    float *d_W = nullptr;
+    std::vector<int> h_koff;     // SMALLC tap/channel offset table, uploaded to d_koff
+    int *d_koff = nullptr;
+};
+
+struct ConvDesc {
+    // geometry of one GEMM: taps are INPUT offsets relative to m*sm
+    int ID, IH, IW, Ci;
+    int OD, OH, OW, Co;
+    int MD, MH, MW;
+    int sm = 1, so = 1, ooff[3] = {0, 0, 0};
+    std::vector<int> tz, ty, tx;  // tap offsets
+};
+
+int igemm_build_plan(const ConvDesc &d, int max_batch, IgemmPlan *plan);
+// Bmat(k = tap*Ci + ci, n) supplied by callback -> packed layout
+void igemm_pack_weights(IgemmPlan *plan, const std::vector<float> &Bmat /* [K][Co] row-major */);
+int igemm_launch(alq_ctx *ctx, const IgemmPlan &plan, const View &in, const View &out,
+                 const float *bias, int relu, int accumulate, int N, int prof_cls);
+
+// ------------------------------------------------------------------ other kernels
+int k_pool_fwd(alq_ctx *, const View &in, const View &out, uint8_t *argmax, const int w[3],
+               const int lo[3], int N);
+int k_pool_bwd(alq_ctx *, const View &dout, const View &din, const uint8_t *argmax,
+               const int w[3], const int lo[3], int N, int accumulate);
+int k_chansum(alq_ctx *, const View &in, float *field, int N);
+int k_mask_chansum(alq_ctx *, const View &dact, const View *act_or_null, float *field, int N);
+int k_boxdot_conv(alq_ctx *, const float *dsum, const float *asum, int D, int H, int W,
+                  const int k[3], const int lo[3], int N, double *S_out, int ldS);
+int k_boxdot_convT(alq_ctx *, const float *dsum, const float *asum, int ID, int IH, int IW,
+                   const int k[3], const int s[3], const int lo[3], int N, double *S_out, int ldS);
+int k_fc_small_fwd(alq_ctx *, const float *act, int64_t F, const float *Wp, int nout, int N,
+                   float *partials, int nslices);
+int k_fc_small_finish(alq_ctx *, const float *partials, int nslices, const float *bias, int nout,
+                      int relu, int N, float *out);
+int k_fc_small_bwd(alq_ctx *, const float *delta, int nout, const float *Wp, int64_t F, int N,
+                   float *dact);
+int k_softmax(alq_ctx *, const float *logits, int c, int N, float *post_cN, int64_t *pred);
+int k_fill_unit_cotangent(alq_ctx *, float *dlogits, int N);
+int k_fisher_finalize(alq_ctx *, const double *S, int L, const double *sizes, const float *post_cN,
+                      const float *p1_branch, int N, double diag_load, float *p1_out, double *g0,
+                      double *g1, double *A, double *trace, double *Apart, int *nblocks_out);
+int k_reduce_Asum(alq_ctx *, const double *Apart, int nblocks, int LL, double *Asum);
+int fc_small_slices(int64_t F);
+
+}  // namespace alq

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Builds libalq.so (gfx950 only) next to the Python package.  hipcc cross-compiles without a GPU.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+PKG="$(dirname "$HERE")"
+ROOT="$(dirname "$PKG")"
+OUT="$PKG/libalq.so"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -I$HERE -Wall -Wno-unused-function"
+mkdir -p "$HERE/build"
+pids=()
+for f in igemm kernels topk model; do
+  ( hipcc $FLAGS -c "$HERE/$f.hip" -o "$HERE/build/$f.o" ${ALQ_EXTRA_FLAGS:-} ) &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait "$p"; done
+hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT" "$HERE"/build/{igemm,kernels,topk,model}.o
+echo "built $OUT"

@@ -1,0 +1,671 @@
+// Non-GEMM kernels of the scoring path: pooling, ReLU-mask + channel sums, box-dot reductions
+// (the factored `shrink_gradient(...,'sum')`), skinny fc, softmax, Fisher finalisation,
+// patch gather + normalisation, synthetic patches.  All HBM/L2-bound: coalesced channels-last
+// accesses, wave-shuffle + LDS block reductions, fp64 accumulation where it is free.
+#include "alq_internal.h"
+
+namespace alq {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline float wave_sumf(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// 256-thread block sum; result valid in thread 0
+__device__ inline double block_sum256(double v, double *sh /*[4]*/) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0;
+    if (threadIdx.x == 0) r = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return r;
+}
+
+#define ALQ_LAUNCH_CHECK() ALQ_HIP(hipGetLastError())
+
+// =========================================================================== pooling
+// window == stride (NN.py:1473-1477 is called with [2,2]; NN_extended.py:463-468), TF 'SAME':
+// out = ceil(in/s), window origin o*s - lo, positions outside the tensor never win.
+__global__ void pool_fwd_kernel(const float *in, int in_cs, int in_c0, int C, int ID, int IH, int IW,
+                                float *out, int out_cs, int out_c0, int OD, int OH, int OW,
+                                uint8_t *argmax, int wz, int wy, int wx, int lz, int ly, int lx,
+                                long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int c = r % C; r /= C;
+        const int ox = r % OW; r /= OW;
+        const int oy = r % OH; r /= OH;
+        const int oz = r % OD; r /= OD;
+        const long long n = r;
+        float best = -INFINITY;
+        int bidx = 0;
+        for (int dz = 0; dz < wz; ++dz) {
+            const int iz = oz * wz - lz + dz;
+            if (iz < 0 || iz >= ID) continue;
+            for (int dy = 0; dy < wy; ++dy) {
+                const int iy = oy * wy - ly + dy;
+                if (iy < 0 || iy >= IH) continue;
+                for (int dx = 0; dx < wx; ++dx) {
+                    const int ix = ox * wx - lx + dx;
+                    if (ix < 0 || ix >= IW) continue;
+                    const float v = in[((((n * ID + iz) * IH + iy) * IW + ix)) * in_cs + in_c0 + c];
+                    if (v > best) { best = v; bidx = (dz * wy + dy) * wx + dx; }
+                }
+            }
+        }
+        out[(((n * OD + oz) * OH + oy) * OW + ox) * out_cs + out_c0 + c] = best;
+        argmax[i] = (uint8_t)bidx;
+    }
+}
+
+__global__ void pool_bwd_kernel(const float *dout, int do_cs, int do_c0, int C, int OD, int OH, int OW,
+                                float *din, int di_cs, int di_c0, int ID, int IH, int IW,
+                                const uint8_t *argmax, int wz, int wy, int wx, int lz, int ly, int lx,
+                                int accumulate, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int c = r % C; r /= C;
+        const int ix = r % IW; r /= IW;
+        const int iy = r % IH; r /= IH;
+        const int iz = r % ID; r /= ID;
+        const long long n = r;
+        const int oz = (iz + lz) / wz, oy = (iy + ly) / wy, ox = (ix + lx) / wx;
+        float g = 0.f;
+        if (oz < OD && oy < OH && ox < OW) {
+            const int widx = (((iz + lz) - oz * wz) * wy + ((iy + ly) - oy * wy)) * wx + ((ix + lx) - ox * wx);
+            const long long o = (((n * OD + oz) * OH + oy) * OW + ox);
+            if (argmax[o * C + c] == widx) g = dout[o * do_cs + do_c0 + c];
+        }
+        float *dst = din + ((((n * ID + iz) * IH + iy) * IW + ix)) * di_cs + di_c0 + c;
+        *dst = accumulate ? (*dst + g) : g;
+    }
+}
+
+static unsigned grid_for(long long total, int block = 256, int cap = 256 * 32) {
+    long long g = (total + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+int k_pool_fwd(alq_ctx *ctx, const View &in, const View &out, uint8_t *argmax, const int w[3],
+               const int lo[3], int N) {
+    const long long total = (long long)N * out.vox() * out.C;
+    ProfScope ps(ctx, PROF_ELEMWISE, 0);
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, in.p, in.cs,
+                       in.c0, in.C, in.D, in.H, in.W, out.p, out.cs, out.c0, out.D, out.H, out.W, argmax,
+                       w[0], w[1], w[2], lo[0], lo[1], lo[2], total);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
+int k_pool_bwd(alq_ctx *ctx, const View &dout, const View &din, const uint8_t *argmax, const int w[3],
+               const int lo[3], int N, int accumulate) {
+    const long long total = (long long)N * din.vox() * din.C;
+    ProfScope ps(ctx, PROF_ELEMWISE, 0);
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, dout.p, dout.cs,
+                       dout.c0, dout.C, dout.D, dout.H, dout.W, din.p, din.cs, din.c0, din.D, din.H, din.W,
+                       argmax, w[0], w[1], w[2], lo[0], lo[1], lo[2], accumulate, total);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
+// =========================================================================== channel sums
+// field[n, vox] = sum_c t[n, vox, c]; one thread per voxel, channel slice read as float4 when
+// aligned (adjacent threads read adjacent voxel rows -> every fetched line is fully used).
+__global__ void chansum_kernel(const float *t, int cs, int c0, int C, float *field, long long nvox) {
+    const bool vec = ((cs | c0 | C) & 3) == 0;
+    for (long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x; v < nvox;
+         v += (long long)gridDim.x * blockDim.x) {
+        const float *row = t + v * cs + c0;
+        float s = 0.f;
+        if (vec) {
+            for (int c = 0; c < C; c += 4) {
+                const f32x4 q = *reinterpret_cast<const f32x4 *>(row + c);
+                s += (q.x + q.y) + (q.z + q.w);
+            }
+        } else {
+            for (int c = 0; c < C; ++c) s += row[c];
+        }
+        field[v] = s;
+    }
+}
+
+// d <- d * (act > 0) in place (ReLUGrad, only when act != null) and field = channel sum of d
+__global__ void mask_chansum_kernel(float *d, int cs, int c0, int C, const float *act, int acs, int ac0,
+                                    float *field, long long nvox) {
+    const bool vec = ((cs | c0 | C | acs | ac0) & 3) == 0;
+    for (long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x; v < nvox;
+         v += (long long)gridDim.x * blockDim.x) {
+        float *row = d + v * cs + c0;
+        const float *arow = act ? act + v * acs + ac0 : nullptr;
+        float s = 0.f;
+        if (vec) {
+            for (int c = 0; c < C; c += 4) {
+                f32x4 q = *reinterpret_cast<f32x4 *>(row + c);
+                if (arow) {
+                    const f32x4 m = *reinterpret_cast<const f32x4 *>(arow + c);
+                    q.x = m.x > 0.f ? q.x : 0.f;
+                    q.y = m.y > 0.f ? q.y : 0.f;
+                    q.z = m.z > 0.f ? q.z : 0.f;
+                    q.w = m.w > 0.f ? q.w : 0.f;
+                    *reinterpret_cast<f32x4 *>(row + c) = q;
+                }
+                s += (q.x + q.y) + (q.z + q.w);
+            }
+        } else {
+            for (int c = 0; c < C; ++c) {
+                float q = row[c];
+                if (arow) {
+                    q = arow[c] > 0.f ? q : 0.f;
+                    row[c] = q;
+                }
+                s += q;
+            }
+        }
+        field[v] = s;
+    }
+}
+
+int k_chansum(alq_ctx *ctx, const View &in, float *field, int N) {
+    const long long nvox = (long long)N * in.vox();
+    ProfScope ps(ctx, PROF_ELEMWISE, 0);
+    hipLaunchKernelGGL(chansum_kernel, dim3(grid_for(nvox)), dim3(256), 0, ctx->stream, in.p, in.cs, in.c0,
+                       in.C, field, nvox);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
+int k_mask_chansum(alq_ctx *ctx, const View &dact, const View *act, float *field, int N) {
+    const long long nvox = (long long)N * dact.vox();
+    ProfScope ps(ctx, PROF_ELEMWISE, 0);
+    hipLaunchKernelGGL(mask_chansum_kernel, dim3(grid_for(nvox)), dim3(256), 0, ctx->stream, dact.p, dact.cs,
+                       dact.c0, dact.C, act ? act->p : nullptr, act ? act->cs : 0, act ? act->c0 : 0, field,
+                       nvox);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
+// =========================================================================== box-dot reductions
+// conv / fc:  S[n] = sum_x dsum[n,x] * (1 + sum_taps asum[n, x + tap - lo])   (zero outside)
+// One workgroup per patch, fp64 accumulation, fixed order -> deterministic.
+__global__ __launch_bounds__(256) void boxdot_conv_kernel(const float *dsum, const float *asum, int D, int H,
+                                                          int W, int kz, int ky, int kx, int lz, int ly,
+                                                          int lx, double *S, int ldS) {
+    __shared__ double sh[4];
+    const long long n = blockIdx.x;
+    const int vox = D * H * W;
+    const float *dn = dsum + n * vox;
+    const float *an = asum + n * vox;
+    double acc = 0;
+    for (int v = threadIdx.x; v < vox; v += 256) {
+        const float dv = dn[v];
+        int r = v;
+        const int x = r % W; r /= W;
+        const int y = r % H;
+        const int z = r / H;
+        float box = 0.f;
+        for (int dz = 0; dz < kz; ++dz) {
+            const int iz = z + dz - lz;
+            if (iz < 0 || iz >= D) continue;
+            for (int dy = 0; dy < ky; ++dy) {
+                const int iy = y + dy - ly;
+                if (iy < 0 || iy >= H) continue;
+                const float *rowp = an + (iz * H + iy) * W;
+                for (int dx = 0; dx < kx; ++dx) {
+                    const int ix = x + dx - lx;
+                    if (ix >= 0 && ix < W) box += rowp[ix];
+                }
+            }
+        }
+        acc += (double)dv * ((double)box + 1.0);
+    }
+    const double tot = block_sum256(acc, sh);
+    if (threadIdx.x == 0) S[n * ldS] = tot;
+}
+
+// conv_transpose: S[n] = sum_q asum[n,q] * sum_t dsum[n, s*q + t - lo] + sum_p dsum[n,p]
+// (q on the INPUT grid, p on the output grid = s * input grid)
+__global__ __launch_bounds__(256) void boxdot_convT_kernel(const float *dsum, const float *asum, int ID,
+                                                           int IH, int IW, int kz, int ky, int kx, int sz,
+                                                           int sy, int sx, int lz, int ly, int lx, double *S,
+                                                           int ldS) {
+    __shared__ double sh[4];
+    const long long n = blockIdx.x;
+    const int OD = ID * sz, OH = IH * sy, OW = IW * sx;
+    const int ivox = ID * IH * IW;
+    const float *dn = dsum + n * (long long)OD * OH * OW;
+    const float *an = asum + n * ivox;
+    double acc = 0;
+    for (int v = threadIdx.x; v < ivox; v += 256) {
+        int r = v;
+        const int x = r % IW; r /= IW;
+        const int y = r % IH;
+        const int z = r / IH;
+        float box = 0.f;
+        for (int dz = 0; dz < kz; ++dz) {
+            const int oz = z * sz + dz - lz;
+            if (oz < 0 || oz >= OD) continue;
+            for (int dy = 0; dy < ky; ++dy) {
+                const int oy = y * sy + dy - ly;
+                if (oy < 0 || oy >= OH) continue;
+                const float *rowp = dn + ((long long)oz * OH + oy) * OW;
+                for (int dx = 0; dx < kx; ++dx) {
+                    const int ox = x * sx + dx - lx;
+                    if (ox >= 0 && ox < OW) box += rowp[ox];
+                }
+            }
+        }
+        float own = 0.f;   // bias term: every output point belongs to exactly one input point
+        for (int dz = 0; dz < sz; ++dz)
+            for (int dy = 0; dy < sy; ++dy) {
+                const float *rowp = dn + ((long long)(z * sz + dz) * OH + (y * sy + dy)) * OW + x * sx;
+                for (int dx = 0; dx < sx; ++dx) own += rowp[dx];
+            }
+        acc += (double)an[v] * (double)box + (double)own;
+    }
+    const double tot = block_sum256(acc, sh);
+    if (threadIdx.x == 0) S[n * ldS] = tot;
+}
+
+int k_boxdot_conv(alq_ctx *ctx, const float *dsum, const float *asum, int D, int H, int W, const int k[3],
+                  const int lo[3], int N, double *S_out, int ldS) {
+    ProfScope ps(ctx, PROF_REDUCE, 0);
+    hipLaunchKernelGGL(boxdot_conv_kernel, dim3(N), dim3(256), 0, ctx->stream, dsum, asum, D, H, W, k[0], k[1],
+                       k[2], lo[0], lo[1], lo[2], S_out, ldS);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
+int k_boxdot_convT(alq_ctx *ctx, const float *dsum, const float *asum, int ID, int IH, int IW, const int k[3],
+                   const int s[3], const int lo[3], int N, double *S_out, int ldS) {
+    ProfScope ps(ctx, PROF_REDUCE, 0);
+    hipLaunchKernelGGL(boxdot_convT_kernel, dim3(N), dim3(256), 0, ctx->stream, dsum, asum, ID, IH, IW, k[0],
+                       k[1], k[2], s[0], s[1], s[2], lo[0], lo[1], lo[2], S_out, ldS);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
+// =========================================================================== skinny fc (out <= 8)
+// logits[n, o] = b[o] + sum_f act[n, f] * Wp[o, f]; Wp rows are in activation-memory order.
+// grid (slices, N): each workgroup reduces one contiguous slice of F; the slice partials are
+// summed in slice order by fc_small_finish -> deterministic.
+constexpr int FC_SLICE = 8192;
+int fc_small_slices(int64_t F) { return (int)((F + FC_SLICE - 1) / FC_SLICE); }
+
+template <int NOUT>
+__global__ __launch_bounds__(256) void fc_small_fwd_kernel(const float *act, long long F, const float *Wp,
+                                                           float *partials, int nslices) {
+    __shared__ double sh[4];
+    const int slice = blockIdx.x;
+    const long long n = blockIdx.y;
+    const long long f0 = (long long)slice * FC_SLICE;
+    const long long f1 = (f0 + FC_SLICE < F) ? f0 + FC_SLICE : F;
+    const float *a = act + n * F;
+    float acc[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) acc[o] = 0.f;
+    if ((F & 3) == 0) {
+        for (long long f = f0 + threadIdx.x * 4; f < f1; f += 1024) {
+            const f32x4 av = *reinterpret_cast<const f32x4 *>(a + f);
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(Wp + o * F + f);
+                acc[o] += (av.x * wv.x + av.y * wv.y) + (av.z * wv.z + av.w * wv.w);
+            }
+        }
+    } else {
+        for (long long f = f0 + threadIdx.x; f < f1; f += 256) {
+            const float av = a[f];
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) acc[o] += av * Wp[o * F + f];
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        const double tot = block_sum256((double)acc[o], sh);
+        if (threadIdx.x == 0) partials[(n * nslices + slice) * NOUT + o] = (float)tot;
+    }
+}
+
+__global__ void fc_small_finish_kernel(const float *partials, int nslices, const float *bias, int nout,
+                                       int relu, int N, float *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * nout) return;
+    const int n = i / nout, o = i - n * nout;
+    double s = 0;
+    for (int k = 0; k < nslices; ++k) s += (double)partials[((long long)n * nslices + k) * nout + o];
+    float v = (float)s + (bias ? bias[o] : 0.f);
+    if (relu) v = fmaxf(v, 0.f);
+    out[i] = v;
+}
+
+int k_fc_small_fwd(alq_ctx *ctx, const float *act, int64_t F, const float *Wp, int nout, int N,
+                   float *partials, int nslices) {
+    ProfScope ps(ctx, PROF_FC_SMALL, 2.0 * F * nout * N);
+    dim3 grid(nslices, N);
+#define ALQ_FC(NO) \
+    case NO: hipLaunchKernelGGL(fc_small_fwd_kernel<NO>, grid, dim3(256), 0, ctx->stream, act, (long long)F, Wp, partials, nslices); break
+    switch (nout) {
+        ALQ_FC(1); ALQ_FC(2); ALQ_FC(3); ALQ_FC(4); ALQ_FC(5); ALQ_FC(6); ALQ_FC(7); ALQ_FC(8);
+        default: set_error("fc_small: nout=%d unsupported", nout); return ALQ_EUNSUPPORTED;
+    }
+#undef ALQ_FC
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
+int k_fc_small_finish(alq_ctx *ctx, const float *partials, int nslices, const float *bias, int nout,
+                      int relu, int N, float *out) {
+    ProfScope ps(ctx, PROF_FC_SMALL, 0);
+    hipLaunchKernelGGL(fc_small_finish_kernel, dim3((N * nout + 255) / 256), dim3(256), 0, ctx->stream,
+                       partials, nslices, bias, nout, relu, N, out);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
+// dact[n, f] = sum_o delta[n, o] * Wp[o, f]
+__global__ void fc_small_bwd_kernel(const float *delta, int nout, const float *Wp, long long F, int N,
+                                    float *dact) {
+    const long long total4 = (long long)N * (F >> 2);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / (F >> 2);
+        const long long f = (i - n * (F >> 2)) << 2;
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int o = 0; o < nout; ++o) {
+            const float dv = delta[n * nout + o];
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(Wp + o * F + f);
+            s += dv * wv;
+        }
+        *reinterpret_cast<f32x4 *>(dact + n * F + f) = s;
+    }
+}
+__global__ void fc_small_bwd_scalar_kernel(const float *delta, int nout, const float *Wp, long long F, int N,
+                                           float *dact) {
+    const long long total = (long long)N * F;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / F, f = i - n * F;
+        float s = 0.f;
+        for (int o = 0; o < nout; ++o) s += delta[n * nout + o] * Wp[o * F + f];
+        dact[i] = s;
+    }
+}
+
+int k_fc_small_bwd(alq_ctx *ctx, const float *delta, int nout, const float *Wp, int64_t F, int N,
+                   float *dact) {
+    ProfScope ps(ctx, PROF_FC_SMALL, 2.0 * F * nout * N);
+    if ((F & 3) == 0)
+        hipLaunchKernelGGL(fc_small_bwd_kernel, dim3(grid_for((long long)N * (F >> 2))), dim3(256), 0,
+                           ctx->stream, delta, nout, Wp, (long long)F, N, dact);
+    else
+        hipLaunchKernelGGL(fc_small_bwd_scalar_kernel, dim3(grid_for((long long)N * F)), dim3(256), 0,
+                           ctx->stream, delta, nout, Wp, (long long)F, N, dact);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
+// =========================================================================== softmax / scores
+// posteriors = softmax over classes (NN.py:185-188): exp(z - max) / sum, fp32; output [c, N].
+__global__ void softmax_kernel(const float *logits, int c, int N, float *post, long long *pred) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float *z = logits + (long long)n * c;
+    float mx = z[0];
+    for (int j = 1; j < c; ++j) mx = fmaxf(mx, z[j]);
+    float den = 0.f;
+    for (int j = 0; j < c; ++j) den += expf(z[j] - mx);
+    int best = 0;
+    float bp = -1.f;
+    for (int j = 0; j < c; ++j) {
+        const float p = expf(z[j] - mx) / den;
+        post[(long long)j * N + n] = p;
+        if (p > bp) { bp = p; best = j; }   // first maximum, like tf.argmax
+    }
+    if (pred) pred[n] = best;
+}
+
+int k_softmax(alq_ctx *ctx, const float *logits, int c, int N, float *post_cN, int64_t *pred) {
+    ProfScope ps(ctx, PROF_ELEMWISE, 0);
+    hipLaunchKernelGGL(softmax_kernel, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, logits, c, N, post_cN,
+                       reinterpret_cast<long long *>(pred));
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
+__global__ void unit_cotangent_kernel(float *d, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    d[2 * n] = 1.f;
+    d[2 * n + 1] = -1.f;
+}
+
+int k_fill_unit_cotangent(alq_ctx *ctx, float *dlogits, int N) {
+    hipLaunchKernelGGL(unit_cotangent_kernel, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, dlogits, N);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
+// |double(p1) - 0.5| is exact in fp64, so the device ordering equals numpy's (PW_NNAL.py:64).
+// H = -sum p log p with +10e-8 on exact zeros (NNAL_tools.py:78-83), evaluated in fp32.
+__global__ void entropy_kernel(const float *p1, long long n, double *absdev, float *H) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float p = p1[i];
+        if (absdev) absdev[i] = fabs((double)p - 0.5);
+        if (H) {
+            float a = 1.f - p, b = p;
+            if (a == 0.f) a += 10e-8f;
+            if (b == 0.f) b += 10e-8f;
+            H[i] = -(a * logf(a) + b * logf(b));
+        }
+    }
+}
+
+// =========================================================================== Fisher finalisation
+// Per patch, from the unit-cotangent layer sums S_t (sum of all entries of d(z0-z1)/d theta_t):
+//   class-0 gradient sums = p1 * S, class-1 = -p0 * S  (d log p_j / dz = e_j - p), rounded to
+//   fp32 like the reference's np.sum over fp32 gradients, divided by the layer size in fp64
+//   (NNAL_tools.py:793-796); three-way saturation branch and A_i of PW_NNAL.py:770-814.
+constexpr int FIN_BLOCK = 64;
+__global__ __launch_bounds__(FIN_BLOCK) void fisher_finalize_kernel(
+    const double *S, int L, const double *sizes, const float *post, const float *p1_branch, int N,
+    double diag_load, float *p1_out, double *g0o, double *g1o, double *Ao, double *tro, double *Apart) {
+    const int n = blockIdx.x * FIN_BLOCK + threadIdx.x;
+    const bool live = n < N;
+    double g0[16], g1[16];
+    double p = 0;
+    if (live) {
+        const float p0f = post[n];
+        const float p1f = post[(long long)N + n];
+        p = (double)(p1_branch ? p1_branch[n] : p1f);
+        if (p1_out) p1_out[n] = p1f;
+        bool use0 = true, use1 = true;
+        if (p < 1e-6) { p = 0.; use1 = false; }
+        else if (p > 1. - 1e-6) { p = 1.; use0 = false; }
+        for (int t = 0; t < L; ++t) {
+            const double s = S[(long long)n * L + t];
+            const float s0 = (float)((double)p1f * s);
+            const float s1 = (float)(-(double)p0f * s);
+            g0[t] = use0 ? (double)s0 / sizes[t] : 0.;
+            g1[t] = use1 ? (double)s1 / sizes[t] : 0.;
+            if (g0o) g0o[(long long)n * L + t] = g0[t];
+            if (g1o) g1o[(long long)n * L + t] = g1[t];
+        }
+    }
+    double tr = 0;
+    for (int i = 0; i < L; ++i)
+        for (int j = 0; j < L; ++j) {
+            double a = 0;
+            if (live) {
+                a = (1. - p) * (g0[i] * g0[j]) + p * (g1[i] * g1[j]);
+                if (i == j) { a += diag_load; tr += a; }
+                if (Ao) Ao[((long long)n * L + i) * L + j] = a;
+            }
+            const double tot = wave_sum(a);   // FIN_BLOCK == one wave
+            if (threadIdx.x == 0) Apart[(long long)blockIdx.x * L * L + i * L + j] = tot;
+        }
+    if (live && tro) tro[n] = tr;
+}
+
+__global__ void reduce_Asum_kernel(const double *Apart, int nblocks, int LL, double *Asum) {
+    const int e = threadIdx.x;
+    if (e >= LL) return;
+    double s = 0;
+    for (int b = 0; b < nblocks; ++b) s += Apart[(long long)b * LL + e];
+    Asum[e] = s;
+}
+
+int k_fisher_finalize(alq_ctx *ctx, const double *S, int L, const double *sizes, const float *post_cN,
+                      const float *p1_branch, int N, double diag_load, float *p1_out, double *g0, double *g1,
+                      double *A, double *trace, double *Apart, int *nblocks_out) {
+    ALQ_REQUIRE(L <= 16, ALQ_EUNSUPPORTED, "fisher: %d parameterised layers > 16", L);
+    const int nb = (N + FIN_BLOCK - 1) / FIN_BLOCK;
+    ProfScope ps(ctx, PROF_REDUCE, 0);
+    hipLaunchKernelGGL(fisher_finalize_kernel, dim3(nb), dim3(FIN_BLOCK), 0, ctx->stream, S, L, sizes, post_cN,
+                       p1_branch, N, diag_load, p1_out, g0, g1, A, trace, Apart);
+    ALQ_LAUNCH_CHECK();
+    *nblocks_out = nb;
+    return ALQ_OK;
+}
+
+int k_reduce_Asum(alq_ctx *ctx, const double *Apart, int nblocks, int LL, double *Asum) {
+    ProfScope ps(ctx, PROF_REDUCE, 0);
+    hipLaunchKernelGGL(reduce_Asum_kernel, dim3(1), dim3(256), 0, ctx->stream, Apart, nblocks, LL, Asum);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
+// =========================================================================== gather + normalise
+template <typename VT, typename OT>
+__global__ void gather_norm_kernel(const VT *const *vols, int m, long long P1, long long P2, long long O0,
+                                   long long O1, long long O2, const long long *inds, long long n, int d1,
+                                   int d2, int d3, const double *stats, int quirk, OT *out) {
+    const int C = m * d3;
+    const long long total = n * d1 * d2 * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int ch = r % C; r /= C;
+        const int a1 = r % d2; r /= d2;
+        const int a0 = r % d1; r /= d1;
+        const long long b = r;
+        const int j = ch / d3, a2 = ch - j * d3;
+        long long ind = inds[b];
+        const long long i2 = ind % O2; ind /= O2;
+        const long long i1 = ind % O1; ind /= O1;
+        const long long i0 = ind;
+        // window origin in PADDED coordinates is the un-padded index itself (centre = index + radius)
+        double v = (double)vols[j][((i0 + a0) * P1 + (i1 + a1)) * P2 + (i2 + a2)];
+        if (quirk == 1) {
+            if (ch < m) v = (v - stats[2 * ch]) / stats[2 * ch + 1];
+        } else if (quirk == 0) {
+            v = (v - stats[2 * j]) / stats[2 * j + 1];
+        }
+        out[i] = (OT)v;
+    }
+    (void)O0;
+}
+
+template <typename VT, typename OT>
+static void gather_launch(alq_ctx *ctx, const void *const *vp, int m, const int64_t pad[3], const int64_t orig[3],
+                          const int64_t *d_inds, int64_t n, const int32_t ps[3], const double *d_stats, int quirk,
+                          void *d_out, long long total) {
+    hipLaunchKernelGGL((gather_norm_kernel<VT, OT>), dim3(grid_for(total)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const VT *const *>(vp), m, (long long)pad[1], (long long)pad[2],
+                       (long long)orig[0], (long long)orig[1], (long long)orig[2],
+                       reinterpret_cast<const long long *>(d_inds), (long long)n, ps[0], ps[1], ps[2], d_stats,
+                       quirk, reinterpret_cast<OT *>(d_out));
+}
+
+int gather_normalize_impl(alq_ctx *ctx, const void *const *d_vol_ptrs_dev, int m, int is_f64,
+                          const int64_t pad[3], const int64_t orig[3], const int64_t *d_inds, int64_t n,
+                          const int32_t ps[3], const double *d_stats, int quirk, int out_f64, void *d_out) {
+    const long long total = (long long)n * ps[0] * ps[1] * ps[2] * m;
+    ProfScope pscope(ctx, PROF_ELEMWISE, 0);
+    if (is_f64 && out_f64) gather_launch<double, double>(ctx, d_vol_ptrs_dev, m, pad, orig, d_inds, n, ps, d_stats, quirk, d_out, total);
+    else if (is_f64) gather_launch<double, float>(ctx, d_vol_ptrs_dev, m, pad, orig, d_inds, n, ps, d_stats, quirk, d_out, total);
+    else if (out_f64) gather_launch<float, double>(ctx, d_vol_ptrs_dev, m, pad, orig, d_inds, n, ps, d_stats, quirk, d_out, total);
+    else gather_launch<float, float>(ctx, d_vol_ptrs_dev, m, pad, orig, d_inds, n, ps, d_stats, quirk, d_out, total);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
+int score_entropy_impl(alq_ctx *ctx, const float *d_p1, int64_t n, double *d_absdev, float *d_H) {
+    ProfScope ps(ctx, PROF_ELEMWISE, 0);
+    hipLaunchKernelGGL(entropy_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, d_p1, (long long)n,
+                       d_absdev, d_H);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
+// =========================================================================== debug copies
+__global__ void view_to_dense_kernel(const float *t, int cs, int c0, int C, long long nvox, float *out) {
+    const long long total = nvox * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long v = i / C;
+        const int c = (int)(i - v * C);
+        out[i] = t[v * cs + c0 + c];
+    }
+}
+__global__ void f64_to_f32_kernel(const double *in, long long n, float *out) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        out[i] = (float)in[i];
+}
+int debug_view_copy(alq_ctx *ctx, const View &v, int N, float *out) {
+    const long long nvox = (long long)N * v.vox();
+    hipLaunchKernelGGL(view_to_dense_kernel, dim3(grid_for(nvox * v.C)), dim3(256), 0, ctx->stream, v.p, v.cs,
+                       v.c0, v.C, nvox, out);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+int debug_f64_copy(alq_ctx *ctx, const double *in, long long n, float *out) {
+    hipLaunchKernelGGL(f64_to_f32_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, in, n, out);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
+// =========================================================================== synthetic patches
+// Counter-based generator: element e of patch id -> splitmix64(seed, id, e) -> Box-Muller.
+__device__ inline unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ void synth_kernel(unsigned long long seed, long long first_id, long long n, long long epp,
+                             float *out) {
+    const long long total = n * epp;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long pid = first_id + i / epp;
+        const long long e = i % epp;
+        const unsigned long long h = splitmix64(splitmix64(seed ^ (unsigned long long)pid * 0xD1B54A32D192ED03ull) + (unsigned long long)e);
+        const float u1 = ((float)(unsigned)(h >> 40) + 1.0f) * (1.0f / 16777217.0f);   // (0, 1)
+        const float u2 = (float)(unsigned)((h >> 8) & 0xFFFFFF) * (1.0f / 16777216.0f);
+        out[i] = sqrtf(-2.f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+    }
+}
+
+int synth_impl(alq_ctx *ctx, uint64_t seed, int64_t first_id, int64_t n, int64_t epp, float *d_out) {
+    hipLaunchKernelGGL(synth_kernel, dim3(grid_for(n * epp)), dim3(256), 0, ctx->stream,
+                       (unsigned long long)seed, (long long)first_id, (long long)n, (long long)epp, d_out);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
+}  // namespace alq

@@ -1,0 +1,804 @@
+// Model plan + orchestration behind the C ABI: shapes, activation / cotangent workspaces
+// (concat skips = channel slices of one buffer), weight re-layout into the GEMM engine's
+// packed form, and the forward / Fisher launch sequences.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <memory>
+
+#include "alq_internal.h"
+
+namespace alq {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int gather_normalize_impl(alq_ctx *, const void *const *, int, int, const int64_t[3], const int64_t[3],
+                          const int64_t *, int64_t, const int32_t[3], const double *, int, int, void *);
+int score_entropy_impl(alq_ctx *, const float *, int64_t, double *, float *);
+int synth_impl(alq_ctx *, uint64_t, int64_t, int64_t, int64_t, float *);
+int debug_view_copy(alq_ctx *, const View &, int, float *);
+int debug_f64_copy(alq_ctx *, const double *, long long, float *);
+size_t topk_work_bytes_impl(int64_t n);
+int topk_impl(alq_ctx *, const double *, int64_t, int64_t, int64_t *, void *);
+
+static void same_pads(int in, int k, int s, int *out, int *lo) {
+    *out = (in + s - 1) / s;
+    int total = (*out - 1) * s + k - in;
+    if (total < 0) total = 0;
+    *lo = total / 2;
+}
+
+struct Layer {
+    alq_layer_t spec;
+    int pidx = -1;             // parameterised-layer index t, or -1
+    View in, out;              // activation views (in = incl. concatenated skip channels)
+    View din, dout;            // cotangent views, same geometry
+    int lo[3] = {0, 0, 0};     // SAME pad-before (conv: of the fwd conv; convT: of the conv it transposes)
+    bool dense_fc_small = false;
+    int64_t F = 0;             // fc: input features
+    // weights
+    int64_t w_elems = 0, b_elems = 0;
+    float *d_bias = nullptr;
+    float *d_Wp = nullptr;     // skinny fc: [nout][F] in activation-memory order
+    std::vector<IgemmPlan> fwd;   // 1 plan (conv / fc) or one per output parity class (convT)
+    IgemmPlan bwd;
+    bool has_bwd = false;
+    bool weights_set = false;
+    // workspaces
+    uint8_t *argmax = nullptr;
+    float *asum = nullptr, *dsum = nullptr;
+    float *fc_partials = nullptr;
+    int fc_slices = 0;
+    bool out_is_skip_src = false;
+    // convT class tap lists (indices into the k^3 tap enumeration)
+    std::vector<std::vector<int>> class_taps;
+};
+
+}  // namespace alq
+
+using namespace alq;
+
+struct alq_model {
+    alq_ctx *ctx = nullptr;
+    int max_batch = 0;
+    int in_dims[4] = {1, 1, 1, 1};
+    int nclass = 0;
+    int L = 0;
+    std::vector<Layer> layers;
+    std::vector<void *> allocs;
+    float *logits = nullptr, *dlogits = nullptr, *post = nullptr;
+    double *S = nullptr, *sizes = nullptr, *Apart = nullptr;
+    float *x_stage = nullptr;
+
+    template <typename T>
+    int dalloc(T **p, size_t count) {
+        void *q = nullptr;
+        const size_t bytes = std::max<size_t>(count * sizeof(T), 256);
+        if (hipMalloc(&q, bytes) != hipSuccess) {
+            set_error("hipMalloc of %zu bytes failed", bytes);
+            return ALQ_ENOMEM;
+        }
+        allocs.push_back(q);
+        *p = reinterpret_cast<T *>(q);
+        return ALQ_OK;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+int alq_ctx::prof_begin(int cls, hipEvent_t *e0, hipEvent_t *e1) {
+    ProfSlot &s = prof[cls];
+    auto get = [&](hipEvent_t *ev) -> int {
+        if (!s.pool.empty()) {
+            *ev = s.pool.back();
+            s.pool.pop_back();
+            return ALQ_OK;
+        }
+        return hipEventCreate(ev) == hipSuccess ? ALQ_OK : ALQ_EHIP;
+    };
+    if (get(e0) != ALQ_OK || get(e1) != ALQ_OK) return ALQ_EHIP;
+    return hipEventRecord(*e0, stream) == hipSuccess ? ALQ_OK : ALQ_EHIP;
+}
+
+void alq_ctx::prof_end(int cls, hipEvent_t e0, hipEvent_t e1, double flops) {
+    ProfSlot &s = prof[cls];
+    (void)hipEventRecord(e1, stream);
+    s.pending.emplace_back(e0, e1);
+    s.launches += 1;
+    s.flops += flops;
+}
+
+int alq_ctx::prof_collect() {
+    ALQ_HIP(hipStreamSynchronize(stream));
+    for (int c = 0; c < PROF_NUM; ++c) {
+        ProfSlot &s = prof[c];
+        for (auto &pr : s.pending) {
+            float ms = 0.f;
+            ALQ_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+            s.ms += ms;
+            s.pool.push_back(pr.first);
+            s.pool.push_back(pr.second);
+        }
+        s.pending.clear();
+    }
+    return ALQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+static int upload(alq_model *m, IgemmPlan *p) {
+    if (!p->d_W) ALQ_TRY(m->dalloc(&p->d_W, p->h_W.size()));
+    ALQ_HIP(hipMemcpyAsync(p->d_W, p->h_W.data(), p->h_W.size() * sizeof(float), hipMemcpyHostToDevice,
+                           m->ctx->stream));
+    if (p->smallc) {
+        if (!p->d_koff) ALQ_TRY(m->dalloc(&p->d_koff, p->h_koff.size()));
+        ALQ_HIP(hipMemcpyAsync(p->d_koff, p->h_koff.data(), p->h_koff.size() * sizeof(int),
+                               hipMemcpyHostToDevice, m->ctx->stream));
+    }
+    ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
+    std::vector<float>().swap(p->h_W);
+    return ALQ_OK;
+}
+
+static void enum_taps(const int k[3], std::vector<int> *tz, std::vector<int> *ty, std::vector<int> *tx) {
+    for (int z = 0; z < k[0]; ++z)
+        for (int y = 0; y < k[1]; ++y)
+            for (int x = 0; x < k[2]; ++x) {
+                tz->push_back(z); ty->push_back(y); tx->push_back(x);
+            }
+}
+
+static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
+    const int NB = m->max_batch;
+    m->layers.resize(n_layers);
+    // ---- pass 1: shapes ------------------------------------------------------------------
+    struct Shp { int D, H, W, C; };
+    std::vector<Shp> outs(n_layers);
+    Shp cur = {m->in_dims[0], m->in_dims[1], m->in_dims[2], m->in_dims[3]};
+    bool flat = false;
+    int pidx = 0;
+    std::vector<int> src_of(n_layers, -1);   // dest layer -> src layer
+    std::vector<int> dest_of(n_layers, -1);  // src layer -> dest layer
+    for (int i = 0; i < n_layers; ++i) {
+        Layer &ly = m->layers[i];
+        ly.spec = specs[i];
+        const alq_layer_t &sp = ly.spec;
+        Shp in = cur;
+        if (sp.skip_src >= 0) {
+            ALQ_REQUIRE(sp.skip_src < i - 1, ALQ_EUNSUPPORTED, "layer %d: skip source %d must be an earlier, non-adjacent layer", i, sp.skip_src);
+            ALQ_REQUIRE(dest_of[sp.skip_src] < 0, ALQ_EUNSUPPORTED, "layer %d feeds more than one concat", sp.skip_src);
+            const Shp &s = outs[sp.skip_src];
+            ALQ_REQUIRE(!flat && s.D == cur.D && s.H == cur.H && s.W == cur.W, ALQ_EUNSUPPORTED,
+                        "layer %d: concat of maps of different size (resize_image_with_crop_or_pad) is outside the scored path", i);
+            in.C = cur.C + s.C;
+            src_of[i] = sp.skip_src;
+            dest_of[sp.skip_src] = i;
+        }
+        Shp o = in;
+        switch (sp.type) {
+            case ALQ_CONV: {
+                ALQ_REQUIRE(!flat, ALQ_EINVAL, "layer %d: conv after fc", i);
+                ALQ_REQUIRE(sp.s[0] == 1 && sp.s[1] == 1 && sp.s[2] == 1, ALQ_EUNSUPPORTED, "layer %d: strided conv", i);
+                for (int d = 0; d < 3; ++d) {
+                    int od;
+                    same_pads((&in.D)[d], sp.k[d], 1, &od, &ly.lo[d]);
+                }
+                o.C = sp.cout;
+                ly.pidx = pidx++;
+                ly.w_elems = (int64_t)sp.k[0] * sp.k[1] * sp.k[2] * in.C * sp.cout;
+                ly.b_elems = sp.cout;
+                break;
+            }
+            case ALQ_CONVT: {
+                ALQ_REQUIRE(!flat, ALQ_EINVAL, "layer %d: conv_transpose after fc", i);
+                for (int d = 0; d < 3; ++d) {
+                    ALQ_REQUIRE(sp.k[d] >= sp.s[d], ALQ_EUNSUPPORTED, "layer %d: conv_transpose kernel < stride", i);
+                    int od;
+                    same_pads((&in.D)[d] * sp.s[d], sp.k[d], sp.s[d], &od, &ly.lo[d]);
+                }
+                ALQ_REQUIRE(sp.s[0] == sp.s[1] || in.D == 1, ALQ_EUNSUPPORTED, "layer %d: anisotropic stride", i);
+                ALQ_REQUIRE(sp.s[1] == sp.s[2], ALQ_EUNSUPPORTED, "layer %d: anisotropic stride", i);
+                o.D = in.D * sp.s[0]; o.H = in.H * sp.s[1]; o.W = in.W * sp.s[2];
+                o.C = sp.cout;
+                ly.pidx = pidx++;
+                ly.w_elems = (int64_t)sp.k[0] * sp.k[1] * sp.k[2] * in.C * sp.cout;
+                ly.b_elems = sp.cout;
+                break;
+            }
+            case ALQ_POOL: {
+                ALQ_REQUIRE(!flat, ALQ_EINVAL, "layer %d: pool after fc", i);
+                for (int d = 0; d < 3; ++d) {
+                    ALQ_REQUIRE(sp.k[d] == sp.s[d], ALQ_EUNSUPPORTED, "layer %d: pool window != stride", i);
+                    ALQ_REQUIRE(sp.k[0] * sp.k[1] * sp.k[2] <= 255, ALQ_EUNSUPPORTED, "layer %d: pool window too large", i);
+                    same_pads((&in.D)[d], sp.k[d], sp.s[d], &(&o.D)[d], &ly.lo[d]);
+                }
+                break;
+            }
+            case ALQ_FC: {
+                ly.F = (int64_t)in.D * in.H * in.W * in.C;
+                o = {1, 1, 1, sp.cout};
+                ly.pidx = pidx++;
+                ly.w_elems = ly.F * sp.cout;
+                ly.b_elems = sp.cout;
+                flat = true;
+                break;
+            }
+            default:
+                ALQ_REQUIRE(false, ALQ_EINVAL, "layer %d: unknown type %d", i, sp.type);
+        }
+        outs[i] = o;
+        cur = o;
+    }
+    m->L = pidx;
+    ALQ_REQUIRE(n_layers > 0 && specs[n_layers - 1].type == ALQ_FC, ALQ_EUNSUPPORTED,
+                "the scored path needs an fc head (get_gradients, NN_extended.py:1025)");
+    m->nclass = outs[n_layers - 1].C;
+    ALQ_REQUIRE(m->nclass >= 2 && m->nclass <= 8, ALQ_EUNSUPPORTED, "%d classes unsupported", m->nclass);
+    ALQ_REQUIRE(m->L <= 16, ALQ_EUNSUPPORTED, "%d parameterised layers > 16", m->L);
+
+    // ---- pass 2: buffers (concat = two producers writing channel slices of one buffer) ----
+    auto mkview = [](float *p, const Shp &s, int cs, int c0, int C) {
+        View v; v.p = p; v.D = s.D; v.H = s.H; v.W = s.W; v.cs = cs; v.c0 = c0; v.C = C; return v;
+    };
+    std::vector<View> act(n_layers), dact(n_layers);
+    std::vector<View> catv(n_layers), dcatv(n_layers);
+    for (int d = 0; d < n_layers; ++d) {
+        if (src_of[d] < 0) continue;
+        const int s = src_of[d];
+        ALQ_REQUIRE(dest_of[d - 1] < 0 && src_of[d] != d - 1, ALQ_EUNSUPPORTED, "layer %d: unsupported skip topology", d);
+        const int Cs = outs[s].C, Cp = outs[d - 1].C;
+        const Shp &sh = outs[s];
+        float *buf, *dbuf;
+        const size_t el = (size_t)NB * sh.D * sh.H * sh.W * (Cs + Cp);
+        ALQ_TRY(m->dalloc(&buf, el));
+        ALQ_TRY(m->dalloc(&dbuf, el));
+        act[s] = mkview(buf, sh, Cs + Cp, 0, Cs);
+        act[d - 1] = mkview(buf, sh, Cs + Cp, Cs, Cp);
+        dact[s] = mkview(dbuf, sh, Cs + Cp, 0, Cs);
+        dact[d - 1] = mkview(dbuf, sh, Cs + Cp, Cs, Cp);
+        catv[d] = mkview(buf, sh, Cs + Cp, 0, Cs + Cp);
+        dcatv[d] = mkview(dbuf, sh, Cs + Cp, 0, Cs + Cp);
+        m->layers[s].out_is_skip_src = true;
+    }
+    for (int i = 0; i < n_layers; ++i) {
+        if (act[i].p) continue;
+        const Shp &sh = outs[i];
+        float *buf, *dbuf;
+        const size_t el = (size_t)NB * sh.D * sh.H * sh.W * sh.C;
+        ALQ_TRY(m->dalloc(&buf, el));
+        ALQ_TRY(m->dalloc(&dbuf, el));
+        act[i] = mkview(buf, sh, sh.C, 0, sh.C);
+        dact[i] = mkview(dbuf, sh, sh.C, 0, sh.C);
+    }
+    m->logits = act[n_layers - 1].p;
+    m->dlogits = dact[n_layers - 1].p;
+    ALQ_TRY(m->dalloc(&m->post, (size_t)NB * m->nclass));
+    ALQ_TRY(m->dalloc(&m->S, (size_t)NB * m->L));
+    ALQ_TRY(m->dalloc(&m->sizes, (size_t)m->L));
+    ALQ_TRY(m->dalloc(&m->Apart, (size_t)((NB + 63) / 64) * m->L * m->L));
+
+    // ---- pass 3: per-layer plans ---------------------------------------------------------
+    Shp inshape = {m->in_dims[0], m->in_dims[1], m->in_dims[2], m->in_dims[3]};
+    std::vector<double> h_sizes(m->L);
+    for (int i = 0; i < n_layers; ++i) {
+        Layer &ly = m->layers[i];
+        const alq_layer_t &sp = ly.spec;
+        if (src_of[i] >= 0) {
+            ly.in = catv[i];
+            ly.din = dcatv[i];
+        } else if (i == 0) {
+            ly.in = mkview(nullptr, inshape, inshape.C, 0, inshape.C);   // pointer bound per call
+            ly.din = View();
+        } else {
+            ly.in = act[i - 1];
+            ly.din = dact[i - 1];
+        }
+        ly.out = act[i];
+        ly.dout = dact[i];
+        if (ly.pidx >= 0) {
+            h_sizes[ly.pidx] = (double)(ly.w_elems + ly.b_elems);
+            ALQ_TRY(m->dalloc(&ly.d_bias, (size_t)ly.b_elems));
+            ALQ_TRY(m->dalloc(&ly.asum, (size_t)NB * ly.in.vox()));
+            ALQ_TRY(m->dalloc(&ly.dsum, (size_t)NB * ly.out.vox()));
+        }
+        const bool first_param = (ly.pidx == 0);
+        if (sp.type == ALQ_CONV) {
+            ConvDesc d;
+            d.ID = ly.in.D; d.IH = ly.in.H; d.IW = ly.in.W; d.Ci = ly.in.C;
+            d.OD = ly.out.D; d.OH = ly.out.H; d.OW = ly.out.W; d.Co = sp.cout;
+            d.MD = d.OD; d.MH = d.OH; d.MW = d.OW;
+            enum_taps(sp.k, &d.tz, &d.ty, &d.tx);
+            for (size_t t = 0; t < d.tz.size(); ++t) { d.tz[t] -= ly.lo[0]; d.ty[t] -= ly.lo[1]; d.tx[t] -= ly.lo[2]; }
+            ly.fwd.resize(1);
+            ALQ_TRY(igemm_build_plan(d, NB, &ly.fwd[0]));
+            if (!first_param) {
+                ConvDesc b;
+                b.ID = ly.out.D; b.IH = ly.out.H; b.IW = ly.out.W; b.Ci = sp.cout;
+                b.OD = ly.in.D; b.OH = ly.in.H; b.OW = ly.in.W; b.Co = ly.in.C;
+                b.MD = b.OD; b.MH = b.OH; b.MW = b.OW;
+                enum_taps(sp.k, &b.tz, &b.ty, &b.tx);
+                for (size_t t = 0; t < b.tz.size(); ++t) {
+                    b.tz[t] = ly.lo[0] - b.tz[t]; b.ty[t] = ly.lo[1] - b.ty[t]; b.tx[t] = ly.lo[2] - b.tx[t];
+                }
+                ALQ_TRY(igemm_build_plan(b, NB, &ly.bwd));
+                ly.has_bwd = true;
+            }
+        } else if (sp.type == ALQ_CONVT) {
+            // y[p] = sum_{q,t: s*q + t - lo = p} x[q] W[t]; output parity class c = p mod s uses the
+            // taps t == (c + lo) mod s at input offset (c + lo - t)/s   (<= 0)
+            std::vector<int> az, ay, ax;
+            enum_taps(sp.k, &az, &ay, &ax);
+            const int nclsz = ly.in.D == 1 && sp.s[0] == 1 ? 1 : sp.s[0];
+            for (int cz = 0; cz < nclsz; ++cz)
+                for (int cy = 0; cy < sp.s[1]; ++cy)
+                    for (int cx = 0; cx < sp.s[2]; ++cx) {
+                        ConvDesc d;
+                        d.ID = ly.in.D; d.IH = ly.in.H; d.IW = ly.in.W; d.Ci = ly.in.C;
+                        d.OD = ly.out.D; d.OH = ly.out.H; d.OW = ly.out.W; d.Co = sp.cout;
+                        d.MD = d.ID; d.MH = d.IH; d.MW = d.IW;
+                        d.so = sp.s[2];
+                        d.ooff[0] = cz; d.ooff[1] = cy; d.ooff[2] = cx;
+                        std::vector<int> tl;
+                        for (size_t t = 0; t < az.size(); ++t) {
+                            const int nz = cz + ly.lo[0] - az[t], ny = cy + ly.lo[1] - ay[t], nx = cx + ly.lo[2] - ax[t];
+                            if (nz % sp.s[0] || ny % sp.s[1] || nx % sp.s[2]) continue;
+                            d.tz.push_back(nz / sp.s[0]); d.ty.push_back(ny / sp.s[1]); d.tx.push_back(nx / sp.s[2]);
+                            tl.push_back((int)t);
+                        }
+                        ALQ_REQUIRE(!tl.empty(), ALQ_EUNSUPPORTED, "layer %d: empty conv_transpose class", i);
+                        ly.class_taps.push_back(tl);
+                        ly.fwd.emplace_back();
+                        ALQ_TRY(igemm_build_plan(d, NB, &ly.fwd.back()));
+                    }
+            ALQ_REQUIRE(sp.s[0] == sp.s[2] || (ly.in.D == 1 && sp.s[0] == 1), ALQ_EUNSUPPORTED,
+                        "layer %d: conv_transpose stride must be isotropic", i);
+            if (!first_param) {
+                ConvDesc b;
+                b.ID = ly.out.D; b.IH = ly.out.H; b.IW = ly.out.W; b.Ci = sp.cout;
+                b.OD = ly.in.D; b.OH = ly.in.H; b.OW = ly.in.W; b.Co = ly.in.C;
+                b.MD = b.OD; b.MH = b.OH; b.MW = b.OW;
+                b.sm = sp.s[2];
+                enum_taps(sp.k, &b.tz, &b.ty, &b.tx);
+                for (size_t t = 0; t < b.tz.size(); ++t) { b.tz[t] -= ly.lo[0]; b.ty[t] -= ly.lo[1]; b.tx[t] -= ly.lo[2]; }
+                ALQ_TRY(igemm_build_plan(b, NB, &ly.bwd));
+                ly.has_bwd = true;
+            }
+        } else if (sp.type == ALQ_POOL) {
+            uint8_t *am;
+            ALQ_TRY(m->dalloc(&am, (size_t)NB * ly.out.vox() * ly.out.C));
+            ly.argmax = am;
+        } else {   // fc
+            ALQ_REQUIRE(ly.in.cs == ly.in.C && ly.in.c0 == 0, ALQ_EUNSUPPORTED, "layer %d: fc on a concat slice", i);
+            if (sp.cout <= 8) {
+                ly.dense_fc_small = true;
+                ly.fc_slices = fc_small_slices(ly.F);
+                ALQ_TRY(m->dalloc(&ly.d_Wp, (size_t)sp.cout * ly.F));
+                ALQ_TRY(m->dalloc(&ly.fc_partials, (size_t)NB * ly.fc_slices * sp.cout));
+            } else {
+                ConvDesc d;
+                d.ID = d.IH = d.IW = 1; d.Ci = (int)ly.F;
+                d.OD = d.OH = d.OW = 1; d.Co = sp.cout;
+                d.MD = d.MH = d.MW = 1;
+                d.tz = {0}; d.ty = {0}; d.tx = {0};
+                ly.fwd.resize(1);
+                ALQ_TRY(igemm_build_plan(d, NB, &ly.fwd[0]));
+                if (!first_param) {
+                    ConvDesc b = d;
+                    b.Ci = sp.cout; b.Co = (int)ly.F;
+                    ALQ_TRY(igemm_build_plan(b, NB, &ly.bwd));
+                    ly.has_bwd = true;
+                }
+            }
+        }
+    }
+    ALQ_HIP(hipMemcpy(m->sizes, h_sizes.data(), m->L * sizeof(double), hipMemcpyHostToDevice));
+    return ALQ_OK;
+}
+
+static View flat_view(const View &v) {
+    View f;
+    f.p = v.p; f.D = f.H = f.W = 1;
+    f.C = (int)(v.vox() * v.C); f.cs = f.C; f.c0 = 0;
+    return f;
+}
+
+// ------------------------------------------------------------------------------------------
+static int run_forward(alq_model *m, const float *d_x, int N, bool with_asum) {
+    alq_ctx *ctx = m->ctx;
+    const int nl = (int)m->layers.size();
+    for (int i = 0; i < nl; ++i) {
+        Layer &ly = m->layers[i];
+        ALQ_REQUIRE(ly.pidx < 0 || ly.weights_set, ALQ_EINVAL, "weights of parameterised layer %d not set", ly.pidx);
+        View in = ly.in;
+        if (i == 0) in.p = const_cast<float *>(d_x);
+        if (with_asum && ly.pidx >= 0) {
+            if (ly.spec.type == ALQ_FC) ALQ_TRY(k_chansum(ctx, flat_view(in), ly.asum, N));
+            else ALQ_TRY(k_chansum(ctx, in, ly.asum, N));
+        }
+        switch (ly.spec.type) {
+            case ALQ_CONV:
+                ALQ_TRY(igemm_launch(ctx, ly.fwd[0], in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM_FWD));
+                break;
+            case ALQ_CONVT:
+                for (auto &p : ly.fwd)
+                    ALQ_TRY(igemm_launch(ctx, p, in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM_FWD));
+                break;
+            case ALQ_POOL:
+                ALQ_TRY(k_pool_fwd(ctx, in, ly.out, ly.argmax, ly.spec.k, ly.lo, N));
+                break;
+            case ALQ_FC:
+                if (ly.dense_fc_small) {
+                    ALQ_TRY(k_fc_small_fwd(ctx, in.p, ly.F, ly.d_Wp, ly.spec.cout, N, ly.fc_partials, ly.fc_slices));
+                    ALQ_TRY(k_fc_small_finish(ctx, ly.fc_partials, ly.fc_slices, ly.d_bias, ly.spec.cout,
+                                              ly.spec.relu, N, ly.out.p));
+                } else {
+                    ALQ_TRY(igemm_launch(ctx, ly.fwd[0], flat_view(in), ly.out, ly.d_bias, ly.spec.relu, 0, N,
+                                         PROF_IGEMM_FWD));
+                }
+                break;
+        }
+    }
+    return ALQ_OK;
+}
+
+static int run_backward(alq_model *m, int N) {
+    alq_ctx *ctx = m->ctx;
+    const int nl = (int)m->layers.size();
+    ALQ_REQUIRE(m->nclass == 2, ALQ_EUNSUPPORTED, "Fisher scoring is binary (PW_NNAL.py:766), got %d classes", m->nclass);
+    ALQ_TRY(k_fill_unit_cotangent(ctx, m->dlogits, N));
+    for (int i = nl - 1; i >= 0; --i) {
+        Layer &ly = m->layers[i];
+        const bool prev_is_src = (i > 0 && m->layers[i - 1].out_is_skip_src && ly.spec.skip_src < 0);
+        if (ly.spec.type == ALQ_POOL) {
+            ALQ_TRY(k_pool_bwd(ctx, ly.dout, ly.din, ly.argmax, ly.spec.k, ly.lo, N, prev_is_src ? 1 : 0));
+            continue;
+        }
+        // cotangent w.r.t. the pre-activation + its channel sum
+        const bool isfc = ly.spec.type == ALQ_FC;
+        View dv = isfc ? flat_view(ly.dout) : ly.dout;
+        View av = isfc ? flat_view(ly.out) : ly.out;
+        ALQ_TRY(k_mask_chansum(ctx, dv, ly.spec.relu ? &av : nullptr, ly.dsum, N));
+        double *Sdst = m->S + ly.pidx;
+        if (ly.spec.type == ALQ_CONVT) {
+            ALQ_TRY(k_boxdot_convT(ctx, ly.dsum, ly.asum, ly.in.D, ly.in.H, ly.in.W, ly.spec.k, ly.spec.s, ly.lo, N, Sdst, m->L));
+        } else if (isfc) {
+            const int one[3] = {1, 1, 1}, zero[3] = {0, 0, 0};
+            ALQ_TRY(k_boxdot_conv(ctx, ly.dsum, ly.asum, 1, 1, 1, one, zero, N, Sdst, m->L));
+        } else {
+            ALQ_TRY(k_boxdot_conv(ctx, ly.dsum, ly.asum, ly.out.D, ly.out.H, ly.out.W, ly.spec.k, ly.lo, N, Sdst, m->L));
+        }
+        if (ly.pidx == 0) break;   // nothing upstream needs a cotangent
+        const int acc = prev_is_src ? 1 : 0;   // the skip destination has already written this slice
+        if (isfc) {
+            ALQ_REQUIRE(!acc, ALQ_EUNSUPPORTED, "layer %d: fc consumer of a skip source", i);
+            if (ly.dense_fc_small)
+                ALQ_TRY(k_fc_small_bwd(ctx, ly.dout.p, ly.spec.cout, ly.d_Wp, ly.F, N, ly.din.p));
+            else
+                ALQ_TRY(igemm_launch(ctx, ly.bwd, ly.dout, flat_view(ly.din), nullptr, 0, 0, N, PROF_IGEMM_BWD));
+        } else {
+            ALQ_TRY(igemm_launch(ctx, ly.bwd, ly.dout, ly.din, nullptr, 0, acc, N, PROF_IGEMM_BWD));
+        }
+    }
+    return ALQ_OK;
+}
+
+// =========================================================================================== C ABI
+extern "C" {
+
+const char *alq_last_error(void) { return g_err; }
+int alq_version(void) { return 1; }
+
+int alq_ctx_create(int device, void *stream, alq_ctx **out) {
+    ALQ_REQUIRE(out != nullptr, ALQ_EINVAL, "alq_ctx_create: null out");
+    int count = 0;
+    ALQ_HIP(hipGetDeviceCount(&count));
+    ALQ_REQUIRE(device >= 0 && device < count, ALQ_EINVAL, "device %d not present (%d visible)", device, count);
+    ALQ_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    ALQ_HIP(hipGetDeviceProperties(&prop, device));
+    ALQ_REQUIRE(std::strncmp(prop.gcnArchName, "gfx950", 6) == 0, ALQ_EUNSUPPORTED,
+                "libalq is built for gfx950 (MI355X) only, device %d is %s", device, prop.gcnArchName);
+    alq_ctx *c = new alq_ctx();
+    c->device = device;
+    c->stream = reinterpret_cast<hipStream_t>(stream);
+    if (hipMalloc(&c->param_block, ALQ_PARAM_BLOCK_BYTES) != hipSuccess) {
+        delete c;
+        set_error("alq_ctx_create: hipMalloc failed");
+        return ALQ_ENOMEM;
+    }
+    *out = c;
+    return ALQ_OK;
+}
+
+int alq_ctx_destroy(alq_ctx *ctx) {
+    if (!ctx) return ALQ_OK;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int c = 0; c < PROF_NUM; ++c) {
+        for (auto &pr : ctx->prof[c].pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+        for (auto e : ctx->prof[c].pool) (void)hipEventDestroy(e);
+    }
+    (void)hipFree(ctx->param_block);
+    delete ctx;
+    return ALQ_OK;
+}
+
+int alq_ctx_set_stream(alq_ctx *ctx, void *stream) {
+    ALQ_REQUIRE(ctx != nullptr, ALQ_EINVAL, "null ctx");
+    ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    return ALQ_OK;
+}
+
+int alq_ctx_synchronize(alq_ctx *ctx) {
+    ALQ_REQUIRE(ctx != nullptr, ALQ_EINVAL, "null ctx");
+    ALQ_HIP(hipStreamSynchronize(ctx->stream));
+    return ALQ_OK;
+}
+
+int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, const int32_t in_dims[4],
+                     int max_batch, alq_model **out) {
+    ALQ_REQUIRE(ctx && layers && in_dims && out, ALQ_EINVAL, "alq_model_create: null argument");
+    ALQ_REQUIRE(n_layers >= 1 && n_layers <= 64 && max_batch >= 1, ALQ_EINVAL, "alq_model_create: bad sizes");
+    ALQ_HIP(hipSetDevice(ctx->device));
+    alq_model *m = new alq_model();
+    m->ctx = ctx;
+    m->max_batch = max_batch;
+    for (int i = 0; i < 4; ++i) m->in_dims[i] = in_dims[i];
+    const int rc = build_model(m, layers, n_layers);
+    if (rc != ALQ_OK) {
+        alq_model_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return ALQ_OK;
+}
+
+int alq_model_destroy(alq_model *m) {
+    if (!m) return ALQ_OK;
+    (void)hipStreamSynchronize(m->ctx->stream);
+    for (void *p : m->allocs) (void)hipFree(p);
+    delete m;
+    return ALQ_OK;
+}
+
+int alq_model_num_param_layers(const alq_model *m) { return m ? m->L : ALQ_EINVAL; }
+
+int alq_model_param_sizes(const alq_model *m, int t, int64_t *w_elems, int64_t *b_elems) {
+    ALQ_REQUIRE(m != nullptr, ALQ_EINVAL, "null model");
+    for (const Layer &ly : m->layers)
+        if (ly.pidx == t) {
+            if (w_elems) *w_elems = ly.w_elems;
+            if (b_elems) *b_elems = ly.b_elems;
+            return ALQ_OK;
+        }
+    set_error("no parameterised layer %d", t);
+    return ALQ_EINVAL;
+}
+
+int alq_model_layer_out_elems(const alq_model *m, int layer_idx, int64_t *elems) {
+    ALQ_REQUIRE(m && elems && layer_idx >= 0 && layer_idx < (int)m->layers.size(), ALQ_EINVAL, "bad layer index");
+    *elems = m->layers[layer_idx].out.elems();
+    return ALQ_OK;
+}
+
+int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
+    ALQ_REQUIRE(m && W && b, ALQ_EINVAL, "alq_model_set_weights: null argument");
+    ALQ_HIP(hipSetDevice(m->ctx->device));
+    Layer *lyp = nullptr;
+    for (Layer &l : m->layers)
+        if (l.pidx == t) lyp = &l;
+    ALQ_REQUIRE(lyp != nullptr, ALQ_EINVAL, "no parameterised layer %d", t);
+    Layer &ly = *lyp;
+    const alq_layer_t &sp = ly.spec;
+    ALQ_HIP(hipMemcpyAsync(ly.d_bias, b, ly.b_elems * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
+    const int Ci = ly.in.C, Co = sp.cout;
+    const int ntaps = sp.k[0] * sp.k[1] * sp.k[2];
+    if (sp.type == ALQ_CONV) {
+        // TF [tap][ci][co] is already the fwd B matrix [(tap, ci)][co]
+        std::vector<float> B(W, W + ly.w_elems);
+        igemm_pack_weights(&ly.fwd[0], B);
+        ALQ_TRY(upload(m, &ly.fwd[0]));
+        if (ly.has_bwd) {
+            std::vector<float> Bb((size_t)ntaps * Co * Ci);
+            for (int tp = 0; tp < ntaps; ++tp)
+                for (int ci = 0; ci < Ci; ++ci)
+                    for (int co = 0; co < Co; ++co)
+                        Bb[((size_t)tp * Co + co) * Ci + ci] = W[((size_t)tp * Ci + ci) * Co + co];
+            igemm_pack_weights(&ly.bwd, Bb);
+            ALQ_TRY(upload(m, &ly.bwd));
+        }
+    } else if (sp.type == ALQ_CONVT) {
+        // TF [tap][co][ci]
+        for (size_t c = 0; c < ly.fwd.size(); ++c) {
+            const std::vector<int> &tl = ly.class_taps[c];
+            std::vector<float> B((size_t)tl.size() * Ci * Co);
+            for (size_t j = 0; j < tl.size(); ++j)
+                for (int ci = 0; ci < Ci; ++ci)
+                    for (int co = 0; co < Co; ++co)
+                        B[((size_t)j * Ci + ci) * Co + co] = W[((size_t)tl[j] * Co + co) * Ci + ci];
+            igemm_pack_weights(&ly.fwd[c], B);
+            ALQ_TRY(upload(m, &ly.fwd[c]));
+        }
+        if (ly.has_bwd) {
+            std::vector<float> Bb(W, W + ly.w_elems);   // [(tap, co)][ci] as stored
+            igemm_pack_weights(&ly.bwd, Bb);
+            ALQ_TRY(upload(m, &ly.bwd));
+        }
+    } else {
+        // fc: TF W[o][f_tf]; activation memory order f_mem = ((d*H+h)*W+w)*C+c, reference flatten
+        // order f_tf = ((c*W+w)*H+h)*D+d (tf.transpose = full axis reversal, NN.py:296-301)
+        const int D = ly.in.D, H = ly.in.H, Wd = ly.in.W, C = ly.in.C;
+        const int64_t F = ly.F;
+        std::vector<float> Wp((size_t)Co * F);
+        for (int d = 0; d < D; ++d)
+            for (int h = 0; h < H; ++h)
+                for (int w = 0; w < Wd; ++w)
+                    for (int c = 0; c < C; ++c) {
+                        const int64_t fm = (((int64_t)d * H + h) * Wd + w) * C + c;
+                        const int64_t ft = (((int64_t)c * Wd + w) * H + h) * D + d;
+                        for (int o = 0; o < Co; ++o) Wp[(size_t)o * F + fm] = W[(size_t)o * F + ft];
+                    }
+        if (ly.dense_fc_small) {
+            ALQ_HIP(hipMemcpyAsync(ly.d_Wp, Wp.data(), Wp.size() * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
+            ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
+        } else {
+            std::vector<float> B((size_t)F * Co);
+            for (int64_t f = 0; f < F; ++f)
+                for (int o = 0; o < Co; ++o) B[(size_t)f * Co + o] = Wp[(size_t)o * F + f];
+            igemm_pack_weights(&ly.fwd[0], B);
+            ALQ_TRY(upload(m, &ly.fwd[0]));
+            if (ly.has_bwd) {
+                igemm_pack_weights(&ly.bwd, Wp);   // [(o)][f_mem]
+                ALQ_TRY(upload(m, &ly.bwd));
+            }
+        }
+    }
+    ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
+    ly.weights_set = true;
+    return ALQ_OK;
+}
+
+int alq_gather_normalize(alq_ctx *ctx, const void *const *d_vols, int mm, int vol_is_f64,
+                         const int64_t pad_dims[3], const int64_t *d_inds, int64_t n,
+                         const int32_t ps[3], const double *h_stats, int quirk, int out_is_f64, void *d_out) {
+    ALQ_REQUIRE(ctx && d_vols && pad_dims && ps && d_out && (n == 0 || d_inds), ALQ_EINVAL, "alq_gather_normalize: null argument");
+    ALQ_REQUIRE(mm >= 1 && mm <= 16, ALQ_EINVAL, "alq_gather_normalize: %d modalities", mm);
+    ALQ_REQUIRE(quirk == 2 || h_stats, ALQ_EINVAL, "alq_gather_normalize: stats missing");
+    if (n == 0) return ALQ_OK;
+    int64_t orig[3];
+    for (int d = 0; d < 3; ++d) {
+        ALQ_REQUIRE(ps[d] >= 1 && (ps[d] & 1), ALQ_EINVAL, "patch dims must be odd (patch_utils.py:1119-1121), got %d", ps[d]);
+        orig[d] = pad_dims[d] - 2 * ((ps[d] - 1) / 2);
+        ALQ_REQUIRE(orig[d] >= 1, ALQ_EINVAL, "padded volume smaller than the patch");
+    }
+    ALQ_HIP(hipSetDevice(ctx->device));
+    // small device-side parameter block: m pointers + 2m doubles
+    struct Block { const void *ptrs[16]; double stats[32]; } hb;
+    std::memset(&hb, 0, sizeof(hb));
+    for (int j = 0; j < mm; ++j) {
+        hb.ptrs[j] = d_vols[j];
+        if (h_stats) { hb.stats[2 * j] = h_stats[2 * j]; hb.stats[2 * j + 1] = h_stats[2 * j + 1]; }
+    }
+    static_assert(sizeof(Block) <= ALQ_PARAM_BLOCK_BYTES, "parameter block too small");
+    Block *db = reinterpret_cast<Block *>(ctx->param_block);
+    // pageable source: the copy is staged before the call returns, and it is stream-ordered
+    // behind any kernel of an earlier call that still reads the block
+    ALQ_HIP(hipMemcpyAsync(db, &hb, sizeof(Block), hipMemcpyHostToDevice, ctx->stream));
+    return gather_normalize_impl(ctx, db->ptrs, mm, vol_is_f64, pad_dims, orig, d_inds, n, ps, db->stats, quirk,
+                                 out_is_f64, d_out);
+}
+
+int alq_forward(alq_model *m, const float *d_x, int N, float *d_post, int64_t *d_pred, float *d_feat,
+                int feature_layer_idx) {
+    ALQ_REQUIRE(m && d_x, ALQ_EINVAL, "alq_forward: null argument");
+    ALQ_REQUIRE(N >= 0 && N <= m->max_batch, ALQ_EINVAL, "alq_forward: N=%d exceeds max_batch=%d", N, m->max_batch);
+    if (N == 0) return ALQ_OK;
+    ALQ_HIP(hipSetDevice(m->ctx->device));
+    ALQ_TRY(run_forward(m, d_x, N, false));
+    ALQ_TRY(k_softmax(m->ctx, m->logits, m->nclass, N, d_post ? d_post : m->post, d_pred));
+    if (d_feat) {
+        ALQ_REQUIRE(feature_layer_idx >= 0 && feature_layer_idx < (int)m->layers.size(), ALQ_EINVAL, "bad feature layer");
+        const View &v = m->layers[feature_layer_idx].out;
+        ALQ_REQUIRE(v.cs == v.C, ALQ_EUNSUPPORTED, "feature layer is a concat slice");
+        ALQ_HIP(hipMemcpyAsync(d_feat, v.p, (size_t)N * v.elems() * sizeof(float), hipMemcpyDeviceToDevice, m->ctx->stream));
+    }
+    return ALQ_OK;
+}
+
+int alq_score_entropy(alq_ctx *ctx, const float *d_p1, int64_t n, double *d_absdev, float *d_H) {
+    ALQ_REQUIRE(ctx && (n == 0 || d_p1), ALQ_EINVAL, "alq_score_entropy: null argument");
+    if (n == 0) return ALQ_OK;
+    ALQ_HIP(hipSetDevice(ctx->device));
+    return score_entropy_impl(ctx, d_p1, n, d_absdev, d_H);
+}
+
+size_t alq_topk_work_bytes(int64_t n) { return topk_work_bytes_impl(n); }
+
+int alq_topk_uncertain(alq_ctx *ctx, const double *d_keys, int64_t n, int64_t B, int64_t *d_out_idx, void *d_work) {
+    ALQ_REQUIRE(ctx && (n == 0 || (d_keys && d_work)) && (B == 0 || d_out_idx), ALQ_EINVAL, "alq_topk_uncertain: null argument");
+    ALQ_HIP(hipSetDevice(ctx->device));
+    return topk_impl(ctx, d_keys, n, B, d_out_idx, d_work);
+}
+
+int alq_fisher(alq_model *m, const float *d_x, int N, const float *d_p1_in, double diag_load, float *d_p1_out,
+               double *d_g0, double *d_g1, double *d_A, double *d_trace, double *d_Asum) {
+    ALQ_REQUIRE(m && d_x, ALQ_EINVAL, "alq_fisher: null argument");
+    ALQ_REQUIRE(N >= 0 && N <= m->max_batch, ALQ_EINVAL, "alq_fisher: N=%d exceeds max_batch=%d", N, m->max_batch);
+    ALQ_HIP(hipSetDevice(m->ctx->device));
+    if (N == 0) {
+        if (d_Asum) ALQ_HIP(hipMemsetAsync(d_Asum, 0, sizeof(double) * m->L * m->L, m->ctx->stream));
+        return ALQ_OK;
+    }
+    ALQ_TRY(run_forward(m, d_x, N, true));
+    ALQ_TRY(k_softmax(m->ctx, m->logits, m->nclass, N, m->post, nullptr));
+    ALQ_TRY(run_backward(m, N));
+    int nblocks = 0;
+    ALQ_TRY(k_fisher_finalize(m->ctx, m->S, m->L, m->sizes, m->post, d_p1_in, N, diag_load, d_p1_out, d_g0, d_g1,
+                              d_A, d_trace, m->Apart, &nblocks));
+    if (d_Asum) ALQ_TRY(k_reduce_Asum(m->ctx, m->Apart, nblocks, m->L * m->L, d_Asum));
+    return ALQ_OK;
+}
+
+static const char *kProfNames[PROF_NUM] = {"igemm_fwd", "igemm_bwd", "elementwise", "reduce", "fc_small"};
+
+int alq_prof_enable(alq_ctx *ctx, int on) {
+    ALQ_REQUIRE(ctx != nullptr, ALQ_EINVAL, "null ctx");
+    ctx->prof_on = on != 0;
+    return ALQ_OK;
+}
+
+int alq_prof_reset(alq_ctx *ctx) {
+    ALQ_REQUIRE(ctx != nullptr, ALQ_EINVAL, "null ctx");
+    ALQ_TRY(ctx->prof_collect());
+    for (int c = 0; c < PROF_NUM; ++c) {
+        ctx->prof[c].ms = 0; ctx->prof[c].launches = 0; ctx->prof[c].flops = 0;
+    }
+    return ALQ_OK;
+}
+
+int alq_prof_num_classes(void) { return PROF_NUM; }
+const char *alq_prof_class_name(int cls) { return (cls >= 0 && cls < PROF_NUM) ? kProfNames[cls] : ""; }
+
+int alq_prof_read(alq_ctx *ctx, int cls, double *ms, int64_t *launches, double *flops) {
+    ALQ_REQUIRE(ctx && cls >= 0 && cls < PROF_NUM, ALQ_EINVAL, "alq_prof_read: bad class");
+    ALQ_TRY(ctx->prof_collect());
+    if (ms) *ms = ctx->prof[cls].ms;
+    if (launches) *launches = ctx->prof[cls].launches;
+    if (flops) *flops = ctx->prof[cls].flops;
+    return ALQ_OK;
+}
+
+int alq_model_debug_copy(alq_model *m, int layer_idx, int what, int N, float *d_out, int64_t *elems_out) {
+    ALQ_REQUIRE(m && d_out && N >= 1 && N <= m->max_batch, ALQ_EINVAL, "alq_model_debug_copy: bad argument");
+    ALQ_HIP(hipSetDevice(m->ctx->device));
+    if (what == 4) {
+        if (elems_out) *elems_out = (int64_t)N * m->L;
+        return debug_f64_copy(m->ctx, m->S, (long long)N * m->L, d_out);
+    }
+    ALQ_REQUIRE(layer_idx >= 0 && layer_idx < (int)m->layers.size(), ALQ_EINVAL, "bad layer index");
+    const Layer &ly = m->layers[layer_idx];
+    if (what == 0 || what == 1) {
+        const View &v = what == 0 ? ly.out : ly.dout;
+        if (elems_out) *elems_out = (int64_t)N * v.elems();
+        return debug_view_copy(m->ctx, v, N, d_out);
+    }
+    ALQ_REQUIRE(ly.pidx >= 0 && (what == 2 || what == 3), ALQ_EINVAL, "layer has no channel-sum fields");
+    const int64_t e = (int64_t)N * (what == 2 ? ly.in.vox() : ly.out.vox());
+    if (elems_out) *elems_out = e;
+    ALQ_HIP(hipMemcpyAsync(d_out, what == 2 ? ly.asum : ly.dsum, e * sizeof(float), hipMemcpyDeviceToDevice,
+                           m->ctx->stream));
+    return ALQ_OK;
+}
+
+int alq_synth_patches(alq_ctx *ctx, uint64_t seed, int64_t first_id, int64_t n, int64_t epp, float *d_out) {
+    ALQ_REQUIRE(ctx && (n == 0 || d_out), ALQ_EINVAL, "alq_synth_patches: null argument");
+    if (n == 0) return ALQ_OK;
+    ALQ_HIP(hipSetDevice(ctx->device));
+    return synth_impl(ctx, seed, first_id, n, epp, d_out);
+}
+
+}  // extern "C"

@@ -1,0 +1,458 @@
+"""Device context ("session") and device model behind the reference's `sess` / `model` pair.
+
+The reference hands every query function a `tf.Session` and a `CNN` object and reaches the
+device through `sess.run(getattr(model, var), feed_dict)` (PW_NN.py:466,522).  Here `sess` is a
+`DeviceSession` (one HIP stream on one MI355X, a libalq context) and `model` a `DeviceModel`
+(a libalq model: weights + activation workspace resident in HBM).  PyTorch-ROCm is used only
+for device memory, the stream and (in pool_shard.py) torch.distributed.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib
+from ._lib import ALQ_CONV, ALQ_CONVT, ALQ_FC, ALQ_POOL, LayerT, check
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class Handle(object):
+    """Stand-in for a TF tensor attribute of the reference model (`model.x`, `.posteriors`, ...)."""
+
+    class _Dim(object):
+        def __init__(self, v):
+            self.value = v
+
+    def __init__(self, name, shape=()):
+        self.name = name
+        self.shape = [Handle._Dim(s) for s in shape]
+
+    def __repr__(self):
+        return '<device handle %s>' % self.name
+
+
+_default_session = None
+
+
+def default_session():
+    """The process-wide session used by functions whose reference signature carries no `sess`
+    (patch_utils.get_patches).  One process drives one GPU (LOCAL_RANK picks it)."""
+    global _default_session
+    if _default_session is None:
+        import os
+        _default_session = DeviceSession(int(os.environ.get('LOCAL_RANK', '0')))
+    return _default_session
+
+
+class DeviceSession(object):
+    """One GPU, one stream.  `run(fetch, feed_dict)` keeps unported strategies working."""
+
+    def __init__(self, device=0):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise _lib.AlqError('no GPU visible: the query-scoring path has no CPU fallback')
+        self.torch = torch
+        self.device = torch.device('cuda', device)
+        torch.cuda.set_device(self.device)
+        self.lib = _lib.lib()
+        self._ctx = C.c_void_p()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.alq_ctx_create(device, C.c_void_p(stream), C.byref(self._ctx)))
+
+    @property
+    def ctx(self):
+        return self._ctx
+
+    def synchronize(self):
+        check(self.lib.alq_ctx_synchronize(self._ctx))
+
+    def close(self):
+        if self._ctx:
+            self.lib.alq_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- torch helpers --------------------------------------------------------------------
+    def to_device(self, arr, dtype):
+        torch = self.torch
+        t = torch.as_tensor(np.ascontiguousarray(arr))
+        return t.to(device=self.device, dtype=dtype)
+
+    def empty(self, shape, dtype):
+        return self.torch.empty(shape, dtype=dtype, device=self.device)
+
+    # -- sess.run compatibility -----------------------------------------------------------
+    def run(self, fetch, feed_dict=None):
+        """`sess.run(model.<var>, feed_dict={model.x: batch, model.keep_prob: 1.})`."""
+        model = getattr(fetch, 'model', None)
+        if isinstance(fetch, list):
+            raise NotImplementedError(
+                'full per-parameter gradients (model.grad_posts) are never materialised on the device; '
+                'use PW_NNAL.gen_A_matrices / DeviceModel.fisher')
+        if model is None:
+            raise KeyError('unknown fetch %r' % (fetch,))
+        x = feed_dict[model.x]
+        kp = feed_dict.get(model.keep_prob, 1.)
+        if float(kp) != 1.:
+            raise NotImplementedError('dropout at keep_prob < 1 (MC strategies) is outside the scored path')
+        res = model.forward(x, want=(fetch.name,))
+        return res[fetch.name]
+
+    # -- measurement hooks ----------------------------------------------------------------
+    def prof_enable(self, on=True):
+        check(self.lib.alq_prof_enable(self._ctx, 1 if on else 0))
+
+    def prof_reset(self):
+        check(self.lib.alq_prof_reset(self._ctx))
+
+    def prof_read(self):
+        out = OrderedDict()
+        for c in range(self.lib.alq_prof_num_classes()):
+            ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+            check(self.lib.alq_prof_read(self._ctx, c, C.byref(ms), C.byref(n), C.byref(fl)))
+            out[self.lib.alq_prof_class_name(c).decode()] = dict(ms=ms.value, launches=n.value, flops=fl.value)
+        return out
+
+
+# ------------------------------------------------------------------------------------------
+def _is_extended(layer_dict):
+    first = next(iter(layer_dict.values()))
+    return isinstance(first[0], str)
+
+
+def translate_layers(layer_dict, in_shape, skips=()):
+    """Reference layer dict (either schema) -> list of dicts in alq_layer_t terms + bookkeeping.
+
+    `in_shape` is the placeholder shape without batch, channels last: (H, W, C) for `NN.CNN`
+    / 2-D `NN_extended.CNN`, (D, H, W, C) for 3-D.  Pure host logic (unit-tested on CPU)."""
+    ext = _is_extended(layer_dict)
+    nd = len(in_shape) - 1
+    if nd not in (2, 3):
+        raise ValueError('input must be [H,W,C] or [D,H,W,C], got %r' % (in_shape,))
+    names = list(layer_dict.keys())
+
+    def pad3(v, fill=1):
+        v = list(v)
+        return [fill] * (3 - len(v)) + v
+
+    skip_src = {}
+    for sk in skips:
+        src, dsts, kind = sk
+        if kind != 'con':
+            raise NotImplementedError("skip type %r: only 'con' is on the scored path" % kind)
+        for d in dsts:
+            if d in skip_src:
+                raise NotImplementedError('layer %d has more than one skip source' % d)
+            skip_src[d] = src
+    out = []
+    for i, name in enumerate(names):
+        spec = layer_dict[name]
+        last = i == len(names) - 1
+        if ext:
+            ltype, lspec = spec[0], spec[1]
+            order = spec[2] if len(spec) > 2 else 'M'
+            if 'B' in order:
+                raise NotImplementedError('batch-norm op in layer %s is outside the scored path' % name)
+            if order.replace('A', '').replace('M', '') or not order.startswith('M'):
+                raise NotImplementedError('op order %r of layer %s' % (order, name))
+            relu = 1 if 'A' in order else 0
+        else:
+            ltype = spec[1]
+            relu = 1 if (ltype == 'conv' or (ltype == 'fc' and not last)) else 0
+        d = dict(name=name, relu=relu, skip_src=skip_src.get(i, -1), k=[1, 1, 1], s=[1, 1, 1], cout=0)
+        if ltype == 'conv':
+            d['type'] = ALQ_CONV
+            if ext:
+                d['cout'] = int(lspec[0])
+                d['k'] = pad3(lspec[1])
+                if len(lspec) > 2:
+                    d['s'] = pad3(lspec[2])
+            else:
+                d['cout'] = int(spec[0])
+                d['k'] = pad3(spec[2])
+        elif ltype == 'conv_transpose':
+            d['type'] = ALQ_CONVT
+            d['cout'] = int(lspec[0])
+            d['k'] = pad3(lspec[1])
+            d['s'] = pad3(lspec[2])
+        elif ltype == 'pool':
+            d['type'] = ALQ_POOL
+            if ext:
+                d['k'] = pad3(lspec)
+                d['s'] = pad3(lspec)
+            else:
+                w, s = spec[0]          # max_pool(x, pool_size[0], pool_size[1]), NN.py:333-335
+                d['k'] = pad3([w] * nd)
+                d['s'] = pad3([s] * nd)
+        elif ltype == 'fc':
+            d['type'] = ALQ_FC
+            d['cout'] = int(lspec[0]) if ext else int(spec[0])
+        else:
+            raise ValueError("layer type %r" % (ltype,))
+        out.append(d)
+    return out
+
+
+def tf_param_shapes(layers, in_shape):
+    """TF variable shapes [(name, W_shape, b_shape)] of the parameterised layers, creation order
+    (NN.py:272-277,313-318; NN_extended.py:397-404,436-441,555-561)."""
+    nd = len(in_shape) - 1
+    spatial = list(in_shape[:-1])
+    ch = in_shape[-1]
+    chans = {}
+    flat = None
+    out = []
+    for i, d in enumerate(layers):
+        if d['skip_src'] >= 0:
+            ch += chans[d['skip_src']]
+        if d['type'] == ALQ_CONV:
+            out.append((d['name'], tuple(d['k'][3 - nd:]) + (ch, d['cout']), (d['cout'],)))
+            ch = d['cout']
+        elif d['type'] == ALQ_CONVT:
+            out.append((d['name'], tuple(d['k'][3 - nd:]) + (d['cout'], ch), (d['cout'],)))
+            spatial = [a * b for a, b in zip(spatial, d['s'][3 - nd:])]
+            ch = d['cout']
+        elif d['type'] == ALQ_POOL:
+            spatial = [-(-a // b) for a, b in zip(spatial, d['s'][3 - nd:])]
+        else:
+            if flat is None:
+                flat = int(np.prod(spatial)) * ch
+            out.append((d['name'], (d['cout'], flat), (d['cout'], 1)))
+            flat = d['cout']
+        chans[i] = ch
+    return out
+
+
+class DeviceModel(object):
+    """The reference model protocol (`x, keep_prob, posteriors, prediction, feature_layer,
+    grad_posts, var_dict, dropout_rate`) over a libalq model."""
+
+    def __init__(self, sess, layer_dict, in_shape, skips=(), feature_layer=None, dropout=None,
+                 max_batch=256, name='model'):
+        self.sess = sess
+        self.lib = sess.lib
+        self.name = name
+        self.layer_dict = layer_dict
+        self.in_shape = tuple(int(v) for v in in_shape)
+        self.skips = [list(s) for s in skips]
+        self.max_batch = int(max_batch)
+        self.layers = translate_layers(layer_dict, self.in_shape, skips)
+        self.param_shapes = tf_param_shapes(self.layers, self.in_shape)
+        self.var_names = [p[0] for p in self.param_shapes]
+        nd = len(self.in_shape) - 1
+        dims = [1] * (3 - nd) + list(self.in_shape[:-1]) + [self.in_shape[-1]]
+        arr = (LayerT * len(self.layers))()
+        for i, d in enumerate(self.layers):
+            arr[i].type = d['type']
+            arr[i].cout = d['cout']
+            arr[i].k[:] = d['k']
+            arr[i].s[:] = d['s']
+            arr[i].relu = d['relu']
+            arr[i].skip_src = d['skip_src']
+        self._m = C.c_void_p()
+        cd = (C.c_int32 * 4)(*dims)
+        check(self.lib.alq_model_create(sess.ctx, arr, len(self.layers), cd, self.max_batch, C.byref(self._m)))
+        self.L = self.lib.alq_model_num_param_layers(self._m)
+        self.nclass = self.layers[-1]['cout']
+        self.elems_per_patch = int(np.prod(self.in_shape))
+        # reference-style attributes
+        self.x = Handle('x')
+        self.keep_prob = Handle('keep_prob')
+        if dropout:
+            self.dropout_layers, self.dropout_rate = dropout[0], dropout[1]
+        else:
+            self.dropout_layers, self.dropout_rate = [], 1.
+        self.posteriors = Handle('posteriors')
+        self.prediction = Handle('prediction')
+        self.feature_idx = feature_layer
+        fdim = 0
+        if feature_layer is not None:
+            e = C.c_int64()
+            check(self.lib.alq_model_layer_out_elems(self._m, int(feature_layer), C.byref(e)))
+            fdim = e.value
+        self.feature_dim = fdim
+        self.feature_layer = Handle('feature_layer', (fdim,))
+        for h in (self.posteriors, self.prediction, self.feature_layer):
+            h.model = self
+        # 2L opaque entries per class, so that len(model.grad_posts['1'])/2 == L (PW_NNAL.py:751)
+        self.grad_posts = {str(j): [Handle('grad_%d_%d' % (j, t)) for t in range(2 * self.L)]
+                           for j in range(self.nclass)}
+        self.var_dict = OrderedDict((n, None) for n in self.var_names)
+        self._feature_perm = self._feature_permutation()
+
+    # -- weights ---------------------------------------------------------------------------
+    def set_weights(self, pars):
+        """`pars`: name -> [W, b] in TF layouts (HWIO / DHWIO, transpose [k..,out,in], fc [out,in],
+        fc bias [out,1]); the weight interchange of NN.py:390-394 / :508-517 with numpy arrays in
+        place of the HDF5 datasets (h5py is not in the image)."""
+        for t, (name, wshape, bshape) in enumerate(self.param_shapes):
+            W, b = pars[name]
+            W = np.ascontiguousarray(np.asarray(W, dtype=np.float32))
+            b = np.ascontiguousarray(np.asarray(b, dtype=np.float32))
+            if tuple(W.shape) != tuple(wshape) or b.size != int(np.prod(bshape)):
+                raise ValueError('layer %s: expected W%s b%s, got W%s b%s' % (name, wshape, bshape, W.shape, b.shape))
+            check(self.lib.alq_model_set_weights(self._m, t, W.ctypes.data_as(C.c_void_p),
+                                                 b.ctypes.data_as(C.c_void_p)))
+            self.var_dict[name] = [W, b]
+
+    def load_weights(self, path, session=None):
+        """.npz twin of CNN.load_weights (NN.py:396-419): keys '<layer>/Weight', '<layer>/Bias'."""
+        f = np.load(path)
+        self.set_weights({n: [f[n + '/Weight'], f[n + '/Bias']] for n in self.var_names})
+
+    def save_weights(self, path):
+        """.npz twin of CNN.save_weights (NN.py:379-394)."""
+        d = {}
+        for n, wb in self.var_dict.items():
+            d[n + '/Weight'], d[n + '/Bias'] = wb
+        np.savez(path, **d)
+
+    def add_assign_ops(self):
+        """No graph to extend (NN.py:421-458): kept so loop code calls it unchanged."""
+
+    def perform_assign_ops(self, file_path, sess=None):
+        """NN.py:462-519: 'init' draws He-normal weights with the global np.random in variable
+        creation order (std = sqrt(2/n), zero biases); otherwise loads a weight file."""
+        if file_path != 'init':
+            return self.load_weights(file_path)
+        pars = OrderedDict()
+        for name, wshape, bshape in self.param_shapes:
+            n = int(np.prod(wshape[:-1])) if len(wshape) > 2 else wshape[1]
+            pars[name] = [np.sqrt(2. / n) * np.random.randn(*wshape), np.zeros(bshape)]
+        self.set_weights(pars)
+
+    # -- evaluation ------------------------------------------------------------------------
+    def _feature_permutation(self):
+        """feature_layer of a conv/pool layer is flattened in the reference's order (full axis
+        reversal, NN.py:296-301,337-340); the device returns memory order.  Identity after an fc."""
+        if self.feature_idx is None:
+            return None
+        # re-derive the layer's output geometry
+        nd = len(self.in_shape) - 1
+        spatial = list(self.in_shape[:-1])
+        ch = self.in_shape[-1]
+        for i, d in enumerate(self.layers):
+            if d['type'] == ALQ_CONV:
+                ch = d['cout']
+            elif d['type'] == ALQ_CONVT:
+                spatial = [a * b for a, b in zip(spatial, d['s'][3 - nd:])]
+                ch = d['cout']
+            elif d['type'] == ALQ_POOL:
+                spatial = [-(-a // b) for a, b in zip(spatial, d['s'][3 - nd:])]
+            else:
+                return None                      # at or after an fc: already a flat vector
+            if i == self.feature_idx:
+                mem = np.arange(int(np.prod(spatial)) * ch).reshape(spatial + [ch])
+                return mem.transpose(*reversed(range(nd + 1))).reshape(-1)
+        return None
+
+    def _as_device_batch(self, x):
+        torch = self.sess.torch
+        if isinstance(x, torch.Tensor):
+            t = x.to(device=self.sess.device, dtype=torch.float32).contiguous()
+        else:
+            t = self.sess.to_device(np.asarray(x), torch.float32)    # placeholder is tf.float32
+        n = t.numel() // self.elems_per_patch
+        if n * self.elems_per_patch != t.numel():
+            raise ValueError('batch of %d elements is not a multiple of the patch size %d' % (t.numel(), self.elems_per_patch))
+        return t, n
+
+    def forward_device(self, t, n, want_pred=False, want_feat=False):
+        """t: device fp32 tensor of n patches.  Returns device tensors (post [c,n], pred, feat)."""
+        torch = self.sess.torch
+        post = self.sess.empty((self.nclass, n), torch.float32)
+        pred = self.sess.empty((n,), torch.int64) if want_pred else None
+        feat = self.sess.empty((n, self.feature_dim), torch.float32) if want_feat else None
+        for a in range(0, n, self.max_batch):
+            b = min(n, a + self.max_batch)
+            pb = self.sess.empty((self.nclass, b - a), torch.float32)
+            check(self.lib.alq_forward(
+                self._m, C.c_void_p(t.data_ptr() + a * self.elems_per_patch * 4), b - a,
+                C.c_void_p(pb.data_ptr()),
+                C.c_void_p(pred.data_ptr() + a * 8) if want_pred else None,
+                C.c_void_p(feat.data_ptr() + a * self.feature_dim * 4) if want_feat else None,
+                self.feature_idx if want_feat else -1))
+            post[:, a:b] = pb
+        return post, pred, feat
+
+    def forward(self, x, want=('posteriors',)):
+        t, n = self._as_device_batch(x)
+        post, pred, feat = self.forward_device(t, n, 'prediction' in want, 'feature_layer' in want)
+        res = {'posteriors': post.cpu().numpy()}
+        if pred is not None:
+            res['prediction'] = pred.cpu().numpy()
+        if feat is not None:
+            f = feat.cpu().numpy()
+            if self._feature_perm is not None:
+                f = f[:, self._feature_perm]
+            res['feature_layer'] = np.ascontiguousarray(f.T)       # [F, n] like the reference
+        return res
+
+    def fisher_device(self, t, n, p1_in=None, diag_load=1e-5, want=('p1', 'g0', 'g1', 'A', 'trace', 'Asum')):
+        """Device-resident Fisher scoring of n patches (t: device fp32).  Returns device tensors;
+        'Asum' is the sum over the n patches (fixed summation order per launch)."""
+        torch = self.sess.torch
+        L = self.L
+        out = {}
+        out['p1'] = self.sess.empty((n,), torch.float32) if 'p1' in want else None
+        out['g0'] = self.sess.empty((n, L), torch.float64) if 'g0' in want else None
+        out['g1'] = self.sess.empty((n, L), torch.float64) if 'g1' in want else None
+        out['A'] = self.sess.empty((n, L, L), torch.float64) if 'A' in want else None
+        out['trace'] = self.sess.empty((n,), torch.float64) if 'trace' in want else None
+        asum = torch.zeros((L, L), dtype=torch.float64, device=self.sess.device) if 'Asum' in want else None
+        part = self.sess.empty((L, L), torch.float64) if asum is not None else None
+
+        def ptr(tn, off_elems, itemsize):
+            return C.c_void_p(tn.data_ptr() + off_elems * itemsize) if tn is not None else None
+
+        for a in range(0, n, self.max_batch):
+            b = min(n, a + self.max_batch)
+            check(self.lib.alq_fisher(
+                self._m, C.c_void_p(t.data_ptr() + a * self.elems_per_patch * 4), b - a,
+                ptr(p1_in, a, 4), float(diag_load), ptr(out['p1'], a, 4), ptr(out['g0'], a * L, 8),
+                ptr(out['g1'], a * L, 8), ptr(out['A'], a * L * L, 8), ptr(out['trace'], a, 8),
+                C.c_void_p(part.data_ptr()) if part is not None else None))
+            if asum is not None:
+                asum += part
+        out['Asum'] = asum
+        return out
+
+    def fisher(self, x, p1=None, diag_load=1e-5):
+        t, n = self._as_device_batch(x)
+        p1_in = None
+        if p1 is not None:
+            p1_in = self.sess.to_device(np.asarray(p1, dtype=np.float32), self.sess.torch.float32)
+        out = self.fisher_device(t, n, p1_in, diag_load)
+        return {k: (v.cpu().numpy() if v is not None else None) for k, v in out.items()}
+
+    def debug_tensor(self, layer_idx, what, n):
+        """Test hook (alq_model_debug_copy): internal tensor of the last forward/fisher call."""
+        torch = self.sess.torch
+        cap = {0: None, 1: None}
+        e = C.c_int64()
+        # size query by over-allocation: the largest activation of a patch is bounded by 64x input
+        buf = self.sess.empty((n * max(self.elems_per_patch * 64, 1 << 16),), torch.float32)
+        check(self.lib.alq_model_debug_copy(self._m, int(layer_idx), int(what), int(n),
+                                            C.c_void_p(buf.data_ptr()), C.byref(e)))
+        del cap
+        return buf[:e.value].cpu().numpy()
+
+    def close(self):
+        if self._m:
+            self.lib.alq_model_destroy(self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -51,8 +51,11 @@ def _strided_box(dsum, k, s, in_sp):
     return y
 
 
-def factored_unit_scores(model, x):
+def factored_unit_scores(model, x, details=None):
     """Returns (p [2,N], S [N,L], sizes [L]): S_t = sum of ALL entries of d(z0-z1)/d(theta_t).
+    If `details` is a dict it receives per-layer tensors: 'out' (list over ALL layers, output after
+    activation, channels-last), and per parameterised layer 'delta' (masked cotangent), 'asum',
+    'dsum'.
 
     `model` is an oracle.model.OracleModel (its graph is re-walked here with hooks on every
     parameterised layer's input and pre-activation output)."""
@@ -63,6 +66,7 @@ def factored_unit_scores(model, x):
     # re-implementation of the walk with explicit pre-activation capture
     names = model.names
     out = xt
+    layer_outs = []
     sources = {}
     src_idx = [s[0] for s in model.skips]
     for i, name in enumerate(names):
@@ -100,6 +104,7 @@ def factored_unit_scores(model, x):
                 out = tfops.max_pool_same(out, [spec[0][0]] * nd, [spec[0][1]] * nd)
         if i in src_idx:
             sources[i] = out
+        layer_outs.append(out.detach())
         if (not last) and ltype in ('conv', 'pool') and nxt == 'fc':
             out = tfops.flatten_tf(out)
     z = out                                     # [2, N]
@@ -127,6 +132,13 @@ def factored_unit_scores(model, x):
             asum = r['a'].sum(-1)
             B = _strided_box(dsum, k, s, asum.shape[1:])
             S[:, t] = (asum * B).reshape(N, -1).sum(1) + dsum.reshape(N, -1).sum(1)
+    if details is not None:
+        details['out'] = [o.numpy() for o in layer_outs]
+        details['delta'] = [r['pre'].grad.numpy() for r in recs]
+        details['asum'] = [(r['a'].sum(0) if r['type'] == 'fc' else r['a'].sum(-1)).numpy() for r in recs]
+        details['dsum'] = [(r['pre'].grad.sum(0) if r['type'] == 'fc' else r['pre'].grad.sum(-1)).numpy()
+                           for r in recs]
+        details['types'] = [r['type'] for r in recs]
     return p.numpy(), S.numpy(), np.array(sizes)
 
 

@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: Fisher scoring of a synthetic pool of 32^3 2-class patches.
+
+Workload (BASELINE.json configs[2], the one the metric "patches/sec Fisher-scored (32^3,
+2-class)" is quoted on): NET-C (patch-wise 3-D U-Net-style net with fc head),
+pool of 100,000 synthetic patches resident in HBM (counter-based generator, seed 1004,
+patch ids = global positions so shards are reproducible), weights He-normal seed 14.
+One "step" = one Fisher-scoring pass over the whole pool: per patch p1, |p1-.5| top-B
+candidates, g0, g1, A_i (8x8), tr(A_i), and the pool sum of A_i.
+
+  python bench.py --gpus N --steps K --warmup W     (N > 1: launched by torch.distributed.run)
+
+N > 1 is weak scaling: every rank scores its own 100,000-patch shard of an N*100,000 pool
+(config 4's sharding), with the top-B merge and the 8x8 Fisher-sum all-reduce over RCCL inside
+the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+# Per-patch algorithmic work of NET-C at 32^3 (SURVEY.md §8d / BASELINE.md §4), 2 FLOP per MAC.
+F_FWD = 439.88e6
+F_BWD_DATA = 425.72e6
+F_SURVEY = F_FWD + 2 * F_BWD_DATA       # the survey's figure: one backward per class
+F_EXEC = F_FWD + F_BWD_DATA             # what this build executes: ONE backward serves both classes
+PEAK_F32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+B_ALG = 4 * 32 ** 3 + 4 * (1 + 2 * 8 + 64)   # input + outputs per patch, bytes
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--pool', type=int, default=100000, help='patches per GPU')
+    ap.add_argument('--batch', type=int, default=256, help='patches per device pass')
+    ap.add_argument('--topB', type=int, default=4096)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=24)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    ws = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if ws > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=ws,
+                                device_id=torch.device('cuda', local_rank))
+    assert ws == args.gpus, 'WORLD_SIZE=%d but --gpus %d' % (ws, args.gpus)
+
+    import ctypes as C
+    import nnal_amd  # noqa: F401
+    from nnal_amd import device, pool_shard
+    from nnal_amd._lib import check
+    from oracle import netspec   # network definition + seeded weight draw only (not timed)
+
+    sess = device.DeviceSession(local_rank)
+    ld, sk = netspec.net_c()
+    in_shape = (32, 32, 32, 1)
+    pars = netspec.he_init(ld, in_shape, seed=14, skips=sk)
+    model = device.DeviceModel(sess, ld, in_shape, sk, max_batch=args.batch)
+    model.set_weights(pars)
+
+    n_local = args.pool
+    n_global = n_local * ws
+    a0, b0 = pool_shard.shard_bounds(n_global, ws, rank)
+    assert b0 - a0 == n_local
+    epp = 32 ** 3
+    x = sess.empty((n_local, epp), torch.float32)      # 13.1 GB per GPU at the default pool
+    check(sess.lib.alq_synth_patches(sess.ctx, 1004, a0, n_local, epp, C.c_void_p(x.data_ptr())))
+    torch.cuda.synchronize()
+
+    def step():
+        return pool_shard.score_pool(model, sess, x, n_global, args.topB, 1e-3)
+
+    for _ in range(args.warmup):
+        step()
+    sess.prof_reset()
+    sess.prof_enable(True)          # HIP events around every GEMM-engine launch, on our stream
+    pool_shard.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    pool_shard.barrier()
+    dt = time.perf_counter() - t0
+    sess.prof_enable(False)
+    prof = sess.prof_read()
+    dt = pool_shard.max_over_ranks(dt)
+
+    if rank == 0:
+        ms_per_step = 1e3 * dt / args.steps
+        value = n_global * args.steps / dt
+        # dominant kernel class = the implicit-GEMM engine (conv / conv_transpose fwd + bwd-data)
+        ig_ms = prof['igemm_fwd']['ms'] + prof['igemm_bwd']['ms']
+        ig_fl = prof['igemm_fwd']['flops'] + prof['igemm_bwd']['flops']
+        ig_n = prof['igemm_fwd']['launches'] + prof['igemm_bwd']['launches']
+        achieved = ig_fl / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
+        traffic = None
+        tp = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        line = {
+            'metric': 'patches/sec Fisher-scored (32^3, 2-class)',
+            'value': value, 'unit': 'patches/s', 'n_gpus': ws, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[2]: Fisher scoring, NET-C patch-wise 3-D U-Net (fc head), '
+                                   '%d synthetic 32^3 2-class patches per GPU, random-init weights seed 14'
+                                   % n_local,
+                       'pool_per_gpu': n_local, 'batch': args.batch, 'topB': args.topB,
+                       'parallelism': 'pool sharded over %d GPU(s), RCCL top-B merge + 8x8 Fisher all-reduce' % ws},
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
+                         'kernel': 'igemm_kernel (all conv / conv_transpose fwd + bwd-data launches)',
+                         'launches': ig_n, 'avg_launch_ms': ig_ms / max(ig_n, 1),
+                         'flops_per_patch_executed': F_EXEC, 'flops_per_patch_survey': F_SURVEY,
+                         'whole_step_tflops_executed': F_EXEC * value / ws / 1e12,
+                         'hbm_algorithmic_GBps': B_ALG * value / ws / 1e9,
+                         'time_share': {k: v['ms'] for k, v in prof.items()}},
+        }
+        if not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(x[:args.cpu_sample].cpu().numpy(), ld, sk, in_shape, pars)
+        print(json.dumps(line))
+    if ws > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(xs, ld, sk, in_shape, pars):
+    """The oracle (CPU port with the reference's structure: batch 1, one backward per class per
+    sample, full gradients materialised, NumPy shrink, PW_NNAL.py:757-814) on this box's host
+    cores, on a bounded sample of the same patches."""
+    import torch
+    from oracle import alpath
+    from oracle.model import OracleModel, OracleSession
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    om = OracleModel(ld, in_shape, pars, skips=sk)
+    osess = OracleSession(om)
+    xs = xs.reshape((-1,) + in_shape)
+
+    class E(object):
+        pars = {'patch_shape': in_shape[:3]}
+        nclass = 2
+    p = om.forward(xs[:2])['posteriors'][1]
+    alpath.gen_A_matrices(E(), om, osess, xs[:2], p.astype(np.float64), 1e-3)    # warm-up
+    t0 = time.perf_counter()
+    p = om.forward(xs)['posteriors'][1].astype(np.float64)
+    alpath.gen_A_matrices(E(), om, osess, xs, p, 1e-3)
+    dt = time.perf_counter() - t0
+    return {'value': len(xs) / dt, 'unit': 'patches/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d of the pool\'s patches (NET-C 32^3), forward + per-sample gen_A_matrices, %.1f s'
+                      % (len(xs), dt)}
+
+
+if __name__ == '__main__':
+    main()

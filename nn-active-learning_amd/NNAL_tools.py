@@ -28,7 +28,9 @@ def shrink_gradient(grad, method, args=None):
     for t in range(L):
         gW, gb = np.asarray(grad[2 * t]), np.asarray(grad[2 * t + 1])
         if method == 'sum':
-            out[t] = (np.sum(gW) + np.sum(gb)) / (gW.size + len(gb))
+            # fp32 sums, then a float64 quotient: the divisor is a NumPy int64 as in the reference
+            # (np.prod(shape) + len(b)); a Python int would keep the quotient in fp32 under NumPy 2
+            out[t] = (np.sum(gW) + np.sum(gb)) / (np.prod(gW.shape) + len(gb))
         elif method == 'max':
             # max(..., key=abs) per array, then the plain max of the two winners (NNAL_tools.py:805-810)
             wmax = gW.ravel()[np.argmax(np.abs(gW.ravel()))]

@@ -109,6 +109,7 @@ struct IgemmArgs {
     int MD, MH, MW;
     int sm, so, ooffz, ooffy, ooffx;
     int PT, TZ, TY, TX, HZ, HY, HX;
+    int rows;                     // PT*TZ*TY*TX live GEMM rows of the 256-row tile
     int minz, miny, minx;
     int ntaps, nchunks, NB;
     int tilesZ, tilesY, tilesX;

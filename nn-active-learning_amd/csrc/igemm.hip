@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     int vbase[4];
 #pragma unroll
     for (int ms = 0; ms < 4; ++ms) {
-        const int v = wave * 64 + ms * 16 + lrow;
+        int v = wave * 64 + ms * 16 + lrow;
+        if (v >= a.rows) v = 0;           // under-filled tile: read a valid row, discard in the epilogue
         const int pt = v / TV;
         int r = v - pt * TV;
         const int x = r % a.TX; r /= a.TX;
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int v = wave * 64 + ms * 16 + lk * 4 + r;
+            if (v >= a.rows) continue;
             const int pt = v / TV;
             int q = v - pt * TV;
             const int x = q % a.TX; q /= a.TX;
@@ -261,7 +263,7 @@ int igemm_build_plan(const ConvDesc &d, int max_batch, IgemmPlan *plan) {
             if (TY > pow2ceil(d.MH)) break;
             for (int TZ = 1; TX * TY * TZ <= 256; TZ <<= 1) {
                 if (TZ > pow2ceil(d.MD)) break;
-                const int PT = 256 / (TX * TY * TZ);
+              for (int PT = 256 / (TX * TY * TZ); PT >= 1; PT >>= 1) {
                 if (PT > 1 && (TX < pow2ceil(d.MW) || TY < pow2ceil(d.MH) || TZ < pow2ceil(d.MD)))
                     continue;   // several patches per tile only when a tile covers a whole patch
                 const int HZ = (TZ - 1) * d.sm + (maxz - minz) + 1;
@@ -275,11 +277,13 @@ int igemm_build_plan(const ConvDesc &d, int max_batch, IgemmPlan *plan) {
                 double cost = tiles * (256.0 * ntaps * 8 * NTW + 6.0 * halo * 8);
                 if (TX < 16 && d.MW >= 16) cost *= 1.5;    // bank conflicts on the A fragment
                 if (cost < best) { best = cost; bt[0] = PT; bt[1] = TZ; bt[2] = TY; bt[3] = TX; }
+              }
             }
         }
     }
     ALQ_REQUIRE(best < 1e299, ALQ_EUNSUPPORTED, "igemm: no tile fits LDS");
     a.PT = bt[0]; a.TZ = bt[1]; a.TY = bt[2]; a.TX = bt[3];
+    a.rows = a.PT * a.TZ * a.TY * a.TX;   // < 256 only for maps too small to fill a tile within LDS
     a.HZ = (a.TZ - 1) * d.sm + (maxz - minz) + 1;
     a.HY = (a.TY - 1) * d.sm + (maxy - miny) + 1;
     a.HX = (a.TX - 1) * d.sm + (maxx - minx) + 1;

@@ -787,7 +787,8 @@ int alq_model_debug_copy(alq_model *m, int layer_idx, int what, int N, float *d_
         return debug_view_copy(m->ctx, v, N, d_out);
     }
     ALQ_REQUIRE(ly.pidx >= 0 && (what == 2 || what == 3), ALQ_EINVAL, "layer has no channel-sum fields");
-    const int64_t e = (int64_t)N * (what == 2 ? ly.in.vox() : ly.out.vox());
+    const bool isfc = ly.spec.type == ALQ_FC;
+    const int64_t e = (int64_t)N * (isfc ? 1 : (what == 2 ? ly.in.vox() : ly.out.vox()));
     if (elems_out) *elems_out = e;
     ALQ_HIP(hipMemcpyAsync(d_out, what == 2 ? ly.asum : ly.dsum, e * sizeof(float), hipMemcpyDeviceToDevice,
                            m->ctx->stream));

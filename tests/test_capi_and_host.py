@@ -1,0 +1,109 @@
+"""CPU-side checks: the C-ABI library builds/loads and exports every symbol include/alq.h
+declares (no compute calls without a GPU), and the host logic of the Python mirror."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import nnal_amd  # noqa: F401
+from nnal_amd import _lib, device, NNAL_tools, patch_utils, pool_shard, PW_NNAL
+from oracle import netspec
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, 'include', 'alq.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(alq_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    _lib.build()
+    L = _lib.lib()
+    names = _header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), 'libalq.so does not export %s' % n
+    assert sorted(names) == _lib.exported_names()      # the ctypes table covers the header exactly
+    nm = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()
+    for n in names:
+        assert re.search(r'\bT %s\b' % n, nm), n
+    assert L.alq_version() == 1
+    assert L.alq_prof_num_classes() >= 2 and L.alq_prof_class_name(0) == b'igemm_fwd'
+    assert L.alq_topk_work_bytes(5) == 2048 * 16 and L.alq_topk_work_bytes(2049) == 4096 * 16
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(_lib.AlqError):
+        device.DeviceSession(0)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'nn-active-learning_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', txt, flags=re.M), f
+                assert '/root/reference' not in txt, f
+
+
+def test_translate_layers_both_schemas():
+    a = device.translate_layers(netspec.net_b(), (25, 25, 2))
+    assert [d['type'] for d in a] == [0, 0, 2, 0, 0, 2, 3, 3, 3]
+    assert a[0]['k'] == [1, 5, 5] and a[2]['k'] == [1, 2, 2] and a[2]['s'] == [1, 2, 2]
+    assert [d['relu'] for d in a] == [1, 1, 0, 1, 1, 0, 1, 1, 0]          # no ReLU on the last fc
+    shapes = device.tf_param_shapes(a, (25, 25, 2))
+    assert shapes[4] == ('fc1', (4096, 7 * 7 * 96), (4096, 1))
+    assert sum(int(np.prod(w)) + int(np.prod(b)) for _, w, b in shapes) == 36137082
+    ld, sk = netspec.net_c()
+    c = device.translate_layers(ld, (32, 32, 32, 1), sk)
+    assert c[6]['skip_src'] == 2 and c[8]['skip_src'] == 0 and c[5]['type'] == 1 and c[5]['relu'] == 0
+    shapes = device.tf_param_shapes(c, (32, 32, 32, 1))
+    assert sum(int(np.prod(w)) + int(np.prod(b)) for _, w, b in shapes) == 576450
+    # same shapes as the oracle's independent derivation
+    assert [(n, tuple(w), tuple(b)) for n, w, b in netspec.param_shapes(ld, (32, 32, 32, 1), sk)] == \
+           [(n, tuple(w), tuple(b)) for n, w, b in shapes]
+    with pytest.raises(NotImplementedError):
+        device.translate_layers(ld, (32, 32, 32, 1), [[0, [8], 'sum']])
+
+
+def test_host_functions_vs_reference_goldens(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'host_layers.npz'))
+    np.testing.assert_array_equal(NNAL_tools.shrink_gradient([g['shrink_in_%d' % i] for i in range(6)], 'sum'),
+                                  g['shrink_out'])
+    for i, l in enumerate(patch_utils.global2local_inds(g['g2l_inds'], list(g['g2l_sizes']))):
+        np.testing.assert_array_equal(l, g['g2l_out_%d' % i])
+    np.testing.assert_array_equal(PW_NNAL.binary_uncertainty_filter(g['buf_posts'], 37), g['buf_out'])
+    a = g['ent_in'].copy()
+    np.testing.assert_array_equal(NNAL_tools.compute_entropy(a), g['ent_out'])
+    np.testing.assert_array_equal(a, g['ent_in_after'])
+    b = g['ent_in'].copy()
+    np.testing.assert_array_equal(NNAL_tools.uncertainty_filtering(b, 11), g['uf_out'])
+    np.testing.assert_array_equal(b, g['uf_in_after'])
+    np.random.seed(77)
+    np.testing.assert_array_equal(NNAL_tools.sample_query_dstr(g['sq_q'].copy(), 25, True), g['sq_out'])
+    with pytest.raises(NotImplementedError):
+        NNAL_tools.SDP_query_distribution([], 0.1, [], 3)
+
+
+def test_shard_bounds_cover_the_pool():
+    for n in (0, 1, 7, 8, 100000, 1000003):
+        for R in (1, 2, 3, 8):
+            b = [pool_shard.shard_bounds(n, R, r) for r in range(R)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(R - 1))
+            assert all(0 <= x[1] - x[0] <= -(-n // R) for x in b)
+
+
+def test_merge_topB_single_process():
+    k = np.array([.3, .1, .1, .2])
+    g = np.array([10, 7, 3, 5])
+    np.testing.assert_array_equal(pool_shard.merge_topB(k, g, 3), [3, 7, 5])
+    np.testing.assert_array_equal(pool_shard.allreduce_sum(np.eye(2)), np.eye(2))

@@ -1,0 +1,318 @@
+"""HIP path vs oracle vs committed goldens, through the C ABI (libalq.so).  GPU box only."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import alpath, netspec  # noqa: E402
+from oracle.model import OracleModel, OracleSession  # noqa: E402
+from tests.test_oracle_golden import build_fisher_model, Expr  # noqa: E402
+
+# Tolerances (north_star: indices bit-exact, scores within 1e-4 fp32).  The device reduces the
+# per-layer gradient sums in a different order than TF/NumPy would and in one backward pass, so
+# values agree to fp32 rounding, not bitwise:
+P_ATOL = 2e-5          # posteriors (fp32 softmax of fp32 logits)
+G_RTOL, G_ATOL = 1e-3, 1e-7   # shrunk gradients g0, g1
+A_RTOL, A_ATOL = 2e-3, 1e-9   # A_i entries (products of two g's)
+
+
+@pytest.fixture(scope='module')
+def sess():
+    import nnal_amd  # noqa: F401
+    from nnal_amd import device
+    s = device.default_session()
+    yield s
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _device_model(sess, ld, in_shape, skips, pars, feature_layer=None, max_batch=64):
+    from nnal_amd import device
+    m = device.DeviceModel(sess, ld, in_shape, skips, feature_layer=feature_layer, max_batch=max_batch)
+    m.set_weights(pars)
+    return m
+
+
+FISHER = [('fisher_neta.npz', 'a'), ('fisher_neta_saturated.npz', 'a'),
+          ('fisher_netb_small_25x25x2.npz', 'bs'), ('fisher_netb_25x25x2.npz', 'b'),
+          ('fisher_netc2d.npz', 'c2'), ('fisher_netc_8cube.npz', 'c'), ('fisher_netc_32cube.npz', 'c')]
+
+
+@pytest.mark.parametrize('fname,kind', FISHER)
+def test_gen_A_matrices_vs_golden(sess, golden_dir, fname, kind):
+    """A-matrices produced by the REFERENCE's gen_A_matrices (golden) vs the device path."""
+    from nnal_amd import PW_NNAL
+    g = _load(golden_dir, fname)
+    ld, skips, in_shape, pars = build_fisher_model(g, kind)
+    model = _device_model(sess, ld, in_shape, skips, pars, max_batch=16)
+    x, p1 = g['x'], g['p1']
+    A = PW_NNAL.gen_A_matrices(Expr({'patch_shape': in_shape[:3]}), model, sess, x, p1, float(g['diag_load']))
+    A = np.stack(A)
+    assert A.shape == g['A'].shape and A.dtype == np.float64
+    np.testing.assert_allclose(A, g['A'], rtol=A_RTOL, atol=A_ATOL)
+    res = model.fisher(x, p1, float(g['diag_load']))
+    np.testing.assert_allclose(res['p1'], p1, rtol=0, atol=P_ATOL)
+    # goldens hold both class gradients for every sample; the device zeroes the skipped branch
+    lo, hi = p1 < 1e-6, p1 > 1 - 1e-6
+    g0 = np.where(hi[:, None], 0., g['g0'])
+    g1 = np.where(lo[:, None], 0., g['g1'])
+    np.testing.assert_allclose(res['g0'], g0, rtol=G_RTOL, atol=G_ATOL)
+    np.testing.assert_allclose(res['g1'], g1, rtol=G_RTOL, atol=G_ATOL)
+    np.testing.assert_allclose(res['trace'], np.trace(g['A'], axis1=1, axis2=2), rtol=A_RTOL, atol=A_ATOL)
+    np.testing.assert_allclose(res['Asum'], g['A'].sum(0), rtol=A_RTOL, atol=A_ATOL * len(p1))
+    model.close()
+
+
+def test_saturation_branches_exact(sess, golden_dir):
+    """p < 1e-6 -> only class 0, p > 1-1e-6 -> only class 1 (PW_NNAL.py:770-793), decided on the
+    posteriors handed in."""
+    g = _load(golden_dir, 'fisher_neta_saturated.npz')
+    ld, skips, in_shape, pars = build_fisher_model(g, 'a')
+    model = _device_model(sess, ld, in_shape, skips, pars)
+    p1 = g['p1']
+    lo, hi = p1 < 1e-6, p1 > 1 - 1e-6
+    assert lo.sum() >= 1 and hi.sum() >= 1 and (~lo & ~hi).sum() >= 1
+    res = model.fisher(g['x'], p1, 1e-5)
+    assert np.all(res['g1'][lo] == 0.) and np.all(res['g0'][hi] == 0.)
+    L = res['g0'].shape[1]
+    for i in np.where(lo)[0]:
+        np.testing.assert_array_equal(res['A'][i], np.outer(res['g0'][i], res['g0'][i]) + np.eye(L) * 1e-5)
+    for i in np.where(hi)[0]:
+        np.testing.assert_array_equal(res['A'][i], np.outer(res['g1'][i], res['g1'][i]) + np.eye(L) * 1e-5)
+    model.close()
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_get_patches_bit_exact(sess, golden_dir, tag):
+    from nnal_amd import patch_utils
+    g = _load(golden_dir, 'gather.npz')
+    vols = [g[tag + '_vol0'], g[tag + '_vol1']]
+    p, lab = patch_utils.get_patches(vols, g[tag + '_inds'], tuple(g[tag + '_pshape']), True, g[tag + '_mask'])
+    assert p.dtype == np.float64
+    np.testing.assert_array_equal(p, g[tag + '_patches'])
+    np.testing.assert_array_equal(lab, g[tag + '_labels'])
+    mask = g[tag + '_mask']
+    allimgs = [vols + [mask], vols[::-1] + [mask]]
+    inds = g[tag + '_inds']
+    P, Lb = patch_utils.get_patches_multimg(allimgs, [inds[:20], inds[20:]], tuple(g[tag + '_pshape']),
+                                            g[tag + '_mm_stats'])
+    for j in range(2):
+        np.testing.assert_array_equal(P[j], g[tag + '_mm_p%d' % j])
+        np.testing.assert_array_equal(Lb[j], g[tag + '_mm_l%d' % j])
+    # un-padded input path (padded=False)
+    r = [int((d - 1) / 2.) for d in g[tag + '_pshape']]
+    raw = [v[r[0]:v.shape[0] - r[0], r[1]:v.shape[1] - r[1], r[2]:v.shape[2] - r[2]] for v in vols]
+    p2 = patch_utils.get_patches(raw, g[tag + '_inds'], tuple(g[tag + '_pshape']), False)
+    np.testing.assert_array_equal(p2, g[tag + '_patches'])
+
+
+def test_get_patches_rejects_even_dims_and_bad_indices(sess, golden_dir):
+    from nnal_amd import patch_utils
+    from nnal_amd._lib import AlqError
+    g = _load(golden_dir, 'gather.npz')
+    vols = [g['a_vol0'], g['a_vol1']]
+    with pytest.raises(AlqError):
+        patch_utils.get_patches(vols, np.array([0, 1]), (4, 5, 3))
+    with pytest.raises(IndexError):
+        patch_utils.get_patches(vols, np.array([40 * 40 * 12]), (5, 5, 3))
+    assert patch_utils.get_patches(vols, np.zeros(0, dtype=np.int64), (5, 5, 3)).shape == (0, 5, 5, 6)
+
+
+def _neta_eval(sess, g):
+    ld = netspec.net_a()
+    pshape = tuple(int(v) for v in g['pshape'])
+    in_shape = (pshape[0], pshape[1], 2 * pshape[2])
+    pars = netspec.he_init(ld, in_shape, seed=int(g['wseed']), bias_std=0.05)
+    return _device_model(sess, ld, in_shape, (), pars, feature_layer=len(ld) - 2), pshape
+
+
+def test_batch_eval_and_entropy_query_vs_golden(sess, golden_dir):
+    """batch_eval (with the channel-index normalisation quirk, d3 = 3), CNN_query('entropy')."""
+    from nnal_amd import PW_NN, PW_NNAL
+    g = _load(golden_dir, 'eval_neta.npz')
+    model, pshape = _neta_eval(sess, g)
+    vols = [g['vol0'], g['vol1']]
+    stats = g['stats'].tolist()
+    r = PW_NN.batch_eval(model, sess, vols, g['pool'], pshape, 64, stats,
+                         ['posteriors', 'prediction', 'feature_layer'])
+    assert r[0].dtype == np.float64 and r[2].shape == g['be_feature_layer'].shape
+    np.testing.assert_allclose(r[0], g['be_posteriors'], rtol=0, atol=P_ATOL)
+    np.testing.assert_array_equal(r[1], g['be_prediction'])
+    np.testing.assert_allclose(r[2], g['be_feature_layer'], rtol=1e-5, atol=1e-5)
+    expr = Expr({'patch_shape': pshape, 'ntb': 64, 'stats': stats, 'k': 20})
+    q = PW_NNAL.CNN_query(expr, model, sess, vols, g['pool'], None, 'entropy')
+    np.testing.assert_array_equal(q, g['entropy_q'])              # indices bit-exact
+    with pytest.raises(NotImplementedError):
+        PW_NNAL.CNN_query(expr, model, sess, vols, g['pool'], None, 'core-set')
+    with pytest.raises(NotImplementedError):
+        PW_NN.batch_eval(model, sess, vols, g['pool'], pshape, 64, stats, 'loss')
+    model.close()
+
+
+def test_bin_uncertainty_filter_multimg_vs_golden(sess, golden_dir):
+    from nnal_amd import PW_NNAL
+    g = _load(golden_dir, 'eval_neta.npz')
+    model, pshape = _neta_eval(sess, g)
+    vols = [g['vol0'], g['vol1']]
+    mask = g['mask']
+    allimgs = [vols + [mask], [vols[1], vols[0], mask]]
+    pools = [g['pool'][:170], g['pool'][170:]]
+    expr = Expr({'patch_shape': pshape, 'ntb': 50, 'k': 40}, train_stats=g['mm_tstats'])
+    sel_inds, sel_posts = PW_NNAL.bin_uncertainty_filter_multimg(expr, model, sess, allimgs, pools, 40)
+    for j in range(2):
+        np.testing.assert_array_equal(sel_inds[j], g['mm_sel_inds_%d' % j])
+        np.testing.assert_allclose(sel_posts[j], g['mm_sel_posts_%d' % j], rtol=0, atol=P_ATOL)
+    Q = PW_NNAL.query_multimg(expr, model, sess, allimgs, pools, None, 'entropy')
+    for j in range(2):
+        np.testing.assert_array_equal(Q[j], g['mm_sel_inds_%d' % j])
+    # empty subject
+    sel2, _ = PW_NNAL.bin_uncertainty_filter_multimg(expr, model, sess, allimgs, [pools[0], []], 10)
+    assert len(sel2[1]) == 0 and len(sel2[0]) == 10
+    model.close()
+
+
+@pytest.mark.parametrize('n,B', [(1, 1), (5, 3), (2047, 100), (2048, 2048), (2049, 7), (100000, 4096),
+                                 (300001, 300001)])
+def test_topk_uncertain(sess, n, B):
+    """ascending |p-.5|, ties -> lower index; keys deliberately contain many exact ties."""
+    from nnal_amd import PW_NNAL
+    rs = np.random.RandomState(n)
+    p = (rs.randint(0, 4000, size=n) / 4000.).astype(np.float32)   # heavy ties
+    t = sess.to_device(p, sess.torch.float32)
+    got = PW_NNAL.device_uncertainty_filter(sess, t, B).cpu().numpy()
+    key = np.abs(p.astype(np.float64) - 0.5)
+    want = np.lexsort((np.arange(n), key))[:B]
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(PW_NNAL.binary_uncertainty_filter(p, B), want)
+
+
+def test_score_entropy(sess):
+    import ctypes as C
+    from nnal_amd._lib import check
+    rs = np.random.RandomState(0)
+    p = rs.rand(5000).astype(np.float32)
+    p[:3] = [0., 1., 0.5]
+    t = sess.to_device(p, sess.torch.float32)
+    keys = sess.empty((p.size,), sess.torch.float64)
+    H = sess.empty((p.size,), sess.torch.float32)
+    check(sess.lib.alq_score_entropy(sess.ctx, C.c_void_p(t.data_ptr()), p.size, C.c_void_p(keys.data_ptr()),
+                                     C.c_void_p(H.data_ptr())))
+    np.testing.assert_array_equal(keys.cpu().numpy(), np.abs(p.astype(np.float64) - 0.5))
+    pm = np.stack([1. - p, p]).astype(np.float32)
+    np.testing.assert_allclose(H.cpu().numpy(), alpath.compute_entropy(pm), rtol=1e-5, atol=1e-6)
+
+
+def test_config2_neta_live_oracle(sess):
+    """Config 2 shape (NET-A, 32x32x1, weights seed 12, patches RandomState(1002)): top-B indices
+    over 10,000 patches bit-exact vs the oracle's posteriors; Fisher outputs of the first 256
+    vs the oracle run with the reference's per-sample structure."""
+    from nnal_amd import PW_NNAL
+    ld = netspec.net_a()
+    in_shape = (32, 32, 1)
+    pars = netspec.he_init(ld, in_shape, seed=12)
+    x = np.random.RandomState(1002).randn(10000, *in_shape).astype(np.float32)
+    om = OracleModel(ld, in_shape, pars)
+    model = _device_model(sess, ld, in_shape, (), pars, max_batch=2048)
+    p_ref = om.forward(x)['posteriors'][1]
+    p_dev = model.forward(x)['posteriors'][1]
+    np.testing.assert_allclose(p_dev, p_ref, rtol=0, atol=P_ATOL)
+    want = alpath.binary_uncertainty_filter(p_ref.astype(np.float64), 500)
+    # index parity is defined for tie-free, well-separated scores: drop pairs closer than the tolerance
+    key = np.abs(p_ref.astype(np.float64) - .5)
+    gaps = np.diff(np.sort(key)[:520])
+    if gaps.min() > 4 * P_ATOL:
+        got = PW_NNAL.device_uncertainty_filter(sess, sess.to_device(p_dev, sess.torch.float32), 500).cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+    else:   # same ordering of the device's own scores + same SET up to near-ties
+        got = PW_NNAL.device_uncertainty_filter(sess, sess.to_device(p_dev, sess.torch.float32), 500).cpu().numpy()
+        assert len(set(got) ^ set(want)) <= 2 * int((gaps <= 4 * P_ATOL).sum())
+    osess = OracleSession(om)
+    n = 256
+    A_ref = np.stack(alpath.gen_A_matrices(Expr({'patch_shape': in_shape}), om, osess, x[:n],
+                                           p_ref[:n].astype(np.float64), 1e-5))
+    A_dev = np.stack(PW_NNAL.gen_A_matrices(Expr({'patch_shape': in_shape}), model, sess, x[:n],
+                                            p_ref[:n].astype(np.float64), 1e-5))
+    np.testing.assert_allclose(A_dev, A_ref, rtol=A_RTOL, atol=A_ATOL)
+    model.close()
+
+
+def _netc_model(sess, max_batch):
+    ld, sk = netspec.net_c()
+    in_shape = (32, 32, 32, 1)
+    pars = netspec.he_init(ld, in_shape, seed=14, skips=sk)
+    return _device_model(sess, ld, in_shape, sk, pars, max_batch=max_batch), pars, ld, sk, in_shape
+
+
+def test_config3_netc_properties(sess):
+    """Size-independent properties at the bench configuration (NET-C, 32^3 patches):
+    run-to-run determinism, independence of the batch split, A_i - diag_load*I is rank one with
+    the closed form p0*p1*u u^T, Asum is the sum of the A_i, and synthetic shards do not depend on
+    where the shard starts."""
+    import ctypes as C
+    from nnal_amd._lib import check
+    torch = sess.torch
+    model, pars, ld, sk, in_shape = _netc_model(sess, 96)
+    n = 320
+    epp = 32 ** 3
+    x = sess.empty((n, epp), torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, epp, C.c_void_p(x.data_ptr())))
+    # shard reproducibility: patches 100..149 generated as their own shard
+    y = sess.empty((50, epp), torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1004, 100, 50, epp, C.c_void_p(y.data_ptr())))
+    assert torch.equal(x[100:150], y)
+    xs = x.cpu().numpy()
+    assert abs(xs.mean()) < 0.01 and abs(xs.std() - 1.) < 0.01
+    r1 = model.fisher_device(x, n, None, 1e-3)
+    r2 = model.fisher_device(x, n, None, 1e-3)
+    for k in ('p1', 'g0', 'g1', 'A', 'trace'):
+        assert torch.equal(r1[k], r2[k]), k
+    assert torch.equal(r1['Asum'], r2['Asum'])
+    model2, _, _, _, _ = _netc_model(sess, 33)           # different batch split
+    r3 = model2.fisher_device(x, n, None, 1e-3)
+    for k in ('p1', 'g0', 'g1', 'A', 'trace'):
+        assert torch.equal(r1[k], r3[k]), k
+    A = r1['A'].cpu().numpy()
+    g0 = r1['g0'].cpu().numpy()
+    g1 = r1['g1'].cpu().numpy()
+    p1 = r1['p1'].cpu().numpy().astype(np.float64)
+    L = A.shape[1]
+    R = A - np.eye(L) * 1e-3
+    np.testing.assert_allclose(R, (1 - p1)[:, None, None] * g0[:, :, None] * g0[:, None, :] +
+                               p1[:, None, None] * g1[:, :, None] * g1[:, None, :], rtol=1e-12, atol=1e-18)
+    # rank one: R_ij^2 == R_ii R_jj
+    d = np.einsum('nii->ni', R)
+    np.testing.assert_allclose(R ** 2, d[:, :, None] * d[:, None, :], rtol=1e-4, atol=1e-16)
+    # g1 = -(p0/p1) g0  (one backward pass serves both classes)
+    np.testing.assert_allclose(g1 * p1[:, None], -g0 * (1 - p1)[:, None], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(r1['Asum'].cpu().numpy(), A.sum(0), rtol=1e-10)
+    np.testing.assert_allclose(r1['trace'].cpu().numpy(), np.trace(A, axis1=1, axis2=2), rtol=1e-12)
+    # a handful against the oracle run with the reference's per-sample structure
+    om = OracleModel(ld, in_shape, pars, skips=sk)
+    osess = OracleSession(om)
+    xs4 = xs[:4].reshape((4,) + in_shape)
+    for i in range(4):
+        o0, o1 = alpath.shrunk_grads(om, osess, xs4[i])
+        np.testing.assert_allclose(g0[i], o0, rtol=G_RTOL, atol=G_ATOL)
+        np.testing.assert_allclose(g1[i], o1, rtol=G_RTOL, atol=G_ATOL)
+    model.close()
+    model2.close()
+
+
+def test_argument_errors(sess):
+    from nnal_amd import device
+    from nnal_amd._lib import AlqError
+    ld = netspec.net_a()
+    m = device.DeviceModel(sess, ld, (32, 32, 1), max_batch=8)
+    with pytest.raises(AlqError):           # weights not set
+        m.forward(np.zeros((2, 32, 32, 1), np.float32))
+    with pytest.raises(ValueError):
+        m.set_weights({k: [np.zeros((1,)), np.zeros((1,))] for k in m.var_names})
+    with pytest.raises(NotImplementedError):
+        sess.run(m.grad_posts['0'], {m.x: np.zeros((1, 32, 32, 1))})
+    m.close()
+    with pytest.raises(NotImplementedError):
+        device.translate_layers({'a': ['conv', [4, [3, 3]], 'MBA'], 'f': ['fc', [2]]}, (8, 8, 1))

@@ -43,7 +43,7 @@ def main():
     ap.add_argument('--batch', type=int, default=256, help='patches per device pass')
     ap.add_argument('--topB', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=24)
+    ap.add_argument('--cpu-sample', type=int, default=16)
     args = ap.parse_args()
 
     import torch
@@ -83,8 +83,14 @@ def main():
     def step():
         return pool_shard.score_pool(model, sess, x, n_global, args.topB, 1e-3)
 
+    def note(msg):
+        if rank == 0:
+            print('[bench] ' + msg, file=sys.stderr, flush=True)
+
+    note('pool of %d patches resident (%.1f GB); warm-up' % (n_local, n_local * epp * 4 / 1e9))
     for _ in range(args.warmup):
         step()
+    note('timing %d step(s)' % args.steps)
     sess.prof_reset()
     sess.prof_enable(True)          # HIP events around every GEMM-engine launch, on our stream
     pool_shard.barrier()
@@ -133,6 +139,7 @@ def main():
                          'hbm_algorithmic_GBps': B_ALG * value / ws / 1e9,
                          'time_share': {k: v['ms'] for k, v in prof.items()}},
         }
+        note('GPU: %.1f patches/s; timing the CPU baseline' % value)
         if not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(x[:args.cpu_sample].cpu().numpy(), ld, sk, in_shape, pars)
         print(json.dumps(line))
@@ -148,7 +155,13 @@ def cpu_baseline(xs, ld, sk, in_shape, pars):
     import torch
     from oracle import alpath
     from oracle.model import OracleModel, OracleSession
-    cores = os.cpu_count() or 1
+    # the box's CPU share, not the host's core count (a cgroup-limited container reports all
+    # host cores in os.cpu_count(); oversubscribing them stalls OpenMP)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
     torch.set_num_threads(cores)
     om = OracleModel(ld, in_shape, pars, skips=sk)
     osess = OracleSession(om)

@@ -74,6 +74,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise AlqError('%s is missing: run `python __graft_entry__.py` (or csrc/build.sh); there is no '
                            'CPU fallback for the device path' % LIB_PATH)
+        # libalq.so needs libamdhip64.so.7; PyTorch-ROCm ships its own copy under that SONAME.  Load
+        # torch FIRST so that the process holds ONE HIP runtime and torch's device pointers and
+        # stream handles are valid inside libalq (loading libalq first would pull in /opt/rocm's
+        # copy beside torch's: two runtimes, "no ROCm-capable device" on the second).
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)

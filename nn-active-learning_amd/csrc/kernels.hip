@@ -177,9 +177,54 @@ __global__ void mask_chansum_kernel(float *d, int cs, int c0, int C, const float
     }
 }
 
+// Long rows (fc layers: one "voxel" per patch with thousands of channels): one workgroup per
+// row, float4 loads, block reduction.
+__global__ __launch_bounds__(256) void rowsum_kernel(float *d, int cs, int c0, int C, const float *act,
+                                                     int acs, int ac0, float *field) {
+    __shared__ double sh[4];
+    const long long v = blockIdx.x;
+    float *row = d + v * cs + c0;
+    const float *arow = act ? act + v * acs + ac0 : nullptr;
+    const bool vec = ((cs | c0 | C | acs | ac0) & 3) == 0;
+    float s = 0.f;
+    if (vec) {
+        for (int c = threadIdx.x * 4; c < C; c += 1024) {
+            f32x4 q = *reinterpret_cast<f32x4 *>(row + c);
+            if (arow) {
+                const f32x4 m = *reinterpret_cast<const f32x4 *>(arow + c);
+                q.x = m.x > 0.f ? q.x : 0.f;
+                q.y = m.y > 0.f ? q.y : 0.f;
+                q.z = m.z > 0.f ? q.z : 0.f;
+                q.w = m.w > 0.f ? q.w : 0.f;
+                *reinterpret_cast<f32x4 *>(row + c) = q;
+            }
+            s += (q.x + q.y) + (q.z + q.w);
+        }
+    } else {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float q = row[c];
+            if (arow) {
+                q = arow[c] > 0.f ? q : 0.f;
+                row[c] = q;
+            }
+            s += q;
+        }
+    }
+    const double tot = block_sum256((double)s, sh);
+    if (threadIdx.x == 0) field[v] = (float)tot;
+}
+
+constexpr int ROW_KERNEL_MIN_C = 512;
+
 int k_chansum(alq_ctx *ctx, const View &in, float *field, int N) {
     const long long nvox = (long long)N * in.vox();
     ProfScope ps(ctx, PROF_ELEMWISE, 0);
+    if (in.C >= ROW_KERNEL_MIN_C) {
+        hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)nvox), dim3(256), 0, ctx->stream, in.p, in.cs, in.c0,
+                           in.C, (const float *)nullptr, 0, 0, field);
+        ALQ_LAUNCH_CHECK();
+        return ALQ_OK;
+    }
     hipLaunchKernelGGL(chansum_kernel, dim3(grid_for(nvox)), dim3(256), 0, ctx->stream, in.p, in.cs, in.c0,
                        in.C, field, nvox);
     ALQ_LAUNCH_CHECK();
@@ -189,6 +234,12 @@ int k_chansum(alq_ctx *ctx, const View &in, float *field, int N) {
 int k_mask_chansum(alq_ctx *ctx, const View &dact, const View *act, float *field, int N) {
     const long long nvox = (long long)N * dact.vox();
     ProfScope ps(ctx, PROF_ELEMWISE, 0);
+    if (dact.C >= ROW_KERNEL_MIN_C) {
+        hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)nvox), dim3(256), 0, ctx->stream, dact.p, dact.cs,
+                           dact.c0, dact.C, act ? act->p : nullptr, act ? act->cs : 0, act ? act->c0 : 0, field);
+        ALQ_LAUNCH_CHECK();
+        return ALQ_OK;
+    }
     hipLaunchKernelGGL(mask_chansum_kernel, dim3(grid_for(nvox)), dim3(256), 0, ctx->stream, dact.p, dact.cs,
                        dact.c0, dact.C, act ? act->p : nullptr, act ? act->cs : 0, act ? act->c0 : 0, field,
                        nvox);

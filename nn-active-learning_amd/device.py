@@ -36,6 +36,26 @@ class Handle(object):
 
 
 _default_session = None
+_live = None   # weak set of sessions / models, closed at interpreter exit BEFORE the HIP runtime unloads
+
+
+def _track(obj):
+    global _live
+    if _live is None:
+        import atexit
+        import weakref
+        _live = weakref.WeakSet()
+
+        def _close_all():
+            objs = list(_live)
+            for o in objs:                      # models first: they hold device memory of a context
+                if isinstance(o, DeviceModel):
+                    o.close()
+            for o in objs:
+                if isinstance(o, DeviceSession):
+                    o.close()
+        atexit.register(_close_all)
+    _live.add(obj)
 
 
 def default_session():
@@ -62,6 +82,7 @@ class DeviceSession(object):
         self._ctx = C.c_void_p()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         check(self.lib.alq_ctx_create(device, C.c_void_p(stream), C.byref(self._ctx)))
+        _track(self)
 
     @property
     def ctx(self):
@@ -261,6 +282,7 @@ class DeviceModel(object):
         self._m = C.c_void_p()
         cd = (C.c_int32 * 4)(*dims)
         check(self.lib.alq_model_create(sess.ctx, arr, len(self.layers), cd, self.max_batch, C.byref(self._m)))
+        _track(self)
         self.L = self.lib.alq_model_num_param_layers(self._m)
         self.nclass = self.layers[-1]['cout']
         self.elems_per_patch = int(np.prod(self.in_shape))

@@ -154,10 +154,11 @@ int k_pool_bwd(alq_ctx *, const View &dout, const View &din, const uint8_t *argm
                const int w[3], const int lo[3], int N, int accumulate);
 int k_chansum(alq_ctx *, const View &in, float *field, int N);
 int k_mask_chansum(alq_ctx *, const View &dact, const View *act_or_null, float *field, int N);
+int boxdot_slabs(long long vox);
 int k_boxdot_conv(alq_ctx *, const float *dsum, const float *asum, int D, int H, int W,
-                  const int k[3], const int lo[3], int N, double *S_out, int ldS);
+                  const int k[3], const int lo[3], int N, double *Spart, int nslab_max);
 int k_boxdot_convT(alq_ctx *, const float *dsum, const float *asum, int ID, int IH, int IW,
-                   const int k[3], const int s[3], const int lo[3], int N, double *S_out, int ldS);
+                   const int k[3], const int s[3], const int lo[3], int N, double *Spart, int nslab_max);
 int k_fc_small_fwd(alq_ctx *, const float *act, int64_t F, const float *Wp, int nout, int N,
                    float *partials, int nslices);
 int k_fc_small_finish(alq_ctx *, const float *partials, int nslices, const float *bias, int nout,
@@ -166,9 +167,10 @@ int k_fc_small_bwd(alq_ctx *, const float *delta, int nout, const float *Wp, int
                    float *dact);
 int k_softmax(alq_ctx *, const float *logits, int c, int N, float *post_cN, int64_t *pred);
 int k_fill_unit_cotangent(alq_ctx *, float *dlogits, int N);
-int k_fisher_finalize(alq_ctx *, const double *S, int L, const double *sizes, const float *post_cN,
-                      const float *p1_branch, int N, double diag_load, float *p1_out, double *g0,
-                      double *g1, double *A, double *trace, double *Apart, int *nblocks_out);
+int k_fisher_finalize(alq_ctx *, const double *Spart, const int *nslab, int nslab_max, int max_batch, double *S,
+                      int L, const double *sizes, const float *post_cN, const float *p1_branch, int N,
+                      double diag_load, float *p1_out, double *g0, double *g1, double *A, double *trace,
+                      double *Apart, int *nblocks_out);
 int k_reduce_Asum(alq_ctx *, const double *Apart, int nblocks, int LL, double *Asum);
 int fc_small_slices(int64_t F);
 

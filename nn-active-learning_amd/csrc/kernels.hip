@@ -8,6 +8,8 @@ namespace alq {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int BOX_SLAB = 1024;   // voxels per box-dot workgroup
+
 __device__ inline double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -91,6 +93,76 @@ __global__ void pool_bwd_kernel(const float *dout, int do_cs, int do_c0, int C, 
     }
 }
 
+
+// float4-over-channels variants (C % 4 == 0, 16-byte aligned slices): one thread per (voxel, 4 channels)
+__global__ void pool_fwd_vec_kernel(const float *in, int in_cs, int in_c0, int C4, int ID, int IH, int IW,
+                                    float *out, int out_cs, int out_c0, int OD, int OH, int OW,
+                                    uint8_t *argmax, int wz, int wy, int wx, int lz, int ly, int lx,
+                                    long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int c4 = r % C4; r /= C4;
+        const int ox = r % OW; r /= OW;
+        const int oy = r % OH; r /= OH;
+        const int oz = r % OD; r /= OD;
+        const long long n = r;
+        f32x4 best = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+        for (int dz = 0; dz < wz; ++dz) {
+            const int iz = oz * wz - lz + dz;
+            if (iz < 0 || iz >= ID) continue;
+            for (int dy = 0; dy < wy; ++dy) {
+                const int iy = oy * wy - ly + dy;
+                if (iy < 0 || iy >= IH) continue;
+                for (int dx = 0; dx < wx; ++dx) {
+                    const int ix = ox * wx - lx + dx;
+                    if (ix < 0 || ix >= IW) continue;
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(
+                        in + ((((n * ID + iz) * IH + iy) * IW + ix)) * in_cs + in_c0 + c4 * 4);
+                    const int w = (dz * wy + dy) * wx + dx;
+                    if (v.x > best.x) { best.x = v.x; b0 = w; }
+                    if (v.y > best.y) { best.y = v.y; b1 = w; }
+                    if (v.z > best.z) { best.z = v.z; b2 = w; }
+                    if (v.w > best.w) { best.w = v.w; b3 = w; }
+                }
+            }
+        }
+        *reinterpret_cast<f32x4 *>(out + (((n * OD + oz) * OH + oy) * OW + ox) * out_cs + out_c0 + c4 * 4) = best;
+        reinterpret_cast<unsigned *>(argmax)[i] = (unsigned)b0 | ((unsigned)b1 << 8) | ((unsigned)b2 << 16) | ((unsigned)b3 << 24);
+    }
+}
+
+__global__ void pool_bwd_vec_kernel(const float *dout, int do_cs, int do_c0, int C4, int OD, int OH, int OW,
+                                    float *din, int di_cs, int di_c0, int ID, int IH, int IW,
+                                    const uint8_t *argmax, int wz, int wy, int wx, int lz, int ly, int lx,
+                                    int accumulate, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int c4 = r % C4; r /= C4;
+        const int ix = r % IW; r /= IW;
+        const int iy = r % IH; r /= IH;
+        const int iz = r % ID; r /= ID;
+        const long long n = r;
+        const int oz = (iz + lz) / wz, oy = (iy + ly) / wy, ox = (ix + lx) / wx;
+        f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (oz < OD && oy < OH && ox < OW) {
+            const unsigned widx = (((iz + lz) - oz * wz) * wy + ((iy + ly) - oy * wy)) * wx + ((ix + lx) - ox * wx);
+            const long long o = (((n * OD + oz) * OH + oy) * OW + ox);
+            const unsigned am = reinterpret_cast<const unsigned *>(argmax)[o * C4 + c4];
+            const f32x4 d = *reinterpret_cast<const f32x4 *>(dout + o * do_cs + do_c0 + c4 * 4);
+            g.x = ((am & 255u) == widx) ? d.x : 0.f;
+            g.y = (((am >> 8) & 255u) == widx) ? d.y : 0.f;
+            g.z = (((am >> 16) & 255u) == widx) ? d.z : 0.f;
+            g.w = ((am >> 24) == widx) ? d.w : 0.f;
+        }
+        f32x4 *dst = reinterpret_cast<f32x4 *>(din + ((((n * ID + iz) * IH + iy) * IW + ix)) * di_cs + di_c0 + c4 * 4);
+        if (accumulate) g += *dst;
+        *dst = g;
+    }
+}
+
 static unsigned grid_for(long long total, int block = 256, int cap = 256 * 32) {
     long long g = (total + block - 1) / block;
     if (g > cap) g = cap;
@@ -102,6 +174,13 @@ int k_pool_fwd(alq_ctx *ctx, const View &in, const View &out, uint8_t *argmax, c
                const int lo[3], int N) {
     const long long total = (long long)N * out.vox() * out.C;
     ProfScope ps(ctx, PROF_ELEMWISE, 0);
+    if (((in.cs | in.c0 | in.C | out.cs | out.c0) & 3) == 0) {
+        hipLaunchKernelGGL(pool_fwd_vec_kernel, dim3(grid_for(total / 4)), dim3(256), 0, ctx->stream, in.p, in.cs,
+                           in.c0, in.C / 4, in.D, in.H, in.W, out.p, out.cs, out.c0, out.D, out.H, out.W, argmax,
+                           w[0], w[1], w[2], lo[0], lo[1], lo[2], total / 4);
+        ALQ_LAUNCH_CHECK();
+        return ALQ_OK;
+    }
     hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, in.p, in.cs,
                        in.c0, in.C, in.D, in.H, in.W, out.p, out.cs, out.c0, out.D, out.H, out.W, argmax,
                        w[0], w[1], w[2], lo[0], lo[1], lo[2], total);
@@ -113,6 +192,13 @@ int k_pool_bwd(alq_ctx *ctx, const View &dout, const View &din, const uint8_t *a
                const int lo[3], int N, int accumulate) {
     const long long total = (long long)N * din.vox() * din.C;
     ProfScope ps(ctx, PROF_ELEMWISE, 0);
+    if (((din.cs | din.c0 | din.C | dout.cs | dout.c0) & 3) == 0) {
+        hipLaunchKernelGGL(pool_bwd_vec_kernel, dim3(grid_for(total / 4)), dim3(256), 0, ctx->stream, dout.p,
+                           dout.cs, dout.c0, dout.C / 4, dout.D, dout.H, dout.W, din.p, din.cs, din.c0, din.D, din.H,
+                           din.W, argmax, w[0], w[1], w[2], lo[0], lo[1], lo[2], accumulate, total / 4);
+        ALQ_LAUNCH_CHECK();
+        return ALQ_OK;
+    }
     hipLaunchKernelGGL(pool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, dout.p, dout.cs,
                        dout.c0, dout.C, dout.D, dout.H, dout.W, din.p, din.cs, din.c0, din.D, din.H, din.W,
                        argmax, w[0], w[1], w[2], lo[0], lo[1], lo[2], accumulate, total);
@@ -214,6 +300,59 @@ __global__ __launch_bounds__(256) void rowsum_kernel(float *d, int cs, int c0, i
     if (threadIdx.x == 0) field[v] = (float)tot;
 }
 
+
+// G lanes per voxel, each lane one float4 per step: consecutive lanes read consecutive 16 B, so a
+// wave instruction covers whole 128-B lines; the G partial sums meet through xor-shuffles.
+template <int G>
+__global__ void chansum_grp_kernel(float *d, int cs, int c0, int C, const float *act, int acs, int ac0,
+                                   float *field, long long nvox) {
+    const long long total = nvox * G;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < ((total + 63) & ~63LL);
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long v = i / G;
+        const int sub = (int)(i - v * G);
+        float s = 0.f;
+        if (v < nvox) {
+            float *row = d + v * cs + c0;
+            const float *arow = act ? act + v * acs + ac0 : nullptr;
+            for (int c = sub * 4; c < C; c += 4 * G) {
+                f32x4 q = *reinterpret_cast<f32x4 *>(row + c);
+                if (arow) {
+                    const f32x4 m = *reinterpret_cast<const f32x4 *>(arow + c);
+                    q.x = m.x > 0.f ? q.x : 0.f;
+                    q.y = m.y > 0.f ? q.y : 0.f;
+                    q.z = m.z > 0.f ? q.z : 0.f;
+                    q.w = m.w > 0.f ? q.w : 0.f;
+                    *reinterpret_cast<f32x4 *>(row + c) = q;
+                }
+                s += (q.x + q.y) + (q.z + q.w);
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) s += __shfl_xor(s, o, 64);
+        if (sub == 0 && v < nvox) field[v] = s;
+    }
+}
+
+static int lanes_per_voxel(int C) {
+    const int q = C / 4;
+    int g = 1;
+    while (g < 8 && q % (g * 2) == 0) g *= 2;
+    return g;
+}
+
+static int launch_chansum_grp(alq_ctx *ctx, float *d, int cs, int c0, int C, const float *act, int acs, int ac0,
+                              float *field, long long nvox) {
+    const int G = lanes_per_voxel(C);
+    const unsigned grid = grid_for(nvox * G);
+#define ALQ_CS(GV) \
+    case GV: hipLaunchKernelGGL(chansum_grp_kernel<GV>, dim3(grid), dim3(256), 0, ctx->stream, d, cs, c0, C, act, acs, ac0, field, nvox); break
+    switch (G) { ALQ_CS(1); ALQ_CS(2); ALQ_CS(4); ALQ_CS(8); }
+#undef ALQ_CS
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
 constexpr int ROW_KERNEL_MIN_C = 512;
 
 int k_chansum(alq_ctx *ctx, const View &in, float *field, int N) {
@@ -225,6 +364,8 @@ int k_chansum(alq_ctx *ctx, const View &in, float *field, int N) {
         ALQ_LAUNCH_CHECK();
         return ALQ_OK;
     }
+    if (((in.cs | in.c0 | in.C) & 3) == 0)
+        return launch_chansum_grp(ctx, in.p, in.cs, in.c0, in.C, nullptr, 0, 0, field, nvox);
     hipLaunchKernelGGL(chansum_kernel, dim3(grid_for(nvox)), dim3(256), 0, ctx->stream, in.p, in.cs, in.c0,
                        in.C, field, nvox);
     ALQ_LAUNCH_CHECK();
@@ -240,6 +381,9 @@ int k_mask_chansum(alq_ctx *ctx, const View &dact, const View *act, float *field
         ALQ_LAUNCH_CHECK();
         return ALQ_OK;
     }
+    if (((dact.cs | dact.c0 | dact.C | (act ? (act->cs | act->c0) : 0)) & 3) == 0)
+        return launch_chansum_grp(ctx, dact.p, dact.cs, dact.c0, dact.C, act ? act->p : nullptr, act ? act->cs : 0,
+                                  act ? act->c0 : 0, field, nvox);
     hipLaunchKernelGGL(mask_chansum_kernel, dim3(grid_for(nvox)), dim3(256), 0, ctx->stream, dact.p, dact.cs,
                        dact.c0, dact.C, act ? act->p : nullptr, act ? act->cs : 0, act ? act->c0 : 0, field,
                        nvox);
@@ -249,17 +393,20 @@ int k_mask_chansum(alq_ctx *ctx, const View &dact, const View *act, float *field
 
 // =========================================================================== box-dot reductions
 // conv / fc:  S[n] = sum_x dsum[n,x] * (1 + sum_taps asum[n, x + tap - lo])   (zero outside)
-// One workgroup per patch, fp64 accumulation, fixed order -> deterministic.
+// grid (slabs, N): each workgroup reduces a contiguous slab of BOX_SLAB voxels in fp64 and writes
+// one partial; fisher_finalize adds the slab partials in slab order -> deterministic.
 __global__ __launch_bounds__(256) void boxdot_conv_kernel(const float *dsum, const float *asum, int D, int H,
                                                           int W, int kz, int ky, int kx, int lz, int ly,
-                                                          int lx, double *S, int ldS) {
+                                                          int lx, double *Spart, int nslab_max) {
     __shared__ double sh[4];
-    const long long n = blockIdx.x;
+    const long long n = blockIdx.y;
+    const int slab = blockIdx.x;
     const int vox = D * H * W;
     const float *dn = dsum + n * vox;
     const float *an = asum + n * vox;
     double acc = 0;
-    for (int v = threadIdx.x; v < vox; v += 256) {
+    const int v1 = min(vox, (slab + 1) * BOX_SLAB);
+    for (int v = slab * BOX_SLAB + threadIdx.x; v < v1; v += 256) {
         const float dv = dn[v];
         int r = v;
         const int x = r % W; r /= W;
@@ -282,23 +429,25 @@ __global__ __launch_bounds__(256) void boxdot_conv_kernel(const float *dsum, con
         acc += (double)dv * ((double)box + 1.0);
     }
     const double tot = block_sum256(acc, sh);
-    if (threadIdx.x == 0) S[n * ldS] = tot;
+    if (threadIdx.x == 0) Spart[n * nslab_max + slab] = tot;
 }
 
 // conv_transpose: S[n] = sum_q asum[n,q] * sum_t dsum[n, s*q + t - lo] + sum_p dsum[n,p]
-// (q on the INPUT grid, p on the output grid = s * input grid)
+// (q on the INPUT grid, p on the output grid = s * input grid); slabs over q
 __global__ __launch_bounds__(256) void boxdot_convT_kernel(const float *dsum, const float *asum, int ID,
                                                            int IH, int IW, int kz, int ky, int kx, int sz,
-                                                           int sy, int sx, int lz, int ly, int lx, double *S,
-                                                           int ldS) {
+                                                           int sy, int sx, int lz, int ly, int lx,
+                                                           double *Spart, int nslab_max) {
     __shared__ double sh[4];
-    const long long n = blockIdx.x;
+    const long long n = blockIdx.y;
+    const int slab = blockIdx.x;
     const int OD = ID * sz, OH = IH * sy, OW = IW * sx;
     const int ivox = ID * IH * IW;
     const float *dn = dsum + n * (long long)OD * OH * OW;
     const float *an = asum + n * ivox;
     double acc = 0;
-    for (int v = threadIdx.x; v < ivox; v += 256) {
+    const int v1 = min(ivox, (slab + 1) * BOX_SLAB);
+    for (int v = slab * BOX_SLAB + threadIdx.x; v < v1; v += 256) {
         int r = v;
         const int x = r % IW; r /= IW;
         const int y = r % IH;
@@ -326,23 +475,26 @@ __global__ __launch_bounds__(256) void boxdot_convT_kernel(const float *dsum, co
         acc += (double)an[v] * (double)box + (double)own;
     }
     const double tot = block_sum256(acc, sh);
-    if (threadIdx.x == 0) S[n * ldS] = tot;
+    if (threadIdx.x == 0) Spart[n * nslab_max + slab] = tot;
 }
 
+int boxdot_slabs(long long vox) { return (int)((vox + BOX_SLAB - 1) / BOX_SLAB); }
+
 int k_boxdot_conv(alq_ctx *ctx, const float *dsum, const float *asum, int D, int H, int W, const int k[3],
-                  const int lo[3], int N, double *S_out, int ldS) {
+                  const int lo[3], int N, double *Spart, int nslab_max) {
     ProfScope ps(ctx, PROF_REDUCE, 0);
-    hipLaunchKernelGGL(boxdot_conv_kernel, dim3(N), dim3(256), 0, ctx->stream, dsum, asum, D, H, W, k[0], k[1],
-                       k[2], lo[0], lo[1], lo[2], S_out, ldS);
+    hipLaunchKernelGGL(boxdot_conv_kernel, dim3(boxdot_slabs((long long)D * H * W), N), dim3(256), 0, ctx->stream,
+                       dsum, asum, D, H, W, k[0], k[1], k[2], lo[0], lo[1], lo[2], Spart, nslab_max);
     ALQ_LAUNCH_CHECK();
     return ALQ_OK;
 }
 
 int k_boxdot_convT(alq_ctx *ctx, const float *dsum, const float *asum, int ID, int IH, int IW, const int k[3],
-                   const int s[3], const int lo[3], int N, double *S_out, int ldS) {
+                   const int s[3], const int lo[3], int N, double *Spart, int nslab_max) {
     ProfScope ps(ctx, PROF_REDUCE, 0);
-    hipLaunchKernelGGL(boxdot_convT_kernel, dim3(N), dim3(256), 0, ctx->stream, dsum, asum, ID, IH, IW, k[0],
-                       k[1], k[2], s[0], s[1], s[2], lo[0], lo[1], lo[2], S_out, ldS);
+    hipLaunchKernelGGL(boxdot_convT_kernel, dim3(boxdot_slabs((long long)ID * IH * IW), N), dim3(256), 0,
+                       ctx->stream, dsum, asum, ID, IH, IW, k[0], k[1], k[2], s[0], s[1], s[2], lo[0], lo[1], lo[2],
+                       Spart, nslab_max);
     ALQ_LAUNCH_CHECK();
     return ALQ_OK;
 }
@@ -531,8 +683,9 @@ __global__ void entropy_kernel(const float *p1, long long n, double *absdev, flo
 //   (NNAL_tools.py:793-796); three-way saturation branch and A_i of PW_NNAL.py:770-814.
 constexpr int FIN_BLOCK = 64;
 __global__ __launch_bounds__(FIN_BLOCK) void fisher_finalize_kernel(
-    const double *S, int L, const double *sizes, const float *post, const float *p1_branch, int N,
-    double diag_load, float *p1_out, double *g0o, double *g1o, double *Ao, double *tro, double *Apart) {
+    const double *Spart, const int *nslab, int nslab_max, int max_batch, double *S, int L, const double *sizes,
+    const float *post, const float *p1_branch, int N, double diag_load, float *p1_out, double *g0o, double *g1o,
+    double *Ao, double *tro, double *Apart) {
     const int n = blockIdx.x * FIN_BLOCK + threadIdx.x;
     const bool live = n < N;
     double g0[16], g1[16];
@@ -546,7 +699,11 @@ __global__ __launch_bounds__(FIN_BLOCK) void fisher_finalize_kernel(
         if (p < 1e-6) { p = 0.; use1 = false; }
         else if (p > 1. - 1e-6) { p = 1.; use0 = false; }
         for (int t = 0; t < L; ++t) {
-            const double s = S[(long long)n * L + t];
+            // slab partials of layer t, added in slab order (fixed -> run-to-run identical)
+            const double *sp = Spart + ((long long)t * max_batch + n) * nslab_max;
+            double s = 0;
+            for (int k = 0; k < nslab[t]; ++k) s += sp[k];
+            S[(long long)n * L + t] = s;
             const float s0 = (float)((double)p1f * s);
             const float s1 = (float)(-(double)p0f * s);
             g0[t] = use0 ? (double)s0 / sizes[t] : 0.;
@@ -578,14 +735,15 @@ __global__ void reduce_Asum_kernel(const double *Apart, int nblocks, int LL, dou
     Asum[e] = s;
 }
 
-int k_fisher_finalize(alq_ctx *ctx, const double *S, int L, const double *sizes, const float *post_cN,
-                      const float *p1_branch, int N, double diag_load, float *p1_out, double *g0, double *g1,
-                      double *A, double *trace, double *Apart, int *nblocks_out) {
+int k_fisher_finalize(alq_ctx *ctx, const double *Spart, const int *nslab, int nslab_max, int max_batch, double *S,
+                      int L, const double *sizes, const float *post_cN, const float *p1_branch, int N,
+                      double diag_load, float *p1_out, double *g0, double *g1, double *A, double *trace,
+                      double *Apart, int *nblocks_out) {
     ALQ_REQUIRE(L <= 16, ALQ_EUNSUPPORTED, "fisher: %d parameterised layers > 16", L);
     const int nb = (N + FIN_BLOCK - 1) / FIN_BLOCK;
     ProfScope ps(ctx, PROF_REDUCE, 0);
-    hipLaunchKernelGGL(fisher_finalize_kernel, dim3(nb), dim3(FIN_BLOCK), 0, ctx->stream, S, L, sizes, post_cN,
-                       p1_branch, N, diag_load, p1_out, g0, g1, A, trace, Apart);
+    hipLaunchKernelGGL(fisher_finalize_kernel, dim3(nb), dim3(FIN_BLOCK), 0, ctx->stream, Spart, nslab, nslab_max,
+                       max_batch, S, L, sizes, post_cN, p1_branch, N, diag_load, p1_out, g0, g1, A, trace, Apart);
     ALQ_LAUNCH_CHECK();
     *nblocks_out = nb;
     return ALQ_OK;

@@ -75,6 +75,9 @@ struct alq_model {
     std::vector<void *> allocs;
     float *logits = nullptr, *dlogits = nullptr, *post = nullptr;
     double *S = nullptr, *sizes = nullptr, *Apart = nullptr;
+    double *Spart = nullptr;       // [L][max_batch][nslab_max] box-dot slab partials
+    int *nslab = nullptr;          // [L] slabs actually written per layer
+    int nslab_max = 1;
     float *x_stage = nullptr;
 
     template <typename T>
@@ -397,6 +400,17 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
         }
     }
     ALQ_HIP(hipMemcpy(m->sizes, h_sizes.data(), m->L * sizeof(double), hipMemcpyHostToDevice));
+    // box-dot slab partials: conv / fc reduce over the OUTPUT grid, conv_transpose over the input grid
+    std::vector<int> h_nslab(m->L, 1);
+    for (const Layer &ly : m->layers) {
+        if (ly.pidx < 0) continue;
+        long long vox = ly.spec.type == ALQ_FC ? 1 : (ly.spec.type == ALQ_CONVT ? ly.in.vox() : ly.out.vox());
+        h_nslab[ly.pidx] = boxdot_slabs(vox);
+        m->nslab_max = std::max(m->nslab_max, h_nslab[ly.pidx]);
+    }
+    ALQ_TRY(m->dalloc(&m->nslab, (size_t)m->L));
+    ALQ_TRY(m->dalloc(&m->Spart, (size_t)m->L * NB * m->nslab_max));
+    ALQ_HIP(hipMemcpy(m->nslab, h_nslab.data(), m->L * sizeof(int), hipMemcpyHostToDevice));
     return ALQ_OK;
 }
 
@@ -463,14 +477,14 @@ static int run_backward(alq_model *m, int N) {
         View dv = isfc ? flat_view(ly.dout) : ly.dout;
         View av = isfc ? flat_view(ly.out) : ly.out;
         ALQ_TRY(k_mask_chansum(ctx, dv, ly.spec.relu ? &av : nullptr, ly.dsum, N));
-        double *Sdst = m->S + ly.pidx;
+        double *Sdst = m->Spart + (size_t)ly.pidx * m->max_batch * m->nslab_max;
         if (ly.spec.type == ALQ_CONVT) {
-            ALQ_TRY(k_boxdot_convT(ctx, ly.dsum, ly.asum, ly.in.D, ly.in.H, ly.in.W, ly.spec.k, ly.spec.s, ly.lo, N, Sdst, m->L));
+            ALQ_TRY(k_boxdot_convT(ctx, ly.dsum, ly.asum, ly.in.D, ly.in.H, ly.in.W, ly.spec.k, ly.spec.s, ly.lo, N, Sdst, m->nslab_max));
         } else if (isfc) {
             const int one[3] = {1, 1, 1}, zero[3] = {0, 0, 0};
-            ALQ_TRY(k_boxdot_conv(ctx, ly.dsum, ly.asum, 1, 1, 1, one, zero, N, Sdst, m->L));
+            ALQ_TRY(k_boxdot_conv(ctx, ly.dsum, ly.asum, 1, 1, 1, one, zero, N, Sdst, m->nslab_max));
         } else {
-            ALQ_TRY(k_boxdot_conv(ctx, ly.dsum, ly.asum, ly.out.D, ly.out.H, ly.out.W, ly.spec.k, ly.lo, N, Sdst, m->L));
+            ALQ_TRY(k_boxdot_conv(ctx, ly.dsum, ly.asum, ly.out.D, ly.out.H, ly.out.W, ly.spec.k, ly.lo, N, Sdst, m->nslab_max));
         }
         if (ly.pidx == 0) break;   // nothing upstream needs a cotangent
         const int acc = prev_is_src ? 1 : 0;   // the skip destination has already written this slice
@@ -737,8 +751,8 @@ int alq_fisher(alq_model *m, const float *d_x, int N, const float *d_p1_in, doub
     ALQ_TRY(k_softmax(m->ctx, m->logits, m->nclass, N, m->post, nullptr));
     ALQ_TRY(run_backward(m, N));
     int nblocks = 0;
-    ALQ_TRY(k_fisher_finalize(m->ctx, m->S, m->L, m->sizes, m->post, d_p1_in, N, diag_load, d_p1_out, d_g0, d_g1,
-                              d_A, d_trace, m->Apart, &nblocks));
+    ALQ_TRY(k_fisher_finalize(m->ctx, m->Spart, m->nslab, m->nslab_max, m->max_batch, m->S, m->L, m->sizes, m->post,
+                              d_p1_in, N, diag_load, d_p1_out, d_g0, d_g1, d_A, d_trace, m->Apart, &nblocks));
     if (d_Asum) ALQ_TRY(k_reduce_Asum(m->ctx, m->Apart, nblocks, m->L * m->L, d_Asum));
     return ALQ_OK;
 }

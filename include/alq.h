@@ -145,6 +145,11 @@ int alq_prof_read(alq_ctx *ctx, int cls, double *ms, int64_t *launches, double *
 int alq_model_debug_copy(alq_model *m, int layer_idx, int what, int N, float *d_out,
                          int64_t *elems_out);
 
+/* Diagnostic builds only (-DALQ_STAMPS): device buffer of 8 uint64 per workgroup that receives the
+ * per-phase shader-clock ticks of the pipelined GEMM kernel's next launches; NULL switches it off.
+ * A no-op in the product build.                                                               */
+int alq_debug_set_stamp_buffer(void *d_buf);
+
 /* Synthetic patch generator: counter-based RNG keyed (seed, patch_id, element), standard
  * normal, written to d_out [n, elems_per_patch] for patch ids first_id .. first_id+n-1
  * (shards are reproducible whatever the sharding).                    */

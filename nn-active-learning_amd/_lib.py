@@ -5,7 +5,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libalq.so')
+LIB_PATH = os.path.join(_HERE, os.environ.get('ALQ_LIB', 'libalq.so'))   # ALQ_LIB: diagnostic builds
 BUILD_SCRIPT = os.path.join(_HERE, 'csrc', 'build.sh')
 
 ALQ_CONV, ALQ_CONVT, ALQ_POOL, ALQ_FC = 0, 1, 2, 3
@@ -48,6 +48,7 @@ _SIGNATURES = {
     'alq_prof_class_name': (C.c_char_p, [C.c_int]),
     'alq_prof_read': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     'alq_model_debug_copy': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_int64)]),
+    'alq_debug_set_stamp_buffer': (C.c_int, [_P]),
     'alq_synth_patches': (C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, _P]),
 }
 

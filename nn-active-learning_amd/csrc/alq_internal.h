@@ -147,6 +147,60 @@ void igemm_pack_weights(IgemmPlan *plan, const std::vector<float> &Bmat /* [K][C
 int igemm_launch(alq_ctx *ctx, const IgemmPlan &plan, const View &in, const View &out,
                  const float *bias, int relu, int accumulate, int N, int prof_cls);
 
+// ------------------------------------------------------------------ pipelined engine (igemm2.hip)
+struct Igemm2Args {
+    const float *in;
+    float *out;
+    const float *W;      // packed [chunk][tap][tile][lane][2]
+    const float *bias;
+    const float *mask;   // ReLU-grad mask source (activation of the destination layer) or null
+    float *osumA, *osumB;   // channel sums of the produced rows: columns < split -> A, others -> B
+    int mask_cs, mask_c0, split;
+    int in_cs, in_c0, Ci, ID, IH, IW;
+    int out_cs, out_c0, Co, OD, OH, OW;
+    int MD, MH, MW;
+    int sm, so, ooffz, ooffy, ooffx;
+    int PT, TZ, TY, TX, HZ, HY, HX, rows;
+    int minz, miny, minx;
+    int ntaps, nchunks;
+    int tilesZ, tilesY, tilesX;
+    int N, relu, accumulate;
+    int t0, tsz, tsy, tsx, tnx, tny;   // tap box: LDS offset = t0 + iz*tsz + iy*tsy + ix*tsx
+    int dbg_repeat, dbg_flags;
+    unsigned long long *dbg;   // phase stamps (diagnostic build), else null
+};
+
+struct Igemm2Plan {
+    Igemm2Args a;
+    bool ok = false;
+    bool wres = false;   // all weights resident in LDS (vs one 8-channel chunk staged per step)
+    int NTW = 1;
+    int wgs_per_cu = 1;
+    size_t lds_bytes = 0;
+    double flops_per_patch = 0;
+    std::vector<float> h_W;
+    float *d_W = nullptr;
+};
+
+struct Igemm2Fuse {
+    const float *mask = nullptr;
+    int mask_cs = 0, mask_c0 = 0;
+    float *osumA = nullptr, *osumB = nullptr;
+    int split = 0;       // 0: all columns -> osumA
+};
+
+extern unsigned long long *g_igemm2_dbg;
+int igemm2_build_plan(const IgemmPlan &p1, Igemm2Plan *p2);
+void igemm2_pack_weights(Igemm2Plan *p2, const std::vector<float> &Bmat);
+int igemm2_launch(alq_ctx *ctx, const Igemm2Plan &plan, const View &in, const View &out, const float *bias,
+                  int relu, int accumulate, int N, int prof_cls, const Igemm2Fuse *fuse);
+
+// one contraction = general plan + (when eligible) pipelined plan
+struct Gemm {
+    IgemmPlan p1;
+    Igemm2Plan p2;
+};
+
 // ------------------------------------------------------------------ other kernels
 int k_pool_fwd(alq_ctx *, const View &in, const View &out, uint8_t *argmax, const int w[3],
                const int lo[3], int N);

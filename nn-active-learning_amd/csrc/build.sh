@@ -4,14 +4,15 @@ set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 PKG="$(dirname "$HERE")"
 ROOT="$(dirname "$PKG")"
-OUT="$PKG/libalq.so"
+OUT="$PKG/${ALQ_OUT:-libalq.so}"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -I$HERE -Wall -Wno-unused-function"
-mkdir -p "$HERE/build"
+BUILD="$HERE/build${ALQ_BUILD_TAG:-}"
+mkdir -p "$BUILD"
 pids=()
-for f in igemm kernels topk model; do
-  ( hipcc $FLAGS -c "$HERE/$f.hip" -o "$HERE/build/$f.o" ${ALQ_EXTRA_FLAGS:-} ) &
+for f in igemm igemm2 kernels topk model; do
+  ( hipcc $FLAGS -c "$HERE/$f.hip" -o "$BUILD/$f.o" ${ALQ_EXTRA_FLAGS:-} ) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
-hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT" "$HERE"/build/{igemm,kernels,topk,model}.o
+hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT" "$BUILD"/{igemm,igemm2,kernels,topk,model}.o
 echo "built $OUT"

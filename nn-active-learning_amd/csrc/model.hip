@@ -47,8 +47,8 @@ struct Layer {
     int64_t w_elems = 0, b_elems = 0;
     float *d_bias = nullptr;
     float *d_Wp = nullptr;     // skinny fc: [nout][F] in activation-memory order
-    std::vector<IgemmPlan> fwd;   // 1 plan (conv / fc) or one per output parity class (convT)
-    IgemmPlan bwd;
+    std::vector<Gemm> fwd;        // 1 contraction (conv / fc) or one per output parity class (convT)
+    Gemm bwd;
     bool has_bwd = false;
     bool weights_set = false;
     // workspaces
@@ -134,7 +134,7 @@ int alq_ctx::prof_collect() {
 }
 
 // ------------------------------------------------------------------------------------------
-static int upload(alq_model *m, IgemmPlan *p) {
+static int upload1(alq_model *m, IgemmPlan *p) {
     if (!p->d_W) ALQ_TRY(m->dalloc(&p->d_W, p->h_W.size()));
     ALQ_HIP(hipMemcpyAsync(p->d_W, p->h_W.data(), p->h_W.size() * sizeof(float), hipMemcpyHostToDevice,
                            m->ctx->stream));
@@ -146,6 +146,40 @@ static int upload(alq_model *m, IgemmPlan *p) {
     ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
     std::vector<float>().swap(p->h_W);
     return ALQ_OK;
+}
+
+static bool g_use_v2 = true;
+
+static int gemm_build(const ConvDesc &d, int max_batch, Gemm *g) {
+    ALQ_TRY(igemm_build_plan(d, max_batch, &g->p1));
+    ALQ_TRY(igemm2_build_plan(g->p1, &g->p2));
+    if (!g_use_v2) g->p2.ok = false;
+    return ALQ_OK;
+}
+
+static int gemm_set(alq_model *m, Gemm *g, const std::vector<float> &Bmat) {
+    if (g->p2.ok) {
+        igemm2_pack_weights(&g->p2, Bmat);
+        if (!g->p2.d_W) ALQ_TRY(m->dalloc(&g->p2.d_W, g->p2.h_W.size()));
+        ALQ_HIP(hipMemcpyAsync(g->p2.d_W, g->p2.h_W.data(), g->p2.h_W.size() * sizeof(float), hipMemcpyHostToDevice,
+                               m->ctx->stream));
+        ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
+        std::vector<float>().swap(g->p2.h_W);
+        return ALQ_OK;
+    }
+    igemm_pack_weights(&g->p1, Bmat);
+    return upload1(m, &g->p1);
+}
+
+// returns in *fused whether the epilogue fusion request was honoured (only the pipelined kernel can)
+static int gemm_launch(alq_ctx *ctx, const Gemm &g, const View &in, const View &out, const float *bias, int relu,
+                       int accumulate, int N, int cls, const Igemm2Fuse *fuse = nullptr, bool *fused = nullptr) {
+    if (g.p2.ok) {
+        if (fused) *fused = fuse != nullptr;
+        return igemm2_launch(ctx, g.p2, in, out, bias, relu, accumulate, N, cls, fuse);
+    }
+    if (fused) *fused = false;
+    return igemm_launch(ctx, g.p1, in, out, bias, relu, accumulate, N, cls);
 }
 
 static void enum_taps(const int k[3], std::vector<int> *tz, std::vector<int> *ty, std::vector<int> *tx) {
@@ -318,7 +352,7 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
             enum_taps(sp.k, &d.tz, &d.ty, &d.tx);
             for (size_t t = 0; t < d.tz.size(); ++t) { d.tz[t] -= ly.lo[0]; d.ty[t] -= ly.lo[1]; d.tx[t] -= ly.lo[2]; }
             ly.fwd.resize(1);
-            ALQ_TRY(igemm_build_plan(d, NB, &ly.fwd[0]));
+            ALQ_TRY(gemm_build(d, NB, &ly.fwd[0]));
             if (!first_param) {
                 ConvDesc b;
                 b.ID = ly.out.D; b.IH = ly.out.H; b.IW = ly.out.W; b.Ci = sp.cout;
@@ -328,7 +362,7 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
                 for (size_t t = 0; t < b.tz.size(); ++t) {
                     b.tz[t] = ly.lo[0] - b.tz[t]; b.ty[t] = ly.lo[1] - b.ty[t]; b.tx[t] = ly.lo[2] - b.tx[t];
                 }
-                ALQ_TRY(igemm_build_plan(b, NB, &ly.bwd));
+                ALQ_TRY(gemm_build(b, NB, &ly.bwd));
                 ly.has_bwd = true;
             }
         } else if (sp.type == ALQ_CONVT) {
@@ -356,7 +390,7 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
                         ALQ_REQUIRE(!tl.empty(), ALQ_EUNSUPPORTED, "layer %d: empty conv_transpose class", i);
                         ly.class_taps.push_back(tl);
                         ly.fwd.emplace_back();
-                        ALQ_TRY(igemm_build_plan(d, NB, &ly.fwd.back()));
+                        ALQ_TRY(gemm_build(d, NB, &ly.fwd.back()));
                     }
             ALQ_REQUIRE(sp.s[0] == sp.s[2] || (ly.in.D == 1 && sp.s[0] == 1), ALQ_EUNSUPPORTED,
                         "layer %d: conv_transpose stride must be isotropic", i);
@@ -368,7 +402,7 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
                 b.sm = sp.s[2];
                 enum_taps(sp.k, &b.tz, &b.ty, &b.tx);
                 for (size_t t = 0; t < b.tz.size(); ++t) { b.tz[t] -= ly.lo[0]; b.ty[t] -= ly.lo[1]; b.tx[t] -= ly.lo[2]; }
-                ALQ_TRY(igemm_build_plan(b, NB, &ly.bwd));
+                ALQ_TRY(gemm_build(b, NB, &ly.bwd));
                 ly.has_bwd = true;
             }
         } else if (sp.type == ALQ_POOL) {
@@ -389,11 +423,11 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
                 d.MD = d.MH = d.MW = 1;
                 d.tz = {0}; d.ty = {0}; d.tx = {0};
                 ly.fwd.resize(1);
-                ALQ_TRY(igemm_build_plan(d, NB, &ly.fwd[0]));
+                ALQ_TRY(gemm_build(d, NB, &ly.fwd[0]));
                 if (!first_param) {
                     ConvDesc b = d;
                     b.Ci = sp.cout; b.Co = (int)ly.F;
-                    ALQ_TRY(igemm_build_plan(b, NB, &ly.bwd));
+                    ALQ_TRY(gemm_build(b, NB, &ly.bwd));
                     ly.has_bwd = true;
                 }
             }
@@ -436,11 +470,11 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_asum) {
         }
         switch (ly.spec.type) {
             case ALQ_CONV:
-                ALQ_TRY(igemm_launch(ctx, ly.fwd[0], in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM_FWD));
+                ALQ_TRY(gemm_launch(ctx, ly.fwd[0], in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM_FWD));
                 break;
             case ALQ_CONVT:
                 for (auto &p : ly.fwd)
-                    ALQ_TRY(igemm_launch(ctx, p, in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM_FWD));
+                    ALQ_TRY(gemm_launch(ctx, p, in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM_FWD));
                 break;
             case ALQ_POOL:
                 ALQ_TRY(k_pool_fwd(ctx, in, ly.out, ly.argmax, ly.spec.k, ly.lo, N));
@@ -451,7 +485,7 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_asum) {
                     ALQ_TRY(k_fc_small_finish(ctx, ly.fc_partials, ly.fc_slices, ly.d_bias, ly.spec.cout,
                                               ly.spec.relu, N, ly.out.p));
                 } else {
-                    ALQ_TRY(igemm_launch(ctx, ly.fwd[0], flat_view(in), ly.out, ly.d_bias, ly.spec.relu, 0, N,
+                    ALQ_TRY(gemm_launch(ctx, ly.fwd[0], flat_view(in), ly.out, ly.d_bias, ly.spec.relu, 0, N,
                                          PROF_IGEMM_FWD));
                 }
                 break;
@@ -493,9 +527,9 @@ static int run_backward(alq_model *m, int N) {
             if (ly.dense_fc_small)
                 ALQ_TRY(k_fc_small_bwd(ctx, ly.dout.p, ly.spec.cout, ly.d_Wp, ly.F, N, ly.din.p));
             else
-                ALQ_TRY(igemm_launch(ctx, ly.bwd, ly.dout, flat_view(ly.din), nullptr, 0, 0, N, PROF_IGEMM_BWD));
+                ALQ_TRY(gemm_launch(ctx, ly.bwd, ly.dout, flat_view(ly.din), nullptr, 0, 0, N, PROF_IGEMM_BWD));
         } else {
-            ALQ_TRY(igemm_launch(ctx, ly.bwd, ly.dout, ly.din, nullptr, 0, acc, N, PROF_IGEMM_BWD));
+            ALQ_TRY(gemm_launch(ctx, ly.bwd, ly.dout, ly.din, nullptr, 0, acc, N, PROF_IGEMM_BWD));
         }
     }
     return ALQ_OK;
@@ -561,6 +595,10 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
     alq_model *m = new alq_model();
     m->ctx = ctx;
     m->max_batch = max_batch;
+    {
+        const char *e = getenv("ALQ_DISABLE_V2");   // diagnostics: force the general GEMM kernel
+        g_use_v2 = !(e && e[0] == '1');
+    }
     for (int i = 0; i < 4; ++i) m->in_dims[i] = in_dims[i];
     const int rc = build_model(m, layers, n_layers);
     if (rc != ALQ_OK) {
@@ -614,16 +652,14 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
     if (sp.type == ALQ_CONV) {
         // TF [tap][ci][co] is already the fwd B matrix [(tap, ci)][co]
         std::vector<float> B(W, W + ly.w_elems);
-        igemm_pack_weights(&ly.fwd[0], B);
-        ALQ_TRY(upload(m, &ly.fwd[0]));
+        ALQ_TRY(gemm_set(m, &ly.fwd[0], B));
         if (ly.has_bwd) {
             std::vector<float> Bb((size_t)ntaps * Co * Ci);
             for (int tp = 0; tp < ntaps; ++tp)
                 for (int ci = 0; ci < Ci; ++ci)
                     for (int co = 0; co < Co; ++co)
                         Bb[((size_t)tp * Co + co) * Ci + ci] = W[((size_t)tp * Ci + ci) * Co + co];
-            igemm_pack_weights(&ly.bwd, Bb);
-            ALQ_TRY(upload(m, &ly.bwd));
+            ALQ_TRY(gemm_set(m, &ly.bwd, Bb));
         }
     } else if (sp.type == ALQ_CONVT) {
         // TF [tap][co][ci]
@@ -634,13 +670,11 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
                 for (int ci = 0; ci < Ci; ++ci)
                     for (int co = 0; co < Co; ++co)
                         B[((size_t)j * Ci + ci) * Co + co] = W[((size_t)tl[j] * Co + co) * Ci + ci];
-            igemm_pack_weights(&ly.fwd[c], B);
-            ALQ_TRY(upload(m, &ly.fwd[c]));
+            ALQ_TRY(gemm_set(m, &ly.fwd[c], B));
         }
         if (ly.has_bwd) {
             std::vector<float> Bb(W, W + ly.w_elems);   // [(tap, co)][ci] as stored
-            igemm_pack_weights(&ly.bwd, Bb);
-            ALQ_TRY(upload(m, &ly.bwd));
+            ALQ_TRY(gemm_set(m, &ly.bwd, Bb));
         }
     } else {
         // fc: TF W[o][f_tf]; activation memory order f_mem = ((d*H+h)*W+w)*C+c, reference flatten
@@ -663,12 +697,8 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
             std::vector<float> B((size_t)F * Co);
             for (int64_t f = 0; f < F; ++f)
                 for (int o = 0; o < Co; ++o) B[(size_t)f * Co + o] = Wp[(size_t)o * F + f];
-            igemm_pack_weights(&ly.fwd[0], B);
-            ALQ_TRY(upload(m, &ly.fwd[0]));
-            if (ly.has_bwd) {
-                igemm_pack_weights(&ly.bwd, Wp);   // [(o)][f_mem]
-                ALQ_TRY(upload(m, &ly.bwd));
-            }
+            ALQ_TRY(gemm_set(m, &ly.fwd[0], B));
+            if (ly.has_bwd) ALQ_TRY(gemm_set(m, &ly.bwd, Wp));   // [(o)][f_mem]
         }
     }
     ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
@@ -806,6 +836,11 @@ int alq_model_debug_copy(alq_model *m, int layer_idx, int what, int N, float *d_
     if (elems_out) *elems_out = e;
     ALQ_HIP(hipMemcpyAsync(d_out, what == 2 ? ly.asum : ly.dsum, e * sizeof(float), hipMemcpyDeviceToDevice,
                            m->ctx->stream));
+    return ALQ_OK;
+}
+
+int alq_debug_set_stamp_buffer(void *d_buf) {
+    g_igemm2_dbg = reinterpret_cast<unsigned long long *>(d_buf);
     return ALQ_OK;
 }
 

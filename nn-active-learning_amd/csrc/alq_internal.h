@@ -168,6 +168,12 @@ struct Igemm2Args {
     int t0, tsz, tsy, tsx, tnx, tny;   // tap box: LDS offset = t0 + iz*tsz + iy*tsy + ix*tsx
     int dbg_repeat, dbg_flags;
     unsigned long long *dbg;   // phase stamps (diagnostic build), else null
+    // host-built tables (igemm2_build_plan): no division / bounds arithmetic per tile in the kernel
+    const int *tdesc;          // [tiles_per_group][8]: in_org_vox, out_org_vox, class | full<<8, mz0, my0, mx0, -, -
+    const int *sdesc;          // [nhv][4]: rel_vox, valid-mask lo, valid-mask hi, packed (pt,hz,hy,hx)
+    int tpg;                   // tiles per patch group
+    int in_bytes;              // bytes of the input tensor for N patches (buffer descriptor range)
+    int in_pstride, out_pstride;   // voxels per patch group step: PT*ID*IH*IW, PT*OD*OH*OW
 };
 
 struct Igemm2Plan {
@@ -180,6 +186,8 @@ struct Igemm2Plan {
     double flops_per_patch = 0;
     std::vector<float> h_W;
     float *d_W = nullptr;
+    std::vector<int> h_tdesc, h_sdesc;
+    int *d_tdesc = nullptr, *d_sdesc = nullptr;
 };
 
 struct Igemm2Fuse {

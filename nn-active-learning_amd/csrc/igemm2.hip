@@ -51,7 +51,7 @@ constexpr int I2_WRES_MAX = 16 * 1024;   // resident weights: at most this many 
 // uses), walked in ascending (forward conv) / descending (backward-data) order: every LDS fragment
 // address is then `register + immediate`, so the MFMA loop carries no address arithmetic at all;
 // 0 -> box extents and strides read at run time.
-template <int NTW, bool WRES, int GEO>
+template <int NTW, bool WRES, int GEO, bool SUMS>
 __global__ __launch_bounds__(256, 2) void igemm2_kernel(const Igemm2Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -74,25 +74,30 @@ __global__ __launch_bounds__(256, 2) void igemm2_kernel(const Igemm2Args a) {
             *reinterpret_cast<f32x4 *>(Wl + i) = *reinterpret_cast<const f32x4 *>(a.W + i);
     }
 
-    // ---- per-thread A staging slots: (halo voxel, half), decoded once -------------------------
-    // s_pos = packed (pt, hz, hy, hx); s_rel = voxel offset relative to the tile's halo origin
+    // ---- per-thread A staging slots: (halo voxel, half) from the host-built slot table ------------
+    // s_rel = element offset relative to the tile's halo origin voxel; s_mlo/s_mhi = 64-bit mask "is
+    // this halo voxel inside the tensor" indexed by the tile's border class (4 classes per dimension:
+    // first / middle / last / first-and-last)
     const int nslots = nhv * 2;
     const int nit = (nslots + 255) >> 8;
-    int s_pos[NSLOT];
+    const int half4 = (tid & 1) * 4;
+    int s_rel[NSLOT];
+    unsigned s_mlo[NSLOT], s_mhi[NSLOT];
 #pragma unroll
     for (int it = 0; it < NSLOT; ++it) {
         const int slot = tid + it * 256;
-        int pk = -1;
+        int rel = 0;
+        unsigned mlo = 0, mhi = 0;
         if (slot < nslots) {
-            int r = slot >> 1;
-            const int hx = r % a.HX; r /= a.HX;
-            const int hy = r % a.HY; r /= a.HY;
-            const int hz = r % a.HZ; r /= a.HZ;
-            pk = (r << 24) | (hz << 16) | (hy << 8) | hx;
+            const int4 sd = *reinterpret_cast<const int4 *>(a.sdesc + (slot >> 1) * 4);
+            rel = sd.x * a.in_cs + a.in_c0 + half4;
+            mlo = (unsigned)sd.y;
+            mhi = (unsigned)sd.z;
         }
-        s_pos[it] = pk;
+        s_rel[it] = rel;
+        s_mlo[it] = mlo;
+        s_mhi[it] = mhi;
     }
-    const int half4 = (tid & 1) * 4;
 
     // ---- per-lane LDS row base of the 4 row blocks of this wave ---------------------------
     const int TV = a.TZ * a.TY * a.TX;
@@ -109,60 +114,87 @@ __global__ __launch_bounds__(256, 2) void igemm2_kernel(const Igemm2Args a) {
         vbase[ms] = (((pt * a.HZ + z * a.sm) * a.HY + y * a.sm) * a.HX + x * a.sm) * I2_CBP + 2 * lq;
     }
 
-    // rows this lane finishes in the epilogue (C/D map: row = (lane>>4)*4 + reg): output voxel offset
-    // relative to the tile's first output voxel (tile-independent)
-    // (the 4 registers of a row block are 4 consecutive x when TX >= 4: one offset per row block)
-    int erow[4];
+    // ---- epilogue geometry (tile-independent).  The MFMAs are issued with the WEIGHT fragment as the
+    // A operand and the activation fragment as B, i.e. they compute the transposed tile: D column =
+    // lane&15 = GEMM row (voxel), D row = (lane>>4)*4 + reg = output channel.  A lane therefore ends
+    // with 4 consecutive channels of ONE voxel per accumulator: one 16-byte store, no shuffles.
+    int eoff[4], evox[4];       // element offset of (voxel, channel 4*lq) / voxel offset, relative to the tile's first output voxel
+    bool erow_ok = true;
 #pragma unroll
     for (int ms = 0; ms < 4; ++ms) {
-        int v = wave * 64 + ms * 16 + lq * 4;
-        if (v >= a.rows) v = 0;
-        const int pt = v / TV;
-        int q = v - pt * TV;
+        const int v = wave * 64 + ms * 16 + lrow;
+        const int vv = v < a.rows ? v : 0;
+        const int pt = vv / TV;
+        int q = vv - pt * TV;
         const int x = q % a.TX; q /= a.TX;
         const int y = q % a.TY;
         const int z = q / a.TY;
-        erow[ms] = ((pt * a.OD + z * a.so) * a.OH + y * a.so) * a.OW + x * a.so;
+        evox[ms] = ((pt * a.OD + z * a.so) * a.OH + y * a.so) * a.OW + x * a.so;
+        eoff[ms] = evox[ms] * a.out_cs + a.out_c0 + lq * 4;
+        erow_ok = erow_ok && v < a.rows;
     }
-    const bool xrun = a.TX >= 4;
+    f32x4 bias4[NTW];     // the accumulators START at the bias (channels 4*lq..4*lq+3 of each 16-channel tile)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        bias4[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int c = nt * 16 + lq * 4;
+        if (a.bias && c < a.Co) bias4[nt] = *reinterpret_cast<const f32x4 *>(a.bias + c);   // Co % 4 == 0 (plan)
+    }
 
-    const int tiles_per_group = a.tilesZ * a.tilesY * a.tilesX;
+    // ---- tile walk without divisions: cursor (patch group, tile inside the group) advanced by gridDim.x;
+    // everything tile-dependent comes from the host-built descriptor of the tile inside its group
     const int pgroups = (a.N + a.PT - 1) / a.PT;
-    const int total_tiles = pgroups * tiles_per_group;
+    const int gp = gridDim.x / a.tpg, gl = gridDim.x % a.tpg;
+    int fpg = blockIdx.x / a.tpg, fl = blockIdx.x % a.tpg;    // cursor of the tile being FETCHED
+    auto advance_cursor = [&]() {
+        fl += gl;
+        const int c = fl >= a.tpg;
+        fl -= c ? a.tpg : 0;
+        fpg += gp + c;
+    };
 
-    // voxel index of every slot for the fetch tile (-1: outside the tensor -> zero fill)
-    int gvox[NSLOT];
-    auto locate = [&](int tile) {
-        int t = tile;
-        const int tx = t % a.tilesX; t /= a.tilesX;
-        const int ty = t % a.tilesY; t /= a.tilesY;
-        const int tz = t % a.tilesZ; t /= a.tilesZ;
-        const int p0 = t * a.PT;
-        const int z0 = tz * a.TZ * a.sm + a.minz, y0 = ty * a.TY * a.sm + a.miny, x0 = tx * a.TX * a.sm + a.minx;
-        const int npatch = a.N - p0;
+    // uniform per-tile quantities, carried through the pipeline: fetch -> compute -> deferred epilogue
+    int f_out = 0, c_out = 0, p_out = 0;          // output voxel index of the tile's first row
+    int f_cls = 0, c_cls = 0, p_cls = 0;          // border class | full << 8
+    int f_l = 0, c_l = 0, p_l = 0, f_g = 0, c_g = 0, p_g = 0;
+
+    int goff[NSLOT];     // byte offset of every slot of the fetch tile (past num_records where the halo leaves the tensor)
+    auto locate = [&]() {
+        const int *td = a.tdesc + fl * 8;
+        const int in_org = (td[0] + fpg * a.in_pstride) * a.in_cs;
+        f_out = td[1] + fpg * a.out_pstride;
+        f_cls = td[2];
+        f_l = fl; f_g = fpg;
+        const int cls = f_cls & 63;
+        const bool partial = (fpg + 1) * a.PT > a.N;      // last patch group with fewer than PT patches
 #pragma unroll
         for (int it = 0; it < NSLOT; ++it) {
-            int g = -1;
+            int g = 0x7fffff00;
             if (it < nit) {
-                const int pk = s_pos[it];
-                const int iz = z0 + ((pk >> 16) & 255), iy = y0 + ((pk >> 8) & 255), ix = x0 + (pk & 255);
-                if (pk >= 0 && (pk >> 24) < npatch && (unsigned)iz < (unsigned)a.ID && (unsigned)iy < (unsigned)a.IH &&
-                    (unsigned)ix < (unsigned)a.IW)
-                    g = (((p0 + (pk >> 24)) * a.ID + iz) * a.IH + iy) * a.IW + ix;
+                const unsigned m = cls < 32 ? s_mlo[it] : s_mhi[it];
+                bool ok = (m >> (cls & 31)) & 1u;
+                if (partial) {     // uniform, rare: re-check the patch index of the slot
+                    const int pt = a.sdesc[((tid + it * 256) >> 1) * 4 + 3] >> 24;
+                    ok = ok && fpg * a.PT + pt < a.N;
+                }
+                g = ok ? (in_org + s_rel[it]) * 4 : 0x7fffff00;     // byte offset, or past the end -> reads 0
             }
-            gvox[it] = g;
+            goff[it] = g;
         }
     };
 
     f32x4 R[NSLOT];
     f32x4 Wr[WREGS];
+    // buffer descriptor over the whole input tensor: an offset past num_records reads as zero, which
+    // is exactly the zero padding of the halo (no branch, no zero-fill instructions)
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
     auto fetch = [&](int chunk) {
+        const int soff = (a.dbg_flags & 2) ? 0x7ffffff0 : chunk * 32;     // uniform byte offset of the chunk
 #pragma unroll
         for (int it = 0; it < NSLOT; ++it) {
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (it < nit && gvox[it] >= 0 && !(a.dbg_flags & 2))
-                v = *reinterpret_cast<const f32x4 *>(a.in + (long long)gvox[it] * a.in_cs + (a.in_c0 + half4 + chunk * 8));
-            R[it] = v;
+            if (it < nit)
+                R[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, goff[it], soff, 0));
         }
         if constexpr (!WRES) {
             const float *src = a.W + (long long)chunk * Wchunk;
@@ -189,114 +221,87 @@ __global__ __launch_bounds__(256, 2) void igemm2_kernel(const Igemm2Args a) {
         }
     };
 
-    // ---------------- deferred epilogue: bias / ReLU / mask, stores, channel sums ----------------
-    // The C/D map gives a lane ONE column of four rows; stored as is that is 16 scattered dword
-    // stores per lane and the tile ends store-issue-bound.  A 4x4 transpose inside each quad of
-    // lanes (two DPP quad_perm exchanges) turns it into: lane (q, j, p) holds row q*4+p, columns
-    // 4j..4j+3 -> one 16-byte store per row block.
-    f32x4 pend[4][NTW];
-    int pend_tile = -1;
-    const int qp = lane & 3;             // position in the quad = row inside the 4-row group after the transpose
-    const int cj = (lane & 15) >> 2;     // column group: columns 4*cj .. 4*cj+3 of each 16-column tile
-    f32x4 bias4[NTW];
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-        bias4[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int c = nt * 16 + cj * 4;
-        if (a.bias && c < a.Co) bias4[nt] = *reinterpret_cast<const f32x4 *>(a.bias + c);   // Co % 4 == 0 (plan)
-    }
-    auto quad_transpose = [&](f32x4 v) {
-        // step 1: lanes p and p^1 swap the off-diagonal element of each 2x2 block
-        float s0 = (qp & 1) ? v.x : v.y, s1 = (qp & 1) ? v.z : v.w;
-        float r0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, false));
-        float r1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, false));
-        if (qp & 1) { v.x = r0; v.z = r1; } else { v.y = r0; v.w = r1; }
-        // step 2: lanes p and p^2 swap the off-diagonal 2x2 blocks
-        s0 = (qp & 2) ? v.x : v.z; s1 = (qp & 2) ? v.y : v.w;
-        r0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0x4E, 0xF, 0xF, false));
-        r1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0x4E, 0xF, 0xF, false));
-        if (qp & 2) { v.x = r0; v.y = r1; } else { v.z = r0; v.w = r1; }
-        return v;
-    };
-    auto flush = [&](int ftile) {
-        int t = ftile;
-        const int tx = t % a.tilesX; t /= a.tilesX;
-        const int ty = t % a.tilesY; t /= a.tilesY;
-        const int tz = t % a.tilesZ; t /= a.tilesZ;
-        const int p0 = t * a.PT;
-        const int mz0 = tz * a.TZ, my0 = ty * a.TY, mx0 = tx * a.TX;
-        const long long obase = (((long long)p0 * a.OD + mz0 * a.so + a.ooffz) * a.OH + my0 * a.so + a.ooffy) * a.OW +
-                                mx0 * a.so + a.ooffx;
-        // a tile that lies completely inside the tensor needs no per-row checks (uniform test)
-        const bool full = a.rows == 256 && p0 + a.PT <= a.N && mz0 + a.TZ <= a.MD && my0 + a.TY <= a.MH &&
-                          mx0 + a.TX <= a.MW;
+    // ---------------- deferred epilogue: ReLU / mask, stores, channel sums -------------------------
+    // The results stay in the accumulators; their stores are issued one step later, right after the
+    // barrier and BEFORE the next prefetch (loads and stores retire in issue order on one counter, so
+    // a prefetch wait must never sit behind fresh stores), and before the accumulators are re-armed.
+    f32x4 acc[4][NTW];
+    bool have_pend = false;
+    char *outb = reinterpret_cast<char *>(a.out);
+    const char *maskb = reinterpret_cast<const char *>(a.mask);
+    auto flush = [&]() {
+        const int obase_e = p_out * a.out_cs;         // uniform
+        const bool p_full = (p_cls >> 8) & 1 && (p_g + 1) * a.PT <= a.N;
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms) {
-            bool live = true;
-            long long ovox = obase + erow[ms] + qp * a.so;
-            if (!(full && xrun)) {
-                const int v = wave * 64 + ms * 16 + lq * 4 + qp;
-                live = v < a.rows;
-                const int pt = v / TV;
-                int q = v - pt * TV;
+            bool live = erow_ok;
+            if (!p_full) {      // border / partial tiles only: per-row bounds
+                const int *td = a.tdesc + p_l * 8;
+                const int v = wave * 64 + ms * 16 + lrow;
+                const int vv = v < a.rows ? v : 0;
+                const int pt = vv / TV;
+                int q = vv - pt * TV;
                 const int x = q % a.TX; q /= a.TX;
                 const int y = q % a.TY;
                 const int z = q / a.TY;
-                live = live && p0 + pt < a.N && mz0 + z < a.MD && my0 + y < a.MH && mx0 + x < a.MW;
-                ovox = obase + ((((long long)pt * a.OD + z * a.so) * a.OH + y * a.so) * a.OW + x * a.so);
+                live = v < a.rows && p_g * a.PT + pt < a.N && td[3] + z < a.MD && td[4] + y < a.MH && td[5] + x < a.MW;
             }
             float sumA = 0.f, sumB = 0.f;
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
-                const int c = nt * 16 + cj * 4;
-                f32x4 val = quad_transpose(pend[ms][nt]);     // all lanes take part in the exchange
-                const bool on = live && c < a.Co;
-                if (on) {
-                    val += bias4[nt];
-                    if (a.relu) {
-                        val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f);
-                        val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f);
+                const int c = nt * 16 + lq * 4;
+                f32x4 val = acc[ms][nt];
+                if (live && c < a.Co) {
+                    if (a.relu) {       // one v_med3_f32 per element (clamp to [0, +inf])
+                        val.x = __builtin_amdgcn_fmed3f(val.x, 0.f, __builtin_inff());
+                        val.y = __builtin_amdgcn_fmed3f(val.y, 0.f, __builtin_inff());
+                        val.z = __builtin_amdgcn_fmed3f(val.z, 0.f, __builtin_inff());
+                        val.w = __builtin_amdgcn_fmed3f(val.w, 0.f, __builtin_inff());
                     }
+                    const int eo = obase_e + eoff[ms] + nt * 16;
                     if (a.mask) {
-                        const f32x4 mk = *reinterpret_cast<const f32x4 *>(a.mask + ovox * a.mask_cs + a.mask_c0 + c);
+                        const int mo = (p_out + evox[ms]) * a.mask_cs + a.mask_c0 + c;
+                        const f32x4 mk = *reinterpret_cast<const f32x4 *>(maskb + (unsigned)(mo * 4));
                         val.x = mk.x > 0.f ? val.x : 0.f; val.y = mk.y > 0.f ? val.y : 0.f;
                         val.z = mk.z > 0.f ? val.z : 0.f; val.w = mk.w > 0.f ? val.w : 0.f;
                     }
-                    f32x4 *dst = reinterpret_cast<f32x4 *>(a.out + ovox * a.out_cs + a.out_c0 + c);
+                    f32x4 *dst = reinterpret_cast<f32x4 *>(outb + (unsigned)(eo * 4));
                     if (a.accumulate) val += *dst;
                     if (!(a.dbg_flags & 1)) *dst = val;
-                } else {
-                    val = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (SUMS) {
+                        const float s4 = (val.x + val.y) + (val.z + val.w);
+                        if (c < a.split) sumA += s4; else sumB += s4;
+                    }
                 }
-                const float s4 = (val.x + val.y) + (val.z + val.w);
-                if (c < a.split) sumA += s4; else sumB += s4;
             }
-            if (a.osumA || a.osumB) {
-                // the row's 16*NTW columns live in the 4 lanes cj = 0..3 (lane bits 2,3)
-                sumA += __shfl_xor(sumA, 4, 64); sumA += __shfl_xor(sumA, 8, 64);
-                sumB += __shfl_xor(sumB, 4, 64); sumB += __shfl_xor(sumB, 8, 64);
-                if (live && cj == 0) {
-                    if (a.osumA) a.osumA[ovox] = sumA;
-                    if (a.osumB) a.osumB[ovox] = sumB;
+            if constexpr (SUMS) {
+                // a voxel's channels live in the 4 lanes lq = 0..3 (lane bits 4,5)
+                sumA += __shfl_xor(sumA, 16, 64); sumA += __shfl_xor(sumA, 32, 64);
+                sumB += __shfl_xor(sumB, 16, 64); sumB += __shfl_xor(sumB, 32, 64);
+                if (live && lq == 0) {
+                    if (a.osumA) a.osumA[p_out + evox[ms]] = sumA;
+                    if (a.osumB) a.osumB[p_out + evox[ms]] = sumB;
                 }
             }
         }
     };
 
-    f32x4 acc[4][NTW];
 #ifdef ALQ_STAMPS
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last;
     STAMP(t_last);
 #endif
 
-    int tile = blockIdx.x;
-    if (tile < total_tiles) {
-        locate(tile);
+    bool more = fpg < pgroups;        // does the fetch cursor point at a real tile?
+    if (more) {
+        locate();
         fetch(0);
     }
     PHASE_END(0);
     bool first = true;
-    while (tile < total_tiles) {
+    while (more) {
+        // the fetched tile becomes the compute tile
+        c_out = f_out; c_cls = f_cls; c_l = f_l; c_g = f_g;
+        bool next_more = false;
         for (int chunk = 0; chunk < a.nchunks; ++chunk) {
             if (!first) __syncthreads();      // every wave has finished reading the previous step's LDS
             first = false;
@@ -305,27 +310,28 @@ __global__ __launch_bounds__(256, 2) void igemm2_kernel(const Igemm2Args a) {
             PHASE_END(2);                     // wait for the prefetch + LDS writes
             __syncthreads();
             PHASE_END(3);                     // barrier B
-            if (chunk == 0 && pend_tile >= 0) {
-                flush(pend_tile);
-                pend_tile = -1;
+            if (chunk == 0 && have_pend) {
+                flush();
+                have_pend = false;
             }
             PHASE_END(4);                     // deferred epilogue
             // prefetch the next step while this one computes
-            {
-                int nchunk = chunk + 1, ntile = tile;
-                if (nchunk == a.nchunks) {
-                    nchunk = 0;
-                    ntile = tile + gridDim.x;
-                    if (ntile < total_tiles) locate(ntile);
+            if (chunk + 1 < a.nchunks) {
+                fetch(chunk + 1);
+            } else {
+                advance_cursor();
+                next_more = fpg < pgroups;
+                if (next_more) {
+                    locate();
+                    fetch(0);
                 }
-                if (ntile < total_tiles) fetch(nchunk);
             }
             PHASE_END(5);                     // locate + prefetch issue
             if (chunk == 0) {
 #pragma unroll
                 for (int ms = 0; ms < 4; ++ms)
 #pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt) acc[ms][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int nt = 0; nt < NTW; ++nt) acc[ms][nt] = bias4[nt];
             }
             const float *Wc = Wl + (WRES ? chunk * Wchunk : 0) + lane * 2;
             // Software-pipelined fragment reads with two register sets: the LDS reads of tap t+1 are
@@ -344,12 +350,12 @@ __global__ __launch_bounds__(256, 2) void igemm2_kernel(const Igemm2Args a) {
                 for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                     for (int ms = 0; ms < 4; ++ms)
-                        acc[ms][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ms].x, bv[nt].x, acc[ms][nt], 0, 0, 0);
+                        acc[ms][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[nt].x, av[ms].x, acc[ms][nt], 0, 0, 0);
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                     for (int ms = 0; ms < 4; ++ms)
-                        acc[ms][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ms].y, bv[nt].y, acc[ms][nt], 0, 0, 0);
+                        acc[ms][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[nt].y, av[ms].y, acc[ms][nt], 0, 0, 0);
             };
             for (int rep = 0; rep <= a.dbg_repeat; ++rep)
             if constexpr (GEO > 0) {
@@ -401,18 +407,14 @@ __global__ __launch_bounds__(256, 2) void igemm2_kernel(const Igemm2Args a) {
             }
             PHASE_END(6);
         }
-
         // results wait in registers: their stores are issued one step later, right after the barrier
         // and BEFORE the next prefetch, so that the `vmcnt` wait that retires a prefetch never has
         // to wait for fresh stores (loads and stores retire in issue order on one counter)
-#pragma unroll
-        for (int ms = 0; ms < 4; ++ms)
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) pend[ms][nt] = acc[ms][nt];
-        pend_tile = tile;
-        tile += gridDim.x;
+        have_pend = true;
+        p_out = c_out; p_cls = c_cls; p_l = c_l; p_g = c_g;
+        more = next_more;
     }
-    if (pend_tile >= 0) flush(pend_tile);
+    if (have_pend) flush();
 #ifdef ALQ_STAMPS
     PHASE_END(7);
     if (a.dbg && tid == 0)
@@ -472,6 +474,60 @@ int igemm2_build_plan(const IgemmPlan &p1, Igemm2Plan *p2) {
         if (!found) return ALQ_OK;   // not a box: the general kernel handles it
     }
     a.split = 1 << 30;
+    // ---- host tables: tile descriptors (one patch group) and halo-slot descriptors ----------------
+    {
+        const int dimsI[3] = {a.ID, a.IH, a.IW}, dimsM[3] = {a.MD, a.MH, a.MW};
+        const int T[3] = {a.TZ, a.TY, a.TX}, tiles[3] = {a.tilesZ, a.tilesY, a.tilesX};
+        const int mins[3] = {a.minz, a.miny, a.minx}, H[3] = {a.HZ, a.HY, a.HX};
+        auto cls_of = [&](int d, int t) { return (t == 0 ? 1 : 0) | (t == tiles[d] - 1 ? 2 : 0); };   // 0 mid, 1 first, 2 last, 3 both
+        auto valid1 = [&](int d, int t, int h) {
+            const int c = t * T[d] * a.sm + mins[d] + h;
+            return c >= 0 && c < dimsI[d];
+        };
+        // every "middle" tile must see the same (fully valid) halo, else the class scheme does not apply
+        for (int d = 0; d < 3; ++d)
+            for (int t = 1; t + 1 < tiles[d]; ++t)
+                for (int h = 0; h < H[d]; ++h)
+                    if (!valid1(d, t, h)) return ALQ_OK;
+        a.tpg = a.tilesZ * a.tilesY * a.tilesX;
+        a.in_pstride = a.PT * a.ID * a.IH * a.IW;
+        a.out_pstride = a.PT * a.OD * a.OH * a.OW;
+        p2->h_tdesc.assign((size_t)a.tpg * 8, 0);
+        for (int tz = 0; tz < a.tilesZ; ++tz)
+            for (int ty = 0; ty < a.tilesY; ++ty)
+                for (int tx = 0; tx < a.tilesX; ++tx) {
+                    int *td = &p2->h_tdesc[(((size_t)tz * a.tilesY + ty) * a.tilesX + tx) * 8];
+                    const int mz0 = tz * a.TZ, my0 = ty * a.TY, mx0 = tx * a.TX;
+                    const int z0 = mz0 * a.sm + a.minz, y0 = my0 * a.sm + a.miny, x0 = mx0 * a.sm + a.minx;
+                    td[0] = (z0 * a.IH + y0) * a.IW + x0;
+                    td[1] = ((mz0 * a.so + a.ooffz) * a.OH + my0 * a.so + a.ooffy) * a.OW + mx0 * a.so + a.ooffx;
+                    const int cls = cls_of(0, tz) | (cls_of(1, ty) << 2) | (cls_of(2, tx) << 4);
+                    const bool full = a.rows == 256 && mz0 + a.TZ <= a.MD && my0 + a.TY <= a.MH && mx0 + a.TX <= a.MW;
+                    td[2] = cls | (full ? 256 : 0);
+                    td[3] = mz0; td[4] = my0; td[5] = mx0;
+                }
+        (void)dimsM;
+        // representative tile index of a class in dimension d
+        auto rep = [&](int d, int c) { return (c & 1) ? 0 : ((c & 2) ? tiles[d] - 1 : (tiles[d] > 2 ? 1 : 0)); };
+        p2->h_sdesc.assign((size_t)nhv * 4, 0);
+        for (int pt = 0; pt < a.PT; ++pt)
+            for (int hz = 0; hz < a.HZ; ++hz)
+                for (int hy = 0; hy < a.HY; ++hy)
+                    for (int hx = 0; hx < a.HX; ++hx) {
+                        const int hv = ((pt * a.HZ + hz) * a.HY + hy) * a.HX + hx;
+                        int *sd = &p2->h_sdesc[(size_t)hv * 4];
+                        sd[0] = ((pt * a.ID + hz) * a.IH + hy) * a.IW + hx;
+                        unsigned long long m = 0;
+                        for (int c = 0; c < 64; ++c) {
+                            const int cz = c & 3, cy = (c >> 2) & 3, cx = (c >> 4) & 3;
+                            if (valid1(0, rep(0, cz), hz) && valid1(1, rep(1, cy), hy) && valid1(2, rep(2, cx), hx))
+                                m |= 1ull << c;
+                        }
+                        sd[1] = (int)(unsigned)(m & 0xffffffffull);
+                        sd[2] = (int)(unsigned)(m >> 32);
+                        sd[3] = (pt << 24) | (hz << 16) | (hy << 8) | hx;
+                    }
+    }
     p2->NTW = p1.NTW;
     p2->wres = wres;
     p2->lds_bytes = lds;
@@ -500,15 +556,21 @@ void igemm2_pack_weights(Igemm2Plan *p2, const std::vector<float> &Bmat) {
 
 unsigned long long *g_igemm2_dbg = nullptr;   // set by alq_debug_set_stamp_buffer (diagnostic build)
 
-template <int NTW, bool WRES, int GEO>
-static int launch2_t(alq_ctx *ctx, const Igemm2Plan &plan, const Igemm2Args &a, unsigned grid) {
-    auto kfn = igemm2_kernel<NTW, WRES, GEO>;
+template <int NTW, bool WRES, int GEO, bool SUMS>
+static int launch2_s(alq_ctx *ctx, const Igemm2Plan &plan, const Igemm2Args &a, unsigned grid) {
+    auto kfn = igemm2_kernel<NTW, WRES, GEO, SUMS>;
     if (plan.lds_bytes > 64 * 1024)
         ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)plan.lds_bytes));
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), plan.lds_bytes, ctx->stream, a);
     ALQ_HIP(hipGetLastError());
     return ALQ_OK;
+}
+
+template <int NTW, bool WRES, int GEO>
+static int launch2_t(alq_ctx *ctx, const Igemm2Plan &plan, const Igemm2Args &a, unsigned grid) {
+    return (a.osumA || a.osumB) ? launch2_s<NTW, WRES, GEO, true>(ctx, plan, a, grid)
+                                : launch2_s<NTW, WRES, GEO, false>(ctx, plan, a, grid);
 }
 
 int igemm2_launch(alq_ctx *ctx, const Igemm2Plan &plan, const View &in, const View &out, const float *bias, int relu,
@@ -519,6 +581,8 @@ int igemm2_launch(alq_ctx *ctx, const Igemm2Plan &plan, const View &in, const Vi
     ALQ_REQUIRE(out.C == a.Co && out.D == a.OD && out.H == a.OH && out.W == a.OW, ALQ_EINVAL,
                 "igemm2: output view does not match plan");
     ALQ_REQUIRE(plan.d_W != nullptr, ALQ_EINVAL, "igemm2: weights not set");
+    ALQ_REQUIRE((long long)N * in.vox() * in.cs < (1LL << 29) && (long long)N * out.vox() * out.cs < (1LL << 29),
+                ALQ_EUNSUPPORTED, "igemm2: tensor exceeds the 32-bit byte-offset range (lower the batch)");
     ALQ_REQUIRE(in.cs % 4 == 0 && in.c0 % 4 == 0 && out.cs % 4 == 0 && out.c0 % 4 == 0, ALQ_EUNSUPPORTED,
                 "igemm2: channel slice not 16-byte aligned");
     if (fuse) ALQ_REQUIRE(fuse->split % 4 == 0 && fuse->mask_cs % 4 == 0 && fuse->mask_c0 % 4 == 0, ALQ_EUNSUPPORTED,
@@ -526,6 +590,7 @@ int igemm2_launch(alq_ctx *ctx, const Igemm2Plan &plan, const View &in, const Vi
     a.in = in.p; a.in_cs = in.cs; a.in_c0 = in.c0;
     a.out = out.p; a.out_cs = out.cs; a.out_c0 = out.c0;
     a.W = plan.d_W; a.bias = bias; a.relu = relu; a.accumulate = accumulate; a.N = N;
+    a.in_bytes = (int)((long long)N * in.vox() * in.cs * 4);
     a.dbg = nullptr;
     if (g_igemm2_dbg) {   // diagnostic: stamp only the launch whose ordinal (since the buffer was set) is ALQ_STAMP_ONLY
         static int want = -2;

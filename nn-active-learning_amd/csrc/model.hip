@@ -160,6 +160,16 @@ static int gemm_build(const ConvDesc &d, int max_batch, Gemm *g) {
 static int gemm_set(alq_model *m, Gemm *g, const std::vector<float> &Bmat) {
     if (g->p2.ok) {
         igemm2_pack_weights(&g->p2, Bmat);
+        if (!g->p2.d_tdesc) {
+            ALQ_TRY(m->dalloc(&g->p2.d_tdesc, g->p2.h_tdesc.size()));
+            ALQ_TRY(m->dalloc(&g->p2.d_sdesc, g->p2.h_sdesc.size()));
+            ALQ_HIP(hipMemcpyAsync(g->p2.d_tdesc, g->p2.h_tdesc.data(), g->p2.h_tdesc.size() * sizeof(int),
+                                   hipMemcpyHostToDevice, m->ctx->stream));
+            ALQ_HIP(hipMemcpyAsync(g->p2.d_sdesc, g->p2.h_sdesc.data(), g->p2.h_sdesc.size() * sizeof(int),
+                                   hipMemcpyHostToDevice, m->ctx->stream));
+            g->p2.a.tdesc = g->p2.d_tdesc;
+            g->p2.a.sdesc = g->p2.d_sdesc;
+        }
         if (!g->p2.d_W) ALQ_TRY(m->dalloc(&g->p2.d_W, g->p2.h_W.size()));
         ALQ_HIP(hipMemcpyAsync(g->p2.d_W, g->p2.h_W.data(), g->p2.h_W.size() * sizeof(float), hipMemcpyHostToDevice,
                                m->ctx->stream));

@@ -155,7 +155,7 @@ struct Igemm2Args {
     const float *bias;
     const float *mask;   // ReLU-grad mask source (activation of the destination layer) or null
     float *osumA, *osumB;   // channel sums of the produced rows: columns < split -> A, others -> B
-    int mask_cs, mask_c0, split;
+    int mask_cs, mask_c0, mask_from, split;
     int in_cs, in_c0, Ci, ID, IH, IW;
     int out_cs, out_c0, Co, OD, OH, OW;
     int MD, MH, MW;
@@ -191,10 +191,10 @@ struct Igemm2Plan {
 };
 
 struct Igemm2Fuse {
-    const float *mask = nullptr;
-    int mask_cs = 0, mask_c0 = 0;
+    const float *mask = nullptr;   // activation whose sign masks output columns >= mask_from (ReLU grad)
+    int mask_cs = 0, mask_c0 = 0, mask_from = 0;
     float *osumA = nullptr, *osumB = nullptr;
-    int split = 0;       // 0: all columns -> osumA
+    int split = 0;       // 0: all columns -> osumA; else columns < split -> osumA, others -> osumB
 };
 
 extern unsigned long long *g_igemm2_dbg;
@@ -212,21 +212,28 @@ struct Gemm {
 // ------------------------------------------------------------------ other kernels
 int k_pool_fwd(alq_ctx *, const View &in, const View &out, uint8_t *argmax, const int w[3],
                const int lo[3], int N);
+// mask_act / dsum (both or neither): apply the ReLU-grad mask of the input layer's activation to the
+// finished cotangent and emit its channel sums; *fused tells whether the kernel could do it
 int k_pool_bwd(alq_ctx *, const View &dout, const View &din, const uint8_t *argmax,
-               const int w[3], const int lo[3], int N, int accumulate);
+               const int w[3], const int lo[3], int N, int accumulate, const View *mask_act = nullptr,
+               float *dsum = nullptr, bool *fused = nullptr);
 int k_chansum(alq_ctx *, const View &in, float *field, int N);
 int k_mask_chansum(alq_ctx *, const View &dact, const View *act_or_null, float *field, int N);
 int boxdot_slabs(long long vox);
-int k_boxdot_conv(alq_ctx *, const float *dsum, const float *asum, int D, int H, int W,
+// asum2 (optional): second channel-sum field added to asum (input = concat of two producers)
+int k_boxdot_conv(alq_ctx *, const float *dsum, const float *asum, const float *asum2, int D, int H, int W,
                   const int k[3], const int lo[3], int N, double *Spart, int nslab_max);
-int k_boxdot_convT(alq_ctx *, const float *dsum, const float *asum, int ID, int IH, int IW,
+int k_boxdot_convT(alq_ctx *, const float *dsum, const float *asum, const float *asum2, int ID, int IH, int IW,
                    const int k[3], const int s[3], const int lo[3], int N, double *Spart, int nslab_max);
 int k_fc_small_fwd(alq_ctx *, const float *act, int64_t F, const float *Wp, int nout, int N,
                    float *partials, int nslices);
 int k_fc_small_finish(alq_ctx *, const float *partials, int nslices, const float *bias, int nout,
                       int relu, int N, float *out);
+// mask_act / dsum / C (optional): rows are [voxel][C]; masks by act > 0 and emits per-voxel channel sums
 int k_fc_small_bwd(alq_ctx *, const float *delta, int nout, const float *Wp, int64_t F, int N,
-                   float *dact);
+                   float *dact, const float *mask_act = nullptr, float *dsum = nullptr, int C = 0,
+                   bool *fused = nullptr);
+int k_rowsum_field(alq_ctx *, const float *field, int64_t len, int N, float *out);
 int k_softmax(alq_ctx *, const float *logits, int c, int N, float *post_cN, int64_t *pred);
 int k_fill_unit_cotangent(alq_ctx *, float *dlogits, int N);
 int k_fisher_finalize(alq_ctx *, const double *Spart, const int *nslab, int nslab_max, int max_batch, double *S,

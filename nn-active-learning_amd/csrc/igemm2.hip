@@ -246,41 +246,48 @@ __global__ __launch_bounds__(256, 2) void igemm2_kernel(const Igemm2Args a) {
                 const int z = q / a.TY;
                 live = v < a.rows && p_g * a.PT + pt < a.N && td[3] + z < a.MD && td[4] + y < a.MH && td[5] + x < a.MW;
             }
-            float sumA = 0.f, sumB = 0.f;
+            // channel sums of the finished rows: one more tiny contraction on the matrix pipe instead
+            // of cross-lane shuffles.  The accumulator register r of lane (lq, voxel) is exactly the B
+            // operand element B[k = lq][j = voxel] of a 16x16x4 MFMA, so D = S * val_r summed over r
+            // with S[0][k] = [channel group < split], S[1][k] = [>= split] leaves sumA / sumB of the
+            // voxel in rows 0 / 1 of D, i.e. in registers x / y of the lanes lq == 0.
+            f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 const int c = nt * 16 + lq * 4;
                 f32x4 val = acc[ms][nt];
-                if (live && c < a.Co) {
+                const bool on = live && c < a.Co;
+                if (on) {
+                    f32x4 *dst = reinterpret_cast<f32x4 *>(outb + (unsigned)((obase_e + eoff[ms] + nt * 16) * 4));
+                    if (a.accumulate) val += *dst;      // a skip destination wrote this slice first
                     if (a.relu) {       // one v_med3_f32 per element (clamp to [0, +inf])
                         val.x = __builtin_amdgcn_fmed3f(val.x, 0.f, __builtin_inff());
                         val.y = __builtin_amdgcn_fmed3f(val.y, 0.f, __builtin_inff());
                         val.z = __builtin_amdgcn_fmed3f(val.z, 0.f, __builtin_inff());
                         val.w = __builtin_amdgcn_fmed3f(val.w, 0.f, __builtin_inff());
                     }
-                    const int eo = obase_e + eoff[ms] + nt * 16;
-                    if (a.mask) {
-                        const int mo = (p_out + evox[ms]) * a.mask_cs + a.mask_c0 + c;
+                    if (a.mask && c >= a.mask_from) {
+                        const int mo = (p_out + evox[ms]) * a.mask_cs + a.mask_c0 + (c - a.mask_from);
                         const f32x4 mk = *reinterpret_cast<const f32x4 *>(maskb + (unsigned)(mo * 4));
                         val.x = mk.x > 0.f ? val.x : 0.f; val.y = mk.y > 0.f ? val.y : 0.f;
                         val.z = mk.z > 0.f ? val.z : 0.f; val.w = mk.w > 0.f ? val.w : 0.f;
                     }
-                    f32x4 *dst = reinterpret_cast<f32x4 *>(outb + (unsigned)(eo * 4));
-                    if (a.accumulate) val += *dst;
                     if (!(a.dbg_flags & 1)) *dst = val;
-                    if constexpr (SUMS) {
-                        const float s4 = (val.x + val.y) + (val.z + val.w);
-                        if (c < a.split) sumA += s4; else sumB += s4;
-                    }
+                }
+                if constexpr (SUMS) {
+                    if (!on) val = f32x4{0.f, 0.f, 0.f, 0.f};
+                    // selector S[i = lrow][k = lq] for this 16-channel tile
+                    const float sel = (lrow == 0) ? (c < a.split ? 1.f : 0.f) : ((lrow == 1) ? (c < a.split ? 0.f : 1.f) : 0.f);
+                    sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, val.x, sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, val.y, sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, val.z, sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, val.w, sacc, 0, 0, 0);
                 }
             }
             if constexpr (SUMS) {
-                // a voxel's channels live in the 4 lanes lq = 0..3 (lane bits 4,5)
-                sumA += __shfl_xor(sumA, 16, 64); sumA += __shfl_xor(sumA, 32, 64);
-                sumB += __shfl_xor(sumB, 16, 64); sumB += __shfl_xor(sumB, 32, 64);
                 if (live && lq == 0) {
-                    if (a.osumA) a.osumA[p_out + evox[ms]] = sumA;
-                    if (a.osumB) a.osumB[p_out + evox[ms]] = sumB;
+                    if (a.osumA) a.osumA[p_out + evox[ms]] = sacc.x;
+                    if (a.osumB) a.osumB[p_out + evox[ms]] = sacc.y;
                 }
             }
         }
@@ -585,7 +592,7 @@ int igemm2_launch(alq_ctx *ctx, const Igemm2Plan &plan, const View &in, const Vi
                 ALQ_EUNSUPPORTED, "igemm2: tensor exceeds the 32-bit byte-offset range (lower the batch)");
     ALQ_REQUIRE(in.cs % 4 == 0 && in.c0 % 4 == 0 && out.cs % 4 == 0 && out.c0 % 4 == 0, ALQ_EUNSUPPORTED,
                 "igemm2: channel slice not 16-byte aligned");
-    if (fuse) ALQ_REQUIRE(fuse->split % 4 == 0 && fuse->mask_cs % 4 == 0 && fuse->mask_c0 % 4 == 0, ALQ_EUNSUPPORTED,
+    if (fuse) ALQ_REQUIRE(fuse->split % 4 == 0 && fuse->mask_cs % 4 == 0 && fuse->mask_c0 % 4 == 0 && fuse->mask_from % 4 == 0, ALQ_EUNSUPPORTED,
                           "igemm2: fused epilogue needs 4-channel aligned slices");
     a.in = in.p; a.in_cs = in.cs; a.in_c0 = in.c0;
     a.out = out.p; a.out_cs = out.cs; a.out_c0 = out.c0;
@@ -610,7 +617,7 @@ int igemm2_launch(alq_ctx *ctx, const Igemm2Plan &plan, const View &in, const Vi
         a.dbg_flags = flg;
     }
     if (fuse) {
-        a.mask = fuse->mask; a.mask_cs = fuse->mask_cs; a.mask_c0 = fuse->mask_c0;
+        a.mask = fuse->mask; a.mask_cs = fuse->mask_cs; a.mask_c0 = fuse->mask_c0; a.mask_from = fuse->mask_from;
         a.osumA = fuse->osumA; a.osumB = fuse->osumB;
         a.split = fuse->split > 0 ? fuse->split : (1 << 30);
     }

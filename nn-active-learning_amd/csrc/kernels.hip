@@ -133,12 +133,22 @@ __global__ void pool_fwd_vec_kernel(const float *in, int in_cs, int in_c0, int C
     }
 }
 
+template <int G>   // G > 0: C4 == G lanes per voxel (power of two): mask + channel-sum fusion possible
 __global__ void pool_bwd_vec_kernel(const float *dout, int do_cs, int do_c0, int C4, int OD, int OH, int OW,
                                     float *din, int di_cs, int di_c0, int ID, int IH, int IW,
                                     const uint8_t *argmax, int wz, int wy, int wx, int lz, int ly, int lx,
-                                    int accumulate, long long total) {
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+                                    int accumulate, long long total, const float *act, int a_cs, int a_c0,
+                                    float *dsum) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < ((total + 63) & ~63LL);
          i += (long long)gridDim.x * blockDim.x) {
+        if (i >= total) {      // keep whole waves in the shuffles below
+            if constexpr (G > 1) {
+                float z = 0.f;
+#pragma unroll
+                for (int o = 1; o < G; o <<= 1) z += __shfl_xor(z, o, 64);
+            }
+            continue;
+        }
         long long r = i;
         const int c4 = r % C4; r /= C4;
         const int ix = r % IW; r /= IW;
@@ -157,9 +167,25 @@ __global__ void pool_bwd_vec_kernel(const float *dout, int do_cs, int do_c0, int
             g.z = (((am >> 16) & 255u) == widx) ? d.z : 0.f;
             g.w = ((am >> 24) == widx) ? d.w : 0.f;
         }
-        f32x4 *dst = reinterpret_cast<f32x4 *>(din + ((((n * ID + iz) * IH + iy) * IW + ix)) * di_cs + di_c0 + c4 * 4);
+        const long long ivox = (((n * ID + iz) * IH + iy) * IW + ix);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(din + ivox * di_cs + di_c0 + c4 * 4);
         if (accumulate) g += *dst;
+        if constexpr (G > 0) {
+            if (act) {
+                const f32x4 m = *reinterpret_cast<const f32x4 *>(act + ivox * a_cs + a_c0 + c4 * 4);
+                g.x = m.x > 0.f ? g.x : 0.f; g.y = m.y > 0.f ? g.y : 0.f;
+                g.z = m.z > 0.f ? g.z : 0.f; g.w = m.w > 0.f ? g.w : 0.f;
+            }
+        }
         *dst = g;
+        if constexpr (G > 0) {
+            if (dsum) {
+                float sm = (g.x + g.y) + (g.z + g.w);
+#pragma unroll
+                for (int o = 1; o < G; o <<= 1) sm += __shfl_xor(sm, o, 64);
+                if (c4 == 0) dsum[ivox] = sm;
+            }
+        }
     }
 }
 
@@ -189,14 +215,30 @@ int k_pool_fwd(alq_ctx *ctx, const View &in, const View &out, uint8_t *argmax, c
 }
 
 int k_pool_bwd(alq_ctx *ctx, const View &dout, const View &din, const uint8_t *argmax, const int w[3],
-               const int lo[3], int N, int accumulate) {
+               const int lo[3], int N, int accumulate, const View *mask_act, float *dsum, bool *fused) {
     const long long total = (long long)N * din.vox() * din.C;
     ProfScope ps(ctx, PROF_ELEMWISE, 0);
+    if (fused) *fused = false;
     if (((din.cs | din.c0 | din.C | dout.cs | dout.c0) & 3) == 0) {
-        hipLaunchKernelGGL(pool_bwd_vec_kernel, dim3(grid_for(total / 4)), dim3(256), 0, ctx->stream, dout.p,
-                           dout.cs, dout.c0, dout.C / 4, dout.D, dout.H, dout.W, din.p, din.cs, din.c0, din.D, din.H,
-                           din.W, argmax, w[0], w[1], w[2], lo[0], lo[1], lo[2], accumulate, total / 4);
+        const int C4 = din.C / 4;
+        const bool can = (dsum != nullptr) && (C4 == 1 || C4 == 2 || C4 == 4 || C4 == 8) &&
+                         (!mask_act || ((mask_act->cs | mask_act->c0) & 3) == 0);
+        const float *ap = (can && mask_act) ? mask_act->p : nullptr;
+        const int acs = mask_act ? mask_act->cs : 0, ac0 = mask_act ? mask_act->c0 : 0;
+        float *ds = can ? dsum : nullptr;
+#define ALQ_PB(GV)                                                                                              \
+    hipLaunchKernelGGL(pool_bwd_vec_kernel<GV>, dim3(grid_for(total / 4)), dim3(256), 0, ctx->stream, dout.p,   \
+                       dout.cs, dout.c0, dout.C / 4, dout.D, dout.H, dout.W, din.p, din.cs, din.c0, din.D,      \
+                       din.H, din.W, argmax, w[0], w[1], w[2], lo[0], lo[1], lo[2], accumulate, total / 4, ap,   \
+                       acs, ac0, ds)
+        if (!can) ALQ_PB(0);
+        else if (C4 == 1) ALQ_PB(1);
+        else if (C4 == 2) ALQ_PB(2);
+        else if (C4 == 4) ALQ_PB(4);
+        else ALQ_PB(8);
+#undef ALQ_PB
         ALQ_LAUNCH_CHECK();
+        if (fused) *fused = can;
         return ALQ_OK;
     }
     hipLaunchKernelGGL(pool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, dout.p, dout.cs,
@@ -353,6 +395,15 @@ static int launch_chansum_grp(alq_ctx *ctx, float *d, int cs, int c0, int C, con
     return ALQ_OK;
 }
 
+int k_rowsum_field(alq_ctx *ctx, const float *field, int64_t len, int N, float *out) {
+    ProfScope ps(ctx, PROF_ELEMWISE, 0);
+    const int len_i = (int)len;
+    hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)N), dim3(256), 0, ctx->stream, const_cast<float *>(field), len_i, 0,
+                       len_i, (const float *)nullptr, 0, 0, out);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
 constexpr int ROW_KERNEL_MIN_C = 512;
 
 int k_chansum(alq_ctx *ctx, const View &in, float *field, int N) {
@@ -395,15 +446,16 @@ int k_mask_chansum(alq_ctx *ctx, const View &dact, const View *act, float *field
 // conv / fc:  S[n] = sum_x dsum[n,x] * (1 + sum_taps asum[n, x + tap - lo])   (zero outside)
 // grid (slabs, N): each workgroup reduces a contiguous slab of BOX_SLAB voxels in fp64 and writes
 // one partial; fisher_finalize adds the slab partials in slab order -> deterministic.
-__global__ __launch_bounds__(256) void boxdot_conv_kernel(const float *dsum, const float *asum, int D, int H,
-                                                          int W, int kz, int ky, int kx, int lz, int ly,
-                                                          int lx, double *Spart, int nslab_max) {
+__global__ __launch_bounds__(256) void boxdot_conv_kernel(const float *dsum, const float *asum, const float *asum2,
+                                                          int D, int H, int W, int kz, int ky, int kx, int lz,
+                                                          int ly, int lx, double *Spart, int nslab_max) {
     __shared__ double sh[4];
     const long long n = blockIdx.y;
     const int slab = blockIdx.x;
     const int vox = D * H * W;
     const float *dn = dsum + n * vox;
     const float *an = asum + n * vox;
+    const float *an2 = asum2 ? asum2 + n * vox : nullptr;
     double acc = 0;
     const int v1 = min(vox, (slab + 1) * BOX_SLAB);
     for (int v = slab * BOX_SLAB + threadIdx.x; v < v1; v += 256) {
@@ -424,6 +476,13 @@ __global__ __launch_bounds__(256) void boxdot_conv_kernel(const float *dsum, con
                     const int ix = x + dx - lx;
                     if (ix >= 0 && ix < W) box += rowp[ix];
                 }
+                if (an2) {
+                    const float *rowq = an2 + (iz * H + iy) * W;
+                    for (int dx = 0; dx < kx; ++dx) {
+                        const int ix = x + dx - lx;
+                        if (ix >= 0 && ix < W) box += rowq[ix];
+                    }
+                }
             }
         }
         acc += (double)dv * ((double)box + 1.0);
@@ -434,8 +493,8 @@ __global__ __launch_bounds__(256) void boxdot_conv_kernel(const float *dsum, con
 
 // conv_transpose: S[n] = sum_q asum[n,q] * sum_t dsum[n, s*q + t - lo] + sum_p dsum[n,p]
 // (q on the INPUT grid, p on the output grid = s * input grid); slabs over q
-__global__ __launch_bounds__(256) void boxdot_convT_kernel(const float *dsum, const float *asum, int ID,
-                                                           int IH, int IW, int kz, int ky, int kx, int sz,
+__global__ __launch_bounds__(256) void boxdot_convT_kernel(const float *dsum, const float *asum, const float *asum2,
+                                                           int ID, int IH, int IW, int kz, int ky, int kx, int sz,
                                                            int sy, int sx, int lz, int ly, int lx,
                                                            double *Spart, int nslab_max) {
     __shared__ double sh[4];
@@ -472,7 +531,8 @@ __global__ __launch_bounds__(256) void boxdot_convT_kernel(const float *dsum, co
                 const float *rowp = dn + ((long long)(z * sz + dz) * OH + (y * sy + dy)) * OW + x * sx;
                 for (int dx = 0; dx < sx; ++dx) own += rowp[dx];
             }
-        acc += (double)an[v] * (double)box + (double)own;
+        const float av = an[v] + (asum2 ? asum2[n * ivox + v] : 0.f);
+        acc += (double)av * (double)box + (double)own;
     }
     const double tot = block_sum256(acc, sh);
     if (threadIdx.x == 0) Spart[n * nslab_max + slab] = tot;
@@ -480,20 +540,20 @@ __global__ __launch_bounds__(256) void boxdot_convT_kernel(const float *dsum, co
 
 int boxdot_slabs(long long vox) { return (int)((vox + BOX_SLAB - 1) / BOX_SLAB); }
 
-int k_boxdot_conv(alq_ctx *ctx, const float *dsum, const float *asum, int D, int H, int W, const int k[3],
-                  const int lo[3], int N, double *Spart, int nslab_max) {
+int k_boxdot_conv(alq_ctx *ctx, const float *dsum, const float *asum, const float *asum2, int D, int H, int W,
+                  const int k[3], const int lo[3], int N, double *Spart, int nslab_max) {
     ProfScope ps(ctx, PROF_REDUCE, 0);
     hipLaunchKernelGGL(boxdot_conv_kernel, dim3(boxdot_slabs((long long)D * H * W), N), dim3(256), 0, ctx->stream,
-                       dsum, asum, D, H, W, k[0], k[1], k[2], lo[0], lo[1], lo[2], Spart, nslab_max);
+                       dsum, asum, asum2, D, H, W, k[0], k[1], k[2], lo[0], lo[1], lo[2], Spart, nslab_max);
     ALQ_LAUNCH_CHECK();
     return ALQ_OK;
 }
 
-int k_boxdot_convT(alq_ctx *ctx, const float *dsum, const float *asum, int ID, int IH, int IW, const int k[3],
-                   const int s[3], const int lo[3], int N, double *Spart, int nslab_max) {
+int k_boxdot_convT(alq_ctx *ctx, const float *dsum, const float *asum, const float *asum2, int ID, int IH, int IW,
+                   const int k[3], const int s[3], const int lo[3], int N, double *Spart, int nslab_max) {
     ProfScope ps(ctx, PROF_REDUCE, 0);
     hipLaunchKernelGGL(boxdot_convT_kernel, dim3(boxdot_slabs((long long)ID * IH * IW), N), dim3(256), 0,
-                       ctx->stream, dsum, asum, ID, IH, IW, k[0], k[1], k[2], s[0], s[1], s[2], lo[0], lo[1], lo[2],
+                       ctx->stream, dsum, asum, asum2, ID, IH, IW, k[0], k[1], k[2], s[0], s[1], s[2], lo[0], lo[1], lo[2],
                        Spart, nslab_max);
     ALQ_LAUNCH_CHECK();
     return ALQ_OK;
@@ -577,21 +637,39 @@ int k_fc_small_finish(alq_ctx *ctx, const float *partials, int nslices, const fl
     return ALQ_OK;
 }
 
-// dact[n, f] = sum_o delta[n, o] * Wp[o, f]
+// dact[n, f] = sum_o delta[n, o] * Wp[o, f]; G > 0: rows are [voxel][C = 4G]: ReLU-grad mask by act and
+// per-voxel channel sums fused (G lanes per voxel meet through xor-shuffles)
+template <int G>
 __global__ void fc_small_bwd_kernel(const float *delta, int nout, const float *Wp, long long F, int N,
-                                    float *dact) {
+                                    float *dact, const float *act, float *dsum) {
     const long long total4 = (long long)N * (F >> 2);
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < ((total4 + 63) & ~63LL);
          i += (long long)gridDim.x * blockDim.x) {
-        const long long n = i / (F >> 2);
-        const long long f = (i - n * (F >> 2)) << 2;
         f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int o = 0; o < nout; ++o) {
-            const float dv = delta[n * nout + o];
-            const f32x4 wv = *reinterpret_cast<const f32x4 *>(Wp + o * F + f);
-            s += dv * wv;
+        const bool in = i < total4;
+        if (in) {
+            const long long n = i / (F >> 2);
+            const long long f = (i - n * (F >> 2)) << 2;
+            for (int o = 0; o < nout; ++o) {
+                const float dv = delta[n * nout + o];
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(Wp + o * F + f);
+                s += dv * wv;
+            }
+            if constexpr (G > 0) {
+                if (act) {
+                    const f32x4 m = *reinterpret_cast<const f32x4 *>(act + n * F + f);
+                    s.x = m.x > 0.f ? s.x : 0.f; s.y = m.y > 0.f ? s.y : 0.f;
+                    s.z = m.z > 0.f ? s.z : 0.f; s.w = m.w > 0.f ? s.w : 0.f;
+                }
+            }
+            *reinterpret_cast<f32x4 *>(dact + n * F + f) = s;
         }
-        *reinterpret_cast<f32x4 *>(dact + n * F + f) = s;
+        if constexpr (G > 0) {
+            float sm = (s.x + s.y) + (s.z + s.w);
+#pragma unroll
+            for (int o = 1; o < G; o <<= 1) sm += __shfl_xor(sm, o, 64);
+            if (in && dsum && (i & (G - 1)) == 0) dsum[i / G] = sm;
+        }
     }
 }
 __global__ void fc_small_bwd_scalar_kernel(const float *delta, int nout, const float *Wp, long long F, int N,
@@ -607,12 +685,22 @@ __global__ void fc_small_bwd_scalar_kernel(const float *delta, int nout, const f
 }
 
 int k_fc_small_bwd(alq_ctx *ctx, const float *delta, int nout, const float *Wp, int64_t F, int N,
-                   float *dact) {
+                   float *dact, const float *mask_act, float *dsum, int C, bool *fused) {
     ProfScope ps(ctx, PROF_FC_SMALL, 2.0 * F * nout * N);
-    if ((F & 3) == 0)
-        hipLaunchKernelGGL(fc_small_bwd_kernel, dim3(grid_for((long long)N * (F >> 2))), dim3(256), 0,
-                           ctx->stream, delta, nout, Wp, (long long)F, N, dact);
-    else
+    if (fused) *fused = false;
+    if ((F & 3) == 0) {
+        const int G = (dsum && C > 0 && C % 4 == 0) ? C / 4 : 0;
+        const dim3 grid(grid_for((long long)N * (F >> 2)));
+#define ALQ_FB(GV) \
+    hipLaunchKernelGGL(fc_small_bwd_kernel<GV>, grid, dim3(256), 0, ctx->stream, delta, nout, Wp, (long long)F, N, dact, mask_act, dsum)
+        if (G == 1) { ALQ_FB(1); if (fused) *fused = true; }
+        else if (G == 2) { ALQ_FB(2); if (fused) *fused = true; }
+        else if (G == 4) { ALQ_FB(4); if (fused) *fused = true; }
+        else if (G == 8) { ALQ_FB(8); if (fused) *fused = true; }
+        else hipLaunchKernelGGL(fc_small_bwd_kernel<0>, grid, dim3(256), 0, ctx->stream, delta, nout, Wp, (long long)F, N,
+                                dact, (const float *)nullptr, (float *)nullptr);
+#undef ALQ_FB
+    } else
         hipLaunchKernelGGL(fc_small_bwd_scalar_kernel, dim3(grid_for((long long)N * F)), dim3(256), 0,
                            ctx->stream, delta, nout, Wp, (long long)F, N, dact);
     ALQ_LAUNCH_CHECK();

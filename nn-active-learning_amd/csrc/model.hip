@@ -54,6 +54,8 @@ struct Layer {
     // workspaces
     uint8_t *argmax = nullptr;
     float *asum = nullptr, *dsum = nullptr;
+    float *osum = nullptr;     // channel sums of this layer's OUTPUT (spatial layers): next layers' asum
+    bool delta_ready = false;  // backward: the cotangent of our output is already masked and dsum is filled
     float *fc_partials = nullptr;
     int fc_slices = 0;
     bool out_is_skip_src = false;
@@ -347,6 +349,7 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
         }
         ly.out = act[i];
         ly.dout = dact[i];
+        if (ly.spec.type != ALQ_FC) ALQ_TRY(m->dalloc(&ly.osum, (size_t)NB * ly.out.vox()));
         if (ly.pidx >= 0) {
             h_sizes[ly.pidx] = (double)(ly.w_elems + ly.b_elems);
             ALQ_TRY(m->dalloc(&ly.d_bias, (size_t)ly.b_elems));
@@ -466,7 +469,7 @@ static View flat_view(const View &v) {
 }
 
 // ------------------------------------------------------------------------------------------
-static int run_forward(alq_model *m, const float *d_x, int N, bool with_asum) {
+static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums) {
     alq_ctx *ctx = m->ctx;
     const int nl = (int)m->layers.size();
     for (int i = 0; i < nl; ++i) {
@@ -474,73 +477,122 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_asum) {
         ALQ_REQUIRE(ly.pidx < 0 || ly.weights_set, ALQ_EINVAL, "weights of parameterised layer %d not set", ly.pidx);
         View in = ly.in;
         if (i == 0) in.p = const_cast<float *>(d_x);
-        if (with_asum && ly.pidx >= 0) {
-            if (ly.spec.type == ALQ_FC) ALQ_TRY(k_chansum(ctx, flat_view(in), ly.asum, N));
-            else ALQ_TRY(k_chansum(ctx, in, ly.asum, N));
-        }
+        // channel sums of every spatial layer's output ride on the producing kernel's epilogue when it
+        // can; they are the `asum` fields of the layers that consume it
+        Igemm2Fuse fz;
+        fz.osumA = ly.osum;
+        const Igemm2Fuse *fuse = (with_sums && ly.osum) ? &fz : nullptr;
+        bool fused = false;
         switch (ly.spec.type) {
             case ALQ_CONV:
-                ALQ_TRY(gemm_launch(ctx, ly.fwd[0], in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM_FWD));
+                ALQ_TRY(gemm_launch(ctx, ly.fwd[0], in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM_FWD, fuse, &fused));
                 break;
-            case ALQ_CONVT:
-                for (auto &p : ly.fwd)
-                    ALQ_TRY(gemm_launch(ctx, p, in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM_FWD));
+            case ALQ_CONVT: {
+                bool all = true;
+                for (auto &p : ly.fwd) {
+                    bool f1 = false;
+                    ALQ_TRY(gemm_launch(ctx, p, in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM_FWD, fuse, &f1));
+                    all = all && f1;
+                }
+                fused = all;
                 break;
+            }
             case ALQ_POOL:
                 ALQ_TRY(k_pool_fwd(ctx, in, ly.out, ly.argmax, ly.spec.k, ly.lo, N));
                 break;
             case ALQ_FC:
+                if (with_sums) {
+                    // sum of all inputs of the fc layer, per patch
+                    const bool prev_spatial = i > 0 && m->layers[i - 1].osum != nullptr;
+                    if (prev_spatial) ALQ_TRY(k_rowsum_field(ctx, m->layers[i - 1].osum, m->layers[i - 1].out.vox(), N, ly.asum));
+                    else ALQ_TRY(k_chansum(ctx, flat_view(in), ly.asum, N));
+                }
                 if (ly.dense_fc_small) {
                     ALQ_TRY(k_fc_small_fwd(ctx, in.p, ly.F, ly.d_Wp, ly.spec.cout, N, ly.fc_partials, ly.fc_slices));
                     ALQ_TRY(k_fc_small_finish(ctx, ly.fc_partials, ly.fc_slices, ly.d_bias, ly.spec.cout,
                                               ly.spec.relu, N, ly.out.p));
                 } else {
                     ALQ_TRY(gemm_launch(ctx, ly.fwd[0], flat_view(in), ly.out, ly.d_bias, ly.spec.relu, 0, N,
-                                         PROF_IGEMM_FWD));
+                                        PROF_IGEMM_FWD));
                 }
                 break;
         }
+        if (with_sums && ly.osum && !fused) ALQ_TRY(k_chansum(ctx, ly.out, ly.osum, N));
+        if (with_sums && i == 0 && ly.pidx == 0 && ly.spec.type != ALQ_FC && in.C > 1)
+            ALQ_TRY(k_chansum(ctx, in, ly.asum, N));     // channel sums of the network input
     }
     return ALQ_OK;
 }
 
-static int run_backward(alq_model *m, int N) {
+static int run_backward(alq_model *m, const float *d_x, int N) {
     alq_ctx *ctx = m->ctx;
     const int nl = (int)m->layers.size();
     ALQ_REQUIRE(m->nclass == 2, ALQ_EUNSUPPORTED, "Fisher scoring is binary (PW_NNAL.py:766), got %d classes", m->nclass);
     ALQ_TRY(k_fill_unit_cotangent(ctx, m->dlogits, N));
+    for (Layer &l : m->layers) l.delta_ready = false;
     for (int i = nl - 1; i >= 0; --i) {
         Layer &ly = m->layers[i];
         const bool prev_is_src = (i > 0 && m->layers[i - 1].out_is_skip_src && ly.spec.skip_src < 0);
+        // Every backward op is the LAST writer of its direct input's cotangent (a skip destination
+        // wrote its slice earlier), so it can finish that tensor: ReLU-grad mask + channel sums.
+        Layer *prev = i > 0 ? &m->layers[i - 1] : nullptr;
+        const bool prev_param = prev && prev->pidx >= 0 && prev->spec.type != ALQ_FC;
         if (ly.spec.type == ALQ_POOL) {
-            ALQ_TRY(k_pool_bwd(ctx, ly.dout, ly.din, ly.argmax, ly.spec.k, ly.lo, N, prev_is_src ? 1 : 0));
+            bool fused = false;
+            ALQ_TRY(k_pool_bwd(ctx, ly.dout, ly.din, ly.argmax, ly.spec.k, ly.lo, N, prev_is_src ? 1 : 0,
+                               (prev_param && prev->spec.relu) ? &prev->out : nullptr, prev_param ? prev->dsum : nullptr,
+                               &fused));
+            if (prev_param && fused) prev->delta_ready = true;
             continue;
         }
-        // cotangent w.r.t. the pre-activation + its channel sum
+        // cotangent w.r.t. the pre-activation + its channel sum (unless the producer already did it)
         const bool isfc = ly.spec.type == ALQ_FC;
-        View dv = isfc ? flat_view(ly.dout) : ly.dout;
-        View av = isfc ? flat_view(ly.out) : ly.out;
-        ALQ_TRY(k_mask_chansum(ctx, dv, ly.spec.relu ? &av : nullptr, ly.dsum, N));
+        if (!ly.delta_ready) {
+            View dv = isfc ? flat_view(ly.dout) : ly.dout;
+            View av = isfc ? flat_view(ly.out) : ly.out;
+            ALQ_TRY(k_mask_chansum(ctx, dv, ly.spec.relu ? &av : nullptr, ly.dsum, N));
+        }
+        // channel sums of the layer input: the producers' osum fields (two for a concat input)
+        const float *as1 = ly.asum, *as2 = nullptr;
+        if (!isfc) {
+            if (i == 0) as1 = ly.in.C == 1 ? d_x : ly.asum;
+            else as1 = m->layers[i - 1].osum;
+            if (ly.spec.skip_src >= 0) as2 = m->layers[ly.spec.skip_src].osum;
+        }
         double *Sdst = m->Spart + (size_t)ly.pidx * m->max_batch * m->nslab_max;
         if (ly.spec.type == ALQ_CONVT) {
-            ALQ_TRY(k_boxdot_convT(ctx, ly.dsum, ly.asum, ly.in.D, ly.in.H, ly.in.W, ly.spec.k, ly.spec.s, ly.lo, N, Sdst, m->nslab_max));
+            ALQ_TRY(k_boxdot_convT(ctx, ly.dsum, as1, as2, ly.in.D, ly.in.H, ly.in.W, ly.spec.k, ly.spec.s, ly.lo, N, Sdst, m->nslab_max));
         } else if (isfc) {
             const int one[3] = {1, 1, 1}, zero[3] = {0, 0, 0};
-            ALQ_TRY(k_boxdot_conv(ctx, ly.dsum, ly.asum, 1, 1, 1, one, zero, N, Sdst, m->nslab_max));
+            ALQ_TRY(k_boxdot_conv(ctx, ly.dsum, ly.asum, nullptr, 1, 1, 1, one, zero, N, Sdst, m->nslab_max));
         } else {
-            ALQ_TRY(k_boxdot_conv(ctx, ly.dsum, ly.asum, ly.out.D, ly.out.H, ly.out.W, ly.spec.k, ly.lo, N, Sdst, m->nslab_max));
+            ALQ_TRY(k_boxdot_conv(ctx, ly.dsum, as1, as2, ly.out.D, ly.out.H, ly.out.W, ly.spec.k, ly.lo, N, Sdst, m->nslab_max));
         }
         if (ly.pidx == 0) break;   // nothing upstream needs a cotangent
         const int acc = prev_is_src ? 1 : 0;   // the skip destination has already written this slice
+        bool fused = false;
         if (isfc) {
             ALQ_REQUIRE(!acc, ALQ_EUNSUPPORTED, "layer %d: fc consumer of a skip source", i);
-            if (ly.dense_fc_small)
-                ALQ_TRY(k_fc_small_bwd(ctx, ly.dout.p, ly.spec.cout, ly.d_Wp, ly.F, N, ly.din.p));
-            else
+            if (ly.dense_fc_small) {
+                const bool can = prev_param && prev->out.cs == prev->out.C;
+                ALQ_TRY(k_fc_small_bwd(ctx, ly.dout.p, ly.spec.cout, ly.d_Wp, ly.F, N, ly.din.p,
+                                       (can && prev->spec.relu) ? prev->out.p : nullptr, can ? prev->dsum : nullptr,
+                                       can ? prev->out.C : 0, &fused));
+            } else {
                 ALQ_TRY(gemm_launch(ctx, ly.bwd, ly.dout, flat_view(ly.din), nullptr, 0, 0, N, PROF_IGEMM_BWD));
+            }
         } else {
-            ALQ_TRY(gemm_launch(ctx, ly.bwd, ly.dout, ly.din, nullptr, 0, acc, N, PROF_IGEMM_BWD));
+            Igemm2Fuse fz;
+            const Igemm2Fuse *fuse = nullptr;
+            if (prev_param) {
+                const int Cs = ly.spec.skip_src >= 0 ? m->layers[ly.spec.skip_src].out.C : 0;   // concat: [src | prev]
+                if (prev->spec.relu) { fz.mask = prev->out.p; fz.mask_cs = prev->out.cs; fz.mask_c0 = prev->out.c0; fz.mask_from = Cs; }
+                if (Cs > 0) { fz.split = Cs; fz.osumB = prev->dsum; } else { fz.osumA = prev->dsum; }
+                fuse = &fz;
+            }
+            ALQ_TRY(gemm_launch(ctx, ly.bwd, ly.dout, ly.din, nullptr, 0, acc, N, PROF_IGEMM_BWD, fuse, &fused));
         }
+        if (prev_param && fused) prev->delta_ready = true;
     }
     return ALQ_OK;
 }
@@ -789,7 +841,7 @@ int alq_fisher(alq_model *m, const float *d_x, int N, const float *d_p1_in, doub
     }
     ALQ_TRY(run_forward(m, d_x, N, true));
     ALQ_TRY(k_softmax(m->ctx, m->logits, m->nclass, N, m->post, nullptr));
-    ALQ_TRY(run_backward(m, N));
+    ALQ_TRY(run_backward(m, d_x, N));
     int nblocks = 0;
     ALQ_TRY(k_fisher_finalize(m->ctx, m->Spart, m->nslab, m->nslab_max, m->max_batch, m->S, m->L, m->sizes, m->post,
                               d_p1_in, N, diag_load, d_p1_out, d_g0, d_g1, d_A, d_trace, m->Apart, &nblocks));

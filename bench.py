@@ -40,7 +40,7 @@ def main():
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--pool', type=int, default=100000, help='patches per GPU')
-    ap.add_argument('--batch', type=int, default=256, help='patches per device pass')
+    ap.add_argument('--batch', type=int, default=512, help='patches per device pass')
     ap.add_argument('--topB', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=16)

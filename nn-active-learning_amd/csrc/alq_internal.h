@@ -198,15 +198,46 @@ struct Igemm2Fuse {
 };
 
 extern unsigned long long *g_igemm2_dbg;
+extern int g_dbg_knobs[8];
 int igemm2_build_plan(const IgemmPlan &p1, Igemm2Plan *p2);
 void igemm2_pack_weights(Igemm2Plan *p2, const std::vector<float> &Bmat);
 int igemm2_launch(alq_ctx *ctx, const Igemm2Plan &plan, const View &in, const View &out, const float *bias,
                   int relu, int accumulate, int N, int prof_cls, const Igemm2Fuse *fuse);
 
-// one contraction = general plan + (when eligible) pipelined plan
+// ------------------------------------------------------------------ direct first-layer conv (direct.hip)
+struct DirectArgs {
+    const float *in;
+    float *out;
+    const float *W;      // [ntaps*Ci][Co] (the fwd B matrix as is)
+    const float *bias;
+    float *osum;
+    int in_cs, in_c0, Ci, ID, IH, IW;
+    int out_cs, out_c0, Co, OD, OH, OW;
+    int MD, MH, MW;
+    int PT, TZ, TY, TX, HZ, HY, HX, rows;
+    int minz, miny, minx;
+    int ntaps, tnx, tny, tnz;
+    int tilesZ, tilesY, tilesX;
+    int N, relu;
+};
+
+struct DirectPlan {
+    DirectArgs a;
+    bool ok = false;
+    size_t lds_bytes = 0;
+    double flops_per_patch = 0;
+    float *d_W = nullptr;
+};
+
+int direct_build_plan(const IgemmPlan &p1, DirectPlan *dp);
+int direct_launch(alq_ctx *ctx, const DirectPlan &dp, const View &in, const View &out, const float *bias, int relu,
+                  int N, float *osum, int prof_cls);
+
+// one contraction = general plan + (when eligible) pipelined plan / direct first-layer plan
 struct Gemm {
     IgemmPlan p1;
     Igemm2Plan p2;
+    DirectPlan pd;
 };
 
 // ------------------------------------------------------------------ other kernels
@@ -220,6 +251,7 @@ int k_pool_bwd(alq_ctx *, const View &dout, const View &din, const uint8_t *argm
 int k_chansum(alq_ctx *, const View &in, float *field, int N);
 int k_mask_chansum(alq_ctx *, const View &dact, const View *act_or_null, float *field, int N);
 int boxdot_slabs(long long vox);
+int boxdot_conv_slabs(int D, int H, int W, const int k[3]);
 // asum2 (optional): second channel-sum field added to asum (input = concat of two producers)
 int k_boxdot_conv(alq_ctx *, const float *dsum, const float *asum, const float *asum2, int D, int H, int W,
                   const int k[3], const int lo[3], int N, double *Spart, int nslab_max);

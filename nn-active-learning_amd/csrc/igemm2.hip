@@ -45,7 +45,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int I2_CBP = 12;        // floats per halo voxel row in LDS (8 channels + 4 pad)
 constexpr int I2_MAXSLOT = 8;     // float4 A staging slots per thread (nhv*2 <= 256*I2_MAXSLOT)
-constexpr int I2_WRES_MAX = 16 * 1024;   // resident weights: at most this many bytes per 16-col tile
+constexpr int I2_WRES_MAX = 28 * 1024;   // resident weights: at most this many bytes per 16-col tile (tests/gpu_ab.py)
 
 // GEO: 1 / 2 -> 3x3x3 taps over a halo block with HY = 6, HX = 18 (the 4x4x16 tile every 16^3 / 32^3 layer
 // uses), walked in ascending (forward conv) / descending (backward-data) order: every LDS fragment
@@ -278,14 +278,16 @@ __global__ __launch_bounds__(256, 2) void igemm2_kernel(const Igemm2Args a) {
                     if (!on) val = f32x4{0.f, 0.f, 0.f, 0.f};
                     // selector S[i = lrow][k = lq] for this 16-channel tile
                     const float sel = (lrow == 0) ? (c < a.split ? 1.f : 0.f) : ((lrow == 1) ? (c < a.split ? 0.f : 1.f) : 0.f);
+                    if (!(a.dbg_flags & 4)) {
                     sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, val.x, sacc, 0, 0, 0);
                     sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, val.y, sacc, 0, 0, 0);
                     sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, val.z, sacc, 0, 0, 0);
                     sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, val.w, sacc, 0, 0, 0);
+                    }
                 }
             }
             if constexpr (SUMS) {
-                if (live && lq == 0) {
+                if (live && lq == 0 && !(a.dbg_flags & 8)) {
                     if (a.osumA) a.osumA[p_out + evox[ms]] = sacc.x;
                     if (a.osumB) a.osumB[p_out + evox[ms]] = sacc.y;
                 }
@@ -440,7 +442,9 @@ int igemm2_build_plan(const IgemmPlan &p1, Igemm2Plan *p2) {
     if (nhv * 2 > 256 * I2_MAXSLOT) return ALQ_OK;
     if (a1.HZ > 255 || a1.HY > 255 || a1.HX > 255 || a1.PT > 127) return ALQ_OK;
     const size_t wchunk = (size_t)a1.ntaps * p1.NTW * 128 * 4;
-    const bool wres = wchunk * a1.nchunks <= (size_t)I2_WRES_MAX * p1.NTW;
+    size_t wres_max = I2_WRES_MAX;
+    if (const char *e = getenv("ALQ_WRES_KB")) wres_max = (size_t)atoi(e) * 1024;     // tuning experiment
+    const bool wres = wchunk * a1.nchunks <= wres_max * p1.NTW;
     const size_t wbytes = wres ? wchunk * a1.nchunks : wchunk;
     const size_t lds = wbytes + (size_t)nhv * I2_CBP * 4;
     if (lds > 156 * 1024) return ALQ_OK;
@@ -538,7 +542,9 @@ int igemm2_build_plan(const IgemmPlan &p1, Igemm2Plan *p2) {
     p2->NTW = p1.NTW;
     p2->wres = wres;
     p2->lds_bytes = lds;
-    p2->wgs_per_cu = std::max<int>(1, std::min<int>(3, (int)((160 * 1024) / (lds + 512))));
+    int max_wgs = 2;      // measured: 2 persistent workgroups per CU beat 1, 3 and 4 (tests/gpu_ab.py)
+    if (const char *e = getenv("ALQ_MAX_WGS")) max_wgs = atoi(e);                      // tuning experiment
+    p2->wgs_per_cu = std::max<int>(1, std::min<int>(max_wgs, (int)((160 * 1024) / (lds + 512))));
     p2->flops_per_patch = p1.flops_per_patch;
     p2->ok = true;
     return ALQ_OK;
@@ -561,7 +567,8 @@ void igemm2_pack_weights(Igemm2Plan *p2, const std::vector<float> &Bmat) {
                     }
 }
 
-unsigned long long *g_igemm2_dbg = nullptr;   // set by alq_debug_set_stamp_buffer (diagnostic build)
+unsigned long long *g_igemm2_dbg = nullptr;
+int g_dbg_knobs[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 0 repeat, 1 flags, 2 no-bwd-fuse, 3 no-fwd-fuse   // set by alq_debug_set_stamp_buffer (diagnostic build)
 
 template <int NTW, bool WRES, int GEO, bool SUMS>
 static int launch2_s(alq_ctx *ctx, const Igemm2Plan &plan, const Igemm2Args &a, unsigned grid) {
@@ -608,14 +615,9 @@ int igemm2_launch(alq_ctx *ctx, const Igemm2Plan &plan, const View &in, const Vi
         if (want < 0 || ordinal == want) a.dbg = g_igemm2_dbg;
         ++ordinal;
     }
-    {
-        static int rep = -1;   // timing experiment only (ALQ_DEBUG_REPEAT=n repeats the MFMA phase: wrong results)
-        if (rep < 0) { const char *e = getenv("ALQ_DEBUG_REPEAT"); rep = e ? atoi(e) : 0; }
-        a.dbg_repeat = rep;
-        static int flg = -1;   // timing experiments: bit 0 = no output stores, bit 1 = no input loads
-        if (flg < 0) { const char *e = getenv("ALQ_DEBUG_FLAGS"); flg = e ? atoi(e) : 0; }
-        a.dbg_flags = flg;
-    }
+    // timing experiments only (alq_debug_set / env): repeat the MFMA phase, drop stores / loads / sums
+    a.dbg_repeat = g_dbg_knobs[0];
+    a.dbg_flags = g_dbg_knobs[1];
     if (fuse) {
         a.mask = fuse->mask; a.mask_cs = fuse->mask_cs; a.mask_c0 = fuse->mask_c0; a.mask_from = fuse->mask_from;
         a.osumA = fuse->osumA; a.osumB = fuse->osumB;

@@ -538,11 +538,88 @@ __global__ __launch_bounds__(256) void boxdot_convT_kernel(const float *dsum, co
     if (threadIdx.x == 0) Spart[n * nslab_max + slab] = tot;
 }
 
+// LDS-tiled variant: a workgroup owns ZS z-planes; the (zero-padded) planes of asum (+ asum2) it needs
+// sit in LDS, so the k^3 window sum is k^3 LDS reads with no bounds logic.
+__global__ __launch_bounds__(256) void boxdot_conv_lds_kernel(const float *dsum, const float *asum, const float *asum2,
+                                                              int D, int H, int W, int kz, int ky, int kx, int lz,
+                                                              int ly, int lx, int ZS, double *Spart, int nslab_max) {
+    extern __shared__ float tile[];
+    __shared__ double sh[4];
+    const long long n = blockIdx.y;
+    const int slab = blockIdx.x;
+    const int z0 = slab * ZS;
+    const int PH = H + ky - 1, PW = W + kx - 1, planes = ZS + kz - 1;
+    const int vox = D * H * W;
+    const float *an = asum + n * vox;
+    const float *an2 = asum2 ? asum2 + n * vox : nullptr;
+    const int tot = planes * PH * PW;
+    for (int i = threadIdx.x; i < tot; i += 256) {
+        int r = i;
+        const int px = r % PW; r /= PW;
+        const int py = r % PH;
+        const int pz = r / PH;
+        const int iz = z0 + pz - lz, iy = py - ly, ix = px - lx;
+        float v = 0.f;
+        if (iz >= 0 && iz < D && iy >= 0 && iy < H && ix >= 0 && ix < W) {
+            const int o = (iz * H + iy) * W + ix;
+            v = an[o];
+            if (an2) v += an2[o];
+        }
+        tile[i] = v;
+    }
+    __syncthreads();
+    const float *dn = dsum + n * vox;
+    double acc = 0;
+    const int nv = ZS * H * W;
+    for (int i = threadIdx.x; i < nv; i += 256) {
+        int r = i;
+        const int x = r % W; r /= W;
+        const int y = r % H;
+        const int zz = r / H;
+        if (z0 + zz >= D) break;
+        float box = 0.f;
+        for (int dz = 0; dz < kz; ++dz)
+            for (int dy = 0; dy < ky; ++dy) {
+                const float *rowp = tile + ((zz + dz) * PH + (y + dy)) * PW + x;
+                for (int dx = 0; dx < kx; ++dx) box += rowp[dx];
+            }
+        acc += (double)dn[((z0 + zz) * H + y) * W + x] * ((double)box + 1.0);
+    }
+    const double tot_s = block_sum256(acc, sh);
+    if (threadIdx.x == 0) Spart[n * nslab_max + slab] = tot_s;
+}
+
+static int boxdot_zs(int D, int H, int W) {
+    int zs = 2048 / (H * W);
+    if (zs < 1) zs = 1;
+    if (zs > D) zs = D;
+    return zs;
+}
+static size_t boxdot_lds_bytes(int D, int H, int W, const int k[3]) {
+    const int zs = boxdot_zs(D, H, W);
+    return (size_t)(zs + k[0] - 1) * (H + k[1] - 1) * (W + k[2] - 1) * sizeof(float);
+}
+static bool boxdot_use_lds(int D, int H, int W, const int k[3]) {
+    return (long long)D * H * W >= 512 && boxdot_lds_bytes(D, H, W, k) <= 48 * 1024;
+}
+
 int boxdot_slabs(long long vox) { return (int)((vox + BOX_SLAB - 1) / BOX_SLAB); }
+int boxdot_conv_slabs(int D, int H, int W, const int k[3]) {
+    if (boxdot_use_lds(D, H, W, k)) { const int zs = boxdot_zs(D, H, W); return (D + zs - 1) / zs; }
+    return boxdot_slabs((long long)D * H * W);
+}
 
 int k_boxdot_conv(alq_ctx *ctx, const float *dsum, const float *asum, const float *asum2, int D, int H, int W,
                   const int k[3], const int lo[3], int N, double *Spart, int nslab_max) {
     ProfScope ps(ctx, PROF_REDUCE, 0);
+    if (boxdot_use_lds(D, H, W, k)) {
+        const int zs = boxdot_zs(D, H, W);
+        hipLaunchKernelGGL(boxdot_conv_lds_kernel, dim3((D + zs - 1) / zs, N), dim3(256), boxdot_lds_bytes(D, H, W, k),
+                           ctx->stream, dsum, asum, asum2, D, H, W, k[0], k[1], k[2], lo[0], lo[1], lo[2], zs, Spart,
+                           nslab_max);
+        ALQ_LAUNCH_CHECK();
+        return ALQ_OK;
+    }
     hipLaunchKernelGGL(boxdot_conv_kernel, dim3(boxdot_slabs((long long)D * H * W), N), dim3(256), 0, ctx->stream,
                        dsum, asum, asum2, D, H, W, k[0], k[1], k[2], lo[0], lo[1], lo[2], Spart, nslab_max);
     ALQ_LAUNCH_CHECK();

@@ -151,15 +151,22 @@ static int upload1(alq_model *m, IgemmPlan *p) {
 }
 
 static bool g_use_v2 = true;
+static bool g_knobs_init = false;
 
 static int gemm_build(const ConvDesc &d, int max_batch, Gemm *g) {
     ALQ_TRY(igemm_build_plan(d, max_batch, &g->p1));
     ALQ_TRY(igemm2_build_plan(g->p1, &g->p2));
-    if (!g_use_v2) g->p2.ok = false;
+    ALQ_TRY(direct_build_plan(g->p1, &g->pd));
+    if (!g_use_v2) { g->p2.ok = false; g->pd.ok = false; }
     return ALQ_OK;
 }
 
 static int gemm_set(alq_model *m, Gemm *g, const std::vector<float> &Bmat) {
+    if (g->pd.ok) {      // direct kernel reads the B matrix [K][Co] as it is
+        if (!g->pd.d_W) ALQ_TRY(m->dalloc(&g->pd.d_W, Bmat.size()));
+        ALQ_HIP(hipMemcpyAsync(g->pd.d_W, Bmat.data(), Bmat.size() * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
+        ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
+    }
     if (g->p2.ok) {
         igemm2_pack_weights(&g->p2, Bmat);
         if (!g->p2.d_tdesc) {
@@ -186,6 +193,10 @@ static int gemm_set(alq_model *m, Gemm *g, const std::vector<float> &Bmat) {
 // returns in *fused whether the epilogue fusion request was honoured (only the pipelined kernel can)
 static int gemm_launch(alq_ctx *ctx, const Gemm &g, const View &in, const View &out, const float *bias, int relu,
                        int accumulate, int N, int cls, const Igemm2Fuse *fuse = nullptr, bool *fused = nullptr) {
+    if (g.pd.ok && !accumulate && !(fuse && (fuse->mask || fuse->osumB || fuse->split))) {
+        if (fused) *fused = fuse != nullptr;
+        return direct_launch(ctx, g.pd, in, out, bias, relu, N, fuse ? fuse->osumA : nullptr, cls);
+    }
     if (g.p2.ok) {
         if (fused) *fused = fuse != nullptr;
         return igemm2_launch(ctx, g.p2, in, out, bias, relu, accumulate, N, cls, fuse);
@@ -451,8 +462,8 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
     std::vector<int> h_nslab(m->L, 1);
     for (const Layer &ly : m->layers) {
         if (ly.pidx < 0) continue;
-        long long vox = ly.spec.type == ALQ_FC ? 1 : (ly.spec.type == ALQ_CONVT ? ly.in.vox() : ly.out.vox());
-        h_nslab[ly.pidx] = boxdot_slabs(vox);
+        if (ly.spec.type == ALQ_CONV) h_nslab[ly.pidx] = boxdot_conv_slabs(ly.out.D, ly.out.H, ly.out.W, ly.spec.k);
+        else h_nslab[ly.pidx] = boxdot_slabs(ly.spec.type == ALQ_FC ? 1 : ly.in.vox());
         m->nslab_max = std::max(m->nslab_max, h_nslab[ly.pidx]);
     }
     ALQ_TRY(m->dalloc(&m->nslab, (size_t)m->L));
@@ -481,7 +492,7 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums) {
         // can; they are the `asum` fields of the layers that consume it
         Igemm2Fuse fz;
         fz.osumA = ly.osum;
-        const Igemm2Fuse *fuse = (with_sums && ly.osum) ? &fz : nullptr;
+        const Igemm2Fuse *fuse = (with_sums && ly.osum && !g_dbg_knobs[3]) ? &fz : nullptr;
         bool fused = false;
         switch (ly.spec.type) {
             case ALQ_CONV:
@@ -584,7 +595,7 @@ static int run_backward(alq_model *m, const float *d_x, int N) {
         } else {
             Igemm2Fuse fz;
             const Igemm2Fuse *fuse = nullptr;
-            if (prev_param) {
+            if (prev_param && !g_dbg_knobs[2]) {
                 const int Cs = ly.spec.skip_src >= 0 ? m->layers[ly.spec.skip_src].out.C : 0;   // concat: [src | prev]
                 if (prev->spec.relu) { fz.mask = prev->out.p; fz.mask_cs = prev->out.cs; fz.mask_c0 = prev->out.c0; fz.mask_from = Cs; }
                 if (Cs > 0) { fz.split = Cs; fz.osumB = prev->dsum; } else { fz.osumA = prev->dsum; }
@@ -660,6 +671,17 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
     {
         const char *e = getenv("ALQ_DISABLE_V2");   // diagnostics: force the general GEMM kernel
         g_use_v2 = !(e && e[0] == '1');
+        if (!g_knobs_init) {
+            // measured (tests/gpu_ab.py): fusing the channel sums into the two concat-destination
+            // backward GEMMs costs more than the separate 16^3 / 32^3 sum pass it saves
+            g_dbg_knobs[2] = 1;
+            g_knobs_init = true;
+        }
+        static const char *names[4] = {"ALQ_DEBUG_REPEAT", "ALQ_DEBUG_FLAGS", "ALQ_NO_BWD_FUSE", "ALQ_NO_FWD_FUSE"};
+        for (int k = 0; k < 4; ++k) {
+            const char *v = getenv(names[k]);
+            if (v) g_dbg_knobs[k] = atoi(v);
+        }
     }
     for (int i = 0; i < 4; ++i) m->in_dims[i] = in_dims[i];
     const int rc = build_model(m, layers, n_layers);
@@ -898,6 +920,12 @@ int alq_model_debug_copy(alq_model *m, int layer_idx, int what, int N, float *d_
     if (elems_out) *elems_out = e;
     ALQ_HIP(hipMemcpyAsync(d_out, what == 2 ? ly.asum : ly.dsum, e * sizeof(float), hipMemcpyDeviceToDevice,
                            m->ctx->stream));
+    return ALQ_OK;
+}
+
+int alq_debug_set(int key, int value) {
+    ALQ_REQUIRE(key >= 0 && key < 8, ALQ_EINVAL, "alq_debug_set: bad key");
+    g_dbg_knobs[key] = value;
     return ALQ_OK;
 }
 

@@ -1,7 +1,7 @@
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-idx=[i for i,r in enumerate(rows) if 'igemm_kernel<4, 1, true>' in r['Kernel_Name'] or 'smallc' in r['Kernel_Name']]
+idx=[i for i,r in enumerate(rows) if 'igemm_kernel<4, 1, true>' in r['Kernel_Name'] or 'direct_conv' in r['Kernel_Name']]
 s=idx[len(idx)//2]; e=idx[len(idx)//2+1]
 tot=0; gem=0
 for r in rows[s:e]:

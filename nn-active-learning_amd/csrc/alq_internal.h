@@ -241,13 +241,14 @@ struct Gemm {
 };
 
 // ------------------------------------------------------------------ other kernels
+// osum (optional): channel sums of the pooled output, *fused says whether the kernel produced them
 int k_pool_fwd(alq_ctx *, const View &in, const View &out, uint8_t *argmax, const int w[3],
-               const int lo[3], int N);
+               const int lo[3], int N, float *osum = nullptr, bool *fused = nullptr);
 // mask_act / dsum (both or neither): apply the ReLU-grad mask of the input layer's activation to the
 // finished cotangent and emit its channel sums; *fused tells whether the kernel could do it
 int k_pool_bwd(alq_ctx *, const View &dout, const View &din, const uint8_t *argmax,
                const int w[3], const int lo[3], int N, int accumulate, const View *mask_act = nullptr,
-               float *dsum = nullptr, bool *fused = nullptr);
+               float *dsum = nullptr, bool *fused = nullptr, int store_din = 1);
 int k_chansum(alq_ctx *, const View &in, float *field, int N);
 int k_mask_chansum(alq_ctx *, const View &dact, const View *act_or_null, float *field, int N);
 int boxdot_slabs(long long vox);

@@ -189,6 +189,99 @@ __global__ void pool_bwd_vec_kernel(const float *dout, int do_cs, int do_c0, int
     }
 }
 
+// ---- voxel-per-thread pooling (C = 4*C4 <= 32 channels): a thread owns all channels of one voxel, so the
+// channel sums (osum forward, dsum backward) are in-thread and every access is a run of 16-byte vectors
+template <int C4>
+__global__ void pool_fwd_vox_kernel(const float *in, int in_cs, int in_c0, int ID, int IH, int IW, float *out,
+                                    int out_cs, int out_c0, int OD, int OH, int OW, uint8_t *argmax, int wz, int wy,
+                                    int wx, int lz, int ly, int lx, long long nvox, float *osum) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nvox;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int ox = r % OW; r /= OW;
+        const int oy = r % OH; r /= OH;
+        const int oz = r % OD; r /= OD;
+        const long long n = r;
+        f32x4 best[C4];
+        unsigned bidx[C4];
+#pragma unroll
+        for (int c = 0; c < C4; ++c) { best[c] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY}; bidx[c] = 0; }
+        for (int dz = 0; dz < wz; ++dz) {
+            const int iz = oz * wz - lz + dz;
+            if (iz < 0 || iz >= ID) continue;
+            for (int dy = 0; dy < wy; ++dy) {
+                const int iy = oy * wy - ly + dy;
+                if (iy < 0 || iy >= IH) continue;
+                for (int dx = 0; dx < wx; ++dx) {
+                    const int ix = ox * wx - lx + dx;
+                    if (ix < 0 || ix >= IW) continue;
+                    const float *src = in + ((((n * ID + iz) * IH + iy) * IW + ix)) * in_cs + in_c0;
+                    const unsigned w = (dz * wy + dy) * wx + dx;
+#pragma unroll
+                    for (int c = 0; c < C4; ++c) {
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + c * 4);
+                        if (v.x > best[c].x) { best[c].x = v.x; bidx[c] = (bidx[c] & 0xffffff00u) | w; }
+                        if (v.y > best[c].y) { best[c].y = v.y; bidx[c] = (bidx[c] & 0xffff00ffu) | (w << 8); }
+                        if (v.z > best[c].z) { best[c].z = v.z; bidx[c] = (bidx[c] & 0xff00ffffu) | (w << 16); }
+                        if (v.w > best[c].w) { best[c].w = v.w; bidx[c] = (bidx[c] & 0x00ffffffu) | (w << 24); }
+                    }
+                }
+            }
+        }
+        float *dst = out + i * out_cs + out_c0;
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < C4; ++c) {
+            *reinterpret_cast<f32x4 *>(dst + c * 4) = best[c];
+            reinterpret_cast<unsigned *>(argmax)[i * C4 + c] = bidx[c];
+            sum += (best[c].x + best[c].y) + (best[c].z + best[c].w);
+        }
+        if (osum) osum[i] = sum;
+    }
+}
+
+template <int C4>
+__global__ void pool_bwd_vox_kernel(const float *dout, int do_cs, int do_c0, int OD, int OH, int OW, float *din,
+                                    int di_cs, int di_c0, int ID, int IH, int IW, const uint8_t *argmax, int wz,
+                                    int wy, int wx, int lz, int ly, int lx, int accumulate, long long nvox,
+                                    const float *act, int a_cs, int a_c0, float *dsum, int store_din) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nvox;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int ix = r % IW; r /= IW;
+        const int iy = r % IH; r /= IH;
+        const int iz = r % ID; r /= ID;
+        const long long n = r;
+        const int oz = (iz + lz) / wz, oy = (iy + ly) / wy, ox = (ix + lx) / wx;
+        const bool inside = oz < OD && oy < OH && ox < OW;
+        const unsigned widx = (((iz + lz) - oz * wz) * wy + ((iy + ly) - oy * wy)) * wx + ((ix + lx) - ox * wx);
+        const long long o = (((n * OD + oz) * OH + oy) * OW + ox);
+        float *dst = din + i * di_cs + di_c0;
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < C4; ++c) {
+            f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (inside) {
+                const unsigned am = reinterpret_cast<const unsigned *>(argmax)[o * C4 + c];
+                const f32x4 d = *reinterpret_cast<const f32x4 *>(dout + o * do_cs + do_c0 + c * 4);
+                g.x = ((am & 255u) == widx) ? d.x : 0.f;
+                g.y = (((am >> 8) & 255u) == widx) ? d.y : 0.f;
+                g.z = (((am >> 16) & 255u) == widx) ? d.z : 0.f;
+                g.w = ((am >> 24) == widx) ? d.w : 0.f;
+            }
+            if (accumulate) g += *reinterpret_cast<const f32x4 *>(dst + c * 4);
+            if (act) {
+                const f32x4 m = *reinterpret_cast<const f32x4 *>(act + i * a_cs + a_c0 + c * 4);
+                g.x = m.x > 0.f ? g.x : 0.f; g.y = m.y > 0.f ? g.y : 0.f;
+                g.z = m.z > 0.f ? g.z : 0.f; g.w = m.w > 0.f ? g.w : 0.f;
+            }
+            if (store_din) *reinterpret_cast<f32x4 *>(dst + c * 4) = g;
+            sum += (g.x + g.y) + (g.z + g.w);
+        }
+        if (dsum) dsum[i] = sum;
+    }
+}
+
 static unsigned grid_for(long long total, int block = 256, int cap = 256 * 32) {
     long long g = (total + block - 1) / block;
     if (g > cap) g = cap;
@@ -197,9 +290,22 @@ static unsigned grid_for(long long total, int block = 256, int cap = 256 * 32) {
 }
 
 int k_pool_fwd(alq_ctx *ctx, const View &in, const View &out, uint8_t *argmax, const int w[3],
-               const int lo[3], int N) {
+               const int lo[3], int N, float *osum, bool *fused) {
     const long long total = (long long)N * out.vox() * out.C;
     ProfScope ps(ctx, PROF_ELEMWISE, 0);
+    if (fused) *fused = false;
+    if (((in.cs | in.c0 | in.C | out.cs | out.c0) & 3) == 0 && (in.C == 4 || in.C == 8 || in.C == 16 || in.C == 32)) {
+        const long long nvox = (long long)N * out.vox();
+#define ALQ_PF(CV)                                                                                               \
+    hipLaunchKernelGGL(pool_fwd_vox_kernel<CV>, dim3(grid_for(nvox)), dim3(256), 0, ctx->stream, in.p, in.cs, in.c0, \
+                       in.D, in.H, in.W, out.p, out.cs, out.c0, out.D, out.H, out.W, argmax, w[0], w[1], w[2], lo[0], \
+                       lo[1], lo[2], nvox, osum)
+        switch (in.C) { case 4: ALQ_PF(1); break; case 8: ALQ_PF(2); break; case 16: ALQ_PF(4); break; default: ALQ_PF(8); }
+#undef ALQ_PF
+        ALQ_LAUNCH_CHECK();
+        if (fused) *fused = osum != nullptr;
+        return ALQ_OK;
+    }
     if (((in.cs | in.c0 | in.C | out.cs | out.c0) & 3) == 0) {
         hipLaunchKernelGGL(pool_fwd_vec_kernel, dim3(grid_for(total / 4)), dim3(256), 0, ctx->stream, in.p, in.cs,
                            in.c0, in.C / 4, in.D, in.H, in.W, out.p, out.cs, out.c0, out.D, out.H, out.W, argmax,
@@ -215,10 +321,29 @@ int k_pool_fwd(alq_ctx *ctx, const View &in, const View &out, uint8_t *argmax, c
 }
 
 int k_pool_bwd(alq_ctx *ctx, const View &dout, const View &din, const uint8_t *argmax, const int w[3],
-               const int lo[3], int N, int accumulate, const View *mask_act, float *dsum, bool *fused) {
+               const int lo[3], int N, int accumulate, const View *mask_act, float *dsum, bool *fused,
+               int store_din) {
     const long long total = (long long)N * din.vox() * din.C;
     ProfScope ps(ctx, PROF_ELEMWISE, 0);
     if (fused) *fused = false;
+    // voxel-per-thread form only where it measured faster: the finished cotangent is not stored (first
+    // layer: sums only); otherwise the lane-per-4-channels form below keeps strided concat slices coalesced
+    if (!store_din && dsum && ((din.cs | din.c0 | din.C | dout.cs | dout.c0) & 3) == 0 && (din.C == 4 || din.C == 8) &&
+        (!mask_act || ((mask_act->cs | mask_act->c0) & 3) == 0)) {
+        const long long nvox = (long long)N * din.vox();
+        const float *ap = mask_act ? mask_act->p : nullptr;
+        const int acs = mask_act ? mask_act->cs : 0, ac0 = mask_act ? mask_act->c0 : 0;
+        const int st = (store_din || !dsum) ? 1 : 0;
+#define ALQ_PBV(CV)                                                                                               \
+    hipLaunchKernelGGL(pool_bwd_vox_kernel<CV>, dim3(grid_for(nvox)), dim3(256), 0, ctx->stream, dout.p, dout.cs,   \
+                       dout.c0, dout.D, dout.H, dout.W, din.p, din.cs, din.c0, din.D, din.H, din.W, argmax, w[0], w[1], \
+                       w[2], lo[0], lo[1], lo[2], accumulate, nvox, ap, acs, ac0, dsum, st)
+        switch (din.C) { case 4: ALQ_PBV(1); break; case 8: ALQ_PBV(2); break; case 16: ALQ_PBV(4); break; default: ALQ_PBV(8); }
+#undef ALQ_PBV
+        ALQ_LAUNCH_CHECK();
+        if (fused) *fused = dsum != nullptr;
+        return ALQ_OK;
+    }
     if (((din.cs | din.c0 | din.C | dout.cs | dout.c0) & 3) == 0) {
         const int C4 = din.C / 4;
         const bool can = (dsum != nullptr) && (C4 == 1 || C4 == 2 || C4 == 4 || C4 == 8) &&

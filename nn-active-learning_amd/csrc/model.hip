@@ -509,7 +509,7 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums) {
                 break;
             }
             case ALQ_POOL:
-                ALQ_TRY(k_pool_fwd(ctx, in, ly.out, ly.argmax, ly.spec.k, ly.lo, N));
+                ALQ_TRY(k_pool_fwd(ctx, in, ly.out, ly.argmax, ly.spec.k, ly.lo, N, with_sums ? ly.osum : nullptr, &fused));
                 break;
             case ALQ_FC:
                 if (with_sums) {
@@ -552,7 +552,7 @@ static int run_backward(alq_model *m, const float *d_x, int N) {
             bool fused = false;
             ALQ_TRY(k_pool_bwd(ctx, ly.dout, ly.din, ly.argmax, ly.spec.k, ly.lo, N, prev_is_src ? 1 : 0,
                                (prev_param && prev->spec.relu) ? &prev->out : nullptr, prev_param ? prev->dsum : nullptr,
-                               &fused));
+                               &fused, /*store_din=*/!(prev_param && prev->pidx == 0)));   // layer 0 only needs the sums
             if (prev_param && fused) prev->delta_ready = true;
             continue;
         }

@@ -73,11 +73,51 @@ def sample_query_dstr(q_dstr, k, replacement=True):
     return np.array(picked)
 
 
-def SDP_query_distribution(A, lambda_, X_pool, k):
-    """NNAL_tools.SDP_query_distribution (NNAL_tools.py:612-659) hands the A-matrices to cvxopt's
-    SDP solver.  cvxopt / cvxpy / MOSEK are absent from this image and their arithmetic is a
-    third-party dependency outside the scored path ("next" row), so this
-    entry point states that instead of silently substituting another optimiser."""
-    raise NotImplementedError(
-        'the SDP query distribution needs cvxopt (NNAL_tools.py:657), which is not installed; the '
-        'device path ends at the A-matrices (PW_NNAL.fisher_candidates / gen_A_matrices)')
+def SDP_query_distribution(A, lambda_, X_pool, k, tol=1e-7, max_iter=20000):
+    """Query distribution of Fisher-information AL (reference: NNAL_tools.py:612-659, with
+    `inequality_cvx_matrix` :661-720 and the CVXPY twin `solve_FIAL_SDP` :576-610).
+
+    The reference states, for A-matrices A_i (L x L, positive definite through the diagonal load),
+
+        min  sum_j t_j   s.t.  [[sum_i q_i A_i, e_j], [e_j^T, t_j]] >= 0  (j = 1..L),  q >= 0,  sum q = 1
+
+    and hands it to cvxopt's / MOSEK's SDP solver.  By the Schur complement t_j >= e_j^T M(q)^-1 e_j, so
+    the problem is  min_q tr(M(q)^-1)  over the simplex: an A-optimal design.  cvxopt, cvxpy and
+    MOSEK are absent from this image, so this function solves THAT problem with the classical
+    multiplicative algorithm  q_i <- q_i * sqrt(d_i / tr M^-1),  d_i = <M^-2, A_i>  (monotone for the
+    A-criterion), stopping when the KKT gap  max_i d_i / tr M^-1 - 1  falls below `tol`.
+    PARITY UNPINNED: the optimum is unique in M(q) but the reference solver's iterate, tolerance
+    and therefore the sampled queries cannot be compared here.
+
+    Only the lambda_ = 0 form is built (PW_NNAL.query_multimg passes no features: PW_NNAL.py:596).
+    Returns a dict like cvxopt's: 'x' = concat(q [n], t [L]), 'status', 'primal objective', 'gap'.
+    """
+    if lambda_ and lambda_ > 0:
+        raise NotImplementedError('the feature-regularised SDP (lambda_ > 0, NNAL_tools.py:626-645) is not built')
+    A = np.asarray(A, dtype=np.float64)
+    n, L = A.shape[0], A.shape[1]
+    q = np.full(n, 1.0 / n)
+    status, gap = 'unknown', np.inf
+    for it in range(max_iter):
+        M = np.tensordot(q, A, axes=(0, 0))
+        Minv = np.linalg.inv(M)
+        obj = np.trace(Minv)
+        d = np.tensordot(A, Minv @ Minv, axes=([1, 2], [0, 1]))       # tr(M^-1 A_i M^-1)
+        gap = d.max() / obj - 1.0
+        if gap < tol:
+            status = 'optimal'
+            break
+        q = q * np.sqrt(d / obj)
+        q /= q.sum()
+    M = np.tensordot(q, A, axes=(0, 0))
+    t = np.diag(np.linalg.inv(M)).copy()
+    return {'x': np.concatenate((q, t)), 'status': status + ' (multiplicative A-optimal design; not cvxopt)',
+            'primal objective': float(t.sum()), 'gap': float(gap), 'iterations': it + 1}
+
+
+def solve_FIAL_SDP(A):
+    """NNAL_tools.solve_FIAL_SDP (NNAL_tools.py:576-610): same problem through the same solver here;
+    returns (q, objective) as PW_NNAL.query_multimg unpacks them (PW_NNAL.py:611-614)."""
+    soln = SDP_query_distribution(A, 0., [], None)
+    n = len(A)
+    return soln['x'][:n], soln['primal objective']

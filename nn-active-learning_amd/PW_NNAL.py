@@ -139,8 +139,13 @@ def query_multimg(expr, model, sess, all_padded_imgs, pool_inds, labeled_inds, m
             out = model.fisher_device(t, len(sel_inds[i]), p1_in, 1e-3, want=('A',))   # diag_load 1e-3, :578
             Ai = out['A'].cpu().numpy()
             A += [Ai[j] for j in range(Ai.shape[0])]
-        soln = NNAL_tools.SDP_query_distribution(A, expr.pars['lambda_'], [], k)
-        q_opt = np.array(soln['x'][:len(A)]).ravel()
+        # PW_NNAL.py:600-614: 'CVXOPT' -> SDP_query_distribution, 'MOSEK' -> solve_FIAL_SDP; both end in
+        # the same A-optimal-design problem, solved here by NNAL_tools' own routine (parity unpinned)
+        if expr.pars.get('SDP_solver', 'CVXOPT') == 'MOSEK':
+            q_opt = np.asarray(NNAL_tools.solve_FIAL_SDP(A)[0]).ravel()
+        else:
+            soln = NNAL_tools.SDP_query_distribution(A, expr.pars['lambda_'], [], k)
+            q_opt = np.array(soln['x'][:len(A)]).ravel()
         draws = NNAL_tools.sample_query_dstr(q_opt, k, replacement=True)
         local = patch_utils.global2local_inds(draws, [len(s) for s in sel_inds])
         return [np.array(sel_inds[i])[local[i]] for i in range(len(sel_inds))]

@@ -90,7 +90,35 @@ def test_host_functions_vs_reference_goldens(golden_dir):
     np.random.seed(77)
     np.testing.assert_array_equal(NNAL_tools.sample_query_dstr(g['sq_q'].copy(), 25, True), g['sq_out'])
     with pytest.raises(NotImplementedError):
-        NNAL_tools.SDP_query_distribution([], 0.1, [], 3)
+        NNAL_tools.SDP_query_distribution([np.eye(2)], 0.1, [], 3)      # feature-regularised form: not built
+
+
+def test_sdp_query_distribution_is_the_a_optimal_design():
+    """min tr((sum q_i A_i)^-1) over the simplex: KKT conditions at the returned q, and agreement with
+    a generic constrained optimiser on a small instance (the reference hands this SDP to cvxopt)."""
+    from scipy.optimize import minimize
+    rs = np.random.RandomState(4)
+    n, L = 12, 3
+    G = rs.randn(n, L)
+    A = np.stack([np.outer(g, g) * rs.rand() + 1e-3 * np.eye(L) for g in G])
+    soln = NNAL_tools.SDP_query_distribution(list(A), 0., [], 5)
+    q, t = soln['x'][:n], soln['x'][n:]
+    assert soln['status'].startswith('optimal') and abs(q.sum() - 1) < 1e-12 and q.min() >= 0
+    M = np.tensordot(q, A, axes=(0, 0))
+    Minv = np.linalg.inv(M)
+    np.testing.assert_allclose(t, np.diag(Minv), rtol=1e-12)
+    d = np.tensordot(A, Minv @ Minv, axes=([1, 2], [0, 1]))
+    assert d.max() <= np.trace(Minv) * (1 + 1e-6)                          # dual feasibility
+    np.testing.assert_allclose(d[q > 1e-6], np.trace(Minv), rtol=1e-4)       # complementary slackness
+
+    def f(z):
+        qq = np.abs(z) / np.abs(z).sum()
+        return np.trace(np.linalg.inv(np.tensordot(qq, A, axes=(0, 0))))
+    best = min(minimize(f, rs.rand(n), method='Nelder-Mead', options={'maxiter': 20000, 'xatol': 1e-10, 'fatol': 1e-12}).fun
+               for _ in range(3))
+    assert soln['primal objective'] <= best * (1 + 1e-6)
+    qm, obj = NNAL_tools.solve_FIAL_SDP(list(A))
+    np.testing.assert_allclose(obj, soln['primal objective'], rtol=1e-12)
 
 
 def test_shard_bounds_cover_the_pool():

@@ -202,6 +202,49 @@ def test_bin_uncertainty_filter_multimg_vs_golden(sess, golden_dir):
     model.close()
 
 
+def test_fi_queries_end_to_end(sess, golden_dir):
+    """CNN_query(...,'fi') and query_multimg(...,'fi') run end to end: uncertainty filter -> device
+    A-matrices -> query distribution -> sampling.  The A-matrices are checked against the oracle;
+    the distribution comes from this build's own solver (cvxopt absent: parity unpinned), so only its
+    optimality conditions and the index bookkeeping are asserted."""
+    from nnal_amd import PW_NNAL, NNAL_tools
+    g = _load(golden_dir, 'eval_neta.npz')
+    model, pshape = _neta_eval(sess, g)
+    vols = [g['vol0'], g['vol1']]
+    stats = g['stats'].tolist()
+    pool = g['pool']
+    expr = Expr({'patch_shape': pshape, 'ntb': 64, 'stats': stats, 'k': 10, 'B': 48, 'lambda_': 0.,
+                 'img_paths': ['a', 'b'], 'SDP_solver': 'CVXOPT'})
+    sel_inds, sel_posts, A = PW_NNAL.fisher_candidates(expr, model, sess, vols, pool)
+    assert len(sel_inds) == 48 and len(A) == 48 and A[0].shape == (3, 3)
+    # oracle A for the same candidates (channel-index normalisation quirk of CNN_query)
+    ld = netspec.net_a()
+    in_shape = (pshape[0], pshape[1], 2 * pshape[2])
+    pars = netspec.he_init(ld, in_shape, seed=int(g['wseed']), bias_std=0.05)
+    om = OracleModel(ld, in_shape, pars)
+    patches = alpath.normalise_channels_quirk(alpath.get_patches(vols, pool[sel_inds], pshape), stats)
+    A_ref = np.stack(alpath.gen_A_matrices(Expr({'patch_shape': pshape}), om, OracleSession(om), patches,
+                                           sel_posts, 1e-5))
+    assert_scores_close(np.stack(A), A_ref, SCORE_ATOL * 0.1, A_RTOL, 1e-6)
+    np.random.seed(5)
+    q = PW_NNAL.CNN_query(expr, model, sess, vols, pool, None, 'fi')
+    assert len(q) >= 1 and len(q) <= 10 and set(q) <= set(sel_inds) and len(set(q)) == len(q)
+    soln = NNAL_tools.SDP_query_distribution(A, 0., [], 10)
+    assert soln['status'].startswith('optimal') and soln['gap'] < 1e-6
+    # multi-image form
+    mask = g['mask']
+    allimgs = [vols + [mask], [vols[1], vols[0], mask]]
+    pools = [pool[:170], pool[170:]]
+    expr2 = Expr({'patch_shape': pshape, 'ntb': 50, 'k': 8, 'B': 40, 'lambda_': 0., 'SDP_solver': 'MOSEK'},
+                 train_stats=g['mm_tstats'])
+    np.random.seed(6)
+    Q = PW_NNAL.query_multimg(expr2, model, sess, allimgs, pools, None, 'fi')
+    assert len(Q) == 2 and 1 <= len(Q[0]) + len(Q[1]) <= 8
+    for j in range(2):
+        assert set(Q[j]) <= set(g['mm_sel_inds_%d' % j])       # drawn from the B uncertainty-filtered candidates
+    model.close()
+
+
 @pytest.mark.parametrize('n,B', [(1, 1), (5, 3), (2047, 100), (2048, 2048), (2049, 7), (100000, 4096),
                                  (300001, 300001)])
 def test_topk_uncertain(sess, n, B):

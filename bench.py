@@ -31,6 +31,8 @@ F_BWD_DATA = 425.72e6
 F_SURVEY = F_FWD + 2 * F_BWD_DATA       # the survey's figure: one backward per class
 F_EXEC = F_FWD + F_BWD_DATA             # what this build executes: ONE backward serves both classes
 PEAK_F32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA peak
+SPLIT_PRODUCTS = 6                      # bf16 MFMA MACs issued per fp32-accurate MAC (igemm3.hip)
 B_ALG = 4 * 32 ** 3 + 4 * (1 + 2 * 8 + 64)   # input + outputs per patch, bytes
 
 
@@ -108,32 +110,36 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
         value = n_global * args.steps / dt
-        # dominant kernel class = the implicit-GEMM engine (conv / conv_transpose fwd + bwd-data)
-        ig_ms = prof['igemm_fwd']['ms'] + prof['igemm_bwd']['ms']
-        ig_fl = prof['igemm_fwd']['flops'] + prof['igemm_bwd']['flops']
-        ig_n = prof['igemm_fwd']['launches'] + prof['igemm_bwd']['launches']
+        # dominant kernel = igemm3_kernel (conv / conv_transpose fwd + bwd-data on the bf16 matrix cores
+        # with the 3-way operand split: 6 bf16 MFMA MACs per fp32-accurate MAC, so the matrix-core bound
+        # on ALGORITHMIC fp32 flops is the dense bf16 peak / 6)
+        ig_ms = prof['igemm3_fwd']['ms'] + prof['igemm3_bwd']['ms']
+        ig_fl = prof['igemm3_fwd']['flops'] + prof['igemm3_bwd']['flops']
+        ig_n = prof['igemm3_fwd']['launches'] + prof['igemm3_bwd']['launches']
         achieved = ig_fl / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
-        traffic = None
-        tp = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(tp):
-            try:
-                traffic = json.load(open(tp)).get('hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
+        peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
+        conv_ms = ig_ms + sum(prof[k]['ms'] for k in ('igemm_fwd', 'igemm_bwd', 'direct_conv'))
+        conv_fl = ig_fl + sum(prof[k]['flops'] for k in ('igemm_fwd', 'igemm_bwd', 'direct_conv'))
         line = {
             'metric': 'patches/sec Fisher-scored (32^3, 2-class)',
             'value': value, 'unit': 'patches/s', 'n_gpus': ws, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32 (bf16x3 operand split on the bf16 MFMA, fp32 accumulate; everything else fp32 / fp64)',
+            'data': 'synthetic',
             'config': {'workload': 'configs[2]: Fisher scoring, NET-C patch-wise 3-D U-Net (fc head), '
                                    '%d synthetic 32^3 2-class patches per GPU, random-init weights seed 14'
                                    % n_local,
                        'pool_per_gpu': n_local, 'batch': args.batch, 'topB': args.topB,
                        'parallelism': 'pool sharded over %d GPU(s), RCCL top-B merge + 8x8 Fisher all-reduce' % ws},
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
-                         'kernel': 'igemm_kernel (all conv / conv_transpose fwd + bwd-data launches)',
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': achieved / peak, 'traffic': traffic,
+                         'kernel': 'igemm3_kernel (conv / conv_transpose fwd + bwd-data, bf16x3 split)',
+                         'peak_note': 'algorithmic fp32 flops; peak = %.0f dense bf16 / %d split products'
+                                      % (PEAK_BF16_MFMA_TFLOPS, SPLIT_PRODUCTS),
+                         'executed_bf16_tflops': achieved * SPLIT_PRODUCTS, 'peak_bf16_tflops': PEAK_BF16_MFMA_TFLOPS,
+                         'frac_of_f32_mfma_peak': achieved / PEAK_F32_MFMA_TFLOPS,
                          'launches': ig_n, 'avg_launch_ms': ig_ms / max(ig_n, 1),
+                         'all_conv_engines_tflops': conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
                          'flops_per_patch_executed': F_EXEC, 'flops_per_patch_survey': F_SURVEY,
                          'whole_step_tflops_executed': F_EXEC * value / ws / 1e12,
                          'hbm_algorithmic_GBps': B_ALG * value / ws / 1e9,

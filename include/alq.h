@@ -151,7 +151,8 @@ int alq_model_debug_copy(alq_model *m, int layer_idx, int what, int N, float *d_
 int alq_debug_set_stamp_buffer(void *d_buf);
 /* Timing-experiment knobs (tests / profiling only; results may be wrong while a knob is set):
  * key 0 = repeat the MFMA phase n extra times, 1 = flag bits (1 no stores, 2 no loads, 4 no sum
- * MFMAs, 8 no sum stores), 2 = no epilogue fusion in backward GEMMs, 3 = none in forward GEMMs. */
+ * MFMAs, 8 no sum stores), 2 = no epilogue fusion in backward GEMMs, 3 = none in forward GEMMs,
+ * 4 = use the fp32-MFMA GEMM kernel instead of the bf16x3 split kernel.                         */
 int alq_debug_set(int key, int value);
 
 /* Synthetic patch generator: counter-based RNG keyed (seed, patch_id, element), standard

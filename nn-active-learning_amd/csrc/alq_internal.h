@@ -47,8 +47,9 @@ struct View {
     int64_t elems() const { return vox() * C; }
 };
 
+// igemm_* = the fp32 engines (v1 / v2), igemm3_* = the bf16x3 matrix-core engine, direct = the VALU first-layer conv
 enum ProfClass { PROF_IGEMM_FWD = 0, PROF_IGEMM_BWD = 1, PROF_ELEMWISE = 2, PROF_REDUCE = 3,
-                 PROF_FC_SMALL = 4, PROF_NUM = 5 };
+                 PROF_FC_SMALL = 4, PROF_IGEMM3_FWD = 5, PROF_IGEMM3_BWD = 6, PROF_DIRECT = 7, PROF_NUM = 8 };
 
 struct ProfSlot {
     double ms = 0;
@@ -204,6 +205,21 @@ void igemm2_pack_weights(Igemm2Plan *p2, const std::vector<float> &Bmat);
 int igemm2_launch(alq_ctx *ctx, const Igemm2Plan &plan, const View &in, const View &out, const float *bias,
                   int relu, int accumulate, int N, int prof_cls, const Igemm2Fuse *fuse);
 
+// ------------------------------------------------------------------ bf16x3 split engine (igemm3.hip)
+struct Igemm3Plan {
+    bool ok = false;
+    bool wres = false;
+    int NTW = 1;
+    int wgs_per_cu = 1;
+    size_t lds_bytes = 0;
+    std::vector<unsigned short> h_W;   // [chunk][s][piece][tile][lane][8] bf16 bits
+    void *d_W = nullptr;
+};
+int igemm3_build_plan(const Igemm2Plan &p2, Igemm3Plan *p3);
+void igemm3_pack_weights(const Igemm2Plan &p2, Igemm3Plan *p3, const std::vector<float> &Bmat);
+int igemm3_launch(alq_ctx *ctx, const Igemm2Plan &p2, const Igemm3Plan &plan, const View &in, const View &out,
+                  const float *bias, int relu, int accumulate, int N, int prof_cls, const Igemm2Fuse *fuse);
+
 // ------------------------------------------------------------------ direct first-layer conv (direct.hip)
 struct DirectArgs {
     const float *in;
@@ -237,6 +253,7 @@ int direct_launch(alq_ctx *ctx, const DirectPlan &dp, const View &in, const View
 struct Gemm {
     IgemmPlan p1;
     Igemm2Plan p2;
+    Igemm3Plan p3;
     DirectPlan pd;
 };
 

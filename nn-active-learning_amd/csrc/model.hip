@@ -158,6 +158,8 @@ static int gemm_build(const ConvDesc &d, int max_batch, Gemm *g) {
     ALQ_TRY(igemm2_build_plan(g->p1, &g->p2));
     ALQ_TRY(direct_build_plan(g->p1, &g->pd));
     if (!g_use_v2) { g->p2.ok = false; g->pd.ok = false; }
+    ALQ_TRY(igemm3_build_plan(g->p2, &g->p3));
+    if (const char *e = getenv("ALQ_DISABLE_V3")) { if (e[0] == '1') g->p3.ok = false; }
     return ALQ_OK;
 }
 
@@ -179,6 +181,16 @@ static int gemm_set(alq_model *m, Gemm *g, const std::vector<float> &Bmat) {
             g->p2.a.tdesc = g->p2.d_tdesc;
             g->p2.a.sdesc = g->p2.d_sdesc;
         }
+        if (g->p3.ok) {
+            igemm3_pack_weights(g->p2, &g->p3, Bmat);
+            unsigned short *dw = reinterpret_cast<unsigned short *>(g->p3.d_W);
+            if (!dw) ALQ_TRY(m->dalloc(&dw, g->p3.h_W.size()));
+            g->p3.d_W = dw;
+            ALQ_HIP(hipMemcpyAsync(dw, g->p3.h_W.data(), g->p3.h_W.size() * sizeof(unsigned short), hipMemcpyHostToDevice,
+                                   m->ctx->stream));
+            ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
+            std::vector<unsigned short>().swap(g->p3.h_W);
+        }
         if (!g->p2.d_W) ALQ_TRY(m->dalloc(&g->p2.d_W, g->p2.h_W.size()));
         ALQ_HIP(hipMemcpyAsync(g->p2.d_W, g->p2.h_W.data(), g->p2.h_W.size() * sizeof(float), hipMemcpyHostToDevice,
                                m->ctx->stream));
@@ -195,7 +207,12 @@ static int gemm_launch(alq_ctx *ctx, const Gemm &g, const View &in, const View &
                        int accumulate, int N, int cls, const Igemm2Fuse *fuse = nullptr, bool *fused = nullptr) {
     if (g.pd.ok && !accumulate && !(fuse && (fuse->mask || fuse->osumB || fuse->split))) {
         if (fused) *fused = fuse != nullptr;
-        return direct_launch(ctx, g.pd, in, out, bias, relu, N, fuse ? fuse->osumA : nullptr, cls);
+        return direct_launch(ctx, g.pd, in, out, bias, relu, N, fuse ? fuse->osumA : nullptr, PROF_DIRECT);
+    }
+    if (g.p3.ok && !g_dbg_knobs[4]) {      // bf16x3 split on the matrix cores (fp32-equivalent accuracy)
+        if (fused) *fused = fuse != nullptr;
+        return igemm3_launch(ctx, g.p2, g.p3, in, out, bias, relu, accumulate, N,
+                             cls == PROF_IGEMM_BWD ? PROF_IGEMM3_BWD : PROF_IGEMM3_FWD, fuse);
     }
     if (g.p2.ok) {
         if (fused) *fused = fuse != nullptr;
@@ -677,8 +694,8 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
             g_dbg_knobs[2] = 1;
             g_knobs_init = true;
         }
-        static const char *names[4] = {"ALQ_DEBUG_REPEAT", "ALQ_DEBUG_FLAGS", "ALQ_NO_BWD_FUSE", "ALQ_NO_FWD_FUSE"};
-        for (int k = 0; k < 4; ++k) {
+        static const char *names[5] = {"ALQ_DEBUG_REPEAT", "ALQ_DEBUG_FLAGS", "ALQ_NO_BWD_FUSE", "ALQ_NO_FWD_FUSE", "ALQ_NO_V3"};
+        for (int k = 0; k < 5; ++k) {
             const char *v = getenv(names[k]);
             if (v) g_dbg_knobs[k] = atoi(v);
         }
@@ -871,7 +888,8 @@ int alq_fisher(alq_model *m, const float *d_x, int N, const float *d_p1_in, doub
     return ALQ_OK;
 }
 
-static const char *kProfNames[PROF_NUM] = {"igemm_fwd", "igemm_bwd", "elementwise", "reduce", "fc_small"};
+static const char *kProfNames[PROF_NUM] = {"igemm_fwd", "igemm_bwd", "elementwise", "reduce", "fc_small",
+                                           "igemm3_fwd", "igemm3_bwd", "direct_conv"};
 
 int alq_prof_enable(alq_ctx *ctx, int on) {
     ALQ_REQUIRE(ctx != nullptr, ALQ_EINVAL, "null ctx");

@@ -9,6 +9,7 @@ pytestmark = pytest.mark.gpu
 from oracle import alpath, netspec  # noqa: E402
 from oracle.model import OracleModel, OracleSession  # noqa: E402
 from tests.test_oracle_golden import build_fisher_model, Expr  # noqa: E402
+from tests import factored_ref  # noqa: E402
 
 # Tolerances (north_star: indices bit-exact, scores within 1e-4 fp32).  The device reduces the
 # per-layer gradient sums in a different order than TF/NumPy would and in one backward pass, so
@@ -360,25 +361,33 @@ def test_config3_netc_properties(sess):
     np.testing.assert_allclose(g1 * p1[:, None], -g0 * (1 - p1)[:, None], rtol=1e-5, atol=1e-12)
     np.testing.assert_allclose(r1['Asum'].cpu().numpy(), A.sum(0), rtol=1e-10)
     np.testing.assert_allclose(r1['trace'].cpu().numpy(), np.trace(A, axis1=1, axis2=2), rtol=1e-12)
-    # a handful against the oracle run with the reference's per-sample structure.  At 32^3 a patch
-    # has ~0.7M ReLU inputs, about one of which sits within fp32 rounding of zero: device and oracle
-    # (or TF on two machines) put it on different sides of the mask in roughly one patch out of
-    # two, which moves the affected layer sums by up to a few 1e-3 relative (|g| ~ 5e-2 -> a few
-    # 1e-4 absolute).  So: every patch within 5e-4 absolute, and at least half of the checked
-    # patches (the flip-free ones) within 2e-5 relative.
+    # a handful against the oracle run with the reference's per-sample structure, and against an
+    # fp64 evaluation of the same network.  At 32^3 a patch has ~0.7M ReLU inputs, about one of
+    # which sits within fp32 rounding of zero: two fp32 implementations (device and oracle, or TF on
+    # two machines) put it on different sides of the mask in roughly one patch out of two, which
+    # moves the affected layer sums by up to a few 1e-3 relative (|g| ~ 5e-2 -> a few 1e-4
+    # absolute).  tests/gpu_accuracy.py measures each implementation against fp64: the torch fp32
+    # oracle is the noisy party (abs max 2e-4), the device stays within 3e-7 absolute.  So: every
+    # patch within 5e-4 absolute of the fp32 oracle, and within 2e-6 absolute / 1e-3 relative of
+    # the fp64 values -- fifty times inside the 1e-4 parity bar.
     om = OracleModel(ld, in_shape, pars, skips=sk)
     osess = OracleSession(om)
     nchk = 6
     xsn = xs[:nchk].reshape((nchk,) + in_shape)
-    tight = 0
     for i in range(nchk):
         o0, o1 = alpath.shrunk_grads(om, osess, xsn[i])
         e = max(np.abs(g0[i] - o0).max(), np.abs(g1[i] - o1).max())
-        assert e <= 5e-4, 'patch %d: max abs error %.3e' % (i, e)
-        big = np.abs(o0) > 1e-5
-        if (np.abs(g0[i] - o0)[big] / np.abs(o0[big])).max() <= 2e-5:
-            tight += 1
-    assert tight >= nchk // 2, 'only %d of %d patches agree to 2e-5 relative' % (tight, nchk)
+        assert e <= 5e-4, 'patch %d: max abs error %.3e vs the fp32 oracle' % (i, e)
+    pars64 = {k: [v[0].astype(np.float64), v[1].astype(np.float64)] for k, v in pars.items()}
+    om64 = OracleModel(ld, in_shape, pars64, skips=sk, dtype=sess.torch.float64)
+    p64, S64, sizes = factored_ref.factored_unit_scores(om64, xsn.astype(np.float64))
+    g64, h64, _ = factored_ref.fisher_from_unit(p64[1], S64, sizes, 1e-3)
+    for gd, gr in ((g0[:nchk], g64), (g1[:nchk], h64)):
+        err = np.abs(gd - gr)
+        assert err.max() <= 2e-6, 'max abs error %.3e vs fp64' % err.max()
+        big = np.abs(gr) > 1e-5
+        assert (err[big] / np.abs(gr[big])).max() <= 1e-3
+    assert np.abs(p1[:nchk] - p64[1]).max() <= 5e-6
     model.close()
     model2.close()
 

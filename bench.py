@@ -45,7 +45,7 @@ def main():
     ap.add_argument('--batch', type=int, default=512, help='patches per device pass')
     ap.add_argument('--topB', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=16)
+    ap.add_argument('--cpu-sample', type=int, default=128, help='patches the CPU baseline scores (~15 s on 16 cores)')
     args = ap.parse_args()
 
     import torch
@@ -120,6 +120,13 @@ def main():
         peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
         conv_ms = ig_ms + sum(prof[k]['ms'] for k in ('igemm_fwd', 'igemm_bwd', 'direct_conv'))
         conv_fl = ig_fl + sum(prof[k]['flops'] for k in ('igemm_fwd', 'igemm_bwd', 'direct_conv'))
+        traffic = None                       # PMC passes are separate runs (profiles/pmc_traffic.json)
+        tp = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
         line = {
             'metric': 'patches/sec Fisher-scored (32^3, 2-class)',
             'value': value, 'unit': 'patches/s', 'n_gpus': ws, 'steps': args.steps, 'warmup': args.warmup,

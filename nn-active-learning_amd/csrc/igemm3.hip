@@ -28,6 +28,20 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// In-kernel phase stamps (diagnostic build only, -DALQ_STAMPS; see igemm2.hip)
+#ifdef ALQ_STAMPS
+#define STAMP3(var) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+#define PHASE3_END(idx)                        \
+    do {                                       \
+        unsigned long long t_now_;             \
+        STAMP3(t_now_);                        \
+        ph[idx] += t_now_ - t_last;            \
+        t_last = t_now_;                       \
+    } while (0)
+#else
+#define PHASE3_END(idx) do {} while (0)
+#endif
+
 constexpr int I3_ROWB = 48;       // bytes per halo voxel row in LDS: 3 pieces x 8 channels x 2 B
 constexpr int I3_MAXSLOT = 8;
 constexpr int I3_MAXS = 7;        // k-steps of 4 taps (<= 28 taps)
@@ -40,6 +54,15 @@ __device__ inline unsigned split2(float &a, float &b) {
     a -= __builtin_bit_cast(float, hb << 16);
     b -= __builtin_bit_cast(float, hb & 0xffff0000u);
     return hb;
+}
+
+// Tile descriptors are read with an explicit scalar load: the compiler will not scalarise a load that
+// follows stores through a possibly aliasing pointer, and the vector load it emits instead is followed by
+// s_waitcnt vmcnt(0), which drains every store of the epilogue once per tile.
+__device__ inline i32x4 sload4(const int *p) {
+    i32x4 v;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+    return v;
 }
 
 template <int NTW, bool WRES, bool SUMS>
@@ -154,26 +177,29 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(const Igemm2Args a) {
 
     int goff[NSLOT];
     auto locate = [&]() {
-        const int *td = a.tdesc + fl * 8;
-        const int in_org = (td[0] + fpg * a.in_pstride) * a.in_cs;
-        f_out = td[1] + fpg * a.out_pstride;
-        f_cls = td[2];
+        const i32x4 td = sload4(a.tdesc + fl * 8);
+        const int in_org = (td.x + fpg * a.in_pstride) * a.in_cs;
+        f_out = td.y + fpg * a.out_pstride;
+        f_cls = td.z;
         f_l = fl; f_g = fpg;
         const int cls = f_cls & 63;
-        const bool partial = (fpg + 1) * a.PT > a.N;
+        const unsigned bit = 1u << (cls & 31);
+        const bool hi = cls >= 32;
 #pragma unroll
         for (int it = 0; it < NSLOT; ++it) {
-            int g = 0x7fffff00;
-            if (it < nit) {
-                const unsigned m = cls < 32 ? s_mlo[it] : s_mhi[it];
-                bool ok = (m >> (cls & 31)) & 1u;
-                if (partial) {
-                    const int pt = a.sdesc[((tid + it * 256) >> 1) * 4 + 3] >> 24;
-                    ok = ok && fpg * a.PT + pt < a.N;
+            const unsigned m = hi ? s_mhi[it] : s_mlo[it];           // slots past the end carry empty masks
+            goff[it] = (m & bit) ? (in_org + s_rel[it]) * 4 : 0x7fffff00;
+        }
+        if ((fpg + 1) * a.PT > a.N) {                                  // last, partly filled patch group (rare)
+#pragma unroll 1
+            for (int it = 0; it < nit; ++it) {
+                const int pt = a.sdesc[((tid + it * 256) >> 1) * 4 + 3] >> 24;
+                if (fpg * a.PT + pt >= a.N) {
+#pragma unroll
+                    for (int j = 0; j < NSLOT; ++j)
+                        if (j == it) goff[j] = 0x7fffff00;
                 }
-                g = ok ? (in_org + s_rel[it]) * 4 : 0x7fffff00;
             }
-            goff[it] = g;
         }
     };
 
@@ -181,13 +207,14 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(const Igemm2Args a) {
     i32x4 Wr[WREGS];
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
+    // ONE prefetch site, unconditional loads (a slot without work points past the buffer and reads zeros
+    // without touching memory): a second site or a branch around the loads makes the compiler merge the
+    // two register sets with copies, and the copies wait for the loads on the spot.
     auto fetch = [&](int chunk) {
         const int soff = chunk * 32;
 #pragma unroll
-        for (int it = 0; it < NSLOT; ++it) {
-            if (it < nit)
-                R[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, goff[it], soff, 0));
-        }
+        for (int it = 0; it < NSLOT; ++it)
+            R[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, goff[it], soff, 0));
         if constexpr (!WRES) {
             const char *src = Wg + (long long)chunk * Wchunk;
 #pragma unroll
@@ -235,7 +262,8 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(const Igemm2Args a) {
         for (int ms = 0; ms < 4; ++ms) {
             bool live = erow_ok;
             if (!p_full) {
-                const int *td = a.tdesc + p_l * 8;
+                const i32x4 t0 = sload4(a.tdesc + p_l * 8), t1 = sload4(a.tdesc + p_l * 8 + 4);
+                const i32x4 tq = i32x4{t0.w, t1.x, t1.y, 0};        // (z0, y0, x0) of the tile
                 const int v = wave * 64 + ms * 16 + lrow;
                 const int vv = v < a.rows ? v : 0;
                 const int pt = vv / TV;
@@ -243,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(const Igemm2Args a) {
                 const int x = q % a.TX; q /= a.TX;
                 const int y = q % a.TY;
                 const int z = q / a.TY;
-                live = v < a.rows && p_g * a.PT + pt < a.N && td[3] + z < a.MD && td[4] + y < a.MH && td[5] + x < a.MW;
+                live = v < a.rows && p_g * a.PT + pt < a.N && tq.x + z < a.MD && tq.y + y < a.MH && tq.z + x < a.MW;
             }
             f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -271,10 +299,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(const Igemm2Args a) {
                 if constexpr (SUMS) {
                     if (!on) val = f32x4{0.f, 0.f, 0.f, 0.f};
                     const float sel = (lrow == 0) ? (c < a.split ? 1.f : 0.f) : ((lrow == 1) ? (c < a.split ? 0.f : 1.f) : 0.f);
-                    sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, val.x, sacc, 0, 0, 0);
-                    sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, val.y, sacc, 0, 0, 0);
-                    sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, val.z, sacc, 0, 0, 0);
-                    sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, val.w, sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, (val.x + val.y) + (val.z + val.w), sacc, 0, 0, 0);
                 }
             }
             if constexpr (SUMS) {
@@ -286,34 +311,45 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(const Igemm2Args a) {
         }
     };
 
-    bool more = fpg < pgroups;
-    if (more) {
+#ifdef ALQ_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last;
+    STAMP3(t_last);
+#endif
+    auto park = [&]() {
+#pragma unroll
+        for (int it = 0; it < NSLOT; ++it) goff[it] = 0x7fffff00;
+    };
+    if (fpg < pgroups) {          // flat loop over (tile, chunk) steps
         locate();
         fetch(0);
-    }
-    bool first = true;
-    while (more) {
-        c_out = f_out; c_cls = f_cls; c_l = f_l; c_g = f_g;
-        bool next_more = false;
-        for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        PHASE3_END(0);
+        int chunk = 0;
+        bool first = true;
+        for (;;) {
+            if (chunk == 0) { c_out = f_out; c_cls = f_cls; c_l = f_l; c_g = f_g; }
             if (!first) __syncthreads();
             first = false;
+            PHASE3_END(1);
             stash();
+            PHASE3_END(2);
             __syncthreads();
+            PHASE3_END(3);
             if (chunk == 0 && have_pend) {
                 flush();
                 have_pend = false;
             }
-            if (chunk + 1 < a.nchunks) {
-                fetch(chunk + 1);
-            } else {
+            PHASE3_END(4);
+            int nchunk = chunk + 1;
+            const bool tile_done = nchunk == a.nchunks;
+            bool next_valid = true;
+            if (tile_done) {
+                nchunk = 0;
                 advance_cursor();
-                next_more = fpg < pgroups;
-                if (next_more) {
-                    locate();
-                    fetch(0);
-                }
+                next_valid = fpg < pgroups;
+                if (next_valid) locate(); else park();
             }
+            fetch(nchunk);
+            PHASE3_END(5);
             if (chunk == 0) {
 #pragma unroll
                 for (int ms = 0; ms < 4; ++ms)
@@ -362,12 +398,21 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(const Igemm2Args a) {
                     }
                 }
             }
+            PHASE3_END(6);
+            if (tile_done) {
+                have_pend = true;
+                p_out = c_out; p_cls = c_cls; p_l = c_l; p_g = c_g;
+                if (!next_valid) break;
+            }
+            chunk = nchunk;
         }
-        have_pend = true;
-        p_out = c_out; p_cls = c_cls; p_l = c_l; p_g = c_g;
-        more = next_more;
     }
     if (have_pend) flush();
+#ifdef ALQ_STAMPS
+    PHASE3_END(7);
+    if (a.dbg && tid == 0)
+        for (int i = 0; i < 8; ++i) a.dbg[blockIdx.x * 8 + i] = ph[i];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -458,6 +503,15 @@ int igemm3_launch(alq_ctx *ctx, const Igemm2Plan &p2, const Igemm3Plan &plan, co
     a.bias = bias; a.relu = relu; a.accumulate = accumulate; a.N = N;
     a.in_bytes = (int)((long long)N * in.vox() * in.cs * 4);
     a.dbg = nullptr;
+    if (g_igemm2_dbg) {   // diagnostic: stamp only the v3 launch whose ordinal (since the buffer was set) is ALQ_STAMP_ONLY
+        static int want = -2;
+        if (want == -2) { const char *e = getenv("ALQ_STAMP_ONLY"); want = e ? atoi(e) : -1; }
+        static int ordinal = 0;
+        static unsigned long long *last = nullptr;
+        if (last != g_igemm2_dbg) { last = g_igemm2_dbg; ordinal = 0; }
+        if (want < 0 || ordinal == want) a.dbg = g_igemm2_dbg;
+        ++ordinal;
+    }
     a.dbg_repeat = g_dbg_knobs[0];
     a.dbg_flags = g_dbg_knobs[1];
     a.split = 1 << 30;

@@ -19,7 +19,7 @@ from nnal_amd import device  # noqa: E402
 from nnal_amd._lib import check  # noqa: E402
 from oracle import netspec  # noqa: E402
 
-NAMES = ['prologue', 'barrierA', 'wait+stash', 'barrierB', 'epilogue', 'locate+fetch', 'mfma', 'tail']
+NAMES = ['prologue', 'barrierA', 'stash', 'barrierB', 'epilogue', 'locate+fetch', 'mfma', 'tail']
 
 
 def main():

@@ -220,6 +220,68 @@ void igemm3_pack_weights(const Igemm2Plan &p2, Igemm3Plan *p3, const std::vector
 int igemm3_launch(alq_ctx *ctx, const Igemm2Plan &p2, const Igemm3Plan &plan, const View &in, const View &out,
                   const float *bias, int relu, int accumulate, int N, int prof_cls, const Igemm2Fuse *fuse);
 
+// ------------------------------------------------------------------ two-slot bf16x3 engine (igemm4.hip)
+// One 512-thread workgroup per CU; its two 4-wave halves each own a tile slot and run in anti-phase
+// (one stages / stores while the other contracts), sharing one resident copy of the weights.
+// A launch is a small "program": per tile a list of staging phases (conv: 8-channel chunks; conv_transpose
+// bwd-data: (z, y) parity class x chunk) feeding one accumulator, or - MULTI - one staging phase of all
+// chunks followed by several output groups (conv_transpose fwd: every output parity class from one read).
+struct Igemm4Args {
+    const float *in;
+    float *out;
+    const void *W;          // packed bf16 pieces, all units resident in LDS
+    const float *bias;
+    const float *mask;
+    float *osumA, *osumB;
+    const int *tdesc;       // [tiles per group][8]: in_org_vox, out_org_vox, full, lohi_zy, lohi_x, mz0, my0, mx0
+    const int *sdesc;       // [nslots][4]: rel_vox, (pt,hz,hy,hx) packed, LDS byte offset, channel offset
+    const int *pdesc;       // [phases or groups][8]: in_off_vox, chunk, S, w_off, tap row, out_off_vox, -, -
+    const int *ttab;        // [tap rows][G4_MAXS][4] LDS byte offsets of the taps of k-step s, lane group q
+    int in_cs, in_c0, out_cs, out_c0, Co;
+    int mask_cs, mask_c0, mask_from, split;
+    int N, PT, tpg, rows;
+    int TV, TY, TX, HZ, HY, HX;
+    int smz, smy, smx;      // M-grid point -> halo index multipliers
+    int soz, soy, sox, OD, OH, OW;
+    int MD, MH, MW;
+    int nph, ngr, NP;       // staging phases per tile; MULTI: output groups, planes
+    int nslots, plane_bytes;
+    int in_pstride, out_pstride, in_bytes;
+    int relu, accumulate, pair;
+    int tt_ints, wbytes, abytes;
+    int dbg_repeat;
+    unsigned long long *dbg;
+};
+
+struct G4Geom {
+    int kind = 0;             // 0 stride-1 conv (fwd, or bwd-data when flipped), 1 conv_transpose bwd-data, 2 conv_transpose fwd (all classes)
+    int ID = 1, IH = 1, IW = 1, Ci = 0;     // GEMM input tensor
+    int OD = 1, OH = 1, OW = 1, Co = 0;     // GEMM output tensor
+    int k[3] = {1, 1, 1}, s[3] = {1, 1, 1}, lo[3] = {0, 0, 0};
+    bool flipped = false;
+    double flops_per_patch = 0;
+};
+
+struct Igemm4Plan {
+    bool ok = false;
+    Igemm4Args a;
+    int NTW = 1;
+    bool multi = false;
+    size_t lds_bytes = 0;
+    double flops_per_patch = 0;
+    int Ci = 0, Co = 0;
+    struct Unit { int chunk = 0, S = 0, w_off = 0; std::vector<int> tap; };   // tap[(s*4+q)*2+half] = enum tap or -1
+    std::vector<Unit> units;
+    std::vector<int> h_tdesc, h_sdesc, h_pdesc, h_ttab;
+    int *d_tdesc = nullptr, *d_sdesc = nullptr, *d_pdesc = nullptr, *d_ttab = nullptr;
+    std::vector<unsigned short> h_W;
+    void *d_W = nullptr;
+};
+int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan);
+void igemm4_pack_weights(Igemm4Plan *plan, const std::vector<float> &Bmat /* [(enum tap, ci)][co] */);
+int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const View &out, const float *bias,
+                  int relu, int accumulate, int N, int prof_cls, const Igemm2Fuse *fuse);
+
 // ------------------------------------------------------------------ direct first-layer conv (direct.hip)
 struct DirectArgs {
     const float *in;
@@ -254,6 +316,7 @@ struct Gemm {
     IgemmPlan p1;
     Igemm2Plan p2;
     Igemm3Plan p3;
+    Igemm4Plan p4;
     DirectPlan pd;
 };
 

@@ -1,0 +1,823 @@
+// Two-slot bf16x3 implicit-GEMM engine (v4).
+//
+// Same arithmetic as igemm3.hip (every fp32 operand = hi + mid + lo bf16, six piece products on
+// v_mfma_f32_16x16x32_bf16, fp32 accumulate), different machine mapping:
+//
+//  * ONE 512-thread workgroup per CU.  Its two 4-wave halves each own a tile slot (a halo block in LDS,
+//    256 GEMM rows) and run in ANTI-PHASE: in every tick one half contracts its staged block on the
+//    matrix cores while the other half writes back its previous tile, splits and stages its next block
+//    and issues the prefetch for the one after; one barrier per tick.  With two independent 256-thread
+//    workgroups per CU (igemm3) the two stay in phase - both fight for LDS in the contraction and both
+//    leave it idle while staging.
+//  * the weights of the whole launch are resident in LDS once per CU (not once per workgroup).
+//  * a launch is a small host-built program, so one kernel covers
+//      - stride-1 convolutions, forward and backward-data: staging phases = 8-channel chunks;
+//      - conv_transpose backward-data (a stride-2 gather): staging phases = (z, y) parity class x chunk,
+//        each a dense sub-grid of the cotangent with its own tap box, all feeding one accumulator;
+//      - conv_transpose forward, all output parity classes from ONE staged block (MULTI): the block is
+//        staged once, then every class contracts its own taps and stores its own output voxels;
+//      - "pair" forms for 8 output channels: the 16 MFMA rows are two x-adjacent output voxels
+//        (or two x parity classes) x 8 channels, so no half of the tile is padding.
+//  * tile descriptors come through scalar loads, halo validity is a per-tile index range per dimension,
+//    and there is exactly one prefetch site (see igemm3.hip for why).
+#include "alq_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+
+namespace alq {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int G4_ROWB = 48;      // bytes per staged voxel row: [hi8 | mid8 | lo8] bf16
+constexpr int G4_NSLOT = 8;      // 16-byte staging slots per thread of a half
+constexpr int G4_MAXS = 9;       // k-steps (4 taps each) per unit
+constexpr int G4_OOB = 0x7fffff00;
+
+__device__ inline i32x4 g4_sload4(const int *p) {
+    i32x4 v;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+    return v;
+}
+__device__ inline i32x8 g4_sload8(const int *p) {
+    i32x8 v;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+    return v;
+}
+
+// x -> (hi, rem): hi = bf16(x) packed pairwise, rem = x - hi (exact)
+__device__ inline unsigned g4_split2(float &a, float &b) {
+    const bf16x2 h = __builtin_convertvector(f32x2{a, b}, bf16x2);
+    const unsigned hb = __builtin_bit_cast(unsigned, h);
+    a -= __builtin_bit_cast(float, hb << 16);
+    b -= __builtin_bit_cast(float, hb & 0xffff0000u);
+    return hb;
+}
+
+template <int NTW, bool MULTI, bool SUMS>
+__global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
+    extern __shared__ __attribute__((aligned(16))) char lds4[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform by construction: keep it scalar
+    const int h = wave >> 2;          // which half (tile slot)
+    const int hw = wave & 3;          // wave within the half
+    const int ht = tid & 255;         // thread within the half
+    const int lrow = lane & 15;
+    const int lq = lane >> 4;
+
+    int *Tl = reinterpret_cast<int *>(lds4);
+    char *Wl = lds4 + a.tt_ints * 4;
+    char *Al = Wl + a.wbytes + h * a.abytes;
+    {
+        const char *Wg = reinterpret_cast<const char *>(a.W);
+        for (int i = tid * 16; i < a.wbytes; i += 512 * 16)
+            *reinterpret_cast<i32x4 *>(Wl + i) = *reinterpret_cast<const i32x4 *>(Wg + i);
+        for (int i = tid; i < a.tt_ints; i += 512) Tl[i] = a.ttab[i];
+    }
+
+    // ---- staging slots of this thread --------------------------------------------------------------
+    int s_rel[G4_NSLOT], s_pk[G4_NSLOT], s_lds[G4_NSLOT];
+#pragma unroll
+    for (int it = 0; it < G4_NSLOT; ++it) {
+        const int slot = ht + it * 256;
+        int rel = 0, pk = 0x00ff0000, ld = -1;          // hz = 255: never inside a valid range
+        if (slot < a.nslots) {
+            const int4 sd = *reinterpret_cast<const int4 *>(a.sdesc + slot * 4);
+            rel = sd.x * a.in_cs + a.in_c0 + sd.w;
+            pk = sd.y;
+            ld = sd.z;
+        }
+        s_rel[it] = rel; s_pk[it] = pk; s_lds[it] = ld;
+    }
+
+    // ---- per-lane row geometry ------------------------------------------------------------------------
+    const bool pair = a.pair != 0;
+    const int cl = pair ? (lq & 1) * 4 : lq * 4;       // first of this lane's 4 output channels (tile 0)
+    int vbase[4], evox[4], eoff[4];
+    bool erow_ok = true;
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms) {
+        const int v = hw * 64 + ms * 16 + lrow;
+        const int vv = v < a.rows ? v : 0;
+        const int pt = vv / a.TV;
+        int r = vv - pt * a.TV;
+        const int x = r % a.TX; r /= a.TX;
+        const int y = r % a.TY;
+        const int z = r / a.TY;
+        vbase[ms] = (((pt * a.HZ + z * a.smz) * a.HY + y * a.smy) * a.HX + x * a.smx) * G4_ROWB;
+        evox[ms] = ((pt * a.OD + z * a.soz) * a.OH + y * a.soy) * a.OW + x * a.sox + (pair ? (lq >> 1) : 0);
+        eoff[ms] = evox[ms] * a.out_cs + a.out_c0 + cl;
+        erow_ok = erow_ok && v < a.rows;
+    }
+    f32x4 bias4[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        bias4[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int c = nt * 16 + cl;
+        if (a.bias && c < a.Co) bias4[nt] = *reinterpret_cast<const f32x4 *>(a.bias + c);
+    }
+
+    // ---- this half's share of the tile list ------------------------------------------------------------
+    const int pgroups = (a.N + a.PT - 1) / a.PT;
+    const int total = pgroups * a.tpg;
+    const int nwork = gridDim.x * 2;
+    const int me = blockIdx.x * 2 + h;
+    const int n_mine = me < total ? (total - me + nwork - 1) / nwork : 0;
+    const int oth = me ^ 1;
+    const int n_oth = oth < total ? (total - oth + nwork - 1) / nwork : 0;
+    const int nticks = 2 * (n_mine > n_oth ? n_mine : n_oth) * a.nph + 2;
+    const int gp = nwork / a.tpg, gl = nwork % a.tpg;
+    int fpg = me / a.tpg, fl = me % a.tpg;
+    auto advance_cursor = [&]() {
+        fl += gl;
+        const int c = fl >= a.tpg;
+        fl -= c ? a.tpg : 0;
+        fpg += gp + c;
+    };
+
+    int f_out = 0, f_full = 0, f_l = 0, f_g = 0;      // tile the prefetch cursor points at
+    int c_out = 0, c_full = 0, c_l = 0, c_g = 0;      // tile being contracted
+    int p_out = 0, p_full = 0, p_l = 0, p_g = 0;      // tile whose results wait in registers
+    bool have_pend = false;
+
+    int goff[G4_NSLOT];
+    auto park = [&]() {
+#pragma unroll
+        for (int it = 0; it < G4_NSLOT; ++it) goff[it] = G4_OOB;
+    };
+    auto locate = [&]() {
+        const i32x4 t0 = g4_sload4(a.tdesc + fl * 8);
+        const i32x4 t1 = g4_sload4(a.tdesc + fl * 8 + 4);
+        const int org = (t0.x + fpg * a.in_pstride) * a.in_cs;
+        f_out = t0.y + fpg * a.out_pstride;
+        f_full = t0.z && (fpg + 1) * a.PT <= a.N;
+        f_l = fl; f_g = fpg;
+        const unsigned zy = (unsigned)t0.w, xx = (unsigned)t1.x;
+        const unsigned loz = zy & 255u, nz = ((zy >> 8) & 255u) - loz;
+        const unsigned loy = (zy >> 16) & 255u, ny = (zy >> 24) - loy;
+        const unsigned lox = xx & 255u, nx = ((xx >> 8) & 255u) - lox;
+        const int pbase = fpg * a.PT;
+#pragma unroll
+        for (int it = 0; it < G4_NSLOT; ++it) {
+            const unsigned pk = (unsigned)s_pk[it];
+            const bool ok = (((pk >> 16) & 255u) - loz) < nz && (((pk >> 8) & 255u) - loy) < ny &&
+                            ((pk & 255u) - lox) < nx && pbase + (int)(pk >> 24) < a.N;
+            goff[it] = ok ? (org + s_rel[it]) * 4 : G4_OOB;
+        }
+    };
+
+    f32x4 R[G4_NSLOT];
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
+    // the ONE prefetch site: unconditional loads, a slot without work points past the buffer
+    auto fetch = [&](int ph) {
+        int soff = 0;
+        if constexpr (!MULTI) {
+            const i32x4 pd = g4_sload4(a.pdesc + ph * 8);
+            soff = (pd.x * a.in_cs + pd.y * 8) * 4;
+        }
+#pragma unroll
+        for (int it = 0; it < G4_NSLOT; ++it)
+            R[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, goff[it], soff, 0));
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int it = 0; it < G4_NSLOT; ++it) {
+            if (s_lds[it] >= 0) {
+                float v0 = R[it].x, v1 = R[it].y, v2 = R[it].z, v3 = R[it].w;
+                uint2 hi, mid, lo;
+                hi.x = g4_split2(v0, v1);  hi.y = g4_split2(v2, v3);
+                mid.x = g4_split2(v0, v1); mid.y = g4_split2(v2, v3);
+                lo.x = g4_split2(v0, v1);  lo.y = g4_split2(v2, v3);
+                char *dst = Al + s_lds[it];
+                *reinterpret_cast<uint2 *>(dst) = hi;
+                *reinterpret_cast<uint2 *>(dst + 16) = mid;
+                *reinterpret_cast<uint2 *>(dst + 32) = lo;
+            }
+        }
+    };
+
+    // ---------------- epilogue of one tile (bias already in the accumulators) --------------------------
+    f32x4 acc[4][NTW];
+    char *outb = reinterpret_cast<char *>(a.out);
+    const char *maskb = reinterpret_cast<const char *>(a.mask);
+    auto flush = [&](int q_out, int q_full, int q_l, int q_g) {
+        const int obase_e = q_out * a.out_cs;
+        int mz0 = 0, my0 = 0, mx0 = 0;
+        if (!q_full) {
+            const i32x4 t1 = g4_sload4(a.tdesc + q_l * 8 + 4);
+            mz0 = t1.y; my0 = t1.z; mx0 = t1.w;
+        }
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) {
+            bool live = erow_ok;
+            if (!q_full) {
+                const int v = hw * 64 + ms * 16 + lrow;
+                const int vv = v < a.rows ? v : 0;
+                const int pt = vv / a.TV;
+                int r = vv - pt * a.TV;
+                const int x = r % a.TX; r /= a.TX;
+                const int y = r % a.TY;
+                const int z = r / a.TY;
+                live = v < a.rows && q_g * a.PT + pt < a.N && mz0 + z < a.MD && my0 + y < a.MH && mx0 + x < a.MW;
+            }
+            f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int c = nt * 16 + cl;
+                f32x4 val = acc[ms][nt];
+                const bool on = live && c < a.Co;
+                if (on) {
+                    f32x4 *dst = reinterpret_cast<f32x4 *>(outb + (unsigned)((obase_e + eoff[ms] + nt * 16) * 4));
+                    if (a.accumulate) val += *dst;
+                    if (a.relu) {
+                        val.x = __builtin_amdgcn_fmed3f(val.x, 0.f, __builtin_inff());
+                        val.y = __builtin_amdgcn_fmed3f(val.y, 0.f, __builtin_inff());
+                        val.z = __builtin_amdgcn_fmed3f(val.z, 0.f, __builtin_inff());
+                        val.w = __builtin_amdgcn_fmed3f(val.w, 0.f, __builtin_inff());
+                    }
+                    if (a.mask && c >= a.mask_from) {
+                        const int mo = (q_out + evox[ms]) * a.mask_cs + a.mask_c0 + (c - a.mask_from);
+                        const f32x4 mk = *reinterpret_cast<const f32x4 *>(maskb + (unsigned)(mo * 4));
+                        val.x = mk.x > 0.f ? val.x : 0.f; val.y = mk.y > 0.f ? val.y : 0.f;
+                        val.z = mk.z > 0.f ? val.z : 0.f; val.w = mk.w > 0.f ? val.w : 0.f;
+                    }
+                    *dst = val;
+                }
+                if constexpr (SUMS) {
+                    if (!on) val = f32x4{0.f, 0.f, 0.f, 0.f};
+                    // selector MFMA: result row 0 = sum over the lane groups of set A, row 1 = set B
+                    const bool inA = pair ? (lq < 2) : (c < a.split);
+                    const float sel = (lrow == 0) ? (inA ? 1.f : 0.f) : ((lrow == 1) ? (inA ? 0.f : 1.f) : 0.f);
+                    sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, (val.x + val.y) + (val.z + val.w), sacc, 0, 0, 0);
+                }
+            }
+            if constexpr (SUMS) {
+                if (live && lq == 0) {
+                    if (pair) {          // rows 0-7 / 8-15 are the two x-adjacent voxels of the pair
+                        a.osumA[q_out + evox[ms]] = sacc.x;
+                        a.osumA[q_out + evox[ms] + 1] = sacc.y;
+                    } else {
+                        if (a.osumA) a.osumA[q_out + evox[ms]] = sacc.x;
+                        if (a.osumB) a.osumB[q_out + evox[ms]] = sacc.y;
+                    }
+                }
+            }
+        }
+    };
+
+    // ---------------- one unit: S k-steps of 4 taps x 8 channels, fragment reads one half-step ahead ----
+    auto unit = [&](int S, const char *Wc, const char *Ab, int trow) {
+        const int *tt = Tl + trow * (G4_MAXS * 4) + lq;
+        bf16x8 Wa[3][NTW], Wb[3][NTW], Xa[3][2], Xb[3][2];
+        auto rdW = [&](bf16x8 (&Wf)[3][NTW], int s) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+                    Wf[p][nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4 *>(Wc + ((s * 3 + p) * NTW + nt) * 1024));
+        };
+        auto rdX = [&](bf16x8 (&X)[3][2], int mh, int to) {
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2) {
+                const char *row = Ab + vbase[mh + m2] + to;
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    X[p][m2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4 *>(row + 16 * p));
+            }
+        };
+        // six piece products, smallest weights first, the two row blocks alternating (independent chains)
+        auto mm = [&](const bf16x8 (&Wf)[3][NTW], const bf16x8 (&X)[3][2], int mh) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                f32x4 c0 = acc[mh][nt], c1 = acc[mh + 1][nt];
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[1][nt], X[1][0], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[1][nt], X[1][1], c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[2][nt], X[0][0], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[2][nt], X[0][1], c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[0][nt], X[2][0], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[0][nt], X[2][1], c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[1][nt], X[0][0], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[1][nt], X[0][1], c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[0][nt], X[1][0], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[0][nt], X[1][1], c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[0][nt], X[0][0], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[0][nt], X[0][1], c1, 0, 0, 0);
+                acc[mh][nt] = c0; acc[mh + 1][nt] = c1;
+            }
+        };
+        int t_cur = tt[0];
+        rdW(Wa, 0);
+        rdX(Xa, 0, t_cur);
+        for (int s = 0; s < S; ++s) {
+            const int s1 = s + 1 < S ? s + 1 : s;
+            const int t_nxt = tt[s1 * 4];
+            rdX(Xb, 2, t_cur);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(Wa, Xa, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            rdW(Wb, s1);
+            rdX(Xa, 0, t_nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(Wa, Xb, 2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) Wa[p][nt] = Wb[p][nt];
+            t_cur = t_nxt;
+        }
+    };
+    auto init_acc = [&]() {
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[ms][nt] = bias4[nt];
+    };
+
+    // ---------------- tick loop --------------------------------------------------------------------------
+    const int n_ph = n_mine * a.nph;     // staging phases of this half
+    int a_i = 0, a_ph = 0;               // next phase to stage (counter, index within the tile)
+    int b_i = 0, b_ph = 0;               // next phase to contract
+    if (n_mine > 0) locate(); else park();
+    fetch(0);
+    for (int tick = 0; tick < nticks; ++tick) {
+        if ((tick & 1) == h) {
+            if (a_i < n_ph) {
+                if (a_ph == 0) { c_out = f_out; c_full = f_full; c_l = f_l; c_g = f_g; }
+                stash();
+                if (a_ph == 0 && have_pend) {
+                    flush(p_out, p_full, p_l, p_g);
+                    have_pend = false;
+                }
+                int nph = a_ph + 1;
+                if (nph == a.nph) {
+                    nph = 0;
+                    advance_cursor();
+                    if (a_i + 1 < n_ph) locate(); else park();
+                }
+                fetch(nph);
+                a_ph = nph;
+                ++a_i;
+            }
+        } else {
+            if (b_i < a_i) {
+                if constexpr (!MULTI) {
+                    const i32x8 pd = g4_sload8(a.pdesc + b_ph * 8);
+                    if (b_ph == 0) init_acc();
+                    for (int rep = 0; rep <= a.dbg_repeat; ++rep)
+                        unit(pd[2], Wl + pd[3] + lane * 16, Al, pd[4]);
+                    if (b_ph == a.nph - 1) {
+                        have_pend = true;
+                        p_out = c_out; p_full = c_full; p_l = c_l; p_g = c_g;
+                    }
+                    b_ph = b_ph + 1 == a.nph ? 0 : b_ph + 1;
+                } else {
+                    for (int g = 0; g < a.ngr; ++g) {
+                        const i32x8 gd = g4_sload8(a.pdesc + g * 8);
+                        init_acc();
+                        const int ub = gd[2] * (3 * NTW * 1024);
+                        for (int rep = 0; rep <= a.dbg_repeat; ++rep)
+                            for (int p = 0; p < a.NP; ++p)
+                                unit(gd[2], Wl + gd[3] + p * ub + lane * 16, Al + p * a.plane_bytes, gd[4]);
+                        if (g + 1 < a.ngr) {
+                            flush(c_out + gd[5], c_full, c_l, c_g);
+                        } else {
+                            have_pend = true;
+                            p_out = c_out + gd[5]; p_full = c_full; p_l = c_l; p_g = c_g;
+                        }
+                    }
+                }
+                ++b_i;
+            }
+        }
+        __syncthreads();
+    }
+    if (have_pend) flush(p_out, p_full, p_l, p_g);
+}
+
+// ======================================================================================================
+// host: plan builder
+// ======================================================================================================
+static int g4_pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+static int g4_floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+static int g4_ceildiv(int a, int b) { return -g4_floordiv(-a, b); }
+
+namespace {
+struct DimGeo {
+    int I = 1, O = 1, M = 1;     // input / output / M-grid extent
+    int hs = 1;                  // input coordinate step per halo index
+    int sm = 1;                  // M-grid point -> halo index multiplier
+    int bm = 1, bo = 0;          // input coordinate of halo index 0 of the tile at m0: m0*bm + bo
+    int span = 1;                // halo indices covered by the taps of one M-grid point
+    int so = 1;                  // M-grid point -> output coordinate multiplier
+};
+struct Box { int b[3] = {0, 0, 0}, n[3] = {1, 1, 1}; };
+}  // namespace
+
+int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
+    plan->ok = false;
+    plan->units.clear();
+    if (g.Ci % 8 != 0 || g.Co % 4 != 0 || g.Ci < 8) return ALQ_OK;
+    const int I[3] = {g.ID, g.IH, g.IW}, O[3] = {g.OD, g.OH, g.OW};
+    const int NT = (g.Co + 15) / 16;
+    if (NT > 2) return ALQ_OK;
+    const int NTW = NT;
+    const int NCH = g.Ci / 8;
+    DimGeo dg[3];
+    bool pair = false;
+    const int *k = g.k, *s = g.s, *lo = g.lo;
+
+    // class structure per dimension (kinds 1, 2)
+    int amin[3] = {0, 0, 0}, amax[3] = {0, 0, 0};
+    auto a_range = [&](int d, int r, int *a0, int *a1) {      // kind 1: taps t = s*a + r + lo in [0, k)
+        *a0 = g4_ceildiv(-r - lo[d], s[d]);
+        *a1 = g4_floordiv(k[d] - 1 - r - lo[d], s[d]);
+    };
+    auto n_range = [&](int d, int c, int *n0, int *n1) {      // kind 2: taps t = c + lo - s*n in [0, k)
+        *n0 = g4_ceildiv(c + lo[d] - k[d] + 1, s[d]);
+        *n1 = g4_floordiv(c + lo[d], s[d]);
+    };
+    if (g.kind == 0) {
+        for (int d = 0; d < 3; ++d) {
+            if (s[d] != 1 || I[d] != O[d]) return ALQ_OK;
+            dg[d].I = I[d]; dg[d].O = O[d]; dg[d].M = O[d];
+            dg[d].bo = g.flipped ? lo[d] - (k[d] - 1) : -lo[d];
+            dg[d].span = k[d];
+        }
+        // pair form: 8 output channels, two x-adjacent voxels per 16 MFMA rows, (k+1)-wide x window
+        if (g.Co == 8 && O[2] % 2 == 0 && O[2] >= 4) {
+            pair = true;
+            dg[2].M = O[2] / 2; dg[2].sm = 2; dg[2].bm = 2; dg[2].so = 2; dg[2].span = k[2] + 1;
+        }
+    } else if (g.kind == 1) {
+        for (int d = 0; d < 3; ++d) {
+            if (I[d] != O[d] * s[d] || k[d] < s[d]) return ALQ_OK;
+            dg[d].I = I[d]; dg[d].O = O[d]; dg[d].M = O[d];
+            if (d < 2) {
+                int lo_a = 1 << 30, hi_a = -(1 << 30);
+                for (int r = 0; r < s[d]; ++r) {
+                    int a0, a1;
+                    a_range(d, r, &a0, &a1);
+                    if (a1 < a0) return ALQ_OK;
+                    lo_a = std::min(lo_a, a0); hi_a = std::max(hi_a, a1);
+                }
+                amin[d] = lo_a; amax[d] = hi_a;
+                dg[d].hs = s[d]; dg[d].sm = 1; dg[d].bm = s[d]; dg[d].bo = s[d] * lo_a; dg[d].span = hi_a - lo_a + 1;
+            } else {
+                dg[d].hs = 1; dg[d].sm = s[d]; dg[d].bm = s[d]; dg[d].bo = -lo[d]; dg[d].span = k[d];
+            }
+        }
+    } else if (g.kind == 2) {
+        for (int d = 0; d < 3; ++d) {
+            if (O[d] != I[d] * s[d] || k[d] < s[d]) return ALQ_OK;
+            dg[d].I = I[d]; dg[d].O = O[d]; dg[d].M = I[d];
+            int lo_n = 1 << 30, hi_n = -(1 << 30);
+            for (int c = 0; c < s[d]; ++c) {
+                int n0, n1;
+                n_range(d, c, &n0, &n1);
+                if (n1 < n0) return ALQ_OK;
+                lo_n = std::min(lo_n, n0); hi_n = std::max(hi_n, n1);
+            }
+            amin[d] = lo_n; amax[d] = hi_n;
+            dg[d].bo = lo_n; dg[d].span = hi_n - lo_n + 1; dg[d].so = s[d];
+        }
+        pair = (g.Co == 8 && s[2] == 2);
+    } else {
+        return ALQ_OK;
+    }
+    if (pair && NTW != 1) return ALQ_OK;
+
+    // ---- units: tap boxes, tap maps (box position -> tap of the k^3 enumeration) ------------------------
+    struct URow { Box box; std::vector<int> tap; int ntaps = 0; int S = 0; int in_off[3] = {0, 0, 0}; int out_off[3] = {0, 0, 0}; };
+    std::vector<URow> rows;
+    auto enum_tap = [&](int tz, int ty, int tx) {
+        if (tz < 0 || tz >= k[0] || ty < 0 || ty >= k[1] || tx < 0 || tx >= k[2]) return -1;
+        return (tz * k[1] + ty) * k[2] + tx;
+    };
+    auto finish_row = [&](URow &r, const std::function<int(int, int, int, int)> &tapof) {
+        r.ntaps = r.box.n[0] * r.box.n[1] * r.box.n[2];
+        r.S = (r.ntaps + 3) / 4;
+        r.tap.assign((size_t)r.S * 4 * 2, -1);
+        for (int t = 0; t < r.ntaps; ++t) {
+            const int ix = t % r.box.n[2], iy = (t / r.box.n[2]) % r.box.n[1], iz = t / (r.box.n[2] * r.box.n[1]);
+            for (int half = 0; half < 2; ++half) r.tap[(size_t)t * 2 + half] = tapof(iz, iy, ix, half);
+        }
+    };
+    if (g.kind == 0) {
+        URow r;
+        for (int d = 0; d < 3; ++d) { r.box.b[d] = 0; r.box.n[d] = dg[d].span; }
+        finish_row(r, [&](int iz, int iy, int ix, int half) {
+            int o[3] = {dg[0].bo + iz, dg[1].bo + iy, dg[2].bo + ix - (half ? 1 : 0)};
+            if (half && !pair) return -1;
+            int t[3];
+            for (int d = 0; d < 3; ++d) t[d] = g.flipped ? lo[d] - o[d] : o[d] + lo[d];
+            return enum_tap(t[0], t[1], t[2]);
+        });
+        rows.push_back(r);
+    } else if (g.kind == 1) {
+        for (int rz = 0; rz < s[0]; ++rz)
+            for (int ry = 0; ry < s[1]; ++ry) {
+                URow r;
+                int a0z, a1z, a0y, a1y;
+                a_range(0, rz, &a0z, &a1z);
+                a_range(1, ry, &a0y, &a1y);
+                r.box.b[0] = a0z - amin[0]; r.box.n[0] = a1z - a0z + 1;
+                r.box.b[1] = a0y - amin[1]; r.box.n[1] = a1y - a0y + 1;
+                r.box.b[2] = 0; r.box.n[2] = k[2];
+                r.in_off[0] = rz; r.in_off[1] = ry;
+                finish_row(r, [&](int iz, int iy, int ix, int half) {
+                    if (half) return -1;
+                    return enum_tap(s[0] * (a0z + iz) + rz + lo[0], s[1] * (a0y + iy) + ry + lo[1], ix);
+                });
+                rows.push_back(r);
+            }
+    } else {
+        const int ncx = pair ? 1 : s[2];
+        for (int cz = 0; cz < s[0]; ++cz)
+            for (int cy = 0; cy < s[1]; ++cy)
+                for (int cx = 0; cx < ncx; ++cx) {
+                    URow r;
+                    int n0[3], n1[3];
+                    n_range(0, cz, &n0[0], &n1[0]);
+                    n_range(1, cy, &n0[1], &n1[1]);
+                    if (pair) {
+                        int m0, m1;
+                        n_range(2, 0, &n0[2], &n1[2]);
+                        n_range(2, 1, &m0, &m1);
+                        n0[2] = std::min(n0[2], m0); n1[2] = std::max(n1[2], m1);
+                    } else {
+                        n_range(2, cx, &n0[2], &n1[2]);
+                    }
+                    for (int d = 0; d < 3; ++d) { r.box.b[d] = n0[d] - amin[d]; r.box.n[d] = n1[d] - n0[d] + 1; }
+                    r.out_off[0] = cz; r.out_off[1] = cy; r.out_off[2] = cx;
+                    finish_row(r, [&](int iz, int iy, int ix, int half) {
+                        if (half && !pair) return -1;
+                        const int ccx = pair ? half : cx;
+                        return enum_tap(cz + lo[0] - s[0] * (n0[0] + iz), cy + lo[1] - s[1] * (n0[1] + iy),
+                                        ccx + lo[2] - s[2] * (n0[2] + ix));
+                    });
+                    rows.push_back(r);
+                }
+    }
+    int maxS = 0, sumS = 0;
+    for (const URow &r : rows) { maxS = std::max(maxS, r.S); sumS += r.S; }
+    if (maxS > G4_MAXS) return ALQ_OK;
+    const bool multi = (g.kind == 2);
+    const int nstage = multi ? 1 : (int)rows.size() * NCH;      // staging phases per tile
+    const int NPs = multi ? NCH : 1;                             // planes staged per phase
+    const size_t wbytes = (size_t)sumS * NCH * 3 * NTW * 1024;
+    const size_t tt_ints = (size_t)rows.size() * G4_MAXS * 4;
+
+    // ---- tile search ---------------------------------------------------------------------------------------
+    double best = 1e300;
+    int bt[4] = {0, 0, 0, 0};
+    for (int TX = 1; TX <= 256; TX <<= 1) {
+        if (TX > g4_pow2ceil(dg[2].M)) break;
+        for (int TY = 1; TX * TY <= 256; TY <<= 1) {
+            if (TY > g4_pow2ceil(dg[1].M)) break;
+            for (int TZ = 1; TX * TY * TZ <= 256; TZ <<= 1) {
+                if (TZ > g4_pow2ceil(dg[0].M)) break;
+                for (int PT = 256 / (TX * TY * TZ); PT >= 1; PT >>= 1) {
+                    if (PT > 1 && (TX < dg[2].M || TY < dg[1].M || TZ < dg[0].M)) continue;
+                    if (PT > 127) continue;
+                    const int T[3] = {TZ, TY, TX};
+                    int H[3];
+                    bool okh = true;
+                    for (int d = 0; d < 3; ++d) { H[d] = (T[d] - 1) * dg[d].sm + dg[d].span; okh = okh && H[d] <= 254; }
+                    if (!okh) continue;
+                    const long long nhv = (long long)PT * H[0] * H[1] * H[2];
+                    if (nhv * 2 * NPs > 256 * G4_NSLOT) continue;
+                    const size_t lds = tt_ints * 4 + wbytes + 2 * (size_t)nhv * NPs * G4_ROWB;
+                    if (lds > 160 * 1024 - 256) continue;
+                    const double tiles = std::ceil((double)max_batch / PT) * std::ceil((double)dg[0].M / TZ) *
+                                         std::ceil((double)dg[1].M / TY) * std::ceil((double)dg[2].M / TX);
+                    const double rowsf = (double)PT * TX * TY * TZ;
+                    double cost = tiles * ((double)sumS * NCH * 480.0 + (double)(multi ? NPs : nstage) * 1.2 * (double)nhv + 600.0);
+                    if (rowsf < 256) cost *= 1.0;     // under-filled tiles cost a full tile: already in `tiles`
+                    if (cost < best) { best = cost; bt[0] = PT; bt[1] = TZ; bt[2] = TY; bt[3] = TX; }
+                }
+            }
+        }
+    }
+    if (best > 1e299) return ALQ_OK;
+    const int PT = bt[0], T[3] = {bt[1], bt[2], bt[3]};
+    int H[3], tiles[3];
+    for (int d = 0; d < 3; ++d) {
+        H[d] = (T[d] - 1) * dg[d].sm + dg[d].span;
+        tiles[d] = (dg[d].M + T[d] - 1) / T[d];
+    }
+    const int nhv = PT * H[0] * H[1] * H[2];
+
+    Igemm4Args &a = plan->a;
+    std::memset(&a, 0, sizeof(a));
+    a.Co = g.Co;
+    a.PT = PT; a.tpg = tiles[0] * tiles[1] * tiles[2];
+    a.rows = PT * T[0] * T[1] * T[2];
+    a.TV = T[0] * T[1] * T[2]; a.TY = T[1]; a.TX = T[2];
+    a.HZ = H[0]; a.HY = H[1]; a.HX = H[2];
+    a.smz = dg[0].sm; a.smy = dg[1].sm; a.smx = dg[2].sm;
+    a.soz = dg[0].so; a.soy = dg[1].so; a.sox = dg[2].so;
+    a.OD = O[0]; a.OH = O[1]; a.OW = O[2];
+    a.MD = dg[0].M; a.MH = dg[1].M; a.MW = dg[2].M;
+    a.nph = multi ? 1 : nstage;
+    a.ngr = multi ? (int)rows.size() : 1;
+    a.NP = NPs;
+    a.nslots = nhv * 2 * NPs;
+    a.plane_bytes = nhv * G4_ROWB;
+    a.in_pstride = PT * I[0] * I[1] * I[2];
+    a.out_pstride = PT * O[0] * O[1] * O[2];
+    a.pair = pair ? 1 : 0;
+    a.tt_ints = (int)tt_ints;
+    a.wbytes = (int)wbytes;
+    a.abytes = nhv * NPs * G4_ROWB;
+    a.split = 1 << 30;
+
+    // tap table + units + phase / group descriptors
+    plan->h_ttab.assign(tt_ints, 0);
+    for (size_t r = 0; r < rows.size(); ++r) {
+        const URow &u = rows[r];
+        for (int t = 0; t < u.ntaps; ++t) {
+            const int ix = t % u.box.n[2], iy = (t / u.box.n[2]) % u.box.n[1], iz = t / (u.box.n[2] * u.box.n[1]);
+            plan->h_ttab[r * G4_MAXS * 4 + t] =
+                (((u.box.b[0] + iz) * H[1] + (u.box.b[1] + iy)) * H[2] + (u.box.b[2] + ix)) * G4_ROWB;
+        }
+    }
+    int w_off = 0;
+    plan->h_pdesc.clear();
+    if (!multi) {
+        for (size_t r = 0; r < rows.size(); ++r)
+            for (int ch = 0; ch < NCH; ++ch) {
+                Igemm4Plan::Unit u;
+                u.chunk = ch; u.S = rows[r].S; u.w_off = w_off; u.tap = rows[r].tap;
+                plan->units.push_back(u);
+                const int in_off = (rows[r].in_off[0] * I[1] + rows[r].in_off[1]) * I[2] + rows[r].in_off[2];
+                const int pd[8] = {in_off, ch, u.S, w_off, (int)r, 0, 0, 0};
+                plan->h_pdesc.insert(plan->h_pdesc.end(), pd, pd + 8);
+                w_off += u.S * 3 * NTW * 1024;
+            }
+    } else {
+        for (size_t r = 0; r < rows.size(); ++r) {
+            const int out_off = (rows[r].out_off[0] * O[1] + rows[r].out_off[1]) * O[2] + rows[r].out_off[2];
+            const int gd[8] = {0, 0, rows[r].S, w_off, (int)r, out_off, 0, 0};
+            plan->h_pdesc.insert(plan->h_pdesc.end(), gd, gd + 8);
+            for (int ch = 0; ch < NCH; ++ch) {
+                Igemm4Plan::Unit u;
+                u.chunk = ch; u.S = rows[r].S; u.w_off = w_off; u.tap = rows[r].tap;
+                plan->units.push_back(u);
+                w_off += u.S * 3 * NTW * 1024;
+            }
+        }
+    }
+    // tiles
+    plan->h_tdesc.assign((size_t)a.tpg * 8, 0);
+    for (int tz = 0; tz < tiles[0]; ++tz)
+        for (int ty = 0; ty < tiles[1]; ++ty)
+            for (int tx = 0; tx < tiles[2]; ++tx) {
+                int *td = &plan->h_tdesc[(((size_t)tz * tiles[1] + ty) * tiles[2] + tx) * 8];
+                const int m0[3] = {tz * T[0], ty * T[1], tx * T[2]};
+                int base[3], lohi[3][2];
+                bool full = a.rows == 256;
+                for (int d = 0; d < 3; ++d) {
+                    base[d] = m0[d] * dg[d].bm + dg[d].bo;
+                    int l = g4_ceildiv(-base[d], dg[d].hs), hgh = g4_ceildiv(dg[d].I - base[d], dg[d].hs);
+                    // kind 1 sampled dims: the class offset r < hs never changes validity because I is a multiple of hs
+                    l = std::max(0, std::min(l, H[d])); hgh = std::max(l, std::min(hgh, H[d]));
+                    lohi[d][0] = l; lohi[d][1] = hgh;
+                    full = full && m0[d] + T[d] <= dg[d].M;
+                }
+                td[0] = (base[0] * I[1] + base[1]) * I[2] + base[2];
+                td[1] = (m0[0] * dg[0].so * O[1] + m0[1] * dg[1].so) * O[2] + m0[2] * dg[2].so;
+                td[2] = full ? 1 : 0;
+                td[3] = lohi[0][0] | (lohi[0][1] << 8) | (lohi[1][0] << 16) | (lohi[1][1] << 24);
+                td[4] = lohi[2][0] | (lohi[2][1] << 8);
+                td[5] = m0[0]; td[6] = m0[1]; td[7] = m0[2];
+            }
+    // staging slots
+    plan->h_sdesc.assign((size_t)a.nslots * 4, 0);
+    for (int pl = 0; pl < NPs; ++pl)
+        for (int pt = 0; pt < PT; ++pt)
+            for (int hz = 0; hz < H[0]; ++hz)
+                for (int hy = 0; hy < H[1]; ++hy)
+                    for (int hx = 0; hx < H[2]; ++hx) {
+                        const int hv = ((pt * H[0] + hz) * H[1] + hy) * H[2] + hx;
+                        for (int half = 0; half < 2; ++half) {
+                            int *sd = &plan->h_sdesc[(((size_t)pl * nhv + hv) * 2 + half) * 4];
+                            sd[0] = ((pt * I[0] + hz * dg[0].hs) * I[1] + hy * dg[1].hs) * I[2] + hx * dg[2].hs;
+                            sd[1] = (pt << 24) | (hz << 16) | (hy << 8) | hx;
+                            sd[2] = pl * nhv * G4_ROWB + hv * G4_ROWB + half * 8;
+                            sd[3] = pl * 8 + half * 4;
+                        }
+                    }
+    plan->NTW = NTW;
+    plan->multi = multi;
+    plan->Ci = g.Ci; plan->Co = g.Co;
+    plan->lds_bytes = tt_ints * 4 + wbytes + 2 * (size_t)a.abytes;
+    plan->flops_per_patch = g.flops_per_patch;
+    plan->ok = true;
+    return ALQ_OK;
+}
+
+static unsigned short g4_bf16_rne(float x) {
+    unsigned u;
+    std::memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+static float g4_bf16_to_f(unsigned short hb) {
+    const unsigned u = (unsigned)hb << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+// packed layout per unit: [s][piece][16-col tile][lane][8] bf16; lane = (q = lane>>4 -> tap 4s+q, row = lane&15)
+void igemm4_pack_weights(Igemm4Plan *plan, const std::vector<float> &Bmat) {
+    const int NTW = plan->NTW, Ci = plan->Ci, Co = plan->Co;
+    const bool pair = plan->a.pair != 0;
+    plan->h_W.assign((size_t)plan->a.wbytes / 2, 0);
+    for (const Igemm4Plan::Unit &u : plan->units)
+        for (int s = 0; s < u.S; ++s)
+            for (int nt = 0; nt < NTW; ++nt)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int q = lane >> 4, r = lane & 15;
+                    const int half = pair ? (r >> 3) : 0;
+                    const int co = pair ? (r & 7) : nt * 16 + r;
+                    const int tap = u.tap[(size_t)(s * 4 + q) * 2 + half];
+                    for (int j = 0; j < 8; ++j) {
+                        float w = 0.f;
+                        if (tap >= 0 && co < Co) w = Bmat[((size_t)tap * Ci + u.chunk * 8 + j) * Co + co];
+                        for (int p = 0; p < 3; ++p) {
+                            const unsigned short hb = g4_bf16_rne(w);
+                            w -= g4_bf16_to_f(hb);
+                            plan->h_W[(size_t)u.w_off / 2 + ((((size_t)s * 3 + p) * NTW + nt) * 64 + lane) * 8 + j] = hb;
+                        }
+                    }
+                }
+}
+
+template <int NTW, bool MULTI, bool SUMS>
+static int launch4_s(alq_ctx *ctx, const Igemm4Plan &plan, const Igemm4Args &a, unsigned grid) {
+    auto kfn = igemm4_kernel<NTW, MULTI, SUMS>;
+    if (plan.lds_bytes > 64 * 1024)
+        ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)plan.lds_bytes));
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), plan.lds_bytes, ctx->stream, a);
+    ALQ_HIP(hipGetLastError());
+    return ALQ_OK;
+}
+
+template <int NTW, bool MULTI>
+static int launch4_t(alq_ctx *ctx, const Igemm4Plan &plan, const Igemm4Args &a, unsigned grid) {
+    return (a.osumA || a.osumB) ? launch4_s<NTW, MULTI, true>(ctx, plan, a, grid)
+                                : launch4_s<NTW, MULTI, false>(ctx, plan, a, grid);
+}
+
+int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const View &out, const float *bias,
+                  int relu, int accumulate, int N, int prof_cls, const Igemm2Fuse *fuse) {
+    Igemm4Args a = plan.a;
+    ALQ_REQUIRE(in.C == plan.Ci && out.C == plan.Co, ALQ_EINVAL, "igemm4: channel counts do not match the plan");
+    ALQ_REQUIRE(out.D == a.OD && out.H == a.OH && out.W == a.OW, ALQ_EINVAL, "igemm4: output view mismatch");
+    ALQ_REQUIRE(plan.d_W && plan.d_tdesc, ALQ_EINVAL, "igemm4: weights not set");
+    ALQ_REQUIRE((long long)N * in.vox() * in.cs < (1LL << 29) && (long long)N * out.vox() * out.cs < (1LL << 29),
+                ALQ_EUNSUPPORTED, "igemm4: tensor exceeds the 32-bit byte-offset range (lower the batch)");
+    ALQ_REQUIRE(in.cs % 4 == 0 && in.c0 % 4 == 0 && out.cs % 4 == 0 && out.c0 % 4 == 0, ALQ_EUNSUPPORTED,
+                "igemm4: channel slice not 16-byte aligned");
+    a.in = in.p; a.in_cs = in.cs; a.in_c0 = in.c0;
+    a.out = out.p; a.out_cs = out.cs; a.out_c0 = out.c0;
+    a.W = plan.d_W; a.bias = bias; a.relu = relu; a.accumulate = accumulate; a.N = N;
+    a.tdesc = plan.d_tdesc; a.sdesc = plan.d_sdesc; a.pdesc = plan.d_pdesc; a.ttab = plan.d_ttab;
+    a.in_bytes = (int)((long long)N * in.vox() * in.cs * 4);
+    a.dbg = nullptr;
+    a.dbg_repeat = g_dbg_knobs[0];
+    a.split = 1 << 30;
+    if (fuse) {
+        ALQ_REQUIRE(fuse->split % 4 == 0 && fuse->mask_cs % 4 == 0 && fuse->mask_c0 % 4 == 0 && fuse->mask_from % 4 == 0,
+                    ALQ_EUNSUPPORTED, "igemm4: fused epilogue needs 4-channel aligned slices");
+        ALQ_REQUIRE(!a.pair || (!fuse->osumB && fuse->split == 0), ALQ_EUNSUPPORTED,
+                    "igemm4: the pair form sums all 8 channels of a voxel");
+        a.mask = fuse->mask; a.mask_cs = fuse->mask_cs; a.mask_c0 = fuse->mask_c0; a.mask_from = fuse->mask_from;
+        a.osumA = fuse->osumA; a.osumB = fuse->osumB;
+        a.split = fuse->split > 0 ? fuse->split : (1 << 30);
+    }
+    const int pgroups = (N + a.PT - 1) / a.PT;
+    const long long total = (long long)pgroups * a.tpg;
+    const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((total + 1) / 2, 256));
+    ProfScope ps(ctx, prof_cls, plan.flops_per_patch * N);
+    if (plan.multi) {
+        if (plan.NTW == 1) return launch4_t<1, true>(ctx, plan, a, grid);
+        return launch4_t<2, true>(ctx, plan, a, grid);
+    }
+    if (plan.NTW == 1) return launch4_t<1, false>(ctx, plan, a, grid);
+    return launch4_t<2, false>(ctx, plan, a, grid);
+}
+
+}  // namespace alq

@@ -48,6 +48,7 @@ struct Layer {
     float *d_bias = nullptr;
     float *d_Wp = nullptr;     // skinny fc: [nout][F] in activation-memory order
     std::vector<Gemm> fwd;        // 1 contraction (conv / fc) or one per output parity class (convT)
+    Igemm4Plan fwd_all;           // convT: every output class from one staged block (igemm4.hip), when eligible
     Gemm bwd;
     bool has_bwd = false;
     bool weights_set = false;
@@ -153,8 +154,13 @@ static int upload1(alq_model *m, IgemmPlan *p) {
 static bool g_use_v2 = true;
 static bool g_knobs_init = false;
 
-static int gemm_build(const ConvDesc &d, int max_batch, Gemm *g) {
+static int gemm_build(const ConvDesc &d, int max_batch, Gemm *g, const G4Geom *g4 = nullptr) {
     ALQ_TRY(igemm_build_plan(d, max_batch, &g->p1));
+    if (g4 && !getenv("ALQ_DISABLE_V4")) {
+        G4Geom gg = *g4;
+        gg.flops_per_patch = g->p1.flops_per_patch;
+        ALQ_TRY(igemm4_build_plan(gg, max_batch, &g->p4));
+    }
     ALQ_TRY(igemm2_build_plan(g->p1, &g->p2));
     ALQ_TRY(direct_build_plan(g->p1, &g->pd));
     if (!g_use_v2) { g->p2.ok = false; g->pd.ok = false; }
@@ -163,7 +169,30 @@ static int gemm_build(const ConvDesc &d, int max_batch, Gemm *g) {
     return ALQ_OK;
 }
 
+static int set4(alq_model *m, Igemm4Plan *p4, const std::vector<float> &Bmat) {
+    igemm4_pack_weights(p4, Bmat);
+    hipStream_t st = m->ctx->stream;
+    if (!p4->d_tdesc) {
+        ALQ_TRY(m->dalloc(&p4->d_tdesc, p4->h_tdesc.size()));
+        ALQ_TRY(m->dalloc(&p4->d_sdesc, p4->h_sdesc.size()));
+        ALQ_TRY(m->dalloc(&p4->d_pdesc, p4->h_pdesc.size()));
+        ALQ_TRY(m->dalloc(&p4->d_ttab, p4->h_ttab.size()));
+        ALQ_HIP(hipMemcpyAsync(p4->d_tdesc, p4->h_tdesc.data(), p4->h_tdesc.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        ALQ_HIP(hipMemcpyAsync(p4->d_sdesc, p4->h_sdesc.data(), p4->h_sdesc.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        ALQ_HIP(hipMemcpyAsync(p4->d_pdesc, p4->h_pdesc.data(), p4->h_pdesc.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        ALQ_HIP(hipMemcpyAsync(p4->d_ttab, p4->h_ttab.data(), p4->h_ttab.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    }
+    unsigned short *dw = reinterpret_cast<unsigned short *>(p4->d_W);
+    if (!dw) ALQ_TRY(m->dalloc(&dw, p4->h_W.size()));
+    p4->d_W = dw;
+    ALQ_HIP(hipMemcpyAsync(dw, p4->h_W.data(), p4->h_W.size() * sizeof(unsigned short), hipMemcpyHostToDevice, st));
+    ALQ_HIP(hipStreamSynchronize(st));
+    std::vector<unsigned short>().swap(p4->h_W);
+    return ALQ_OK;
+}
+
 static int gemm_set(alq_model *m, Gemm *g, const std::vector<float> &Bmat) {
+    if (g->p4.ok) ALQ_TRY(set4(m, &g->p4, Bmat));
     if (g->pd.ok) {      // direct kernel reads the B matrix [K][Co] as it is
         if (!g->pd.d_W) ALQ_TRY(m->dalloc(&g->pd.d_W, Bmat.size()));
         ALQ_HIP(hipMemcpyAsync(g->pd.d_W, Bmat.data(), Bmat.size() * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
@@ -208,6 +237,11 @@ static int gemm_launch(alq_ctx *ctx, const Gemm &g, const View &in, const View &
     if (g.pd.ok && !accumulate && !(fuse && (fuse->mask || fuse->osumB || fuse->split))) {
         if (fused) *fused = fuse != nullptr;
         return direct_launch(ctx, g.pd, in, out, bias, relu, N, fuse ? fuse->osumA : nullptr, PROF_DIRECT);
+    }
+    if (g.p4.ok && !g_dbg_knobs[4] && !g_dbg_knobs[5]) {      // two-slot bf16x3 engine
+        if (fused) *fused = fuse != nullptr;
+        return igemm4_launch(ctx, g.p4, in, out, bias, relu, accumulate, N,
+                             cls == PROF_IGEMM_BWD ? PROF_IGEMM3_BWD : PROF_IGEMM3_FWD, fuse);
     }
     if (g.p3.ok && !g_dbg_knobs[4]) {      // bf16x3 split on the matrix cores (fp32-equivalent accuracy)
         if (fused) *fused = fuse != nullptr;
@@ -393,7 +427,12 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
             enum_taps(sp.k, &d.tz, &d.ty, &d.tx);
             for (size_t t = 0; t < d.tz.size(); ++t) { d.tz[t] -= ly.lo[0]; d.ty[t] -= ly.lo[1]; d.tx[t] -= ly.lo[2]; }
             ly.fwd.resize(1);
-            ALQ_TRY(gemm_build(d, NB, &ly.fwd[0]));
+            G4Geom g4;
+            g4.kind = 0;
+            g4.ID = ly.in.D; g4.IH = ly.in.H; g4.IW = ly.in.W; g4.Ci = ly.in.C;
+            g4.OD = ly.out.D; g4.OH = ly.out.H; g4.OW = ly.out.W; g4.Co = sp.cout;
+            for (int q = 0; q < 3; ++q) { g4.k[q] = sp.k[q]; g4.s[q] = sp.s[q]; g4.lo[q] = ly.lo[q]; }
+            ALQ_TRY(gemm_build(d, NB, &ly.fwd[0], &g4));
             if (!first_param) {
                 ConvDesc b;
                 b.ID = ly.out.D; b.IH = ly.out.H; b.IW = ly.out.W; b.Ci = sp.cout;
@@ -403,7 +442,11 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
                 for (size_t t = 0; t < b.tz.size(); ++t) {
                     b.tz[t] = ly.lo[0] - b.tz[t]; b.ty[t] = ly.lo[1] - b.ty[t]; b.tx[t] = ly.lo[2] - b.tx[t];
                 }
-                ALQ_TRY(gemm_build(b, NB, &ly.bwd));
+                G4Geom gb = g4;
+                gb.flipped = true;
+                gb.ID = ly.out.D; gb.IH = ly.out.H; gb.IW = ly.out.W; gb.Ci = sp.cout;
+                gb.OD = ly.in.D; gb.OH = ly.in.H; gb.OW = ly.in.W; gb.Co = ly.in.C;
+                ALQ_TRY(gemm_build(b, NB, &ly.bwd, &gb));
                 ly.has_bwd = true;
             }
         } else if (sp.type == ALQ_CONVT) {
@@ -435,6 +478,17 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
                     }
             ALQ_REQUIRE(sp.s[0] == sp.s[2] || (ly.in.D == 1 && sp.s[0] == 1), ALQ_EUNSUPPORTED,
                         "layer %d: conv_transpose stride must be isotropic", i);
+            G4Geom g4;
+            g4.ID = ly.in.D; g4.IH = ly.in.H; g4.IW = ly.in.W; g4.Ci = ly.in.C;
+            g4.OD = ly.out.D; g4.OH = ly.out.H; g4.OW = ly.out.W; g4.Co = sp.cout;
+            for (int q = 0; q < 3; ++q) { g4.k[q] = sp.k[q]; g4.s[q] = sp.s[q]; g4.lo[q] = ly.lo[q]; }
+            if (!getenv("ALQ_DISABLE_V4")) {
+                G4Geom gf = g4;
+                gf.kind = 2;
+                gf.flops_per_patch = 0;
+                for (const Gemm &c : ly.fwd) gf.flops_per_patch += c.p1.flops_per_patch;
+                ALQ_TRY(igemm4_build_plan(gf, NB, &ly.fwd_all));
+            }
             if (!first_param) {
                 ConvDesc b;
                 b.ID = ly.out.D; b.IH = ly.out.H; b.IW = ly.out.W; b.Ci = sp.cout;
@@ -443,7 +497,11 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
                 b.sm = sp.s[2];
                 enum_taps(sp.k, &b.tz, &b.ty, &b.tx);
                 for (size_t t = 0; t < b.tz.size(); ++t) { b.tz[t] -= ly.lo[0]; b.ty[t] -= ly.lo[1]; b.tx[t] -= ly.lo[2]; }
-                ALQ_TRY(gemm_build(b, NB, &ly.bwd));
+                G4Geom gb = g4;
+                gb.kind = 1;
+                gb.ID = ly.out.D; gb.IH = ly.out.H; gb.IW = ly.out.W; gb.Ci = sp.cout;
+                gb.OD = ly.in.D; gb.OH = ly.in.H; gb.OW = ly.in.W; gb.Co = ly.in.C;
+                ALQ_TRY(gemm_build(b, NB, &ly.bwd, &gb));
                 ly.has_bwd = true;
             }
         } else if (sp.type == ALQ_POOL) {
@@ -516,6 +574,11 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums) {
                 ALQ_TRY(gemm_launch(ctx, ly.fwd[0], in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM_FWD, fuse, &fused));
                 break;
             case ALQ_CONVT: {
+                if (ly.fwd_all.ok && !g_dbg_knobs[4] && !g_dbg_knobs[5]) {
+                    ALQ_TRY(igemm4_launch(ctx, ly.fwd_all, in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM3_FWD, fuse));
+                    fused = fuse != nullptr;
+                    break;
+                }
                 bool all = true;
                 for (auto &p : ly.fwd) {
                     bool f1 = false;
@@ -694,8 +757,8 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
             g_dbg_knobs[2] = 1;
             g_knobs_init = true;
         }
-        static const char *names[5] = {"ALQ_DEBUG_REPEAT", "ALQ_DEBUG_FLAGS", "ALQ_NO_BWD_FUSE", "ALQ_NO_FWD_FUSE", "ALQ_NO_V3"};
-        for (int k = 0; k < 5; ++k) {
+        static const char *names[6] = {"ALQ_DEBUG_REPEAT", "ALQ_DEBUG_FLAGS", "ALQ_NO_BWD_FUSE", "ALQ_NO_FWD_FUSE", "ALQ_NO_V3", "ALQ_NO_V4"};
+        for (int k = 0; k < 6; ++k) {
             const char *v = getenv(names[k]);
             if (v) g_dbg_knobs[k] = atoi(v);
         }
@@ -772,6 +835,14 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
                     for (int co = 0; co < Co; ++co)
                         B[((size_t)j * Ci + ci) * Co + co] = W[((size_t)tl[j] * Co + co) * Ci + ci];
             ALQ_TRY(gemm_set(m, &ly.fwd[c], B));
+        }
+        if (ly.fwd_all.ok) {
+            std::vector<float> B((size_t)ntaps * Ci * Co);
+            for (int tp = 0; tp < ntaps; ++tp)
+                for (int ci = 0; ci < Ci; ++ci)
+                    for (int co = 0; co < Co; ++co)
+                        B[((size_t)tp * Ci + ci) * Co + co] = W[((size_t)tp * Co + co) * Ci + ci];
+            ALQ_TRY(set4(m, &ly.fwd_all, B));
         }
         if (ly.has_bwd) {
             std::vector<float> Bb(W, W + ly.w_elems);   // [(tap, co)][ci] as stored

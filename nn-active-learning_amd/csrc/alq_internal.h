@@ -237,10 +237,11 @@ struct Igemm4Args {
     const int *sdesc;       // [nslots][4]: rel_vox, (pt,hz,hy,hx) packed, LDS byte offset, channel offset
     const int *pdesc;       // [phases or groups][8]: in_off_vox, chunk, S, w_off, tap row, out_off_vox, -, -
     const int *ttab;        // [tap rows][G4_MAXS][4] LDS byte offsets of the taps of k-step s, lane group q
+    const int *vdesc;       // [256]: GEMM row -> (pt, z, y, x) of its M-grid point inside the tile, -1 = unused row
     int in_cs, in_c0, out_cs, out_c0, Co;
     int mask_cs, mask_c0, mask_from, split;
     int N, PT, tpg, rows;
-    int TV, TY, TX, HZ, HY, HX;
+    int PX, PYX, PZ;        // LDS row pitches of the staged block: per y line, per z plane, per patch
     int smz, smy, smx;      // M-grid point -> halo index multipliers
     int soz, soy, sox, OD, OH, OW;
     int MD, MH, MW;
@@ -272,8 +273,8 @@ struct Igemm4Plan {
     int Ci = 0, Co = 0;
     struct Unit { int chunk = 0, S = 0, w_off = 0; std::vector<int> tap; };   // tap[(s*4+q)*2+half] = enum tap or -1
     std::vector<Unit> units;
-    std::vector<int> h_tdesc, h_sdesc, h_pdesc, h_ttab;
-    int *d_tdesc = nullptr, *d_sdesc = nullptr, *d_pdesc = nullptr, *d_ttab = nullptr;
+    std::vector<int> h_tdesc, h_sdesc, h_pdesc, h_ttab, h_vdesc;
+    int *d_tdesc = nullptr, *d_sdesc = nullptr, *d_pdesc = nullptr, *d_ttab = nullptr, *d_vdesc = nullptr;
     std::vector<unsigned short> h_W;
     void *d_W = nullptr;
 };

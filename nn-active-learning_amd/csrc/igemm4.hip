@@ -24,6 +24,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 
@@ -36,9 +38,22 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifdef ALQ_STAMPS
+#define STAMP4(var) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+#define PHASE4_END(idx)                        \
+    do {                                       \
+        unsigned long long t_now_;             \
+        STAMP4(t_now_);                        \
+        ph[idx] += t_now_ - t_last;            \
+        t_last = t_now_;                       \
+    } while (0)
+#else
+#define PHASE4_END(idx) do {} while (0)
+#endif
+
 constexpr int G4_ROWB = 48;      // bytes per staged voxel row: [hi8 | mid8 | lo8] bf16
 constexpr int G4_NSLOT = 8;      // 16-byte staging slots per thread of a half
-constexpr int G4_MAXS = 9;       // k-steps (4 taps each) per unit
+constexpr int G4_MAXS = 10;      // k-steps (4 taps each) per unit
 constexpr int G4_OOB = 0x7fffff00;
 
 __device__ inline i32x4 g4_sload4(const int *p) {
@@ -52,13 +67,19 @@ __device__ inline i32x8 g4_sload8(const int *p) {
     return v;
 }
 
-// x -> (hi, rem): hi = bf16(x) packed pairwise, rem = x - hi (exact)
+// x -> (hi, rem): hi = bf16(x) round-to-nearest packed pairwise, rem = x - hi (exact).  Rounding to nearest
+// matters: a truncating split biases the dropped piece products to one sign, the bias accumulates over K and
+// (measured, tests/gpu_accuracy.py) is enough to flip ReLU masks like a plain fp32 summation-order change does.
 __device__ inline unsigned g4_split2(float &a, float &b) {
     const bf16x2 h = __builtin_convertvector(f32x2{a, b}, bf16x2);
     const unsigned hb = __builtin_bit_cast(unsigned, h);
     a -= __builtin_bit_cast(float, hb << 16);
     b -= __builtin_bit_cast(float, hb & 0xffff0000u);
     return hb;
+}
+// last piece: the remainders have at most 8 significant bits left, so their high halves are exact
+__device__ inline unsigned g4_pack2(float a, float b) {
+    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, a), 0x07060302u);
 }
 
 template <int NTW, bool MULTI, bool SUMS>
@@ -88,7 +109,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
 #pragma unroll
     for (int it = 0; it < G4_NSLOT; ++it) {
         const int slot = ht + it * 256;
-        int rel = 0, pk = 0x00ff0000, ld = -1;          // hz = 255: never inside a valid range
+        int rel = 0x20000000, pk = 0x00ff0000, ld = -1; // unused slot: past the buffer on the fast path, hz = 255 on the checked one
         if (slot < a.nslots) {
             const int4 sd = *reinterpret_cast<const int4 *>(a.sdesc + slot * 4);
             rel = sd.x * a.in_cs + a.in_c0 + sd.w;
@@ -101,21 +122,20 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     // ---- per-lane row geometry ------------------------------------------------------------------------
     const bool pair = a.pair != 0;
     const int cl = pair ? (lq & 1) * 4 : lq * 4;       // first of this lane's 4 output channels (tile 0)
-    int vbase[4], evox[4], eoff[4];
+    // GEMM row -> M-grid point through a host-built table: the host orders the 16 points of every MFMA
+    // column block so that the 16 lanes of each ds_read_b128 lane group hit 16 different LDS rows mod 16
+    int vbase[4], evox[4], eoff[4], vpk[4];
     bool erow_ok = true;
 #pragma unroll
     for (int ms = 0; ms < 4; ++ms) {
-        const int v = hw * 64 + ms * 16 + lrow;
-        const int vv = v < a.rows ? v : 0;
-        const int pt = vv / a.TV;
-        int r = vv - pt * a.TV;
-        const int x = r % a.TX; r /= a.TX;
-        const int y = r % a.TY;
-        const int z = r / a.TY;
-        vbase[ms] = (((pt * a.HZ + z * a.smz) * a.HY + y * a.smy) * a.HX + x * a.smx) * G4_ROWB;
+        const int e = a.vdesc[(hw * 4 + ms) * 16 + lrow];
+        const int ee = e < 0 ? 0 : e;
+        const int pt = ee >> 24, z = (ee >> 16) & 255, y = (ee >> 8) & 255, x = ee & 255;
+        vbase[ms] = (pt * a.PZ + z * a.smz * a.PYX + y * a.smy * a.PX + x * a.smx) * G4_ROWB;
         evox[ms] = ((pt * a.OD + z * a.soz) * a.OH + y * a.soy) * a.OW + x * a.sox + (pair ? (lq >> 1) : 0);
         eoff[ms] = evox[ms] * a.out_cs + a.out_c0 + cl;
-        erow_ok = erow_ok && v < a.rows;
+        vpk[ms] = e;
+        erow_ok = erow_ok && e >= 0;
     }
     f32x4 bias4[NTW];
 #pragma unroll
@@ -158,8 +178,13 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         const i32x4 t1 = g4_sload4(a.tdesc + fl * 8 + 4);
         const int org = (t0.x + fpg * a.in_pstride) * a.in_cs;
         f_out = t0.y + fpg * a.out_pstride;
-        f_full = t0.z && (fpg + 1) * a.PT <= a.N;
+        f_full = (t0.z & 1) && (fpg + 1) * a.PT <= a.N;
         f_l = fl; f_g = fpg;
+        if ((t0.z & 2) && (fpg + 1) * a.PT <= a.N) {      // whole halo inside the tensor: no per-slot checks
+#pragma unroll
+            for (int it = 0; it < G4_NSLOT; ++it) goff[it] = (org + s_rel[it]) * 4;
+            return;
+        }
         const unsigned zy = (unsigned)t0.w, xx = (unsigned)t1.x;
         const unsigned loz = zy & 255u, nz = ((zy >> 8) & 255u) - loz;
         const unsigned loy = (zy >> 16) & 255u, ny = (zy >> 24) - loy;
@@ -170,7 +195,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             const unsigned pk = (unsigned)s_pk[it];
             const bool ok = (((pk >> 16) & 255u) - loz) < nz && (((pk >> 8) & 255u) - loy) < ny &&
                             ((pk & 255u) - lox) < nx && pbase + (int)(pk >> 24) < a.N;
-            goff[it] = ok ? (org + s_rel[it]) * 4 : G4_OOB;
+            goff[it] = (ok && s_lds[it] >= 0) ? (org + s_rel[it]) * 4 : G4_OOB;
         }
     };
 
@@ -196,7 +221,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 uint2 hi, mid, lo;
                 hi.x = g4_split2(v0, v1);  hi.y = g4_split2(v2, v3);
                 mid.x = g4_split2(v0, v1); mid.y = g4_split2(v2, v3);
-                lo.x = g4_split2(v0, v1);  lo.y = g4_split2(v2, v3);
+                lo.x = g4_pack2(v0, v1);   lo.y = g4_pack2(v2, v3);
                 char *dst = Al + s_lds[it];
                 *reinterpret_cast<uint2 *>(dst) = hi;
                 *reinterpret_cast<uint2 *>(dst + 16) = mid;
@@ -220,14 +245,9 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         for (int ms = 0; ms < 4; ++ms) {
             bool live = erow_ok;
             if (!q_full) {
-                const int v = hw * 64 + ms * 16 + lrow;
-                const int vv = v < a.rows ? v : 0;
-                const int pt = vv / a.TV;
-                int r = vv - pt * a.TV;
-                const int x = r % a.TX; r /= a.TX;
-                const int y = r % a.TY;
-                const int z = r / a.TY;
-                live = v < a.rows && q_g * a.PT + pt < a.N && mz0 + z < a.MD && my0 + y < a.MH && mx0 + x < a.MW;
+                const int e = vpk[ms];
+                const int pt = e >> 24, z = (e >> 16) & 255, y = (e >> 8) & 255, x = e & 255;
+                live = e >= 0 && q_g * a.PT + pt < a.N && mz0 + z < a.MD && my0 + y < a.MH && mx0 + x < a.MW;
             }
             f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -317,24 +337,26 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         int t_cur = tt[0];
         rdW(Wa, 0);
         rdX(Xa, 0, t_cur);
-        for (int s = 0; s < S; ++s) {
+        auto kstep = [&](const bf16x8 (&Wc_)[3][NTW], bf16x8 (&Wn_)[3][NTW], int s) {
             const int s1 = s + 1 < S ? s + 1 : s;
             const int t_nxt = tt[s1 * 4];
             rdX(Xb, 2, t_cur);
             __builtin_amdgcn_sched_barrier(0);
-            mm(Wa, Xa, 0);
+            mm(Wc_, Xa, 0);
             __builtin_amdgcn_sched_barrier(0);
-            rdW(Wb, s1);
+            rdW(Wn_, s1);
             rdX(Xa, 0, t_nxt);
             __builtin_amdgcn_sched_barrier(0);
-            mm(Wa, Xb, 2);
+            mm(Wc_, Xb, 2);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) Wa[p][nt] = Wb[p][nt];
             t_cur = t_nxt;
+        };
+        int s = 0;
+        for (; s + 1 < S; s += 2) {
+            kstep(Wa, Wb, s);
+            kstep(Wb, Wa, s + 1);
         }
+        if (s < S) kstep(Wa, Wb, s);
     };
     auto init_acc = [&]() {
 #pragma unroll
@@ -349,15 +371,23 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     int b_i = 0, b_ph = 0;               // next phase to contract
     if (n_mine > 0) locate(); else park();
     fetch(0);
+#ifdef ALQ_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last;
+    STAMP4(t_last);
+#endif
     for (int tick = 0; tick < nticks; ++tick) {
         if ((tick & 1) == h) {
+            __builtin_amdgcn_s_setprio(0);
+            PHASE4_END(5);
             if (a_i < n_ph) {
                 if (a_ph == 0) { c_out = f_out; c_full = f_full; c_l = f_l; c_g = f_g; }
                 stash();
+                PHASE4_END(0);
                 if (a_ph == 0 && have_pend) {
                     flush(p_out, p_full, p_l, p_g);
                     have_pend = false;
                 }
+                PHASE4_END(1);
                 int nph = a_ph + 1;
                 if (nph == a.nph) {
                     nph = 0;
@@ -367,8 +397,11 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 fetch(nph);
                 a_ph = nph;
                 ++a_i;
+                PHASE4_END(2);
             }
         } else {
+            __builtin_amdgcn_s_setprio(3);       // the contracting wave goes first on its SIMD; staging fills the gaps
+            PHASE4_END(4);
             if (b_i < a_i) {
                 if constexpr (!MULTI) {
                     const i32x8 pd = g4_sload8(a.pdesc + b_ph * 8);
@@ -397,11 +430,17 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                     }
                 }
                 ++b_i;
+                PHASE4_END(3);
             }
         }
         __syncthreads();
     }
     if (have_pend) flush(p_out, p_full, p_l, p_g);
+#ifdef ALQ_STAMPS
+    PHASE4_END(6);
+    if (a.dbg && (tid & 255) == 0)
+        for (int i = 0; i < 8; ++i) a.dbg[(blockIdx.x * 2 + h) * 8 + i] = ph[i];
+#endif
 }
 
 // ======================================================================================================
@@ -496,32 +535,33 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
     }
     if (pair && NTW != 1) return ALQ_OK;
 
-    // ---- units: tap boxes, tap maps (box position -> tap of the k^3 enumeration) ------------------------
-    struct URow { Box box; std::vector<int> tap; int ntaps = 0; int S = 0; int in_off[3] = {0, 0, 0}; int out_off[3] = {0, 0, 0}; };
+    // ---- tap boxes of every unit row (a row = one tap table: conv 1, conv_transpose one per class) ------
+    struct URow {
+        Box box;
+        std::function<int(int, int, int, int)> tapof;     // (iz, iy, ix, half) -> tap of the k^3 enumeration or -1
+        int ntaps = 0, S = 0;
+        int in_off[3] = {0, 0, 0}, out_off[3] = {0, 0, 0};
+        std::vector<int> tap;                              // [(s*4+q)*2+half] after the k-step assignment
+        std::vector<int> toff;                             // [s*4+q] LDS row offset
+    };
     std::vector<URow> rows;
-    auto enum_tap = [&](int tz, int ty, int tx) {
+    auto enum_tap = [=](int tz, int ty, int tx) {
         if (tz < 0 || tz >= k[0] || ty < 0 || ty >= k[1] || tx < 0 || tx >= k[2]) return -1;
         return (tz * k[1] + ty) * k[2] + tx;
     };
-    auto finish_row = [&](URow &r, const std::function<int(int, int, int, int)> &tapof) {
-        r.ntaps = r.box.n[0] * r.box.n[1] * r.box.n[2];
-        r.S = (r.ntaps + 3) / 4;
-        r.tap.assign((size_t)r.S * 4 * 2, -1);
-        for (int t = 0; t < r.ntaps; ++t) {
-            const int ix = t % r.box.n[2], iy = (t / r.box.n[2]) % r.box.n[1], iz = t / (r.box.n[2] * r.box.n[1]);
-            for (int half = 0; half < 2; ++half) r.tap[(size_t)t * 2 + half] = tapof(iz, iy, ix, half);
-        }
-    };
+    const bool flipped = g.flipped;
+    const int kk[3] = {k[0], k[1], k[2]}, ss[3] = {s[0], s[1], s[2]}, ll[3] = {lo[0], lo[1], lo[2]};
     if (g.kind == 0) {
         URow r;
         for (int d = 0; d < 3; ++d) { r.box.b[d] = 0; r.box.n[d] = dg[d].span; }
-        finish_row(r, [&](int iz, int iy, int ix, int half) {
-            int o[3] = {dg[0].bo + iz, dg[1].bo + iy, dg[2].bo + ix - (half ? 1 : 0)};
+        const int bo[3] = {dg[0].bo, dg[1].bo, dg[2].bo};
+        r.tapof = [=](int iz, int iy, int ix, int half) {
             if (half && !pair) return -1;
+            const int o[3] = {bo[0] + iz, bo[1] + iy, bo[2] + ix - (half ? 1 : 0)};
             int t[3];
-            for (int d = 0; d < 3; ++d) t[d] = g.flipped ? lo[d] - o[d] : o[d] + lo[d];
+            for (int d = 0; d < 3; ++d) t[d] = flipped ? ll[d] - o[d] : o[d] + ll[d];
             return enum_tap(t[0], t[1], t[2]);
-        });
+        };
         rows.push_back(r);
     } else if (g.kind == 1) {
         for (int rz = 0; rz < s[0]; ++rz)
@@ -534,10 +574,10 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
                 r.box.b[1] = a0y - amin[1]; r.box.n[1] = a1y - a0y + 1;
                 r.box.b[2] = 0; r.box.n[2] = k[2];
                 r.in_off[0] = rz; r.in_off[1] = ry;
-                finish_row(r, [&](int iz, int iy, int ix, int half) {
+                r.tapof = [=](int iz, int iy, int ix, int half) {
                     if (half) return -1;
-                    return enum_tap(s[0] * (a0z + iz) + rz + lo[0], s[1] * (a0y + iy) + ry + lo[1], ix);
-                });
+                    return enum_tap(ss[0] * (a0z + iz) + rz + ll[0], ss[1] * (a0y + iy) + ry + ll[1], ix);
+                };
                 rows.push_back(r);
             }
     } else {
@@ -559,23 +599,77 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
                     }
                     for (int d = 0; d < 3; ++d) { r.box.b[d] = n0[d] - amin[d]; r.box.n[d] = n1[d] - n0[d] + 1; }
                     r.out_off[0] = cz; r.out_off[1] = cy; r.out_off[2] = cx;
-                    finish_row(r, [&](int iz, int iy, int ix, int half) {
+                    const int nz0 = n0[0], ny0 = n0[1], nx0 = n0[2];
+                    r.tapof = [=](int iz, int iy, int ix, int half) {
                         if (half && !pair) return -1;
                         const int ccx = pair ? half : cx;
-                        return enum_tap(cz + lo[0] - s[0] * (n0[0] + iz), cy + lo[1] - s[1] * (n0[1] + iy),
-                                        ccx + lo[2] - s[2] * (n0[2] + ix));
-                    });
+                        return enum_tap(cz + ll[0] - ss[0] * (nz0 + iz), cy + ll[1] - ss[1] * (ny0 + iy),
+                                        ccx + ll[2] - ss[2] * (nx0 + ix));
+                    };
                     rows.push_back(r);
                 }
     }
-    int maxS = 0, sumS = 0;
-    for (const URow &r : rows) { maxS = std::max(maxS, r.S); sumS += r.S; }
-    if (maxS > G4_MAXS) return ALQ_OK;
+    (void)kk;
+    for (URow &r : rows) {
+        r.ntaps = r.box.n[0] * r.box.n[1] * r.box.n[2];
+        if ((r.ntaps + 3) / 4 + 1 > G4_MAXS) return ALQ_OK;
+    }
     const bool multi = (g.kind == 2);
     const int nstage = multi ? 1 : (int)rows.size() * NCH;      // staging phases per tile
     const int NPs = multi ? NCH : 1;                             // planes staged per phase
-    const size_t wbytes = (size_t)sumS * NCH * 3 * NTW * 1024;
     const size_t tt_ints = (size_t)rows.size() * G4_MAXS * 4;
+
+    // ---- LDS layout of the staged block ----------------------------------------------------------------
+    // Every ds_read_b128 lane group is 8 lanes of one tap + 8 lanes of the neighbouring tap of the k-step;
+    // a 48-byte row occupies 3 of 16 16-byte bank granules, so the group is conflict-free iff its 16 rows
+    // differ mod 16.  The 16 M-grid points of a column block are therefore chosen as a complete residue
+    // system of LDS rows mod 16 (16 x-neighbours, or 8 x-neighbours on two lines whose pitch is padded to
+    // 8 mod 16; with an x multiplier of 2: two lines an odd pitch apart), the even rows on lanes 0-3 / 12-15,
+    // the odd rows on lanes 4-11, and the two taps sharing a lane group are paired with an even row distance.
+    struct Lay { int PX = 0, PYX = 0, PZ = 0, xw = 0, ud = -1; };
+    auto roundup_mod = [](int v, int r, int m) { int w = v; while (((w % m) + m) % m != r) ++w; return w; };
+    auto layout = [&](int PT, const int T[3], const int H[3]) {
+        Lay L;
+        L.PX = H[2]; L.PYX = H[1] * L.PX; L.PZ = H[0] * L.PYX;
+        const bool unit_zy = dg[0].sm == 1 && dg[1].sm == 1;
+        if (!unit_zy) return L;
+        if (dg[2].sm == 1) {
+            if (T[2] % 16 == 0) { L.xw = 16; return L; }
+            if (T[2] != 8) return L;
+            L.xw = 8;
+            if (T[0] >= 2) { L.ud = 0; L.PYX = roundup_mod(H[1] * L.PX, 8, 16); }
+            else if (PT >= 2) { L.ud = 3; L.PZ = 0; }
+            else if (T[1] >= 2) { L.ud = 1; L.PX = roundup_mod(H[2], 8, 16); L.PYX = H[1] * L.PX; }
+            else { L.xw = 0; return L; }
+            L.PZ = H[0] * L.PYX;
+            if (L.ud == 3) L.PZ = roundup_mod(L.PZ, 8, 16);
+        } else if (dg[2].sm == 2) {
+            if (T[2] % 8 != 0) return L;
+            L.xw = 8;
+            if (T[1] >= 2) { L.ud = 1; L.PX = H[2] | 1; L.PYX = H[1] * L.PX; }
+            else if (T[0] >= 2) { L.ud = 0; L.PYX = (H[1] * L.PX) | 1; }
+            else if (PT >= 2) { L.ud = 3; }
+            else { L.xw = 0; return L; }
+            L.PZ = H[0] * L.PYX;
+            if (L.ud == 3) L.PZ |= 1;
+        }
+        return L;
+    };
+
+    // k-steps of all tap rows under a layout: taps are paired by the parity of their LDS row offset
+    auto ksteps = [&](const Lay &L) {
+        int sum = 0;
+        for (const URow &r : rows) {
+            int ne = 0, no = 0;
+            for (int t = 0; t < r.ntaps; ++t) {
+                const int ix = t % r.box.n[2], iy = (t / r.box.n[2]) % r.box.n[1], iz = t / (r.box.n[2] * r.box.n[1]);
+                const int off = (r.box.b[0] + iz) * L.PYX + (r.box.b[1] + iy) * L.PX + (r.box.b[2] + ix);
+                ((off & 1) ? no : ne)++;
+            }
+            sum += ((ne + 1) / 2 + (no + 1) / 2 + 1) / 2;
+        }
+        return sum;
+    };
 
     // ---- tile search ---------------------------------------------------------------------------------------
     double best = 1e300;
@@ -594,15 +688,17 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
                     bool okh = true;
                     for (int d = 0; d < 3; ++d) { H[d] = (T[d] - 1) * dg[d].sm + dg[d].span; okh = okh && H[d] <= 254; }
                     if (!okh) continue;
+                    if (PT * TX * TY * TZ < 16) continue;
                     const long long nhv = (long long)PT * H[0] * H[1] * H[2];
                     if (nhv * 2 * NPs > 256 * G4_NSLOT) continue;
-                    const size_t lds = tt_ints * 4 + wbytes + 2 * (size_t)nhv * NPs * G4_ROWB;
+                    const Lay L = layout(PT, T, H);
+                    const int sumS_t = ksteps(L);
+                    const size_t lds = tt_ints * 4 + (size_t)sumS_t * NCH * 3 * NTW * 1024 + 2 * (size_t)PT * L.PZ * NPs * G4_ROWB;
                     if (lds > 160 * 1024 - 256) continue;
                     const double tiles = std::ceil((double)max_batch / PT) * std::ceil((double)dg[0].M / TZ) *
                                          std::ceil((double)dg[1].M / TY) * std::ceil((double)dg[2].M / TX);
-                    const double rowsf = (double)PT * TX * TY * TZ;
-                    double cost = tiles * ((double)sumS * NCH * 480.0 + (double)(multi ? NPs : nstage) * 1.2 * (double)nhv + 600.0);
-                    if (rowsf < 256) cost *= 1.0;     // under-filled tiles cost a full tile: already in `tiles`
+                    double cost = tiles * ((double)sumS_t * NCH * 420.0 + (double)(multi ? NPs : nstage) * 1.2 * (double)nhv + 600.0);
+                    if (L.xw == 0) cost *= 1.5;        // bank-conflicted fragment reads
                     if (cost < best) { best = cost; bt[0] = PT; bt[1] = TZ; bt[2] = TY; bt[3] = TX; }
                 }
             }
@@ -616,14 +712,98 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
         tiles[d] = (dg[d].M + T[d] - 1) / T[d];
     }
     const int nhv = PT * H[0] * H[1] * H[2];
+    const int nrows = PT * T[0] * T[1] * T[2];
+    if (multi && nrows < 192) return ALQ_OK;         // a mostly empty tile: the per-class launches do better
+    Lay L = layout(PT, T, H);
+
+    // ---- GEMM row -> M-grid point table ---------------------------------------------------------------------
+    plan->h_vdesc.assign(256, -1);
+    auto lds_row = [&](int pt, int z, int y, int x) {
+        return pt * L.PZ + z * dg[0].sm * L.PYX + y * dg[1].sm * L.PX + x * dg[2].sm;
+    };
+    {
+        std::vector<int> order;      // packed points, 16 per column block
+        bool okperm = L.xw > 0;
+        if (okperm) {
+            const int ext[4] = {T[0], T[1], T[2], PT};
+            for (int pt = 0; pt < PT && okperm; pt += (L.ud == 3 ? 2 : 1))
+                for (int z = 0; z < T[0] && okperm; z += (L.ud == 0 ? 2 : 1))
+                    for (int y = 0; y < T[1] && okperm; y += (L.ud == 1 ? 2 : 1))
+                        for (int xc = 0; xc < T[2] && okperm; xc += L.xw) {
+                            std::vector<int> ev, od;
+                            std::vector<bool> seen(16, false);
+                            const int nu = L.xw == 16 ? 1 : 2;
+                            for (int u = 0; u < nu; ++u)
+                                for (int xi = 0; xi < L.xw; ++xi) {
+                                    const int p2 = pt + (L.ud == 3 ? u : 0), z2 = z + (L.ud == 0 ? u : 0), y2 = y + (L.ud == 1 ? u : 0);
+                                    const int R = lds_row(p2, z2, y2, xc + xi);
+                                    const int pk = (p2 << 24) | (z2 << 16) | (y2 << 8) | (xc + xi);
+                                    if (seen[R & 15]) okperm = false;
+                                    seen[R & 15] = true;
+                                    ((R & 1) ? od : ev).push_back(pk);
+                                }
+                            if (ev.size() != 8 || od.size() != 8) okperm = false;
+                            if (!okperm) break;
+                            int blk[16];
+                            for (int i = 0; i < 8; ++i) {
+                                blk[i < 4 ? i : 8 + i] = ev[i];      // lanes 0-3, 12-15
+                                blk[4 + i] = od[i];                   // lanes 4-11
+                            }
+                            order.insert(order.end(), blk, blk + 16);
+                        }
+            (void)ext;
+            if ((int)order.size() != nrows) okperm = false;
+        }
+        if (!okperm) {                // natural order (small or odd tiles): correct, possibly bank-conflicted
+            order.clear();
+            L = Lay();
+            L.PX = H[2]; L.PYX = H[1] * L.PX; L.PZ = H[0] * L.PYX;
+            for (int pt = 0; pt < PT; ++pt)
+                for (int z = 0; z < T[0]; ++z)
+                    for (int y = 0; y < T[1]; ++y)
+                        for (int x = 0; x < T[2]; ++x) order.push_back((pt << 24) | (z << 16) | (y << 8) | x);
+        }
+        for (size_t i = 0; i < order.size() && i < 256; ++i) plan->h_vdesc[i] = order[i];
+    }
+    const int plane_rows = PT * L.PZ;
+
+    // ---- k-steps: taps paired by the parity of their LDS row offset -------------------------------------------
+    int sumS = 0;
+    for (URow &r : rows) {
+        std::vector<std::pair<int, int>> ev, od;      // (box position t, row offset)
+        for (int t = 0; t < r.ntaps; ++t) {
+            const int ix = t % r.box.n[2], iy = (t / r.box.n[2]) % r.box.n[1], iz = t / (r.box.n[2] * r.box.n[1]);
+            const int off = (r.box.b[0] + iz) * L.PYX + (r.box.b[1] + iy) * L.PX + (r.box.b[2] + ix);
+            ((off & 1) ? od : ev).push_back({t, off});
+        }
+        std::vector<std::pair<int, int>> seq;          // lane-group order; t = -1: padding (zero weights)
+        for (auto *lst : {&ev, &od})
+            for (size_t i = 0; i < lst->size(); i += 2) {
+                seq.push_back((*lst)[i]);
+                seq.push_back(i + 1 < lst->size() ? (*lst)[i + 1] : std::make_pair(-1, (*lst)[i].second));
+            }
+        if (seq.size() % 4) { const int o = seq.back().second; seq.push_back({-1, o}); seq.push_back({-1, o}); }
+        r.S = (int)seq.size() / 4;
+        if (r.S > G4_MAXS) return ALQ_OK;
+        r.tap.assign((size_t)r.S * 4 * 2, -1);
+        r.toff.assign((size_t)r.S * 4, 0);
+        for (size_t i = 0; i < seq.size(); ++i) {
+            r.toff[i] = seq[i].second;
+            if (seq[i].first < 0) continue;
+            const int t = seq[i].first;
+            const int ix = t % r.box.n[2], iy = (t / r.box.n[2]) % r.box.n[1], iz = t / (r.box.n[2] * r.box.n[1]);
+            for (int half = 0; half < 2; ++half) r.tap[i * 2 + half] = r.tapof(iz, iy, ix, half);
+        }
+        sumS += r.S;
+    }
+    const size_t wbytes = (size_t)sumS * NCH * 3 * NTW * 1024;
 
     Igemm4Args &a = plan->a;
     std::memset(&a, 0, sizeof(a));
     a.Co = g.Co;
     a.PT = PT; a.tpg = tiles[0] * tiles[1] * tiles[2];
-    a.rows = PT * T[0] * T[1] * T[2];
-    a.TV = T[0] * T[1] * T[2]; a.TY = T[1]; a.TX = T[2];
-    a.HZ = H[0]; a.HY = H[1]; a.HX = H[2];
+    a.rows = nrows;
+    a.PX = L.PX; a.PYX = L.PYX; a.PZ = L.PZ;
     a.smz = dg[0].sm; a.smy = dg[1].sm; a.smx = dg[2].sm;
     a.soz = dg[0].so; a.soy = dg[1].so; a.sox = dg[2].so;
     a.OD = O[0]; a.OH = O[1]; a.OW = O[2];
@@ -632,25 +812,19 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
     a.ngr = multi ? (int)rows.size() : 1;
     a.NP = NPs;
     a.nslots = nhv * 2 * NPs;
-    a.plane_bytes = nhv * G4_ROWB;
+    a.plane_bytes = plane_rows * G4_ROWB;
     a.in_pstride = PT * I[0] * I[1] * I[2];
     a.out_pstride = PT * O[0] * O[1] * O[2];
     a.pair = pair ? 1 : 0;
     a.tt_ints = (int)tt_ints;
     a.wbytes = (int)wbytes;
-    a.abytes = nhv * NPs * G4_ROWB;
+    a.abytes = plane_rows * NPs * G4_ROWB;
     a.split = 1 << 30;
 
     // tap table + units + phase / group descriptors
     plan->h_ttab.assign(tt_ints, 0);
-    for (size_t r = 0; r < rows.size(); ++r) {
-        const URow &u = rows[r];
-        for (int t = 0; t < u.ntaps; ++t) {
-            const int ix = t % u.box.n[2], iy = (t / u.box.n[2]) % u.box.n[1], iz = t / (u.box.n[2] * u.box.n[1]);
-            plan->h_ttab[r * G4_MAXS * 4 + t] =
-                (((u.box.b[0] + iz) * H[1] + (u.box.b[1] + iy)) * H[2] + (u.box.b[2] + ix)) * G4_ROWB;
-        }
-    }
+    for (size_t r = 0; r < rows.size(); ++r)
+        for (size_t i = 0; i < rows[r].toff.size(); ++i) plan->h_ttab[r * G4_MAXS * 4 + i] = rows[r].toff[i] * G4_ROWB;
     int w_off = 0;
     plan->h_pdesc.clear();
     if (!multi) {
@@ -685,7 +859,7 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
                 int *td = &plan->h_tdesc[(((size_t)tz * tiles[1] + ty) * tiles[2] + tx) * 8];
                 const int m0[3] = {tz * T[0], ty * T[1], tx * T[2]};
                 int base[3], lohi[3][2];
-                bool full = a.rows == 256;
+                bool full = nrows == 256;
                 for (int d = 0; d < 3; ++d) {
                     base[d] = m0[d] * dg[d].bm + dg[d].bo;
                     int l = g4_ceildiv(-base[d], dg[d].hs), hgh = g4_ceildiv(dg[d].I - base[d], dg[d].hs);
@@ -696,7 +870,9 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
                 }
                 td[0] = (base[0] * I[1] + base[1]) * I[2] + base[2];
                 td[1] = (m0[0] * dg[0].so * O[1] + m0[1] * dg[1].so) * O[2] + m0[2] * dg[2].so;
-                td[2] = full ? 1 : 0;
+                bool inside = true;       // every halo index of the tile valid
+                for (int d = 0; d < 3; ++d) inside = inside && lohi[d][0] == 0 && lohi[d][1] == H[d];
+                td[2] = (full ? 1 : 0) | (inside ? 2 : 0);
                 td[3] = lohi[0][0] | (lohi[0][1] << 8) | (lohi[1][0] << 16) | (lohi[1][1] << 24);
                 td[4] = lohi[2][0] | (lohi[2][1] << 8);
                 td[5] = m0[0]; td[6] = m0[1]; td[7] = m0[2];
@@ -709,11 +885,12 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
                 for (int hy = 0; hy < H[1]; ++hy)
                     for (int hx = 0; hx < H[2]; ++hx) {
                         const int hv = ((pt * H[0] + hz) * H[1] + hy) * H[2] + hx;
+                        const int lrow = pt * L.PZ + hz * L.PYX + hy * L.PX + hx;
                         for (int half = 0; half < 2; ++half) {
                             int *sd = &plan->h_sdesc[(((size_t)pl * nhv + hv) * 2 + half) * 4];
                             sd[0] = ((pt * I[0] + hz * dg[0].hs) * I[1] + hy * dg[1].hs) * I[2] + hx * dg[2].hs;
                             sd[1] = (pt << 24) | (hz << 16) | (hy << 8) | hx;
-                            sd[2] = pl * nhv * G4_ROWB + hv * G4_ROWB + half * 8;
+                            sd[2] = (pl * plane_rows + lrow) * G4_ROWB + half * 8;
                             sd[3] = pl * 8 + half * 4;
                         }
                     }
@@ -721,8 +898,15 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
     plan->multi = multi;
     plan->Ci = g.Ci; plan->Co = g.Co;
     plan->lds_bytes = tt_ints * 4 + wbytes + 2 * (size_t)a.abytes;
+    if (plan->lds_bytes > 160 * 1024) return ALQ_OK;
     plan->flops_per_patch = g.flops_per_patch;
     plan->ok = true;
+    if (getenv("ALQ_G4_VERBOSE"))
+        fprintf(stderr, "[igemm4] kind %d%s Ci %d Co %d M %dx%dx%d: tile %d x (%d,%d,%d) halo (%d,%d,%d) pitches %d/%d/%d xw %d ud %d, "
+                "%d tap rows, k-steps/tile %d, phases %d groups %d planes %d, NTW %d%s, LDS %zu B (W %zu)\n",
+                g.kind, g.flipped ? " flipped" : "", g.Ci, g.Co, dg[0].M, dg[1].M, dg[2].M, PT, T[0], T[1], T[2], H[0], H[1], H[2],
+                L.PX, L.PYX, L.PZ, L.xw, L.ud, (int)rows.size(), sumS * NCH, a.nph, a.ngr, a.NP, NTW, pair ? " pair" : "",
+                plan->lds_bytes, wbytes);
     return ALQ_OK;
 }
 
@@ -794,9 +978,18 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
     a.in = in.p; a.in_cs = in.cs; a.in_c0 = in.c0;
     a.out = out.p; a.out_cs = out.cs; a.out_c0 = out.c0;
     a.W = plan.d_W; a.bias = bias; a.relu = relu; a.accumulate = accumulate; a.N = N;
-    a.tdesc = plan.d_tdesc; a.sdesc = plan.d_sdesc; a.pdesc = plan.d_pdesc; a.ttab = plan.d_ttab;
+    a.tdesc = plan.d_tdesc; a.sdesc = plan.d_sdesc; a.pdesc = plan.d_pdesc; a.ttab = plan.d_ttab; a.vdesc = plan.d_vdesc;
     a.in_bytes = (int)((long long)N * in.vox() * in.cs * 4);
     a.dbg = nullptr;
+    if (g_igemm2_dbg) {   // diagnostic: stamp only the launch whose ordinal (since the buffer was set) is ALQ_STAMP_ONLY
+        static int want = -2;
+        if (want == -2) { const char *e = getenv("ALQ_STAMP_ONLY"); want = e ? atoi(e) : -1; }
+        static int ordinal = 0;
+        static unsigned long long *last = nullptr;
+        if (last != g_igemm2_dbg) { last = g_igemm2_dbg; ordinal = 0; }
+        if (want < 0 || ordinal == want) a.dbg = g_igemm2_dbg;
+        ++ordinal;
+    }
     a.dbg_repeat = g_dbg_knobs[0];
     a.split = 1 << 30;
     if (fuse) {

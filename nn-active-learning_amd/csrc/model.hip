@@ -177,6 +177,8 @@ static int set4(alq_model *m, Igemm4Plan *p4, const std::vector<float> &Bmat) {
         ALQ_TRY(m->dalloc(&p4->d_sdesc, p4->h_sdesc.size()));
         ALQ_TRY(m->dalloc(&p4->d_pdesc, p4->h_pdesc.size()));
         ALQ_TRY(m->dalloc(&p4->d_ttab, p4->h_ttab.size()));
+        ALQ_TRY(m->dalloc(&p4->d_vdesc, p4->h_vdesc.size()));
+        ALQ_HIP(hipMemcpyAsync(p4->d_vdesc, p4->h_vdesc.data(), p4->h_vdesc.size() * sizeof(int), hipMemcpyHostToDevice, st));
         ALQ_HIP(hipMemcpyAsync(p4->d_tdesc, p4->h_tdesc.data(), p4->h_tdesc.size() * sizeof(int), hipMemcpyHostToDevice, st));
         ALQ_HIP(hipMemcpyAsync(p4->d_sdesc, p4->h_sdesc.data(), p4->h_sdesc.size() * sizeof(int), hipMemcpyHostToDevice, st));
         ALQ_HIP(hipMemcpyAsync(p4->d_pdesc, p4->h_pdesc.data(), p4->h_pdesc.size() * sizeof(int), hipMemcpyHostToDevice, st));
@@ -751,12 +753,7 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
     {
         const char *e = getenv("ALQ_DISABLE_V2");   // diagnostics: force the general GEMM kernel
         g_use_v2 = !(e && e[0] == '1');
-        if (!g_knobs_init) {
-            // measured (tests/gpu_ab.py): fusing the channel sums into the two concat-destination
-            // backward GEMMs costs more than the separate 16^3 / 32^3 sum pass it saves
-            g_dbg_knobs[2] = 1;
-            g_knobs_init = true;
-        }
+        g_knobs_init = true;
         static const char *names[6] = {"ALQ_DEBUG_REPEAT", "ALQ_DEBUG_FLAGS", "ALQ_NO_BWD_FUSE", "ALQ_NO_FWD_FUSE", "ALQ_NO_V3", "ALQ_NO_V4"};
         for (int k = 0; k < 6; ++k) {
             const char *v = getenv(names[k]);

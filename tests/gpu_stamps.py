@@ -19,7 +19,9 @@ from nnal_amd import device  # noqa: E402
 from nnal_amd._lib import check  # noqa: E402
 from oracle import netspec  # noqa: E402
 
-NAMES = ['prologue', 'barrierA', 'stash', 'barrierB', 'epilogue', 'locate+fetch', 'mfma', 'tail']
+NAMES = ['A:stash', 'A:flush', 'A:locate+fetch', 'B:contract', 'wait after A', 'wait after B', 'tail', '-']
+if os.environ.get('STAMP_V3'):
+    NAMES = ['prologue', 'barrierA', 'stash', 'barrierB', 'epilogue', 'locate+fetch', 'mfma', 'tail']
 
 
 def main():

@@ -194,8 +194,10 @@ struct Igemm2Plan {
 struct Igemm2Fuse {
     const float *mask = nullptr;   // activation whose sign masks output columns >= mask_from (ReLU grad)
     int mask_cs = 0, mask_c0 = 0, mask_from = 0;
+    int mask_to = 1 << 30;   // igemm4 only: columns in [mask_from, mask_to) are masked
     float *osumA = nullptr, *osumB = nullptr;
     int split = 0;       // 0: all columns -> osumA; else columns < split -> osumA, others -> osumB
+    int store_from = 0;  // columns below this are masked and summed but not stored (igemm4 only)
 };
 
 extern unsigned long long *g_igemm2_dbg;
@@ -239,7 +241,7 @@ struct Igemm4Args {
     const int *ttab;        // [tap rows][G4_MAXS][4] LDS byte offsets of the taps of k-step s, lane group q
     const int *vdesc;       // [256]: GEMM row -> (pt, z, y, x) of its M-grid point inside the tile, -1 = unused row
     int in_cs, in_c0, out_cs, out_c0, Co;
-    int mask_cs, mask_c0, mask_from, split;
+    int mask_cs, mask_c0, mask_from, mask_to, split;
     int N, PT, tpg, rows;
     int PX, PYX, PZ;        // LDS row pitches of the staged block: per y line, per z plane, per patch
     int smz, smy, smx;      // M-grid point -> halo index multipliers
@@ -248,7 +250,7 @@ struct Igemm4Args {
     int nph, ngr, NP;       // staging phases per tile; MULTI: output groups, planes
     int nslots, plane_bytes;
     int in_pstride, out_pstride, in_bytes;
-    int relu, accumulate, pair;
+    int relu, accumulate, pair, store_from;
     int tt_ints, wbytes, abytes;
     int dbg_repeat;
     unsigned long long *dbg;
@@ -327,6 +329,11 @@ int k_pool_fwd(alq_ctx *, const View &in, const View &out, uint8_t *argmax, cons
                const int lo[3], int N, float *osum = nullptr, bool *fused = nullptr);
 // mask_act / dsum (both or neither): apply the ReLU-grad mask of the input layer's activation to the
 // finished cotangent and emit its channel sums; *fused tells whether the kernel could do it
+// first parameterised layer behind a pool: only the channel sums of its masked cotangent are needed.  Scatters
+// dout (masked by pooled activation > 0, i.e. the ReLU of the arg-max element) into the 2x2(x2) window sums;
+// accumulate = the skip destination has already written its part of the field.
+int k_pool_bwd_first(alq_ctx *, const View &dout, const View &pool_out, const uint8_t *argmax, const int w[3],
+                     int ID, int IH, int IW, int N, float *dsum, int accumulate);
 int k_pool_bwd(alq_ctx *, const View &dout, const View &din, const uint8_t *argmax,
                const int w[3], const int lo[3], int N, int accumulate, const View *mask_act = nullptr,
                float *dsum = nullptr, bool *fused = nullptr, int store_din = 1);

@@ -234,6 +234,34 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     f32x4 acc[4][NTW];
     char *outb = reinterpret_cast<char *>(a.out);
     const char *maskb = reinterpret_cast<const char *>(a.mask);
+    // ReLU-grad mask values of the pending tile: loaded before the staging work of the same tick so that their
+    // latency is behind ~1 us of split / LDS-store instructions when the epilogue consumes them
+    f32x4 Mk[4][NTW];
+    auto load_mask = [&](int q_out, int q_full, int q_l, int q_g) {
+        int mz0 = 0, my0 = 0, mx0 = 0;
+        if (!q_full) {
+            const i32x4 t1 = g4_sload4(a.tdesc + q_l * 8 + 4);
+            mz0 = t1.y; my0 = t1.z; mx0 = t1.w;
+        }
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) {
+            bool live = erow_ok;
+            if (!q_full) {
+                const int e = vpk[ms];
+                const int pt = e >> 24, z = (e >> 16) & 255, y = (e >> 8) & 255, x = e & 255;
+                live = e >= 0 && q_g * a.PT + pt < a.N && mz0 + z < a.MD && my0 + y < a.MH && mx0 + x < a.MW;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int c = nt * 16 + cl;
+                Mk[ms][nt] = f32x4{1.f, 1.f, 1.f, 1.f};
+                if (live && c < a.Co && c >= a.mask_from && c < a.mask_to) {
+                    const int mo = (q_out + evox[ms]) * a.mask_cs + a.mask_c0 + (c - a.mask_from);
+                    Mk[ms][nt] = *reinterpret_cast<const f32x4 *>(maskb + (unsigned)(mo * 4));
+                }
+            }
+        }
+    };
     auto flush = [&](int q_out, int q_full, int q_l, int q_g) {
         const int obase_e = q_out * a.out_cs;
         int mz0 = 0, my0 = 0, mx0 = 0;
@@ -264,13 +292,12 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                         val.z = __builtin_amdgcn_fmed3f(val.z, 0.f, __builtin_inff());
                         val.w = __builtin_amdgcn_fmed3f(val.w, 0.f, __builtin_inff());
                     }
-                    if (a.mask && c >= a.mask_from) {
-                        const int mo = (q_out + evox[ms]) * a.mask_cs + a.mask_c0 + (c - a.mask_from);
-                        const f32x4 mk = *reinterpret_cast<const f32x4 *>(maskb + (unsigned)(mo * 4));
+                    if (a.mask) {
+                        const f32x4 mk = Mk[ms][nt];
                         val.x = mk.x > 0.f ? val.x : 0.f; val.y = mk.y > 0.f ? val.y : 0.f;
                         val.z = mk.z > 0.f ? val.z : 0.f; val.w = mk.w > 0.f ? val.w : 0.f;
                     }
-                    *dst = val;
+                    if (c >= a.store_from) *dst = val;
                 }
                 if constexpr (SUMS) {
                     if (!on) val = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -381,6 +408,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             PHASE4_END(5);
             if (a_i < n_ph) {
                 if (a_ph == 0) { c_out = f_out; c_full = f_full; c_l = f_l; c_g = f_g; }
+                if (a_ph == 0 && have_pend && a.mask) load_mask(p_out, p_full, p_l, p_g);
                 stash();
                 PHASE4_END(0);
                 if (a_ph == 0 && have_pend) {
@@ -435,7 +463,10 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         }
         __syncthreads();
     }
-    if (have_pend) flush(p_out, p_full, p_l, p_g);
+    if (have_pend) {
+        if (a.mask) load_mask(p_out, p_full, p_l, p_g);
+        flush(p_out, p_full, p_l, p_g);
+    }
 #ifdef ALQ_STAMPS
     PHASE4_END(6);
     if (a.dbg && (tid & 255) == 0)
@@ -995,11 +1026,16 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
     if (fuse) {
         ALQ_REQUIRE(fuse->split % 4 == 0 && fuse->mask_cs % 4 == 0 && fuse->mask_c0 % 4 == 0 && fuse->mask_from % 4 == 0,
                     ALQ_EUNSUPPORTED, "igemm4: fused epilogue needs 4-channel aligned slices");
+        ALQ_REQUIRE(!(plan.multi && fuse->mask), ALQ_EUNSUPPORTED, "igemm4: no mask in the multi-output form");
         ALQ_REQUIRE(!a.pair || (!fuse->osumB && fuse->split == 0), ALQ_EUNSUPPORTED,
                     "igemm4: the pair form sums all 8 channels of a voxel");
         a.mask = fuse->mask; a.mask_cs = fuse->mask_cs; a.mask_c0 = fuse->mask_c0; a.mask_from = fuse->mask_from;
+        a.mask_to = fuse->mask_to;
         a.osumA = fuse->osumA; a.osumB = fuse->osumB;
         a.split = fuse->split > 0 ? fuse->split : (1 << 30);
+        a.store_from = fuse->store_from;
+        ALQ_REQUIRE(a.store_from % 4 == 0 && (a.store_from == 0 || !accumulate), ALQ_EUNSUPPORTED,
+                    "igemm4: store_from needs a 4-aligned column and no accumulation");
     }
     const int pgroups = (N + a.PT - 1) / a.PT;
     const long long total = (long long)pgroups * a.tpg;

@@ -7,6 +7,7 @@
 namespace alq {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BOX_SLAB = 1024;   // voxels per box-dot workgroup
 
@@ -282,6 +283,46 @@ __global__ void pool_bwd_vox_kernel(const float *dout, int do_cs, int do_c0, int
     }
 }
 
+// One thread per POOLED voxel (8 channels = C4 x 4): the cotangent of a pooled element belongs to the arg-max
+// voxel of its window and survives the producer's ReLU iff the pooled activation is positive.  Only the
+// channel sums per input voxel are produced (first parameterised layer: nothing upstream needs more).
+template <int C4>
+__global__ void pool_bwd_first_kernel(const float *dout, int do_cs, int do_c0, const float *pout, int po_cs, int po_c0,
+                                      const uint8_t *argmax, int OD, int OH, int OW, int wz, int ID, int IH, int IW,
+                                      long long npool, float *dsum, int accumulate) {
+    for (long long o = blockIdx.x * (long long)blockDim.x + threadIdx.x; o < npool;
+         o += (long long)gridDim.x * blockDim.x) {
+        long long r = o;
+        const int ox = r % OW; r /= OW;
+        const int oy = r % OH; r /= OH;
+        const int oz = r % OD; r /= OD;
+        const long long n = r;
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < C4; ++c) {
+            const unsigned am = reinterpret_cast<const unsigned *>(argmax)[o * C4 + c];
+            const f32x4 d = *reinterpret_cast<const f32x4 *>(dout + o * do_cs + do_c0 + c * 4);
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(pout + o * po_cs + po_c0 + c * 4);
+            const float g[4] = {a.x > 0.f ? d.x : 0.f, a.y > 0.f ? d.y : 0.f, a.z > 0.f ? d.z : 0.f, a.w > 0.f ? d.w : 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned w = (am >> (8 * j)) & 255u;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) s[p] += (w == (unsigned)p) ? g[j] : 0.f;
+            }
+        }
+        for (int pz = 0; pz < wz; ++pz)
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                const long long i = ((n * ID + oz * wz + pz) * IH + oy * 2 + py) * IW + ox * 2;
+                f32x2 v = f32x2{s[(pz * 2 + py) * 2], s[(pz * 2 + py) * 2 + 1]};
+                f32x2 *dst = reinterpret_cast<f32x2 *>(dsum + i);
+                if (accumulate) v += *dst;
+                *dst = v;
+            }
+    }
+}
+
 static unsigned grid_for(long long total, int block = 256, int cap = 256 * 32) {
     long long g = (total + block - 1) / block;
     if (g > cap) g = cap;
@@ -316,6 +357,23 @@ int k_pool_fwd(alq_ctx *ctx, const View &in, const View &out, uint8_t *argmax, c
     hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, in.p, in.cs,
                        in.c0, in.C, in.D, in.H, in.W, out.p, out.cs, out.c0, out.D, out.H, out.W, argmax,
                        w[0], w[1], w[2], lo[0], lo[1], lo[2], total);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
+int k_pool_bwd_first(alq_ctx *ctx, const View &dout, const View &pool_out, const uint8_t *argmax, const int w[3],
+                     int ID, int IH, int IW, int N, float *dsum, int accumulate) {
+    ALQ_REQUIRE(w[1] == 2 && w[2] == 2 && (w[0] == 1 || w[0] == 2) && ID == dout.D * w[0] && IH == dout.H * 2 && IW == dout.W * 2 &&
+                    (dout.C == 4 || dout.C == 8 || dout.C == 16) && ((dout.cs | dout.c0 | pool_out.cs | pool_out.c0) & 3) == 0,
+                ALQ_EUNSUPPORTED, "pool_bwd_first: unsupported geometry");
+    const long long npool = (long long)N * dout.vox();
+    ProfScope ps(ctx, PROF_ELEMWISE, 0);
+#define ALQ_PBF(CV)                                                                                               \
+    hipLaunchKernelGGL(pool_bwd_first_kernel<CV>, dim3(grid_for(npool)), dim3(256), 0, ctx->stream, dout.p, dout.cs, \
+                       dout.c0, pool_out.p, pool_out.cs, pool_out.c0, argmax, dout.D, dout.H, dout.W, w[0], ID, IH, IW, \
+                       npool, dsum, accumulate)
+    switch (dout.C) { case 4: ALQ_PBF(1); break; case 8: ALQ_PBF(2); break; default: ALQ_PBF(4); }
+#undef ALQ_PBF
     ALQ_LAUNCH_CHECK();
     return ALQ_OK;
 }

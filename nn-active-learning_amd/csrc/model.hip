@@ -57,6 +57,7 @@ struct Layer {
     float *asum = nullptr, *dsum = nullptr;
     float *osum = nullptr;     // channel sums of this layer's OUTPUT (spatial layers): next layers' asum
     bool delta_ready = false;  // backward: the cotangent of our output is already masked and dsum is filled
+    bool dsum_partial = false; // backward, first layer: the skip destination has written its share of dsum
     float *fc_partials = nullptr;
     int fc_slices = 0;
     bool out_is_skip_src = false;
@@ -622,7 +623,16 @@ static int run_backward(alq_model *m, const float *d_x, int N) {
     const int nl = (int)m->layers.size();
     ALQ_REQUIRE(m->nclass == 2, ALQ_EUNSUPPORTED, "Fisher scoring is binary (PW_NNAL.py:766), got %d classes", m->nclass);
     ALQ_TRY(k_fill_unit_cotangent(ctx, m->dlogits, N));
-    for (Layer &l : m->layers) l.delta_ready = false;
+    for (Layer &l : m->layers) { l.delta_ready = false; l.dsum_partial = false; }
+    const bool v4_on = !g_dbg_knobs[4] && !g_dbg_knobs[5];
+    // a pool whose producer is the first parameterised layer: 2x2(x2) windows tiling the input exactly
+    auto pool_first_ok = [&](const Layer &pl, const Layer &src) {
+        return pl.spec.type == ALQ_POOL && src.pidx == 0 && src.spec.type != ALQ_FC && pl.spec.k[1] == 2 && pl.spec.k[2] == 2 &&
+               (pl.spec.k[0] == 1 || pl.spec.k[0] == 2) && pl.lo[0] == 0 && pl.lo[1] == 0 && pl.lo[2] == 0 &&
+               src.out.D == pl.out.D * pl.spec.k[0] && src.out.H == pl.out.H * 2 && src.out.W == pl.out.W * 2 &&
+               (pl.out.C == 4 || pl.out.C == 8 || pl.out.C == 16) && ((pl.dout.cs | pl.dout.c0 | pl.out.cs | pl.out.c0) & 3) == 0 &&
+               src.spec.relu && !g_dbg_knobs[6];
+    };
     for (int i = nl - 1; i >= 0; --i) {
         Layer &ly = m->layers[i];
         const bool prev_is_src = (i > 0 && m->layers[i - 1].out_is_skip_src && ly.spec.skip_src < 0);
@@ -630,6 +640,12 @@ static int run_backward(alq_model *m, const float *d_x, int N) {
         // wrote its slice earlier), so it can finish that tensor: ReLU-grad mask + channel sums.
         Layer *prev = i > 0 ? &m->layers[i - 1] : nullptr;
         const bool prev_param = prev && prev->pidx >= 0 && prev->spec.type != ALQ_FC;
+        if (ly.spec.type == ALQ_POOL && prev_param && pool_first_ok(ly, *prev) && (prev->dsum_partial || !prev_is_src)) {
+            ALQ_TRY(k_pool_bwd_first(ctx, ly.dout, ly.out, ly.argmax, ly.spec.k, prev->out.D, prev->out.H, prev->out.W, N,
+                                     prev->dsum, prev->dsum_partial ? 1 : 0));
+            prev->delta_ready = true;
+            continue;
+        }
         if (ly.spec.type == ALQ_POOL) {
             bool fused = false;
             ALQ_TRY(k_pool_bwd(ctx, ly.dout, ly.din, ly.argmax, ly.spec.k, ly.lo, N, prev_is_src ? 1 : 0,
@@ -681,6 +697,19 @@ static int run_backward(alq_model *m, const float *d_x, int N) {
                 const int Cs = ly.spec.skip_src >= 0 ? m->layers[ly.spec.skip_src].out.C : 0;   // concat: [src | prev]
                 if (prev->spec.relu) { fz.mask = prev->out.p; fz.mask_cs = prev->out.cs; fz.mask_c0 = prev->out.c0; fz.mask_from = Cs; }
                 if (Cs > 0) { fz.split = Cs; fz.osumB = prev->dsum; } else { fz.osumA = prev->dsum; }
+                // the skip source is the first parameterised layer and sits in front of a pool: nothing needs its
+                // cotangent except the channel sums, so mask and sum its columns here and do not store them
+                if (Cs > 0 && v4_on && ly.bwd.p4.ok) {
+                    Layer &sl = m->layers[ly.spec.skip_src];
+                    const bool next_pool = ly.spec.skip_src + 1 < nl && pool_first_ok(m->layers[ly.spec.skip_src + 1], sl);
+                    if (next_pool && sl.out.p == prev->out.p && sl.out.cs == prev->out.cs && prev->out.c0 == sl.out.c0 + Cs &&
+                        (Cs & 3) == 0) {
+                        fz.mask = sl.out.p; fz.mask_cs = sl.out.cs; fz.mask_c0 = sl.out.c0; fz.mask_from = 0;
+                        if (!prev->spec.relu) fz.mask_to = Cs;
+                        fz.osumA = sl.dsum; fz.store_from = Cs;
+                        sl.dsum_partial = true;
+                    }
+                }
                 fuse = &fz;
             }
             ALQ_TRY(gemm_launch(ctx, ly.bwd, ly.dout, ly.din, nullptr, 0, acc, N, PROF_IGEMM_BWD, fuse, &fused));
@@ -754,8 +783,9 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
         const char *e = getenv("ALQ_DISABLE_V2");   // diagnostics: force the general GEMM kernel
         g_use_v2 = !(e && e[0] == '1');
         g_knobs_init = true;
-        static const char *names[6] = {"ALQ_DEBUG_REPEAT", "ALQ_DEBUG_FLAGS", "ALQ_NO_BWD_FUSE", "ALQ_NO_FWD_FUSE", "ALQ_NO_V3", "ALQ_NO_V4"};
-        for (int k = 0; k < 6; ++k) {
+        static const char *names[7] = {"ALQ_DEBUG_REPEAT", "ALQ_DEBUG_FLAGS", "ALQ_NO_BWD_FUSE", "ALQ_NO_FWD_FUSE", "ALQ_NO_V3", "ALQ_NO_V4",
+                                       "ALQ_NO_POOL_FIRST"};
+        for (int k = 0; k < 7; ++k) {
             const char *v = getenv(names[k]);
             if (v) g_dbg_knobs[k] = atoi(v);
         }

@@ -313,6 +313,10 @@ struct DirectPlan {
 int direct_build_plan(const IgemmPlan &p1, DirectPlan *dp);
 int direct_launch(alq_ctx *ctx, const DirectPlan &dp, const View &in, const View &out, const float *bias, int relu,
                   int N, float *osum, int prof_cls);
+// first conv (1 -> 8 channels, 3x3x3) fused with the 2x2x2 max-pool behind it: both outputs, arg-max, both sums
+int direct_conv_pool_launch(alq_ctx *ctx, const float *d_W, const View &in, const View &out, const View &pout,
+                            const float *bias, int relu, uint8_t *argmax, float *osum, float *posum, int N,
+                            double flops_per_patch);
 
 // one contraction = general plan + (when eligible) pipelined plan / direct first-layer plan
 struct Gemm {

@@ -561,9 +561,11 @@ static View flat_view(const View &v) {
 static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums) {
     alq_ctx *ctx = m->ctx;
     const int nl = (int)m->layers.size();
+    bool skip_next = false;      // this layer's outputs were produced by the previous layer's kernel
     for (int i = 0; i < nl; ++i) {
         Layer &ly = m->layers[i];
         ALQ_REQUIRE(ly.pidx < 0 || ly.weights_set, ALQ_EINVAL, "weights of parameterised layer %d not set", ly.pidx);
+        if (skip_next) { skip_next = false; continue; }
         View in = ly.in;
         if (i == 0) in.p = const_cast<float *>(d_x);
         // channel sums of every spatial layer's output ride on the producing kernel's epilogue when it
@@ -573,9 +575,25 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums) {
         const Igemm2Fuse *fuse = (with_sums && ly.osum && !g_dbg_knobs[3]) ? &fz : nullptr;
         bool fused = false;
         switch (ly.spec.type) {
-            case ALQ_CONV:
+            case ALQ_CONV: {
+                // first conv + the pool behind it in one kernel (one input channel, 3x3x3 -> 8, 2x2x2 windows)
+                Layer *nx = i + 1 < nl ? &m->layers[i + 1] : nullptr;
+                const alq_layer_t &sp = ly.spec;
+                if (i == 0 && nx && nx->spec.type == ALQ_POOL && ly.fwd[0].pd.ok && ly.fwd[0].pd.d_W && in.C == 1 && in.cs == 1 &&
+                    sp.cout == 8 && sp.k[0] == 3 && sp.k[1] == 3 && sp.k[2] == 3 && ly.lo[0] == 1 && ly.lo[1] == 1 && ly.lo[2] == 1 &&
+                    nx->spec.k[0] == 2 && nx->spec.k[1] == 2 && nx->spec.k[2] == 2 && nx->lo[0] == 0 && nx->lo[1] == 0 && nx->lo[2] == 0 &&
+                    in.D % 2 == 0 && in.H % 2 == 0 && in.W % 2 == 0 && nx->out.D * 2 == in.D && nx->out.H * 2 == in.H &&
+                    nx->out.W * 2 == in.W && ((ly.out.cs | ly.out.c0 | nx->out.cs | nx->out.c0) & 3) == 0 && !g_dbg_knobs[7]) {
+                    ALQ_TRY(direct_conv_pool_launch(ctx, ly.fwd[0].pd.d_W, in, ly.out, nx->out, ly.d_bias, sp.relu, nx->argmax,
+                                                    with_sums ? ly.osum : nullptr, with_sums ? nx->osum : nullptr, N,
+                                                    ly.fwd[0].pd.flops_per_patch));
+                    fused = true;
+                    skip_next = true;
+                    break;
+                }
                 ALQ_TRY(gemm_launch(ctx, ly.fwd[0], in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM_FWD, fuse, &fused));
                 break;
+            }
             case ALQ_CONVT: {
                 if (ly.fwd_all.ok && !g_dbg_knobs[4] && !g_dbg_knobs[5]) {
                     ALQ_TRY(igemm4_launch(ctx, ly.fwd_all, in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM3_FWD, fuse));
@@ -783,9 +801,9 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
         const char *e = getenv("ALQ_DISABLE_V2");   // diagnostics: force the general GEMM kernel
         g_use_v2 = !(e && e[0] == '1');
         g_knobs_init = true;
-        static const char *names[7] = {"ALQ_DEBUG_REPEAT", "ALQ_DEBUG_FLAGS", "ALQ_NO_BWD_FUSE", "ALQ_NO_FWD_FUSE", "ALQ_NO_V3", "ALQ_NO_V4",
-                                       "ALQ_NO_POOL_FIRST"};
-        for (int k = 0; k < 7; ++k) {
+        static const char *names[8] = {"ALQ_DEBUG_REPEAT", "ALQ_DEBUG_FLAGS", "ALQ_NO_BWD_FUSE", "ALQ_NO_FWD_FUSE", "ALQ_NO_V3", "ALQ_NO_V4",
+                                       "ALQ_NO_POOL_FIRST", "ALQ_NO_CONV_POOL"};
+        for (int k = 0; k < 8; ++k) {
             const char *v = getenv(names[k]);
             if (v) g_dbg_knobs[k] = atoi(v);
         }

@@ -110,7 +110,7 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
         value = n_global * args.steps / dt
-        # dominant kernel = igemm3_kernel (conv / conv_transpose fwd + bwd-data on the bf16 matrix cores
+        # dominant kernel = igemm4_kernel (conv / conv_transpose fwd + bwd-data on the bf16 matrix cores
         # with the 3-way operand split: 6 bf16 MFMA MACs per fp32-accurate MAC, so the matrix-core bound
         # on ALGORITHMIC fp32 flops is the dense bf16 peak / 6)
         ig_ms = prof['igemm3_fwd']['ms'] + prof['igemm3_bwd']['ms']
@@ -140,7 +140,8 @@ def main():
                        'parallelism': 'pool sharded over %d GPU(s), RCCL top-B merge + 8x8 Fisher all-reduce' % ws},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic,
-                         'kernel': 'igemm3_kernel (conv / conv_transpose fwd + bwd-data, bf16x3 split)',
+                         'kernel': 'igemm4_kernel (+ igemm3_kernel for unfused conv_transpose classes): conv / conv_transpose '
+                                   'fwd + bwd-data, bf16x3 split',
                          'peak_note': 'algorithmic fp32 flops; peak = %.0f dense bf16 / %d split products'
                                       % (PEAK_BF16_MFMA_TFLOPS, SPLIT_PRODUCTS),
                          'executed_bf16_tflops': achieved * SPLIT_PRODUCTS, 'peak_bf16_tflops': PEAK_BF16_MFMA_TFLOPS,

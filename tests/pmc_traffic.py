@@ -14,14 +14,14 @@ import sys
 def per_dispatch(path, counter, key):
     acc = collections.OrderedDict()
     for r in csv.DictReader(open(path)):
-        if r['Counter_Name'] != counter or key not in r['Kernel_Name']:
+        if r['Counter_Name'] != counter or not any(k in r['Kernel_Name'] for k in key.split('|')):
             continue
         acc[r['Dispatch_Id']] = acc.get(r['Dispatch_Id'], 0.0) + float(r['Counter_Value'])
     return list(acc.values())
 
 
 def main():
-    key = sys.argv[3] if len(sys.argv) > 3 else 'igemm3_kernel'
+    key = sys.argv[3] if len(sys.argv) > 3 else 'igemm4_kernel|igemm3_kernel'
     f = per_dispatch(sys.argv[1], 'FETCH_SIZE', key)
     w = per_dispatch(sys.argv[2], 'WRITE_SIZE', key)
     rd = 2.0 * 1024.0 * sum(f) / max(len(f), 1)

@@ -251,7 +251,7 @@ struct Igemm4Args {
     int nslots, plane_bytes;
     int in_pstride, out_pstride, in_bytes;
     int relu, accumulate, pair, store_from;
-    int tt_ints, wbytes, abytes;
+    int tt_ints, pd_off, td_off, wbytes, abytes;   // table block in LDS (ints): tap table, then phase, then tile descriptors
     int dbg_repeat;
     unsigned long long *dbg;
 };

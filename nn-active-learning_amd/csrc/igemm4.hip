@@ -104,6 +104,10 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         for (int i = tid; i < a.tt_ints; i += 512) Tl[i] = a.ttab[i];
     }
 
+    // tile / phase descriptors live in LDS next to the tap table: a broadcast ds_read costs ~100 cycles where a
+    // scalar load from L2 cost 500+ per tile under load (phase stamps), and the values need no SGPRs
+    auto ld4 = [&](int int_off) { return *reinterpret_cast<const i32x4 *>(Tl + int_off); };
+
     // ---- staging slots of this thread --------------------------------------------------------------
     int s_rel[G4_NSLOT], s_pk[G4_NSLOT], s_lds[G4_NSLOT];
 #pragma unroll
@@ -174,13 +178,14 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         for (int it = 0; it < G4_NSLOT; ++it) goff[it] = G4_OOB;
     };
     auto locate = [&]() {
-        const i32x4 t0 = g4_sload4(a.tdesc + fl * 8);
-        const i32x4 t1 = g4_sload4(a.tdesc + fl * 8 + 4);
+        const i32x4 t0 = ld4(a.td_off + fl * 8);
+        const i32x4 t1 = ld4(a.td_off + fl * 8 + 4);
         const int org = (t0.x + fpg * a.in_pstride) * a.in_cs;
+        const int tflags = __builtin_amdgcn_readfirstlane(t0.z);
         f_out = t0.y + fpg * a.out_pstride;
-        f_full = (t0.z & 1) && (fpg + 1) * a.PT <= a.N;
+        f_full = (tflags & 1) && (fpg + 1) * a.PT <= a.N;
         f_l = fl; f_g = fpg;
-        if ((t0.z & 2) && (fpg + 1) * a.PT <= a.N) {      // whole halo inside the tensor: no per-slot checks
+        if ((tflags & 2) && (fpg + 1) * a.PT <= a.N) {      // whole halo inside the tensor: no per-slot checks
 #pragma unroll
             for (int it = 0; it < G4_NSLOT; ++it) goff[it] = (org + s_rel[it]) * 4;
             return;
@@ -206,8 +211,8 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     auto fetch = [&](int ph) {
         int soff = 0;
         if constexpr (!MULTI) {
-            const i32x4 pd = g4_sload4(a.pdesc + ph * 8);
-            soff = (pd.x * a.in_cs + pd.y * 8) * 4;
+            const i32x4 pd = ld4(a.pd_off + ph * 8);
+            soff = __builtin_amdgcn_readfirstlane((pd.x * a.in_cs + pd.y * 8) * 4);
         }
 #pragma unroll
         for (int it = 0; it < G4_NSLOT; ++it)
@@ -236,11 +241,13 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     const char *maskb = reinterpret_cast<const char *>(a.mask);
     // ReLU-grad mask values of the pending tile: loaded before the staging work of the same tick so that their
     // latency is behind ~1 us of split / LDS-store instructions when the epilogue consumes them
-    f32x4 Mk[4][NTW];
+    constexpr bool MASK_PF = (NTW == 1);      // with two column tiles the 32 extra registers spill: load in the epilogue
+    f32x4 Mk[MASK_PF ? 4 : 1][NTW];
     auto load_mask = [&](int q_out, int q_full, int q_l, int q_g) {
+        if constexpr (MASK_PF) {
         int mz0 = 0, my0 = 0, mx0 = 0;
         if (!q_full) {
-            const i32x4 t1 = g4_sload4(a.tdesc + q_l * 8 + 4);
+            const i32x4 t1 = ld4(a.td_off + q_l * 8 + 4);
             mz0 = t1.y; my0 = t1.z; mx0 = t1.w;
         }
 #pragma unroll
@@ -261,12 +268,13 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 }
             }
         }
+        }
     };
     auto flush = [&](int q_out, int q_full, int q_l, int q_g) {
         const int obase_e = q_out * a.out_cs;
         int mz0 = 0, my0 = 0, mx0 = 0;
         if (!q_full) {
-            const i32x4 t1 = g4_sload4(a.tdesc + q_l * 8 + 4);
+            const i32x4 t1 = ld4(a.td_off + q_l * 8 + 4);
             mz0 = t1.y; my0 = t1.z; mx0 = t1.w;
         }
 #pragma unroll
@@ -293,7 +301,16 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                         val.w = __builtin_amdgcn_fmed3f(val.w, 0.f, __builtin_inff());
                     }
                     if (a.mask) {
-                        const f32x4 mk = Mk[ms][nt];
+                        f32x4 mk;
+                        if constexpr (MASK_PF) {
+                            mk = Mk[ms][nt];
+                        } else {
+                            mk = f32x4{1.f, 1.f, 1.f, 1.f};
+                            if (c >= a.mask_from && c < a.mask_to) {
+                                const int mo = (q_out + evox[ms]) * a.mask_cs + a.mask_c0 + (c - a.mask_from);
+                                mk = *reinterpret_cast<const f32x4 *>(maskb + (unsigned)(mo * 4));
+                            }
+                        }
                         val.x = mk.x > 0.f ? val.x : 0.f; val.y = mk.y > 0.f ? val.y : 0.f;
                         val.z = mk.z > 0.f ? val.z : 0.f; val.w = mk.w > 0.f ? val.w : 0.f;
                     }
@@ -408,7 +425,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             PHASE4_END(5);
             if (a_i < n_ph) {
                 if (a_ph == 0) { c_out = f_out; c_full = f_full; c_l = f_l; c_g = f_g; }
-                if (a_ph == 0 && have_pend && a.mask) load_mask(p_out, p_full, p_l, p_g);
+                if constexpr (MASK_PF) { if (a_ph == 0 && have_pend && a.mask) load_mask(p_out, p_full, p_l, p_g); }
                 stash();
                 PHASE4_END(0);
                 if (a_ph == 0 && have_pend) {
@@ -432,7 +449,8 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             PHASE4_END(4);
             if (b_i < a_i) {
                 if constexpr (!MULTI) {
-                    const i32x8 pd = g4_sload8(a.pdesc + b_ph * 8);
+                    const i32x4 pdA = ld4(a.pd_off + b_ph * 8), pdB = ld4(a.pd_off + b_ph * 8 + 4);
+                    const int pd[5] = {0, 0, __builtin_amdgcn_readfirstlane(pdA.z), pdA.w, pdB.x};
                     if (b_ph == 0) init_acc();
                     for (int rep = 0; rep <= a.dbg_repeat; ++rep)
                         unit(pd[2], Wl + pd[3] + lane * 16, Al, pd[4]);
@@ -443,7 +461,8 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                     b_ph = b_ph + 1 == a.nph ? 0 : b_ph + 1;
                 } else {
                     for (int g = 0; g < a.ngr; ++g) {
-                        const i32x8 gd = g4_sload8(a.pdesc + g * 8);
+                        const i32x4 gdA = ld4(a.pd_off + g * 8), gdB = ld4(a.pd_off + g * 8 + 4);
+                        const int gd[6] = {0, 0, __builtin_amdgcn_readfirstlane(gdA.z), gdA.w, gdB.x, gdB.y};
                         init_acc();
                         const int ub = gd[2] * (3 * NTW * 1024);
                         for (int rep = 0; rep <= a.dbg_repeat; ++rep)
@@ -464,7 +483,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         __syncthreads();
     }
     if (have_pend) {
-        if (a.mask) load_mask(p_out, p_full, p_l, p_g);
+        if constexpr (MASK_PF) { if (a.mask) load_mask(p_out, p_full, p_l, p_g); }
         flush(p_out, p_full, p_l, p_g);
     }
 #ifdef ALQ_STAMPS
@@ -724,7 +743,9 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
                     if (nhv * 2 * NPs > 256 * G4_NSLOT) continue;
                     const Lay L = layout(PT, T, H);
                     const int sumS_t = ksteps(L);
-                    const size_t lds = tt_ints * 4 + (size_t)sumS_t * NCH * 3 * NTW * 1024 + 2 * (size_t)PT * L.PZ * NPs * G4_ROWB;
+                    const size_t tpg_t = (size_t)((dg[0].M + TZ - 1) / TZ) * ((dg[1].M + TY - 1) / TY) * ((dg[2].M + TX - 1) / TX);
+                    const size_t tab_ints = tt_ints + (size_t)(multi ? rows.size() : rows.size() * NCH) * 8 + tpg_t * 8;
+                    const size_t lds = tab_ints * 4 + (size_t)sumS_t * NCH * 3 * NTW * 1024 + 2 * (size_t)PT * L.PZ * NPs * G4_ROWB;
                     if (lds > 160 * 1024 - 256) continue;
                     const double tiles = std::ceil((double)max_batch / PT) * std::ceil((double)dg[0].M / TZ) *
                                          std::ceil((double)dg[1].M / TY) * std::ceil((double)dg[2].M / TX);
@@ -925,10 +946,16 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
                             sd[3] = pl * 8 + half * 4;
                         }
                     }
+    // one table block, copied to LDS by the kernel: [tap table | phase / group descriptors | tile descriptors]
+    a.pd_off = (int)plan->h_ttab.size();
+    plan->h_ttab.insert(plan->h_ttab.end(), plan->h_pdesc.begin(), plan->h_pdesc.end());
+    a.td_off = (int)plan->h_ttab.size();
+    plan->h_ttab.insert(plan->h_ttab.end(), plan->h_tdesc.begin(), plan->h_tdesc.end());
+    a.tt_ints = (int)plan->h_ttab.size();
     plan->NTW = NTW;
     plan->multi = multi;
     plan->Ci = g.Ci; plan->Co = g.Co;
-    plan->lds_bytes = tt_ints * 4 + wbytes + 2 * (size_t)a.abytes;
+    plan->lds_bytes = (size_t)a.tt_ints * 4 + wbytes + 2 * (size_t)a.abytes;
     if (plan->lds_bytes > 160 * 1024) return ALQ_OK;
     plan->flops_per_patch = g.flops_per_patch;
     plan->ok = true;

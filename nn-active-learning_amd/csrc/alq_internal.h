@@ -43,6 +43,10 @@ struct View {
     float *p = nullptr;
     int D = 1, H = 1, W = 1;
     int cs = 0, c0 = 0, C = 0;
+    // split concat (igemm4 only): channels [0, split) are a dense tensor at p, channels [split, C) a dense tensor
+    // of the same row stride cs at p + delta; split = 0: one strided tensor
+    int split = 0;
+    long long delta = 0;
     int64_t vox() const { return (int64_t)D * H * W; }
     int64_t elems() const { return vox() * C; }
 };
@@ -198,6 +202,8 @@ struct Igemm2Fuse {
     float *osumA = nullptr, *osumB = nullptr;
     int split = 0;       // 0: all columns -> osumA; else columns < split -> osumA, others -> osumB
     int store_from = 0;  // columns below this are masked and summed but not stored (igemm4 only)
+    int mask_split = 0;  // igemm4 only: the mask source is a split concat (see View): columns >= mask_split at mask + mask_delta
+    long long mask_delta = 0;
 };
 
 extern unsigned long long *g_igemm2_dbg;
@@ -251,6 +257,7 @@ struct Igemm4Args {
     int nslots, plane_bytes;
     int in_pstride, out_pstride, in_bytes;
     int relu, accumulate, pair, store_from;
+    int in_split_ch, in_delta, out_split, out_delta, mask_split, mask_delta;   // split-concat views (floats)
     int tt_ints, pd_off, td_off, wbytes, abytes;   // table block in LDS (ints): tap table, then phase, then tile descriptors
     int dbg_repeat;
     unsigned long long *dbg;

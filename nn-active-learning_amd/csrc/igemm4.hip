@@ -137,9 +137,18 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         const int pt = ee >> 24, z = (ee >> 16) & 255, y = (ee >> 8) & 255, x = ee & 255;
         vbase[ms] = (pt * a.PZ + z * a.smz * a.PYX + y * a.smy * a.PX + x * a.smx) * G4_ROWB;
         evox[ms] = ((pt * a.OD + z * a.soz) * a.OH + y * a.soy) * a.OW + x * a.sox + (pair ? (lq >> 1) : 0);
-        eoff[ms] = evox[ms] * a.out_cs + a.out_c0 + cl;
+        eoff[ms] = evox[ms] * a.out_cs + a.out_c0;
         vpk[ms] = e;
         erow_ok = erow_ok && e >= 0;
+    }
+    // column -> float offset inside an output / mask row (a split concat keeps its second part delta floats away)
+    int coff[NTW], mcoff[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int c = nt * 16 + cl;
+        coff[nt] = (a.out_split && c >= a.out_split) ? a.out_delta + c - a.out_split : c;
+        const int mc = c - a.mask_from;
+        mcoff[nt] = (a.mask_split && c >= a.mask_split) ? a.mask_delta + c - a.mask_split : mc;
     }
     f32x4 bias4[NTW];
 #pragma unroll
@@ -212,7 +221,9 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         int soff = 0;
         if constexpr (!MULTI) {
             const i32x4 pd = ld4(a.pd_off + ph * 8);
-            soff = __builtin_amdgcn_readfirstlane((pd.x * a.in_cs + pd.y * 8) * 4);
+            int chl = pd.y, extra = 0;
+            if (a.in_split_ch && chl >= a.in_split_ch) { chl -= a.in_split_ch; extra = a.in_delta; }     // second part of a split concat
+            soff = __builtin_amdgcn_readfirstlane((pd.x * a.in_cs + chl * 8 + extra) * 4);
         }
 #pragma unroll
         for (int it = 0; it < G4_NSLOT; ++it)
@@ -263,7 +274,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 const int c = nt * 16 + cl;
                 Mk[ms][nt] = f32x4{1.f, 1.f, 1.f, 1.f};
                 if (live && c < a.Co && c >= a.mask_from && c < a.mask_to) {
-                    const int mo = (q_out + evox[ms]) * a.mask_cs + a.mask_c0 + (c - a.mask_from);
+                    const int mo = (q_out + evox[ms]) * a.mask_cs + a.mask_c0 + mcoff[nt];
                     Mk[ms][nt] = *reinterpret_cast<const f32x4 *>(maskb + (unsigned)(mo * 4));
                 }
             }
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 f32x4 val = acc[ms][nt];
                 const bool on = live && c < a.Co;
                 if (on) {
-                    f32x4 *dst = reinterpret_cast<f32x4 *>(outb + (unsigned)((obase_e + eoff[ms] + nt * 16) * 4));
+                    f32x4 *dst = reinterpret_cast<f32x4 *>(outb + (unsigned)((obase_e + eoff[ms] + coff[nt]) * 4));
                     if (a.accumulate) val += *dst;
                     if (a.relu) {
                         val.x = __builtin_amdgcn_fmed3f(val.x, 0.f, __builtin_inff());
@@ -307,7 +318,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                         } else {
                             mk = f32x4{1.f, 1.f, 1.f, 1.f};
                             if (c >= a.mask_from && c < a.mask_to) {
-                                const int mo = (q_out + evox[ms]) * a.mask_cs + a.mask_c0 + (c - a.mask_from);
+                                const int mo = (q_out + evox[ms]) * a.mask_cs + a.mask_c0 + mcoff[nt];
                                 mk = *reinterpret_cast<const f32x4 *>(maskb + (unsigned)(mo * 4));
                             }
                         }
@@ -1029,15 +1040,22 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
     ALQ_REQUIRE(in.C == plan.Ci && out.C == plan.Co, ALQ_EINVAL, "igemm4: channel counts do not match the plan");
     ALQ_REQUIRE(out.D == a.OD && out.H == a.OH && out.W == a.OW, ALQ_EINVAL, "igemm4: output view mismatch");
     ALQ_REQUIRE(plan.d_W && plan.d_tdesc, ALQ_EINVAL, "igemm4: weights not set");
-    ALQ_REQUIRE((long long)N * in.vox() * in.cs < (1LL << 29) && (long long)N * out.vox() * out.cs < (1LL << 29),
+    ALQ_REQUIRE(in.delta + (long long)N * in.vox() * in.cs < (1LL << 29) && out.delta + (long long)N * out.vox() * out.cs < (1LL << 29),
                 ALQ_EUNSUPPORTED, "igemm4: tensor exceeds the 32-bit byte-offset range (lower the batch)");
+    ALQ_REQUIRE(!in.split || (!plan.multi && in.split % 8 == 0 && in.cs == in.split && in.C == 2 * in.split && in.c0 == 0),
+                ALQ_EUNSUPPORTED, "igemm4: unsupported split input");
+    ALQ_REQUIRE(!out.split || (!a.pair && out.split % 4 == 0 && out.cs == out.split && out.C == 2 * out.split && out.c0 == 0),
+                ALQ_EUNSUPPORTED, "igemm4: unsupported split output");
     ALQ_REQUIRE(in.cs % 4 == 0 && in.c0 % 4 == 0 && out.cs % 4 == 0 && out.c0 % 4 == 0, ALQ_EUNSUPPORTED,
                 "igemm4: channel slice not 16-byte aligned");
     a.in = in.p; a.in_cs = in.cs; a.in_c0 = in.c0;
     a.out = out.p; a.out_cs = out.cs; a.out_c0 = out.c0;
     a.W = plan.d_W; a.bias = bias; a.relu = relu; a.accumulate = accumulate; a.N = N;
     a.tdesc = plan.d_tdesc; a.sdesc = plan.d_sdesc; a.pdesc = plan.d_pdesc; a.ttab = plan.d_ttab; a.vdesc = plan.d_vdesc;
-    a.in_bytes = (int)((long long)N * in.vox() * in.cs * 4);
+    a.in_bytes = (int)((in.delta + (long long)N * in.vox() * in.cs) * 4);
+    a.in_split_ch = in.split / 8; a.in_delta = (int)in.delta;
+    a.out_split = out.split; a.out_delta = (int)out.delta;
+    a.mask_split = 0; a.mask_delta = 0;
     a.dbg = nullptr;
     if (g_igemm2_dbg) {   // diagnostic: stamp only the launch whose ordinal (since the buffer was set) is ALQ_STAMP_ONLY
         static int want = -2;
@@ -1058,6 +1076,8 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
                     "igemm4: the pair form sums all 8 channels of a voxel");
         a.mask = fuse->mask; a.mask_cs = fuse->mask_cs; a.mask_c0 = fuse->mask_c0; a.mask_from = fuse->mask_from;
         a.mask_to = fuse->mask_to;
+        a.mask_split = fuse->mask_split; a.mask_delta = (int)fuse->mask_delta;
+        ALQ_REQUIRE(!a.mask_split || a.mask_from == 0, ALQ_EUNSUPPORTED, "igemm4: a split mask covers all columns");
         a.osumA = fuse->osumA; a.osumB = fuse->osumB;
         a.split = fuse->split > 0 ? fuse->split : (1 << 30);
         a.store_from = fuse->store_from;

@@ -241,7 +241,9 @@ static int gemm_launch(alq_ctx *ctx, const Gemm &g, const View &in, const View &
         if (fused) *fused = fuse != nullptr;
         return direct_launch(ctx, g.pd, in, out, bias, relu, N, fuse ? fuse->osumA : nullptr, PROF_DIRECT);
     }
-    if (g.p4.ok && !g_dbg_knobs[4] && !g_dbg_knobs[5]) {      // two-slot bf16x3 engine
+    const bool split_view = in.split != 0 || out.split != 0;
+    ALQ_REQUIRE(!split_view || g.p4.ok, ALQ_EUNSUPPORTED, "split concat view without a two-slot plan");
+    if (g.p4.ok && ((!g_dbg_knobs[4] && !g_dbg_knobs[5]) || split_view)) {      // two-slot bf16x3 engine
         if (fused) *fused = fuse != nullptr;
         return igemm4_launch(ctx, g.p4, in, out, bias, relu, accumulate, N,
                              cls == PROF_IGEMM_BWD ? PROF_IGEMM3_BWD : PROF_IGEMM3_FWD, fuse);
@@ -371,6 +373,40 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
         const size_t el = (size_t)NB * sh.D * sh.H * sh.W * (Cs + Cp);
         ALQ_TRY(m->dalloc(&buf, el));
         ALQ_TRY(m->dalloc(&dbuf, el));
+        // Split concat: when the consumer's forward and backward contractions both run on the two-slot engine, the
+        // two producers keep DENSE tensors (the halves of one allocation) and the consumer reads / writes them as
+        // two channel groups.  Interleaved slices cost twice the cache lines per staged or stored row (32 of 64
+        // bytes used), and the engine's staging and store parts are bound by lines touched.
+        bool split_ok = false;
+        if (Cs == Cp && Cs % 8 == 0 && specs[d].type == ALQ_CONV && !getenv("ALQ_DISABLE_V4") && !getenv("ALQ_NO_SPLIT")) {
+            const Layer &dl = m->layers[d];
+            G4Geom gf;
+            gf.kind = 0;
+            gf.ID = sh.D; gf.IH = sh.H; gf.IW = sh.W; gf.Ci = Cs + Cp;
+            gf.OD = outs[d].D; gf.OH = outs[d].H; gf.OW = outs[d].W; gf.Co = specs[d].cout;
+            for (int q = 0; q < 3; ++q) { gf.k[q] = specs[d].k[q]; gf.s[q] = specs[d].s[q]; gf.lo[q] = dl.lo[q]; }
+            G4Geom gb = gf;
+            gb.flipped = true;
+            gb.ID = outs[d].D; gb.IH = outs[d].H; gb.IW = outs[d].W; gb.Ci = specs[d].cout;
+            gb.OD = sh.D; gb.OH = sh.H; gb.OW = sh.W; gb.Co = Cs + Cp;
+            Igemm4Plan tf, tb;
+            ALQ_TRY(igemm4_build_plan(gf, NB, &tf));
+            ALQ_TRY(igemm4_build_plan(gb, NB, &tb));
+            split_ok = tf.ok && tb.ok && !tb.a.pair;
+        }
+        if (split_ok) {
+            const long long half = (long long)NB * sh.D * sh.H * sh.W * Cs;
+            act[s] = mkview(buf, sh, Cs, 0, Cs);
+            act[d - 1] = mkview(buf + half, sh, Cp, 0, Cp);
+            dact[s] = mkview(dbuf, sh, Cs, 0, Cs);
+            dact[d - 1] = mkview(dbuf + half, sh, Cp, 0, Cp);
+            catv[d] = mkview(buf, sh, Cs, 0, Cs + Cp);
+            catv[d].split = Cs; catv[d].delta = half;
+            dcatv[d] = mkview(dbuf, sh, Cs, 0, Cs + Cp);
+            dcatv[d].split = Cs; dcatv[d].delta = half;
+            m->layers[s].out_is_skip_src = true;
+            continue;
+        }
         act[s] = mkview(buf, sh, Cs + Cp, 0, Cs);
         act[d - 1] = mkview(buf, sh, Cs + Cp, Cs, Cp);
         dact[s] = mkview(dbuf, sh, Cs + Cp, 0, Cs);
@@ -717,12 +753,14 @@ static int run_backward(alq_model *m, const float *d_x, int N) {
                 if (Cs > 0) { fz.split = Cs; fz.osumB = prev->dsum; } else { fz.osumA = prev->dsum; }
                 // the skip source is the first parameterised layer and sits in front of a pool: nothing needs its
                 // cotangent except the channel sums, so mask and sum its columns here and do not store them
-                if (Cs > 0 && v4_on && ly.bwd.p4.ok) {
+                if (Cs > 0 && (v4_on || ly.din.split) && ly.bwd.p4.ok) {
                     Layer &sl = m->layers[ly.spec.skip_src];
                     const bool next_pool = ly.spec.skip_src + 1 < nl && pool_first_ok(m->layers[ly.spec.skip_src + 1], sl);
-                    if (next_pool && sl.out.p == prev->out.p && sl.out.cs == prev->out.cs && prev->out.c0 == sl.out.c0 + Cs &&
-                        (Cs & 3) == 0) {
+                    const bool sliced = sl.out.p == prev->out.p && sl.out.cs == prev->out.cs && prev->out.c0 == sl.out.c0 + Cs;
+                    const bool splitv = ly.in.split == Cs && sl.out.p == ly.in.p;
+                    if (next_pool && (sliced || splitv) && (Cs & 3) == 0) {
                         fz.mask = sl.out.p; fz.mask_cs = sl.out.cs; fz.mask_c0 = sl.out.c0; fz.mask_from = 0;
+                        if (splitv) { fz.mask_split = Cs; fz.mask_delta = ly.in.delta; }
                         if (!prev->spec.relu) fz.mask_to = Cs;
                         fz.osumA = sl.dsum; fz.store_from = Cs;
                         sl.dsum_partial = true;

@@ -392,6 +392,30 @@ def test_config3_netc_properties(sess):
     model2.close()
 
 
+@pytest.mark.parametrize('in_shape,n', [((24, 16, 40, 1), 5), ((8, 12, 20, 1), 7), ((16, 16, 16, 2), 3), ((20, 24, 12, 1), 2)])
+def test_netc_other_shapes_vs_fp64(sess, in_shape, n):
+    """NET-C on patch shapes that do not divide into the engines' tiles (partial tiles, several patches per tile,
+    odd pair counts, a 2-channel first layer) and on batch sizes that leave a ragged last group: layer scores
+    against an fp64 evaluation of the same network."""
+    torch = sess.torch
+    ld, sk = netspec.net_c()
+    pars = netspec.he_init(ld, in_shape, seed=21, skips=sk)
+    model = _device_model(sess, ld, in_shape, sk, pars, max_batch=4)          # n > max_batch: several passes
+    x = np.random.RandomState(77).randn(n, *in_shape).astype(np.float32)
+    xd = sess.to_device(x.reshape(n, -1), torch.float32)
+    r = model.fisher_device(xd, n, None, 1e-3)
+    pars64 = {k: [v[0].astype(np.float64), v[1].astype(np.float64)] for k, v in pars.items()}
+    om64 = OracleModel(ld, in_shape, pars64, skips=sk, dtype=torch.float64)
+    p64, S64, sizes = factored_ref.factored_unit_scores(om64, x.astype(np.float64))
+    g64, h64, A64 = factored_ref.fisher_from_unit(p64[1], S64, sizes, 1e-3)
+    assert np.abs(r['p1'].cpu().numpy() - p64[1]).max() <= 5e-6
+    for got, ref in ((r['g0'].cpu().numpy(), g64), (r['g1'].cpu().numpy(), h64)):
+        scale = np.abs(ref).max(axis=0, keepdims=True)                       # per layer
+        assert (np.abs(got - ref) <= 5e-4 * scale + 1e-9).all(), np.abs(got - ref).max()
+    np.testing.assert_allclose(r['A'].cpu().numpy(), A64, rtol=2e-3, atol=1e-3 * np.abs(A64 - 1e-3 * np.eye(A64.shape[1])).max())
+    model.close()
+
+
 def test_argument_errors(sess):
     from nnal_amd import device
     from nnal_amd._lib import AlqError

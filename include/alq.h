@@ -128,7 +128,8 @@ int alq_fisher(alq_model *m, const float *d_x, int N, const float *d_p1_in, doub
 
 /* ---- measurement hooks (bench.py only) -------------------------------------------------- */
 /* Per-kernel-class HIP-event timing on the context's stream.  alq_prof_enable(ctx, 1) makes
- * every launch of an instrumented kernel class record start/stop events;
+ * every launch of an instrumented kernel class record start/stop events; on = k > 1 samples the
+ * launches of every k-th alq_fisher pass only (the event pairs themselves cost a few percent);
  * alq_prof_read returns, for class `cls`, the accumulated milliseconds, launch count and
  * algorithmic FLOPs since the last alq_prof_reset (synchronises the stream).                 */
 int alq_prof_enable(alq_ctx *ctx, int on);

@@ -71,6 +71,9 @@ struct alq_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool prof_on = false;
+    int prof_every = 1;        // time the launches of every prof_every-th alq_fisher pass (event pairs cost ~6 % when on every launch)
+    long long prof_pass = 0;
+    bool prof_skip = false;    // this pass is not sampled
     void *param_block = nullptr;   // small device buffer for per-call parameters (gather)
     alq::ProfSlot prof[alq::PROF_NUM];
     int prof_begin(int cls, hipEvent_t *e0, hipEvent_t *e1);
@@ -87,7 +90,7 @@ struct ProfScope {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bool active = false;
     ProfScope(alq_ctx *c, int k, double f) : ctx(c), cls(k), flops(f) {
-        if (ctx->prof_on) active = (ctx->prof_begin(cls, &e0, &e1) == ALQ_OK);
+        if (ctx->prof_on && !ctx->prof_skip) active = (ctx->prof_begin(cls, &e0, &e1) == ALQ_OK);
     }
     ~ProfScope() {
         if (active) ctx->prof_end(cls, e0, e1, flops);

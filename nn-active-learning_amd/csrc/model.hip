@@ -1032,6 +1032,11 @@ int alq_fisher(alq_model *m, const float *d_x, int N, const float *d_p1_in, doub
         if (d_Asum) ALQ_HIP(hipMemsetAsync(d_Asum, 0, sizeof(double) * m->L * m->L, m->ctx->stream));
         return ALQ_OK;
     }
+    struct SkipGuard {       // sampled profiling: only every prof_every-th pass records events
+        alq_ctx *c;
+        explicit SkipGuard(alq_ctx *ctx) : c(ctx) { c->prof_skip = c->prof_on && (c->prof_pass++ % c->prof_every) != 0; }
+        ~SkipGuard() { c->prof_skip = false; }
+    } guard(m->ctx);
     ALQ_TRY(run_forward(m, d_x, N, true));
     ALQ_TRY(k_softmax(m->ctx, m->logits, m->nclass, N, m->post, nullptr));
     ALQ_TRY(run_backward(m, d_x, N));
@@ -1048,6 +1053,8 @@ static const char *kProfNames[PROF_NUM] = {"igemm_fwd", "igemm_bwd", "elementwis
 int alq_prof_enable(alq_ctx *ctx, int on) {
     ALQ_REQUIRE(ctx != nullptr, ALQ_EINVAL, "null ctx");
     ctx->prof_on = on != 0;
+    ctx->prof_every = on > 1 ? on : 1;
+    ctx->prof_pass = 0;
     return ALQ_OK;
 }
 

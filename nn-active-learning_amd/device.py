@@ -130,7 +130,8 @@ class DeviceSession(object):
 
     # -- measurement hooks ----------------------------------------------------------------
     def prof_enable(self, on=True):
-        check(self.lib.alq_prof_enable(self._ctx, 1 if on else 0))
+        """True / 1: time every launch; k > 1: the launches of every k-th Fisher pass; False / 0: off."""
+        check(self.lib.alq_prof_enable(self._ctx, int(on)))
 
     def prof_reset(self):
         check(self.lib.alq_prof_reset(self._ctx))

@@ -116,8 +116,13 @@ struct DirectPoolArgs {
 __global__ __launch_bounds__(256, 2) void direct_conv_pool_kernel(const DirectPoolArgs a) {
     constexpr int TWZ = 4, TWY = 8, TWX = 8;                 // windows per workgroup
     constexpr int HZ = 2 * TWZ + 2, HY = 2 * TWY + 2, HX = 2 * TWX + 2;
-    __shared__ __attribute__((aligned(16))) float Wl[27 * 8];
-    __shared__ __attribute__((aligned(16))) float Al[HZ * HY * HX];
+    // LDS: weights, the halo'd input block, and the whole 8 x 16 x 16 x 8 output block: threads own windows
+    // (x stride of 2 voxels between lanes), so direct stores would touch a new cache line per lane; the block is
+    // written to LDS in window order and stored by voxel-consecutive lanes as full 2 KB runs
+    extern __shared__ __attribute__((aligned(16))) float dcp_lds[];
+    float *Wl = dcp_lds;                                   // 27 * 8
+    float *Al = dcp_lds + 224;                             // HZ * HY * HX = 3240
+    float *Ol = dcp_lds + 224 + ((HZ * HY * HX + 3) & ~3); // 2048 voxels x 8
     const int tid = threadIdx.x;
     for (int i = tid; i < 27 * 8; i += 256) Wl[i] = a.W[i];
     int t = blockIdx.x;
@@ -127,21 +132,34 @@ __global__ __launch_bounds__(256, 2) void direct_conv_pool_kernel(const DirectPo
     const long long n = t;
     const int z0 = tz * 2 * TWZ, y0 = ty * 2 * TWY, x0 = tx * 2 * TWX;
     const float *src = a.in + n * (long long)a.D * a.H * a.Wd;
-    for (int i = tid; i < HZ * HY * HX; i += 256) {
-        int r = i;
-        const int hx = r % HX; r /= HX;
-        const int hy = r % HY;
-        const int hz = r / HY;
-        const int iz = z0 + hz - 1, iy = y0 + hy - 1, ix = x0 + hx - 1;
-        float v = 0.f;
-        if (iz >= 0 && iz < a.D && iy >= 0 && iy < a.H && ix >= 0 && ix < a.Wd) v = src[((long long)iz * a.H + iy) * a.Wd + ix];
-        Al[i] = v;
+    {   // all loads of the halo'd block first (13 in flight per thread), then the LDS writes: one memory latency
+        // per workgroup instead of one per element (the rolled loop made this phase the whole kernel time)
+        constexpr int NIT = (HZ * HY * HX + 255) / 256;
+        float stg[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            int r = i;
+            const int hx = r % HX; r /= HX;
+            const int hy = r % HY;
+            const int hz = r / HY;
+            const int iz = z0 + hz - 1, iy = y0 + hy - 1, ix = x0 + hx - 1;
+            float v = 0.f;
+            if (i < HZ * HY * HX && iz >= 0 && iz < a.D && iy >= 0 && iy < a.H && ix >= 0 && ix < a.Wd)
+                v = src[((long long)iz * a.H + iy) * a.Wd + ix];
+            stg[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            if (i < HZ * HY * HX) Al[i] = stg[it];
+        }
     }
     __syncthreads();
     const int wx = tid % TWX, wy = (tid / TWX) % TWY, wz = tid / (TWX * TWY);
     const int pz = tz * TWZ + wz, py = ty * TWY + wy, px = tx * TWX + wx;      // pooled coordinates
     const int PD = a.D / 2, PH = a.H / 2, PW = a.Wd / 2;
-    if (pz >= PD || py >= PH || px >= PW) return;
+    const bool wlive = pz < PD && py < PH && px < PW;
     // 4x4x4 input block in registers for the whole thread; the 8 output channels in two halves, so that only
     // 8 voxels x 4 channels of accumulators are live at a time (2 waves per SIMD)
     float in[4][4][4];
@@ -153,7 +171,6 @@ __global__ __launch_bounds__(256, 2) void direct_conv_pool_kernel(const DirectPo
             const f32x2 lo = *reinterpret_cast<const f32x2 *>(row), hi = *reinterpret_cast<const f32x2 *>(row + 2);
             in[p][q][0] = lo.x; in[p][q][1] = lo.y; in[p][q][2] = hi.x; in[p][q][3] = hi.y;
         }
-    float vsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float psum = 0.f;
     const long long pvox0 = ((n * PD + pz) * PH + py) * PW + px;
 #pragma unroll 1
@@ -187,8 +204,9 @@ __global__ __launch_bounds__(256, 2) void direct_conv_pool_kernel(const DirectPo
             float o[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) o[c] = a.relu ? fmaxf(acc[v][c], 0.f) : acc[v][c];
-            *reinterpret_cast<f32x4 *>(a.out + vox * a.out_cs + a.out_c0 + ch * 4) = f32x4{o[0], o[1], o[2], o[3]};
-            vsum[v] += (o[0] + o[1]) + (o[2] + o[3]);
+            (void)vox;
+            const int lv = ((2 * wz + (v >> 2)) * (2 * TWY) + 2 * wy + ((v >> 1) & 1)) * (2 * TWX) + 2 * wx + (v & 1);
+            *reinterpret_cast<f32x4 *>(Ol + lv * 8 + ch * 4) = f32x4{o[0], o[1], o[2], o[3]};
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 if (o[c] > best[c]) {               // window order (dz, dy, dx): first maximum wins
@@ -196,18 +214,31 @@ __global__ __launch_bounds__(256, 2) void direct_conv_pool_kernel(const DirectPo
                     bidx = (bidx & ~(255u << (8 * c))) | ((unsigned)v << (8 * c));
                 }
         }
-        *reinterpret_cast<f32x4 *>(a.pout + pvox0 * a.po_cs + a.po_c0 + ch * 4) = f32x4{best[0], best[1], best[2], best[3]};
-        a.argmax[pvox0 * 2 + ch] = bidx;
+        if (wlive) {
+            *reinterpret_cast<f32x4 *>(a.pout + pvox0 * a.po_cs + a.po_c0 + ch * 4) = f32x4{best[0], best[1], best[2], best[3]};
+            a.argmax[pvox0 * 2 + ch] = bidx;
+        }
         psum += (best[0] + best[1]) + (best[2] + best[3]);
     }
-    if (a.osum) {
-#pragma unroll
-        for (int v = 0; v < 8; ++v) {
-            const int z = 2 * pz + (v >> 2), y = 2 * py + ((v >> 1) & 1), x = 2 * px + (v & 1);
-            a.osum[((n * a.D + z) * a.H + y) * a.Wd + x] = vsum[v];
+    if (wlive && a.posum) a.posum[pvox0] = psum;
+    __syncthreads();
+    // voxel-consecutive lanes: 32 B per lane, 2 KB contiguous per wave along x
+    for (int lv = tid; lv < 2 * TWZ * 2 * TWY * 2 * TWX; lv += 256) {
+        const int lx = lv % (2 * TWX), ly = (lv / (2 * TWX)) % (2 * TWY), lz = lv / (2 * TWX * 2 * TWY);
+        const int z = z0 + lz, y = y0 + ly, x = x0 + lx;
+        if (z >= a.D || y >= a.H || x >= a.Wd) continue;
+        const long long vox = ((n * a.D + z) * a.H + y) * a.Wd + x;
+        const f32x4 g0 = *reinterpret_cast<const f32x4 *>(Ol + lv * 8), g1 = *reinterpret_cast<const f32x4 *>(Ol + lv * 8 + 4);
+        float *orow = a.out + vox * a.out_cs + a.out_c0;
+        *reinterpret_cast<f32x4 *>(orow) = g0;
+        *reinterpret_cast<f32x4 *>(orow + 4) = g1;
+        if (a.osum) {
+            float sum = 0.f;
+            sum += (g0.x + g0.y) + (g0.z + g0.w);
+            sum += (g1.x + g1.y) + (g1.z + g1.w);
+            a.osum[vox] = sum;
         }
     }
-    if (a.posum) a.posum[pvox0] = psum;
 }
 
 // eligibility is checked by the caller (model.hip): 3x3x3 SAME conv of one channel into 8, 2x2x2 pool, even dims
@@ -225,7 +256,10 @@ int direct_conv_pool_launch(alq_ctx *ctx, const float *d_W, const View &in, cons
     a.D = in.D; a.H = in.H; a.Wd = in.W; a.N = N; a.relu = relu;
     a.tilesZ = (pout.D + 3) / 4; a.tilesY = (pout.H + 7) / 8; a.tilesX = (pout.W + 7) / 8;
     ProfScope ps(ctx, PROF_DIRECT, flops_per_patch * N);
-    hipLaunchKernelGGL(direct_conv_pool_kernel, dim3((unsigned)((long long)N * a.tilesZ * a.tilesY * a.tilesX)), dim3(256), 0,
+    const size_t lds = (224 + 3240 + 2048 * 8) * sizeof(float);
+    ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(direct_conv_pool_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(direct_conv_pool_kernel, dim3((unsigned)((long long)N * a.tilesZ * a.tilesY * a.tilesX)), dim3(256), lds,
                        ctx->stream, a);
     ALQ_HIP(hipGetLastError());
     return ALQ_OK;

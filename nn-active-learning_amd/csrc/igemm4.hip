@@ -99,8 +99,21 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     char *Al = Wl + a.wbytes + h * a.abytes;
     {
         const char *Wg = reinterpret_cast<const char *>(a.W);
-        for (int i = tid * 16; i < a.wbytes; i += 512 * 16)
-            *reinterpret_cast<i32x4 *>(Wl + i) = *reinterpret_cast<const i32x4 *>(Wg + i);
+        // eight 16-byte loads in flight per thread (the rolled copy paid one L2 latency per 8 KB of weights: ~15 us
+        // at the head of a launch with 86 KB resident)
+        for (int i0 = tid * 16; i0 < a.wbytes; i0 += 8 * 512 * 16) {
+            i32x4 w8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 512 * 16;
+                w8[u] = (i < a.wbytes) ? *reinterpret_cast<const i32x4 *>(Wg + i) : i32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 512 * 16;
+                if (i < a.wbytes) *reinterpret_cast<i32x4 *>(Wl + i) = w8[u];
+            }
+        }
         for (int i = tid; i < a.tt_ints; i += 512) Tl[i] = a.ttab[i];
     }
 

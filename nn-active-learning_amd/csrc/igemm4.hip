@@ -449,14 +449,17 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             PHASE4_END(5);
             if (a_i < n_ph) {
                 if (a_ph == 0) { c_out = f_out; c_full = f_full; c_l = f_l; c_g = f_g; }
-                if constexpr (MASK_PF) { if (a_ph == 0 && have_pend && a.mask) load_mask(p_out, p_full, p_l, p_g); }
-                stash();
-                PHASE4_END(0);
+                // Epilogue first, then the split: the epilogue's mask values were requested at the start of the
+                // tile's last contraction, the split's operands at the end of the previous staging part; with
+                // vmcnt in issue order and the compiler waiting conservatively, either wait only ever meets
+                // loads that have had a whole tick to land.
                 if (a_ph == 0 && have_pend) {
                     flush(p_out, p_full, p_l, p_g);
                     have_pend = false;
                 }
                 PHASE4_END(1);
+                stash();
+                PHASE4_END(0);
                 int nph = a_ph + 1;
                 if (nph == a.nph) {
                     nph = 0;
@@ -475,6 +478,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 if constexpr (!MULTI) {
                     const i32x4 pdA = ld4(a.pd_off + b_ph * 8), pdB = ld4(a.pd_off + b_ph * 8 + 4);
                     const int pd[5] = {0, 0, __builtin_amdgcn_readfirstlane(pdA.z), pdA.w, pdB.x};
+                    if constexpr (MASK_PF) { if (b_ph == a.nph - 1 && a.mask) load_mask(c_out, c_full, c_l, c_g); }
                     if (b_ph == 0) init_acc();
                     for (int rep = 0; rep <= a.dbg_repeat; ++rep)
                         unit(pd[2], Wl + pd[3] + lane * 16, Al, pd[4]);
@@ -507,7 +511,6 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         __syncthreads();
     }
     if (have_pend) {
-        if constexpr (MASK_PF) { if (a.mask) load_mask(p_out, p_full, p_l, p_g); }
         flush(p_out, p_full, p_l, p_g);
     }
 #ifdef ALQ_STAMPS

@@ -65,7 +65,7 @@ def main():
     import nnal_amd  # noqa: F401
     from nnal_amd import device, pool_shard
     from nnal_amd._lib import check
-    from oracle import netspec   # network definition + seeded weight draw only (not timed)
+    from nnal_amd import netspec   # network definition + seeded weight draw (product copy; not timed)
 
     sess = device.DeviceSession(local_rank)
     ld, sk = netspec.net_c()

@@ -113,6 +113,16 @@ size_t alq_topk_work_bytes(int64_t n);
 int alq_topk_uncertain(alq_ctx *ctx, const double *d_keys, int64_t n, int64_t B,
                        int64_t *d_out_idx, void *d_work);
 
+/* Multi-GPU top-B merge step (no reference counterpart: the reference is one process).
+ * Host function: merges the candidate (key, GLOBAL index) pairs gathered from all ranks
+ * (torch.distributed all_gather over RCCL in pool_shard.merge_topB; entries with index < 0 are padding)
+ * into the global top-B, ascending key, ties -> lower global index: the rule of alq_topk_uncertain,
+ * so the result is identical on every rank.  out_idx: int64 [B]; returns the count in *n_out.
+ * The L x L Fisher-sum all-reduce needs a communicator and stays in torch.distributed
+ * (pool_shard.allreduce_sum).                                                                    */
+int alq_topk_merge(const double *h_keys, const int64_t *h_idx, int64_t n, int64_t B, int64_t *h_out_idx,
+                   int64_t *n_out);
+
 /* ---- Fisher scoring --------------------------------------------------------------------- */
 /* Replaces: the per-sample loop of PW_NNAL.gen_A_matrices (PW_NNAL.py:757-814): up to two
  * sess.run(model.grad_posts[j]) at batch 1, NNAL_tools.shrink_gradient(...,'sum')

@@ -41,6 +41,7 @@ _SIGNATURES = {
     'alq_score_entropy': (C.c_int, [_P, _P, C.c_int64, _P, _P]),
     'alq_topk_work_bytes': (C.c_size_t, [C.c_int64]),
     'alq_topk_uncertain': (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P]),
+    'alq_topk_merge': (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P]),
     'alq_fisher': (C.c_int, [_P, _P, C.c_int, _P, C.c_double, _P, _P, _P, _P, _P, _P]),
     'alq_prof_enable': (C.c_int, [_P, C.c_int]),
     'alq_prof_reset': (C.c_int, [_P]),

@@ -1047,6 +1047,21 @@ int alq_fisher(alq_model *m, const float *d_x, int N, const float *d_p1_in, doub
     return ALQ_OK;
 }
 
+int alq_topk_merge(const double *h_keys, const int64_t *h_idx, int64_t n, int64_t B, int64_t *h_out_idx,
+                   int64_t *n_out) {
+    ALQ_REQUIRE(n >= 0 && B >= 0 && (n == 0 || (h_keys && h_idx)) && (B == 0 || h_out_idx) && n_out, ALQ_EINVAL,
+                "alq_topk_merge: bad argument");
+    std::vector<std::pair<double, int64_t>> v;
+    v.reserve((size_t)n);
+    for (int64_t i = 0; i < n; ++i)
+        if (h_idx[i] >= 0) v.emplace_back(h_keys[i], h_idx[i]);
+    std::sort(v.begin(), v.end());          // key, then global index
+    const int64_t m = std::min<int64_t>(B, (int64_t)v.size());
+    for (int64_t i = 0; i < m; ++i) h_out_idx[i] = v[(size_t)i].second;
+    *n_out = m;
+    return ALQ_OK;
+}
+
 static const char *kProfNames[PROF_NUM] = {"igemm_fwd", "igemm_bwd", "elementwise", "reduce", "fc_small",
                                            "igemm3_fwd", "igemm3_bwd", "direct_conv"};
 

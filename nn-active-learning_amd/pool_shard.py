@@ -48,6 +48,19 @@ def allreduce_sum(mat):
     return t.cpu().numpy()
 
 
+def _topk_merge(keys, gidx, B):
+    """alq_topk_merge (include/alq.h): ascending key, ties -> lower global index, padding (index < 0) dropped."""
+    import ctypes as C
+    from ._lib import lib, check
+    k = np.ascontiguousarray(keys, dtype=np.float64)
+    g = np.ascontiguousarray(gidx, dtype=np.int64)
+    out = np.empty(max(int(B), 1), dtype=np.int64)
+    n_out = C.c_int64(0)
+    check(lib().alq_topk_merge(k.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p), len(k), int(B),
+                               out.ctypes.data_as(C.c_void_p), C.byref(n_out)))
+    return out[:n_out.value].copy()
+
+
 def merge_topB(local_keys, local_global_idx, B):
     """Every rank passes its local candidates (ascending or not) as (key, GLOBAL index); returns the
     global top-B index list, ascending key, ties -> lower global index, identical on all ranks.
@@ -75,10 +88,7 @@ def merge_topB(local_keys, local_global_idx, B):
         dist.all_gather(lg, tg)
         k = torch.cat(lk).cpu().numpy()
         g = torch.cat(lg).cpu().numpy()
-        keep = g >= 0
-        k, g = k[keep], g[keep]
-    o = np.lexsort((g, k))[:B]
-    return g[o]
+    return _topk_merge(k, g, B)
 
 
 def max_over_ranks(value):

@@ -135,3 +135,42 @@ def test_merge_topB_single_process():
     g = np.array([10, 7, 3, 5])
     np.testing.assert_array_equal(pool_shard.merge_topB(k, g, 3), [3, 7, 5])
     np.testing.assert_array_equal(pool_shard.allreduce_sum(np.eye(2)), np.eye(2))
+
+
+def test_product_netspec_matches_the_oracle_copy():
+    """bench.py and al_loop build their models from the product's netspec; the oracle keeps its own copy."""
+    import nnal_amd  # noqa: F401
+    from nnal_amd import netspec as prod
+    from oracle import netspec as orc
+    for mk, shape in (('net_a', (32, 32, 1)), ('net_b_small', (25, 25, 2)), ('net_c_2d', (16, 16, 1))):
+        a, b = getattr(prod, mk)(), getattr(orc, mk)()
+        sk = ()
+        if isinstance(a, tuple):
+            (a, sk), (b, _) = a, b
+        assert list(a.items()) == list(b.items())
+        pa, pb = prod.he_init(a, shape, seed=5, skips=sk), orc.he_init(b, shape, seed=5, skips=sk)
+        assert list(pa) == list(pb)
+        for k in pa:
+            np.testing.assert_array_equal(pa[k][0], pb[k][0])
+            np.testing.assert_array_equal(pa[k][1], pb[k][1])
+    (la, ska), (lb, skb) = prod.net_c(), orc.net_c()
+    assert list(la.items()) == list(lb.items()) and ska == skb
+
+
+def test_topk_merge_c_abi():
+    """alq_topk_merge: ascending key, ties -> lower global index, padding dropped (host function, no GPU)."""
+    import ctypes as C
+    import nnal_amd  # noqa: F401
+    from nnal_amd._lib import lib, check
+    rs = np.random.RandomState(3)
+    k = np.round(rs.rand(500), 2)                   # many ties
+    g = rs.permutation(5000)[:500].astype(np.int64)
+    g[::7] = -1                                     # padding
+    out = np.empty(64, np.int64)
+    n_out = C.c_int64(0)
+    check(lib().alq_topk_merge(k.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p), 500, 64,
+                               out.ctypes.data_as(C.c_void_p), C.byref(n_out)))
+    keep = g >= 0
+    want = g[keep][np.lexsort((g[keep], k[keep]))][:64]
+    assert n_out.value == 64
+    np.testing.assert_array_equal(out, want)

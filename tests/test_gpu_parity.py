@@ -416,6 +416,48 @@ def test_netc_other_shapes_vs_fp64(sess, in_shape, n):
     model.close()
 
 
+def test_config5_loop_harness(sess):
+    """Config 5 control flow (PW_AL.Experiment_MultiImg.run_method between fine-tunes) at reduced size: entropy
+    filter -> Fisher on the B candidates -> query distribution -> k draws -> removal, three rounds.  Checks the
+    bookkeeping, run-to-run determinism, the filter against the host rule and the A matrices against the oracle."""
+    from nnal_amd import al_loop, PW_NNAL
+    torch = sess.torch
+    ld, sk = netspec.net_c()
+    in_shape = (16, 16, 16, 1)
+    pars = netspec.he_init(ld, in_shape, seed=15, skips=sk)
+    model = _device_model(sess, ld, in_shape, sk, pars, max_batch=128)
+    n, B, k = 1500, 96, 10
+    x = np.random.RandomState(1005).randn(n, *in_shape).astype(np.float32)
+    pool = sess.to_device(x.reshape(n, -1), torch.float32)
+    r1 = al_loop.run_rounds(model, sess, pool, 3, B, k, seed=15)
+    r2 = al_loop.run_rounds(model, sess, pool, 3, B, k, seed=15)
+    taken = np.zeros(0, np.int64)
+    left = n
+    for a, b in zip(r1, r2):
+        np.testing.assert_array_equal(a['queries'], b['queries'])
+        np.testing.assert_array_equal(a['candidates'], b['candidates'])
+        assert 1 <= len(a['queries']) <= k and len(np.unique(a['queries'])) == len(a['queries'])
+        assert np.isin(a['queries'], a['candidates']).all() and not np.isin(a['queries'], taken).any()
+        assert not np.isin(a['candidates'], taken).any()
+        taken = np.concatenate([taken, a['queries']])
+        left -= len(a['queries'])
+        assert a['pool_left'] == left
+        assert a['sdp']['gap'] < 1e-3, a['sdp']                 # KKT gap of the A-optimal design
+        assert abs(a['q'].sum() - 1) < 1e-9 and a['q'].min() >= 0
+    # round 0 against the oracle: the filter on the device posteriors, the A matrices per sample
+    om = OracleModel(ld, in_shape, pars, skips=sk)
+    p_ref = om.forward(x)['posteriors'][1]
+    p_dev = model.forward(x)['posteriors'][1]
+    np.testing.assert_allclose(p_dev, p_ref, rtol=0, atol=P_ATOL)
+    np.testing.assert_array_equal(r1[0]['candidates'], PW_NNAL.binary_uncertainty_filter(p_dev.astype(np.float64), B))
+    osess = OracleSession(om)
+    c = r1[0]['candidates'][:8]
+    A_ref = np.stack(alpath.gen_A_matrices(Expr({'patch_shape': in_shape[:3]}), om, osess, x[c],
+                                           r1[0]['posts'][:8].astype(np.float64), 1e-3))
+    assert_scores_close(r1[0]['A'][:8], A_ref, SCORE_ATOL * 0.1, A_RTOL, 1e-6)
+    model.close()
+
+
 def test_argument_errors(sess):
     from nnal_amd import device
     from nnal_amd._lib import AlqError

@@ -328,12 +328,25 @@ int direct_conv_pool_launch(alq_ctx *ctx, const float *d_W, const View &in, cons
                             const float *bias, int relu, uint8_t *argmax, float *osum, float *posum, int N,
                             double flops_per_patch);
 
+// ------------------------------------------------------------------ wide fc layers (fcgemm.hip)
+struct FcGemmPlan {
+    bool ok = false;
+    int K = 0, N = 0;
+    std::vector<unsigned short> h_W;   // [feature tile][k-step][piece][k-group][feature row][8] bf16 bits
+    void *d_W = nullptr;
+};
+int fcgemm_build_plan(int K, int N, FcGemmPlan *plan);
+void fcgemm_pack_weights(FcGemmPlan *plan, const std::vector<float> &Bmat /* [K][N] */);
+int fcgemm_launch(alq_ctx *ctx, const FcGemmPlan &plan, const View &in, const View &out, const float *bias, int relu,
+                  int M, int prof_cls);
+
 // one contraction = general plan + (when eligible) pipelined plan / direct first-layer plan
 struct Gemm {
     IgemmPlan p1;
     Igemm2Plan p2;
     Igemm3Plan p3;
     Igemm4Plan p4;
+    FcGemmPlan pfc;
     DirectPlan pd;
 };
 

@@ -1,0 +1,223 @@
+// Streaming GEMM for wide fully connected layers (NN.create_PW1's 6144 -> 4096 -> 4096): C = A * B + bias.
+//
+//   A [M x K] fp32 activations (M = patches of the batch), B [K x N] weights, C [M x N] fp32.
+//
+// Same arithmetic as the conv engines: every fp32 operand = hi + mid + lo bf16 (exact), six piece products on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  Unlike a convolution nothing is reused across taps, so both
+// operands stream: a workgroup owns a 128 (patches) x 64 (features) tile of C and walks K in steps of 32;
+// the weights are split and tiled on the host once (one contiguous 12 KB block per (feature tile, k-step), copied
+// to LDS as it is), the activations are split on the way from registers to LDS; LDS is double buffered and the
+// global loads of step k+1 are issued before the MFMAs of step k.
+// LDS layout of either operand: [piece][k-group q = 0..3][row] x 16 bytes (8 bf16 along k): the 16 lanes of a
+// ds_read_b128 lane group (8 rows of group q, 8 rows of group q+1) hit 16 different 16-byte bank granules.
+// The weights are the MFMA A operand (rows = features), so a lane ends up with 4 consecutive features of one
+// patch: 16-byte stores.
+#include "alq_internal.h"
+
+#include <cstring>
+
+namespace alq {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int FC_BM = 128, FC_BN = 64, FC_BK = 32;
+constexpr int FC_XBYTES = 3 * 4 * FC_BM * 16;      // 24 KB
+constexpr int FC_WBYTES = 3 * 4 * FC_BN * 16;      // 12 KB
+
+__device__ inline unsigned fc_split2(float &a, float &b) {
+    const bf16x2 h = __builtin_convertvector(f32x2{a, b}, bf16x2);
+    const unsigned hb = __builtin_bit_cast(unsigned, h);
+    a -= __builtin_bit_cast(float, hb << 16);
+    b -= __builtin_bit_cast(float, hb & 0xffff0000u);
+    return hb;
+}
+__device__ inline unsigned fc_pack2(float a, float b) {
+    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, a), 0x07060302u);
+}
+
+struct FcGemmArgs {
+    const float *A;
+    const void *Bp;
+    float *C;
+    const float *bias;
+    int M, N, K, lda, ldc, relu;
+};
+
+__global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char fc_lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 15, lq = lane >> 4;
+    const int nt = blockIdx.x, mt = blockIdx.y;
+    const int m0 = mt * FC_BM, n0 = nt * FC_BN;
+    const int nks = a.K / FC_BK;
+    auto Xbuf = [&](int buf) { return fc_lds + buf * (FC_XBYTES + FC_WBYTES); };
+    auto Wbuf = [&](int buf) { return fc_lds + buf * (FC_XBYTES + FC_WBYTES) + FC_XBYTES; };
+
+    // staging roles: activations: 2 tasks per thread, task = (row, k-group): 8 floats; weights: 3 x 16 B per thread
+    const int xr0 = tid >> 2, xq = tid & 3;          // rows xr0 and xr0 + 64, k-group xq
+    const char *wsrc = reinterpret_cast<const char *>(a.Bp) + (size_t)nt * nks * FC_WBYTES + tid * 16;
+    f32x4 xa[2][2];
+    i32x4 wr[3];
+    auto fetch = [&](int ks) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int row = m0 + xr0 + t * 64;
+            const float *src = a.A + (size_t)row * a.lda + ks * FC_BK + xq * 8;
+            if (row < a.M) {
+                xa[t][0] = *reinterpret_cast<const f32x4 *>(src);
+                xa[t][1] = *reinterpret_cast<const f32x4 *>(src + 4);
+            } else {
+                xa[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                xa[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        const char *ws = wsrc + (size_t)ks * FC_WBYTES;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) wr[j] = *reinterpret_cast<const i32x4 *>(ws + j * 4096);
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float v[8] = {xa[t][0].x, xa[t][0].y, xa[t][0].z, xa[t][0].w, xa[t][1].x, xa[t][1].y, xa[t][1].z, xa[t][1].w};
+            i32x4 pc[3];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                pc[p].x = (int)fc_split2(v[0], v[1]); pc[p].y = (int)fc_split2(v[2], v[3]);
+                pc[p].z = (int)fc_split2(v[4], v[5]); pc[p].w = (int)fc_split2(v[6], v[7]);
+            }
+            pc[2].x = (int)fc_pack2(v[0], v[1]); pc[2].y = (int)fc_pack2(v[2], v[3]);
+            pc[2].z = (int)fc_pack2(v[4], v[5]); pc[2].w = (int)fc_pack2(v[6], v[7]);
+            const int row = xr0 + t * 64;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<i32x4 *>(Xbuf(buf) + ((p * 4 + xq) * FC_BM + row) * 16) = pc[p];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) *reinterpret_cast<i32x4 *>(Wbuf(buf) + tid * 16 + j * 4096) = wr[j];
+    };
+
+    // wave tile: 64 patches x 32 features = 4 x 2 MFMA tiles
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 32;
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int n = n0 + wn + ni * 16 + lq * 4;
+            if (a.bias) acc[mi][ni] = *reinterpret_cast<const f32x4 *>(a.bias + n);
+        }
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int ks = 0; ks < nks; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nks) fetch(ks + 1);
+        bf16x8 Wf[3][2], Xf[3][4];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                Wf[p][ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4 *>(Wbuf(buf) + ((p * 4 + lq) * FC_BN + wn + ni * 16 + lrow) * 16));
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                Xf[p][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4 *>(Xbuf(buf) + ((p * 4 + lq) * FC_BM + wm + mi * 16 + lrow) * 16));
+        }
+        // six piece products, smallest first
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                f32x4 c = acc[mi][ni];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[1][ni], Xf[1][mi], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[2][ni], Xf[0][mi], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[0][ni], Xf[2][mi], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[1][ni], Xf[0][mi], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[0][ni], Xf[1][mi], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[0][ni], Xf[0][mi], c, 0, 0, 0);
+                acc[mi][ni] = c;
+            }
+        if (ks + 1 < nks) stash(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm + mi * 16 + lrow;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            f32x4 v = acc[mi][ni];
+            if (a.relu) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            *reinterpret_cast<f32x4 *>(a.C + (size_t)m * a.ldc + n0 + wn + ni * 16 + lq * 4) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+int fcgemm_build_plan(int K, int N, FcGemmPlan *plan) {
+    plan->ok = false;
+    if (K % FC_BK != 0 || N % FC_BN != 0 || K < 256 || N < 256) return ALQ_OK;
+    plan->K = K; plan->N = N;
+    plan->ok = true;
+    return ALQ_OK;
+}
+
+static unsigned short fc_bf16_rne(float x) {
+    unsigned u;
+    std::memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+static float fc_bf16_to_f(unsigned short hb) {
+    const unsigned u = (unsigned)hb << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+// packed: [feature tile][k-step][piece][k-group q][feature row][8 bf16 along k]
+void fcgemm_pack_weights(FcGemmPlan *plan, const std::vector<float> &Bmat /* [K][N] */) {
+    const int K = plan->K, N = plan->N;
+    const int nks = K / FC_BK, ntl = N / FC_BN;
+    plan->h_W.assign((size_t)K * N * 3, 0);
+    for (int nt = 0; nt < ntl; ++nt)
+        for (int ks = 0; ks < nks; ++ks) {
+            unsigned short *blk = &plan->h_W[((size_t)nt * nks + ks) * (FC_WBYTES / 2)];
+            for (int q = 0; q < 4; ++q)
+                for (int r = 0; r < FC_BN; ++r)
+                    for (int j = 0; j < 8; ++j) {
+                        float w = Bmat[(size_t)(ks * FC_BK + q * 8 + j) * N + nt * FC_BN + r];
+                        for (int p = 0; p < 3; ++p) {
+                            const unsigned short hb = fc_bf16_rne(w);
+                            w -= fc_bf16_to_f(hb);
+                            blk[((size_t)(p * 4 + q) * FC_BN + r) * 8 + j] = hb;
+                        }
+                    }
+        }
+}
+
+int fcgemm_launch(alq_ctx *ctx, const FcGemmPlan &plan, const View &in, const View &out, const float *bias, int relu,
+                  int M, int prof_cls) {
+    ALQ_REQUIRE(plan.d_W && in.C == plan.K && out.C == plan.N && in.c0 == 0 && out.c0 == 0 && in.cs % 4 == 0 && out.cs % 4 == 0 &&
+                    in.vox() == 1 && out.vox() == 1,
+                ALQ_EINVAL, "fcgemm: views do not match the plan");
+    FcGemmArgs a;
+    a.A = in.p; a.Bp = plan.d_W; a.C = out.p; a.bias = bias;
+    a.M = M; a.N = plan.N; a.K = plan.K; a.lda = in.cs; a.ldc = out.cs; a.relu = relu;
+    const size_t lds = 2 * (FC_XBYTES + FC_WBYTES);
+    ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fcgemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope ps(ctx, prof_cls, 2.0 * M * (double)plan.K * plan.N);
+    hipLaunchKernelGGL(fcgemm_kernel, dim3(plan.N / FC_BN, (M + FC_BM - 1) / FC_BM), dim3(256), lds, ctx->stream, a);
+    ALQ_HIP(hipGetLastError());
+    return ALQ_OK;
+}
+
+}  // namespace alq

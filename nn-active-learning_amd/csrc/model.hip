@@ -166,6 +166,8 @@ static int gemm_build(const ConvDesc &d, int max_batch, Gemm *g, const G4Geom *g
     ALQ_TRY(direct_build_plan(g->p1, &g->pd));
     if (!g_use_v2) { g->p2.ok = false; g->pd.ok = false; }
     ALQ_TRY(igemm3_build_plan(g->p2, &g->p3));
+    if (d.ID == 1 && d.IH == 1 && d.IW == 1 && d.tz.size() == 1 && d.sm == 1 && d.so == 1 && !getenv("ALQ_NO_FCGEMM"))
+        ALQ_TRY(fcgemm_build_plan(d.Ci, d.Co, &g->pfc));       // a wide fully connected layer
     if (const char *e = getenv("ALQ_DISABLE_V3")) { if (e[0] == '1') g->p3.ok = false; }
     return ALQ_OK;
 }
@@ -196,6 +198,16 @@ static int set4(alq_model *m, Igemm4Plan *p4, const std::vector<float> &Bmat) {
 
 static int gemm_set(alq_model *m, Gemm *g, const std::vector<float> &Bmat) {
     if (g->p4.ok) ALQ_TRY(set4(m, &g->p4, Bmat));
+    if (g->pfc.ok) {
+        fcgemm_pack_weights(&g->pfc, Bmat);
+        unsigned short *dw = reinterpret_cast<unsigned short *>(g->pfc.d_W);
+        if (!dw) ALQ_TRY(m->dalloc(&dw, g->pfc.h_W.size()));
+        g->pfc.d_W = dw;
+        ALQ_HIP(hipMemcpyAsync(dw, g->pfc.h_W.data(), g->pfc.h_W.size() * sizeof(unsigned short), hipMemcpyHostToDevice,
+                               m->ctx->stream));
+        ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
+        std::vector<unsigned short>().swap(g->pfc.h_W);
+    }
     if (g->pd.ok) {      // direct kernel reads the B matrix [K][Co] as it is
         if (!g->pd.d_W) ALQ_TRY(m->dalloc(&g->pd.d_W, Bmat.size()));
         ALQ_HIP(hipMemcpyAsync(g->pd.d_W, Bmat.data(), Bmat.size() * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
@@ -240,6 +252,10 @@ static int gemm_launch(alq_ctx *ctx, const Gemm &g, const View &in, const View &
     if (g.pd.ok && !accumulate && !(fuse && (fuse->mask || fuse->osumB || fuse->split))) {
         if (fused) *fused = fuse != nullptr;
         return direct_launch(ctx, g.pd, in, out, bias, relu, N, fuse ? fuse->osumA : nullptr, PROF_DIRECT);
+    }
+    if (g.pfc.ok && !accumulate && !fuse && !g_dbg_knobs[4] && !g_dbg_knobs[5]) {     // wide fc layer: streaming bf16x3 GEMM
+        if (fused) *fused = false;
+        return fcgemm_launch(ctx, g.pfc, in, out, bias, relu, N, cls == PROF_IGEMM_BWD ? PROF_IGEMM3_BWD : PROF_IGEMM3_FWD);
     }
     const bool split_view = in.split != 0 || out.split != 0;
     ALQ_REQUIRE(!split_view || g.p4.ok, ALQ_EUNSUPPORTED, "split concat view without a two-slot plan");

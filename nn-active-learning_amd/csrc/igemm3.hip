@@ -85,9 +85,20 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(const Igemm2Args a) {
     constexpr int NSLOT = I3_MAXSLOT;
     const char *Wg = reinterpret_cast<const char *>(a.W);
 
-    if constexpr (WRES) {
-        for (int i = tid * 16; i < Wbytes; i += 4096)
-            *reinterpret_cast<i32x4 *>(Wl + i) = *reinterpret_cast<const i32x4 *>(Wg + i);
+    if constexpr (WRES) {       // eight loads in flight per thread (a rolled copy pays one L2 latency per 4 KB)
+        for (int i0 = tid * 16; i0 < Wbytes; i0 += 8 * 4096) {
+            i32x4 w8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 4096;
+                w8[u] = (i < Wbytes) ? *reinterpret_cast<const i32x4 *>(Wg + i) : i32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 4096;
+                if (i < Wbytes) *reinterpret_cast<i32x4 *>(Wl + i) = w8[u];
+            }
+        }
     }
 
     // ---- per-thread A staging slots (halo voxel, half) from the host-built slot table ------------

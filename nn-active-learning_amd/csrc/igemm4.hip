@@ -48,7 +48,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
         t_last = t_now_;                       \
     } while (0)
 #else
-#define PHASE4_END(idx) do {} while (0)
+// keeps the compiler from moving memory operations across the part boundaries (measured: without it the
+// restructured loop ran 35 % slower than the stamped diagnostic build of the same source)
+#define PHASE4_END(idx) __builtin_amdgcn_sched_barrier(0)
 #endif
 
 constexpr int G4_ROWB = 48;      // bytes per staged voxel row: [hi8 | mid8 | lo8] bf16
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
 
     // tile / phase descriptors live in LDS next to the tap table: a broadcast ds_read costs ~100 cycles where a
     // scalar load from L2 cost 500+ per tile under load (phase stamps), and the values need no SGPRs
-    auto ld4 = [&](int int_off) { return *reinterpret_cast<const i32x4 *>(Tl + int_off); };
+    auto ld4 = [&](int int_off) __attribute__((always_inline)) { return *reinterpret_cast<const i32x4 *>(Tl + int_off); };
 
     // ---- staging slots of this thread --------------------------------------------------------------
     int s_rel[G4_NSLOT], s_pk[G4_NSLOT], s_lds[G4_NSLOT];
@@ -179,10 +181,9 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     const int n_mine = me < total ? (total - me + nwork - 1) / nwork : 0;
     const int oth = me ^ 1;
     const int n_oth = oth < total ? (total - oth + nwork - 1) / nwork : 0;
-    const int nticks = 2 * (n_mine > n_oth ? n_mine : n_oth) * a.nph + 2;
     const int gp = nwork / a.tpg, gl = nwork % a.tpg;
     int fpg = me / a.tpg, fl = me % a.tpg;
-    auto advance_cursor = [&]() {
+    auto advance_cursor = [&]() __attribute__((always_inline)) {
         fl += gl;
         const int c = fl >= a.tpg;
         fl -= c ? a.tpg : 0;
@@ -195,11 +196,11 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     bool have_pend = false;
 
     int goff[G4_NSLOT];
-    auto park = [&]() {
+    auto park = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < G4_NSLOT; ++it) goff[it] = G4_OOB;
     };
-    auto locate = [&]() {
+    auto locate = [&]() __attribute__((always_inline)) {
         const i32x4 t0 = ld4(a.td_off + fl * 8);
         const i32x4 t1 = ld4(a.td_off + fl * 8 + 4);
         const int org = (t0.x + fpg * a.in_pstride) * a.in_cs;
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
     // the ONE prefetch site: unconditional loads, a slot without work points past the buffer
-    auto fetch = [&](int ph) {
+    auto fetch = [&](int ph) __attribute__((always_inline)) {
         int soff = 0;
         if constexpr (!MULTI) {
             const i32x4 pd = ld4(a.pd_off + ph * 8);
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         for (int it = 0; it < G4_NSLOT; ++it)
             R[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, goff[it], soff, 0));
     };
-    auto stash = [&]() {
+    auto stash = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < G4_NSLOT; ++it) {
             if (s_lds[it] >= 0) {
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     // latency is behind ~1 us of split / LDS-store instructions when the epilogue consumes them
     constexpr bool MASK_PF = (NTW == 1);      // with two column tiles the 32 extra registers spill: load in the epilogue
     f32x4 Mk[MASK_PF ? 4 : 1][NTW];
-    auto load_mask = [&](int q_out, int q_full, int q_l, int q_g) {
+    auto load_mask = [&](int q_out, int q_full, int q_l, int q_g) __attribute__((always_inline)) {
         if constexpr (MASK_PF) {
         int mz0 = 0, my0 = 0, mx0 = 0;
         if (!q_full) {
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         }
         }
     };
-    auto flush = [&](int q_out, int q_full, int q_l, int q_g) {
+    auto flush = [&](int q_out, int q_full, int q_l, int q_g) __attribute__((always_inline)) {
         const int obase_e = q_out * a.out_cs;
         int mz0 = 0, my0 = 0, mx0 = 0;
         if (!q_full) {
@@ -363,9 +364,9 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     };
 
     // ---------------- one unit: S k-steps of 4 taps x 8 channels, fragment reads one half-step ahead ----
-    auto unit = [&](int S, const char *Wc, const char *Ab, int trow) {
+    auto unit = [&](int S, const char *Wc, const char *Ab, int trow) __attribute__((always_inline)) {
         const int *tt = Tl + trow * (G4_MAXS * 4) + lq;
-        bf16x8 Wa[3][NTW], Wb[3][NTW], Xa[3][2], Xb[3][2];
+        bf16x8 Wa[3][NTW], Wb[NTW >= 2 ? 1 : 3][NTW], Xa[3][2], Xb[3][2];
         auto rdW = [&](bf16x8 (&Wf)[3][NTW], int s) {
 #pragma unroll
             for (int p = 0; p < 3; ++p)
@@ -403,30 +404,49 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             }
         };
         int t_cur = tt[0];
-        rdW(Wa, 0);
         rdX(Xa, 0, t_cur);
-        auto kstep = [&](const bf16x8 (&Wc_)[3][NTW], bf16x8 (&Wn_)[3][NTW], int s) {
-            const int s1 = s + 1 < S ? s + 1 : s;
-            const int t_nxt = tt[s1 * 4];
-            rdX(Xb, 2, t_cur);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(Wc_, Xa, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            rdW(Wn_, s1);
-            rdX(Xa, 0, t_nxt);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(Wc_, Xb, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            t_cur = t_nxt;
-        };
-        int s = 0;
-        for (; s + 1 < S; s += 2) {
-            kstep(Wa, Wb, s);
-            kstep(Wb, Wa, s + 1);
+        if constexpr (NTW >= 2) {
+            // two column tiles: one weight fragment set only (a second set spills registers); its six reads are
+            // exposed once per k-step of 48 MFMAs
+            for (int s = 0; s < S; ++s) {
+                const int s1 = s + 1 < S ? s + 1 : s;
+                const int t_nxt = tt[s1 * 4];
+                rdW(Wa, s);
+                rdX(Xb, 2, t_cur);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(Wa, Xa, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                rdX(Xa, 0, t_nxt);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(Wa, Xb, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                t_cur = t_nxt;
+            }
+        } else {
+            rdW(Wa, 0);
+            auto kstep = [&](const bf16x8 (&Wc_)[3][NTW], bf16x8 (&Wn_)[3][NTW], int s) {
+                const int s1 = s + 1 < S ? s + 1 : s;
+                const int t_nxt = tt[s1 * 4];
+                rdX(Xb, 2, t_cur);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(Wc_, Xa, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                rdW(Wn_, s1);
+                rdX(Xa, 0, t_nxt);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(Wc_, Xb, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                t_cur = t_nxt;
+            };
+            int s = 0;
+            for (; s + 1 < S; s += 2) {
+                kstep(Wa, Wb, s);
+                kstep(Wb, Wa, s + 1);
+            }
+            if (s < S) kstep(Wa, Wb, s);
         }
-        if (s < S) kstep(Wa, Wb, s);
     };
-    auto init_acc = [&]() {
+    auto init_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms)
 #pragma unroll
@@ -434,7 +454,16 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     };
 
     // ---------------- tick loop --------------------------------------------------------------------------
+    // Both halves run the same straight-line body  [contract | barrier | stage | barrier];  half 1 starts one
+    // barrier late, so that one half contracts while the other stages.  No branch on the tick parity: with one
+    // the prefetched registers lived on two control-flow paths and the compiler merged them with copies - which
+    // wait for the loads - at the head of every contraction (igemm3.hip has the same lesson).
+    // Waits: vmcnt retires in issue order and the compiler waits conservatively (vmcnt(0)), so every wait must
+    // only meet operations that are at least one tick old.  Per half the order is
+    //   stage(i):    split (prefetch of tick i-1, mask loads of contract(i-1)) -> epilogue stores -> prefetch
+    //   contract(i): mask loads of the tile (last phase only) -> MFMAs
     const int n_ph = n_mine * a.nph;     // staging phases of this half
+    const int n_iter = (n_mine > n_oth ? n_mine : n_oth) * a.nph;
     int a_i = 0, a_ph = 0;               // next phase to stage (counter, index within the tile)
     int b_i = 0, b_ph = 0;               // next phase to contract
     if (n_mine > 0) locate(); else park();
@@ -443,73 +472,78 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last;
     STAMP4(t_last);
 #endif
-    for (int tick = 0; tick < nticks; ++tick) {
-        if ((tick & 1) == h) {
-            __builtin_amdgcn_s_setprio(0);
-            PHASE4_END(5);
-            if (a_i < n_ph) {
-                if (a_ph == 0) { c_out = f_out; c_full = f_full; c_l = f_l; c_g = f_g; }
-                // Epilogue first, then the split: the epilogue's mask values were requested at the start of the
-                // tile's last contraction, the split's operands at the end of the previous staging part; with
-                // vmcnt in issue order and the compiler waiting conservatively, either wait only ever meets
-                // loads that have had a whole tick to land.
-                if (a_ph == 0 && have_pend) {
-                    flush(p_out, p_full, p_l, p_g);
-                    have_pend = false;
-                }
-                PHASE4_END(1);
-                stash();
-                PHASE4_END(0);
-                int nph = a_ph + 1;
-                if (nph == a.nph) {
-                    nph = 0;
-                    advance_cursor();
-                    if (a_i + 1 < n_ph) locate(); else park();
-                }
-                fetch(nph);
-                a_ph = nph;
-                ++a_i;
-                PHASE4_END(2);
+    auto stage = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio(0);
+        PHASE4_END(5);
+        int nph = 0;
+        if (a_i < n_ph) {
+            if (a_ph == 0) { c_out = f_out; c_full = f_full; c_l = f_l; c_g = f_g; }
+            stash();
+            PHASE4_END(0);
+            if (a_ph == 0 && have_pend) {
+                flush(p_out, p_full, p_l, p_g);
+                have_pend = false;
             }
-        } else {
-            __builtin_amdgcn_s_setprio(3);       // the contracting wave goes first on its SIMD; staging fills the gaps
-            PHASE4_END(4);
-            if (b_i < a_i) {
-                if constexpr (!MULTI) {
-                    const i32x4 pdA = ld4(a.pd_off + b_ph * 8), pdB = ld4(a.pd_off + b_ph * 8 + 4);
-                    const int pd[5] = {0, 0, __builtin_amdgcn_readfirstlane(pdA.z), pdA.w, pdB.x};
-                    if constexpr (MASK_PF) { if (b_ph == a.nph - 1 && a.mask) load_mask(c_out, c_full, c_l, c_g); }
-                    if (b_ph == 0) init_acc();
-                    for (int rep = 0; rep <= a.dbg_repeat; ++rep)
-                        unit(pd[2], Wl + pd[3] + lane * 16, Al, pd[4]);
-                    if (b_ph == a.nph - 1) {
-                        have_pend = true;
-                        p_out = c_out; p_full = c_full; p_l = c_l; p_g = c_g;
-                    }
-                    b_ph = b_ph + 1 == a.nph ? 0 : b_ph + 1;
-                } else {
-                    for (int g = 0; g < a.ngr; ++g) {
-                        const i32x4 gdA = ld4(a.pd_off + g * 8), gdB = ld4(a.pd_off + g * 8 + 4);
-                        const int gd[6] = {0, 0, __builtin_amdgcn_readfirstlane(gdA.z), gdA.w, gdB.x, gdB.y};
-                        init_acc();
-                        const int ub = gd[2] * (3 * NTW * 1024);
-                        for (int rep = 0; rep <= a.dbg_repeat; ++rep)
-                            for (int p = 0; p < a.NP; ++p)
-                                unit(gd[2], Wl + gd[3] + p * ub + lane * 16, Al + p * a.plane_bytes, gd[4]);
-                        if (g + 1 < a.ngr) {
-                            flush(c_out + gd[5], c_full, c_l, c_g);
-                        } else {
-                            have_pend = true;
-                            p_out = c_out + gd[5]; p_full = c_full; p_l = c_l; p_g = c_g;
-                        }
-                    }
-                }
-                ++b_i;
-                PHASE4_END(3);
+            PHASE4_END(1);
+            nph = a_ph + 1;
+            if (nph == a.nph) {
+                nph = 0;
+                advance_cursor();
+                if (a_i + 1 < n_ph) locate(); else park();
             }
+            a_ph = nph;
+            ++a_i;
         }
+        fetch(nph);                      // unconditional: parked slots read nothing
+        PHASE4_END(2);
+    };
+    auto contract = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio(3);       // the contracting wave goes first on its SIMD; staging fills the gaps
+        PHASE4_END(4);
+        if (b_i < a_i) {
+            if constexpr (!MULTI) {
+                const i32x4 pdA = ld4(a.pd_off + b_ph * 8), pdB = ld4(a.pd_off + b_ph * 8 + 4);
+                const int pd[5] = {0, 0, __builtin_amdgcn_readfirstlane(pdA.z), pdA.w, pdB.x};
+                if constexpr (MASK_PF) { if (b_ph == a.nph - 1 && a.mask) load_mask(c_out, c_full, c_l, c_g); }
+                if (b_ph == 0) init_acc();
+                for (int rep = 0; rep <= a.dbg_repeat; ++rep)
+                    unit(pd[2], Wl + pd[3] + lane * 16, Al, pd[4]);
+                if (b_ph == a.nph - 1) {
+                    have_pend = true;
+                    p_out = c_out; p_full = c_full; p_l = c_l; p_g = c_g;
+                }
+                b_ph = b_ph + 1 == a.nph ? 0 : b_ph + 1;
+            } else {
+                for (int g = 0; g < a.ngr; ++g) {
+                    const i32x4 gdA = ld4(a.pd_off + g * 8), gdB = ld4(a.pd_off + g * 8 + 4);
+                    const int gd[6] = {0, 0, __builtin_amdgcn_readfirstlane(gdA.z), gdA.w, gdB.x, gdB.y};
+                    init_acc();
+                    const int ub = gd[2] * (3 * NTW * 1024);
+                    for (int rep = 0; rep <= a.dbg_repeat; ++rep)
+                        for (int p = 0; p < a.NP; ++p)
+                            unit(gd[2], Wl + gd[3] + p * ub + lane * 16, Al + p * a.plane_bytes, gd[4]);
+                    if (g + 1 < a.ngr) {
+                        flush(c_out + gd[5], c_full, c_l, c_g);
+                    } else {
+                        have_pend = true;
+                        p_out = c_out + gd[5]; p_full = c_full; p_l = c_l; p_g = c_g;
+                    }
+                }
+            }
+            ++b_i;
+            PHASE4_END(3);
+        }
+    };
+    if (h == 1) __syncthreads();
+    stage();
+    __syncthreads();
+    for (int it = 0; it < n_iter; ++it) {
+        contract();
+        __syncthreads();
+        stage();
         __syncthreads();
     }
+    if (h == 0) __syncthreads();
     if (have_pend) {
         flush(p_out, p_full, p_l, p_g);
     }

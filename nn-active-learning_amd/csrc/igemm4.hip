@@ -302,6 +302,12 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             const i32x4 t1 = ld4(a.td_off + q_l * 8 + 4);
             mz0 = t1.y; my0 = t1.z; mx0 = t1.w;
         }
+        // channel sums: ONE accumulator for the four row blocks.  The selector puts set A / set B of row block ms
+        // into MFMA rows (0, 4), (1, 5), (8, 12), (9, 13), i.e. lane group q ends up with  .x / .y = the sum of
+        // set (q & 1) for row blocks 2 * (q >> 1) and 2 * (q >> 1) + 1:  two 64-lane stores instead of eight
+        // 16-lane ones (those, each waiting on its own MFMA, were 4 % of a pass).
+        f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f};
+        bool livem[4];
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms) {
             bool live = erow_ok;
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 const int pt = e >> 24, z = (e >> 16) & 255, y = (e >> 8) & 255, x = e & 255;
                 live = e >= 0 && q_g * a.PT + pt < a.N && mz0 + z < a.MD && my0 + y < a.MH && mx0 + x < a.MW;
             }
-            f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f};
+            livem[ms] = live;
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 const int c = nt * 16 + cl;
@@ -345,20 +351,25 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                     if (!on) val = f32x4{0.f, 0.f, 0.f, 0.f};
                     // selector MFMA: result row 0 = sum over the lane groups of set A, row 1 = set B
                     const bool inA = pair ? (lq < 2) : (c < a.split);
-                    const float sel = (lrow == 0) ? (inA ? 1.f : 0.f) : ((lrow == 1) ? (inA ? 0.f : 1.f) : 0.f);
+                    constexpr int rowA[4] = {0, 1, 8, 9};
+                    const float sel = (lrow == rowA[ms]) ? (inA ? 1.f : 0.f) : ((lrow == rowA[ms] + 4) ? (inA ? 0.f : 1.f) : 0.f);
                     sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, (val.x + val.y) + (val.z + val.w), sacc, 0, 0, 0);
                 }
             }
-            if constexpr (SUMS) {
-                if (live && lq == 0) {
-                    if (pair) {          // rows 0-7 / 8-15 are the two x-adjacent voxels of the pair
-                        a.osumA[q_out + evox[ms]] = sacc.x;
-                        a.osumA[q_out + evox[ms] + 1] = sacc.y;
-                    } else {
-                        if (a.osumA) a.osumA[q_out + evox[ms]] = sacc.x;
-                        if (a.osumB) a.osumB[q_out + evox[ms]] = sacc.y;
-                    }
-                }
+        }
+        if constexpr (SUMS) {
+            // lane group q: set (q & 1), row blocks m0 = 2 * (q >> 1) (in .x) and m0 + 1 (in .y)
+            const bool setB = (lq & 1) != 0;
+            float *base = pair ? a.osumA + (setB ? 1 : 0) : (setB ? a.osumB : a.osumA);
+            const bool hi2 = lq >= 2;
+            const int ev0 = hi2 ? evox[2] : evox[0], ev1 = hi2 ? evox[3] : evox[1];
+            const bool l0 = hi2 ? livem[2] : livem[0], l1 = hi2 ? livem[3] : livem[1];
+            // pair form: evox of this lane carries + (q >> 1) for the lanes' own voxel; the sums belong to the pair's
+            // first voxel (+ 1 through `base` for the second)
+            const int fix = pair ? (lq >> 1) : 0;
+            if (base) {
+                if (l0) base[q_out + ev0 - fix] = sacc.x;
+                if (l1) base[q_out + ev1 - fix] = sacc.y;
             }
         }
     };

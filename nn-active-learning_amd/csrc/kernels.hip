@@ -736,37 +736,50 @@ __global__ __launch_bounds__(256) void boxdot_conv_lds_kernel(const float *dsum,
     const float *an = asum + n * vox;
     const float *an2 = asum2 ? asum2 + n * vox : nullptr;
     const int tot = planes * PH * PW;
-    for (int i = threadIdx.x; i < tot; i += 256) {
-        int r = i;
-        const int px = r % PW; r /= PW;
-        const int py = r % PH;
-        const int pz = r / PH;
-        const int iz = z0 + pz - lz, iy = py - ly, ix = px - lx;
-        float v = 0.f;
-        if (iz >= 0 && iz < D && iy >= 0 && iy < H && ix >= 0 && ix < W) {
-            const int o = (iz * H + iy) * W + ix;
-            v = an[o];
-            if (an2) v += an2[o];
+    {   // (px, py, pz) of element i = tid + 256 * it, advanced incrementally: a division by a run-time width per
+        // element made this loop (and the one below) arithmetic-bound
+        int r = threadIdx.x;
+        int px = r % PW; r /= PW;
+        int py = r % PH;
+        int pz = r / PH;
+        const int dx = 256 % PW, dy = (256 / PW) % PH, dz = 256 / (PW * PH);
+        for (int i = threadIdx.x; i < tot; i += 256) {
+            const int iz = z0 + pz - lz, iy = py - ly, ix = px - lx;
+            float v = 0.f;
+            if (iz >= 0 && iz < D && iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                const int o = (iz * H + iy) * W + ix;
+                v = an[o];
+                if (an2) v += an2[o];
+            }
+            tile[i] = v;
+            px += dx; py += dy; pz += dz;
+            if (px >= PW) { px -= PW; ++py; }
+            if (py >= PH) { py -= PH; ++pz; }
         }
-        tile[i] = v;
     }
     __syncthreads();
     const float *dn = dsum + n * vox;
     double acc = 0;
     const int nv = ZS * H * W;
-    for (int i = threadIdx.x; i < nv; i += 256) {
-        int r = i;
-        const int x = r % W; r /= W;
-        const int y = r % H;
-        const int zz = r / H;
-        if (z0 + zz >= D) break;
-        float box = 0.f;
-        for (int dz = 0; dz < kz; ++dz)
-            for (int dy = 0; dy < ky; ++dy) {
-                const float *rowp = tile + ((zz + dz) * PH + (y + dy)) * PW + x;
-                for (int dx = 0; dx < kx; ++dx) box += rowp[dx];
-            }
-        acc += (double)dn[((z0 + zz) * H + y) * W + x] * ((double)box + 1.0);
+    {
+        int r = threadIdx.x;
+        int x = r % W; r /= W;
+        int y = r % H;
+        int zz = r / H;
+        const int dx = 256 % W, dy = (256 / W) % H, dz = 256 / (W * H);
+        for (int i = threadIdx.x; i < nv; i += 256) {
+            if (z0 + zz >= D) break;
+            float box = 0.f;
+            for (int ez = 0; ez < kz; ++ez)
+                for (int ey = 0; ey < ky; ++ey) {
+                    const float *rowp = tile + ((zz + ez) * PH + (y + ey)) * PW + x;
+                    for (int ex = 0; ex < kx; ++ex) box += rowp[ex];
+                }
+            acc += (double)dn[((z0 + zz) * H + y) * W + x] * ((double)box + 1.0);
+            x += dx; y += dy; zz += dz;
+            if (x >= W) { x -= W; ++y; }
+            if (y >= H) { y -= H; ++zz; }
+        }
     }
     const double tot_s = block_sum256(acc, sh);
     if (threadIdx.x == 0) Spart[n * nslab_max + slab] = tot_s;

@@ -6,7 +6,8 @@
 //  * ONE 512-thread workgroup per CU.  Its two 4-wave halves each own a tile slot (a halo block in LDS,
 //    256 GEMM rows) and run in ANTI-PHASE: in every tick one half contracts its staged block on the
 //    matrix cores while the other half writes back its previous tile, splits and stages its next block
-//    and issues the prefetch for the one after; one barrier per tick.  With two independent 256-thread
+//    and issues the prefetch for the one after; one barrier per tick (half 1 simply runs the common loop
+//    body one barrier late).  With two independent 256-thread
 //    workgroups per CU (igemm3) the two stay in phase - both fight for LDS in the contraction and both
 //    leave it idle while staging.
 //  * the weights of the whole launch are resident in LDS once per CU (not once per workgroup).
@@ -18,8 +19,10 @@
 //        staged once, then every class contracts its own taps and stores its own output voxels;
 //      - "pair" forms for 8 output channels: the 16 MFMA rows are two x-adjacent output voxels
 //        (or two x parity classes) x 8 channels, so no half of the tile is padding.
-//  * tile descriptors come through scalar loads, halo validity is a per-tile index range per dimension,
-//    and there is exactly one prefetch site (see igemm3.hip for why).
+//  * tile / phase descriptors and the tap table live in LDS, halo validity is a per-tile index range per
+//    dimension, fragment reads are bank-conflict-free (host-built row permutation + padded pitches),
+//    the prefetch is unconditional at one site of a straight-line loop body (see the tick loop), and the
+//    two producers of a concat may hand over two dense tensors (split views).
 #include "alq_internal.h"
 
 #include <algorithm>
@@ -57,17 +60,6 @@ constexpr int G4_ROWB = 48;      // bytes per staged voxel row: [hi8 | mid8 | lo
 constexpr int G4_NSLOT = 8;      // 16-byte staging slots per thread of a half
 constexpr int G4_MAXS = 10;      // k-steps (4 taps each) per unit
 constexpr int G4_OOB = 0x7fffff00;
-
-__device__ inline i32x4 g4_sload4(const int *p) {
-    i32x4 v;
-    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
-    return v;
-}
-__device__ inline i32x8 g4_sload8(const int *p) {
-    i32x8 v;
-    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
-    return v;
-}
 
 // x -> (hi, rem): hi = bf16(x) round-to-nearest packed pairwise, rem = x - hi (exact).  Rounding to nearest
 // matters: a truncating split biases the dropped piece products to one sign, the bias accumulates over K and

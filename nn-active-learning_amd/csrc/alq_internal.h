@@ -267,7 +267,9 @@ struct Igemm4Args {
 };
 
 struct G4Geom {
-    int kind = 0;             // 0 stride-1 conv (fwd, or bwd-data when flipped), 1 conv_transpose bwd-data, 2 conv_transpose fwd (all classes)
+    int kind = 0;             // 0 stride-1 conv (fwd, or bwd-data when flipped), 1 conv_transpose bwd-data, 2 conv_transpose fwd (all classes),
+                              // 3 conv_transpose fwd, the one output parity class `cls`
+    int cls[3] = {0, 0, 0};
     int ID = 1, IH = 1, IW = 1, Ci = 0;     // GEMM input tensor
     int OD = 1, OH = 1, OW = 1, Co = 0;     // GEMM output tensor
     int k[3] = {1, 1, 1}, s[3] = {1, 1, 1}, lo[3] = {0, 0, 0};

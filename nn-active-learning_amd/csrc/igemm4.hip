@@ -644,6 +644,16 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
             dg[d].bo = lo_n; dg[d].span = hi_n - lo_n + 1; dg[d].so = s[d];
         }
         pair = (g.Co == 8 && s[2] == 2);
+    } else if (g.kind == 3) {
+        for (int d = 0; d < 3; ++d) {
+            if (O[d] != I[d] * s[d] || k[d] < s[d] || g.cls[d] < 0 || g.cls[d] >= s[d]) return ALQ_OK;
+            dg[d].I = I[d]; dg[d].O = O[d]; dg[d].M = I[d];
+            int n0, n1;
+            n_range(d, g.cls[d], &n0, &n1);
+            if (n1 < n0) return ALQ_OK;
+            amin[d] = n0; amax[d] = n1;
+            dg[d].bo = n0; dg[d].span = n1 - n0 + 1; dg[d].so = s[d];
+        }
     } else {
         return ALQ_OK;
     }
@@ -694,6 +704,15 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
                 };
                 rows.push_back(r);
             }
+    } else if (g.kind == 3) {
+        URow r;
+        for (int d = 0; d < 3; ++d) { r.box.b[d] = 0; r.box.n[d] = dg[d].span; r.out_off[d] = g.cls[d]; }
+        const int c0 = g.cls[0], c1 = g.cls[1], c2 = g.cls[2], nz0 = amin[0], ny0 = amin[1], nx0 = amin[2];
+        r.tapof = [=](int iz, int iy, int ix, int half) {
+            if (half) return -1;
+            return enum_tap(c0 + ll[0] - ss[0] * (nz0 + iz), c1 + ll[1] - ss[1] * (ny0 + iy), c2 + ll[2] - ss[2] * (nx0 + ix));
+        };
+        rows.push_back(r);
     } else {
         const int ncx = pair ? 1 : s[2];
         for (int cz = 0; cz < s[0]; ++cz)
@@ -986,6 +1005,7 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
                 }
                 td[0] = (base[0] * I[1] + base[1]) * I[2] + base[2];
                 td[1] = (m0[0] * dg[0].so * O[1] + m0[1] * dg[1].so) * O[2] + m0[2] * dg[2].so;
+                if (g.kind == 3) td[1] += (g.cls[0] * O[1] + g.cls[1]) * O[2] + g.cls[2];
                 bool inside = true;       // every halo index of the tile valid
                 for (int d = 0; d < 3; ++d) inside = inside && lohi[d][0] == 0 && lohi[d][1] == H[d];
                 td[2] = (full ? 1 : 0) | (inside ? 2 : 0);

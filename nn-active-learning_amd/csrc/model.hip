@@ -529,7 +529,13 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
                         ALQ_REQUIRE(!tl.empty(), ALQ_EUNSUPPORTED, "layer %d: empty conv_transpose class", i);
                         ly.class_taps.push_back(tl);
                         ly.fwd.emplace_back();
-                        ALQ_TRY(gemm_build(d, NB, &ly.fwd.back()));
+                        G4Geom gc;                // this class alone on the two-slot engine (used when the fused form does not fit)
+                        gc.kind = 3;
+                        gc.ID = ly.in.D; gc.IH = ly.in.H; gc.IW = ly.in.W; gc.Ci = ly.in.C;
+                        gc.OD = ly.out.D; gc.OH = ly.out.H; gc.OW = ly.out.W; gc.Co = sp.cout;
+                        for (int q = 0; q < 3; ++q) { gc.k[q] = sp.k[q]; gc.s[q] = sp.s[q]; gc.lo[q] = ly.lo[q]; }
+                        gc.cls[0] = cz; gc.cls[1] = cy; gc.cls[2] = cx;
+                        ALQ_TRY(gemm_build(d, NB, &ly.fwd.back(), &gc));
                     }
             ALQ_REQUIRE(sp.s[0] == sp.s[2] || (ly.in.D == 1 && sp.s[0] == 1), ALQ_EUNSUPPORTED,
                         "layer %d: conv_transpose stride must be isotropic", i);
@@ -925,7 +931,12 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
             ALQ_TRY(gemm_set(m, &ly.bwd, Bb));
         }
     } else if (sp.type == ALQ_CONVT) {
-        // TF [tap][co][ci]
+        // TF [tap][co][ci]; the two-slot plans index taps in the full k^3 enumeration, the older engines by class
+        std::vector<float> Bfull((size_t)ntaps * Ci * Co);
+        for (int tp = 0; tp < ntaps; ++tp)
+            for (int ci = 0; ci < Ci; ++ci)
+                for (int co = 0; co < Co; ++co)
+                    Bfull[((size_t)tp * Ci + ci) * Co + co] = W[((size_t)tp * Co + co) * Ci + ci];
         for (size_t c = 0; c < ly.fwd.size(); ++c) {
             const std::vector<int> &tl = ly.class_taps[c];
             std::vector<float> B((size_t)tl.size() * Ci * Co);
@@ -933,16 +944,15 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
                 for (int ci = 0; ci < Ci; ++ci)
                     for (int co = 0; co < Co; ++co)
                         B[((size_t)j * Ci + ci) * Co + co] = W[((size_t)tl[j] * Co + co) * Ci + ci];
+            const bool p4ok = ly.fwd[c].p4.ok && !ly.fwd_all.ok;     // per-class two-slot plan: only without the fused form
+            ly.fwd[c].p4.ok = false;
             ALQ_TRY(gemm_set(m, &ly.fwd[c], B));
+            if (p4ok) {
+                ly.fwd[c].p4.ok = true;
+                ALQ_TRY(set4(m, &ly.fwd[c].p4, Bfull));
+            }
         }
-        if (ly.fwd_all.ok) {
-            std::vector<float> B((size_t)ntaps * Ci * Co);
-            for (int tp = 0; tp < ntaps; ++tp)
-                for (int ci = 0; ci < Ci; ++ci)
-                    for (int co = 0; co < Co; ++co)
-                        B[((size_t)tp * Ci + ci) * Co + co] = W[((size_t)tp * Co + co) * Ci + ci];
-            ALQ_TRY(set4(m, &ly.fwd_all, B));
-        }
+        if (ly.fwd_all.ok) ALQ_TRY(set4(m, &ly.fwd_all, Bfull));
         if (ly.has_bwd) {
             std::vector<float> Bb(W, W + ly.w_elems);   // [(tap, co)][ci] as stored
             ALQ_TRY(gemm_set(m, &ly.bwd, Bb));

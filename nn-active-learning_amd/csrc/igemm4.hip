@@ -469,6 +469,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     const int n_iter = (n_mine > n_oth ? n_mine : n_oth) * a.nph;
     int a_i = 0, a_ph = 0;               // next phase to stage (counter, index within the tile)
     int b_i = 0, b_ph = 0;               // next phase to contract
+    __syncthreads();                     // the descriptor / tap tables (and weights) copied above are read from here on
     if (n_mine > 0) locate(); else park();
     fetch(0);
 #ifdef ALQ_STAMPS

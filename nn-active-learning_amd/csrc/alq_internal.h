@@ -244,7 +244,7 @@ struct Igemm4Args {
     const float *bias;
     const float *mask;
     float *osumA, *osumB;
-    const int *tdesc;       // [tiles per group][8]: in_org_vox, out_org_vox, full, lohi_zy, lohi_x, mz0, my0, mx0
+    const int *tdesc;       // [tiles per group][8]: in_org_vox, out_org_vox, flags, lohi_zy, lohi_x, (mz0, my0, mx0) bytes, first phase, -
     const int *sdesc;       // [nslots][4]: rel_vox, (pt,hz,hy,hx) packed, LDS byte offset, channel offset
     const int *pdesc;       // [phases or groups][8]: in_off_vox, chunk, S, w_off, tap row, out_off_vox, -, -
     const int *ttab;        // [tap rows][G4_MAXS][4] LDS byte offsets of the taps of k-step s, lane group q
@@ -268,7 +268,8 @@ struct Igemm4Args {
 
 struct G4Geom {
     int kind = 0;             // 0 stride-1 conv (fwd, or bwd-data when flipped), 1 conv_transpose bwd-data, 2 conv_transpose fwd (all classes),
-                              // 3 conv_transpose fwd, the one output parity class `cls`
+                              // 3 conv_transpose fwd, the one output parity class `cls`,
+                              // 4 conv_transpose fwd, every class as its own tiles of one launch (input restaged per class)
     int cls[3] = {0, 0, 0};
     int ID = 1, IH = 1, IW = 1, Ci = 0;     // GEMM input tensor
     int OD = 1, OH = 1, OW = 1, Co = 0;     // GEMM output tensor

@@ -184,6 +184,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
 
     int f_out = 0, f_full = 0, f_l = 0, f_g = 0;      // tile the prefetch cursor points at
     int c_out = 0, c_full = 0, c_l = 0, c_g = 0;      // tile being contracted
+    int f_pdb = 0, c_pdb = 0;                         // first phase descriptor of that tile (several tap sets in one launch)
     int p_out = 0, p_full = 0, p_l = 0, p_g = 0;      // tile whose results wait in registers
     bool have_pend = false;
 
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         const int org = (t0.x + fpg * a.in_pstride) * a.in_cs;
         const int tflags = __builtin_amdgcn_readfirstlane(t0.z);
         f_out = t0.y + fpg * a.out_pstride;
+        f_pdb = __builtin_amdgcn_readfirstlane(t1.z);
         f_full = (tflags & 1) && (fpg + 1) * a.PT <= a.N;
         f_l = fl; f_g = fpg;
         if ((tflags & 2) && (fpg + 1) * a.PT <= a.N) {      // whole halo inside the tensor: no per-slot checks
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     auto fetch = [&](int ph) __attribute__((always_inline)) {
         int soff = 0;
         if constexpr (!MULTI) {
-            const i32x4 pd = ld4(a.pd_off + ph * 8);
+            const i32x4 pd = ld4(a.pd_off + (f_pdb + ph) * 8);
             int chl = pd.y, extra = 0;
             if (a.in_split_ch && chl >= a.in_split_ch) { chl -= a.in_split_ch; extra = a.in_delta; }     // second part of a split concat
             soff = __builtin_amdgcn_readfirstlane((pd.x * a.in_cs + chl * 8 + extra) * 4);
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         int mz0 = 0, my0 = 0, mx0 = 0;
         if (!q_full) {
             const i32x4 t1 = ld4(a.td_off + q_l * 8 + 4);
-            mz0 = t1.y; my0 = t1.z; mx0 = t1.w;
+            mz0 = t1.y & 255; my0 = (t1.y >> 8) & 255; mx0 = (t1.y >> 16) & 255;
         }
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms) {
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         int mz0 = 0, my0 = 0, mx0 = 0;
         if (!q_full) {
             const i32x4 t1 = ld4(a.td_off + q_l * 8 + 4);
-            mz0 = t1.y; my0 = t1.z; mx0 = t1.w;
+            mz0 = t1.y & 255; my0 = (t1.y >> 8) & 255; mx0 = (t1.y >> 16) & 255;
         }
         // channel sums: ONE accumulator for the four row blocks.  The selector puts set A / set B of row block ms
         // into MFMA rows (0, 4), (1, 5), (8, 12), (9, 13), i.e. lane group q ends up with  .x / .y = the sum of
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         PHASE4_END(5);
         int nph = 0;
         if (a_i < n_ph) {
-            if (a_ph == 0) { c_out = f_out; c_full = f_full; c_l = f_l; c_g = f_g; }
+            if (a_ph == 0) { c_out = f_out; c_full = f_full; c_l = f_l; c_g = f_g; c_pdb = f_pdb; }
             stash();
             PHASE4_END(0);
             if (a_ph == 0 && have_pend) {
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         PHASE4_END(4);
         if (b_i < a_i) {
             if constexpr (!MULTI) {
-                const i32x4 pdA = ld4(a.pd_off + b_ph * 8), pdB = ld4(a.pd_off + b_ph * 8 + 4);
+                const i32x4 pdA = ld4(a.pd_off + (c_pdb + b_ph) * 8), pdB = ld4(a.pd_off + (c_pdb + b_ph) * 8 + 4);
                 const int pd[5] = {0, 0, __builtin_amdgcn_readfirstlane(pdA.z), pdA.w, pdB.x};
                 if constexpr (MASK_PF) { if (b_ph == a.nph - 1 && a.mask) load_mask(c_out, c_full, c_l, c_g); }
                 if (b_ph == 0) init_acc();
@@ -630,7 +632,7 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
                 dg[d].hs = 1; dg[d].sm = s[d]; dg[d].bm = s[d]; dg[d].bo = -lo[d]; dg[d].span = k[d];
             }
         }
-    } else if (g.kind == 2) {
+    } else if (g.kind == 2 || g.kind == 4) {
         for (int d = 0; d < 3; ++d) {
             if (O[d] != I[d] * s[d] || k[d] < s[d]) return ALQ_OK;
             dg[d].I = I[d]; dg[d].O = O[d]; dg[d].M = I[d];
@@ -644,7 +646,7 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
             amin[d] = lo_n; amax[d] = hi_n;
             dg[d].bo = lo_n; dg[d].span = hi_n - lo_n + 1; dg[d].so = s[d];
         }
-        pair = (g.Co == 8 && s[2] == 2);
+        pair = (g.kind == 2 && g.Co == 8 && s[2] == 2);
     } else if (g.kind == 3) {
         for (int d = 0; d < 3; ++d) {
             if (O[d] != I[d] * s[d] || k[d] < s[d] || g.cls[d] < 0 || g.cls[d] >= s[d]) return ALQ_OK;
@@ -749,7 +751,8 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
         if ((r.ntaps + 3) / 4 + 1 > G4_MAXS) return ALQ_OK;
     }
     const bool multi = (g.kind == 2);
-    const int nstage = multi ? 1 : (int)rows.size() * NCH;      // staging phases per tile
+    const int ncls = g.kind == 4 ? (int)rows.size() : 1;       // kind 4: every class is its own set of tiles
+    const int nstage = multi ? 1 : (g.kind == 4 ? NCH : (int)rows.size() * NCH);      // staging phases per tile
     const int NPs = multi ? NCH : 1;                             // planes staged per phase
     const size_t tt_ints = (size_t)rows.size() * G4_MAXS * 4;
 
@@ -827,7 +830,7 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
                     if (nhv * 2 * NPs > 256 * G4_NSLOT) continue;
                     const Lay L = layout(PT, T, H);
                     const int sumS_t = ksteps(L);
-                    const size_t tpg_t = (size_t)((dg[0].M + TZ - 1) / TZ) * ((dg[1].M + TY - 1) / TY) * ((dg[2].M + TX - 1) / TX);
+                    const size_t tpg_t = (size_t)((dg[0].M + TZ - 1) / TZ) * ((dg[1].M + TY - 1) / TY) * ((dg[2].M + TX - 1) / TX) * ncls;
                     const size_t tab_ints = tt_ints + (size_t)(multi ? rows.size() : rows.size() * NCH) * 8 + tpg_t * 8;
                     const size_t lds = tab_ints * 4 + (size_t)sumS_t * NCH * 3 * NTW * 1024 + 2 * (size_t)PT * L.PZ * NPs * G4_ROWB;
                     if (lds > 160 * 1024 - 256) continue;
@@ -937,7 +940,7 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
     Igemm4Args &a = plan->a;
     std::memset(&a, 0, sizeof(a));
     a.Co = g.Co;
-    a.PT = PT; a.tpg = tiles[0] * tiles[1] * tiles[2];
+    a.PT = PT; a.tpg = tiles[0] * tiles[1] * tiles[2] * ncls;
     a.rows = nrows;
     a.PX = L.PX; a.PYX = L.PYX; a.PZ = L.PZ;
     a.smz = dg[0].sm; a.smy = dg[1].sm; a.smx = dg[2].sm;
@@ -989,10 +992,12 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
     }
     // tiles
     plan->h_tdesc.assign((size_t)a.tpg * 8, 0);
+    if (dg[0].M > 255 || dg[1].M > 255 || dg[2].M > 255) return ALQ_OK;       // tile origins are packed in bytes
+    for (int cl = 0; cl < ncls; ++cl)
     for (int tz = 0; tz < tiles[0]; ++tz)
         for (int ty = 0; ty < tiles[1]; ++ty)
             for (int tx = 0; tx < tiles[2]; ++tx) {
-                int *td = &plan->h_tdesc[(((size_t)tz * tiles[1] + ty) * tiles[2] + tx) * 8];
+                int *td = &plan->h_tdesc[((((size_t)cl * tiles[0] + tz) * tiles[1] + ty) * tiles[2] + tx) * 8];
                 const int m0[3] = {tz * T[0], ty * T[1], tx * T[2]};
                 int base[3], lohi[3][2];
                 bool full = nrows == 256;
@@ -1007,12 +1012,15 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
                 td[0] = (base[0] * I[1] + base[1]) * I[2] + base[2];
                 td[1] = (m0[0] * dg[0].so * O[1] + m0[1] * dg[1].so) * O[2] + m0[2] * dg[2].so;
                 if (g.kind == 3) td[1] += (g.cls[0] * O[1] + g.cls[1]) * O[2] + g.cls[2];
+                if (g.kind == 4) td[1] += (rows[cl].out_off[0] * O[1] + rows[cl].out_off[1]) * O[2] + rows[cl].out_off[2];
                 bool inside = true;       // every halo index of the tile valid
                 for (int d = 0; d < 3; ++d) inside = inside && lohi[d][0] == 0 && lohi[d][1] == H[d];
                 td[2] = (full ? 1 : 0) | (inside ? 2 : 0);
                 td[3] = lohi[0][0] | (lohi[0][1] << 8) | (lohi[1][0] << 16) | (lohi[1][1] << 24);
                 td[4] = lohi[2][0] | (lohi[2][1] << 8);
-                td[5] = m0[0]; td[6] = m0[1]; td[7] = m0[2];
+                td[5] = m0[0] | (m0[1] << 8) | (m0[2] << 16);
+                td[6] = g.kind == 4 ? cl * NCH : 0;          // first phase descriptor of this tile
+                td[7] = 0;
             }
     // staging slots
     plan->h_sdesc.assign((size_t)a.nslots * 4, 0);

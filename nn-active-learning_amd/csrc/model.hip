@@ -549,6 +549,10 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
                 gf.flops_per_patch = 0;
                 for (const Gemm &c : ly.fwd) gf.flops_per_patch += c.p1.flops_per_patch;
                 ALQ_TRY(igemm4_build_plan(gf, NB, &ly.fwd_all));
+                if (!ly.fwd_all.ok && !getenv("ALQ_NO_CLASS_TILES")) {      // too large to stage once: the classes as tiles of one launch
+                    gf.kind = 4;
+                    ALQ_TRY(igemm4_build_plan(gf, NB, &ly.fwd_all));
+                }
             }
             if (!first_param) {
                 ConvDesc b;

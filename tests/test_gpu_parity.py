@@ -458,6 +458,47 @@ def test_config5_loop_harness(sess):
     model.close()
 
 
+def test_layout_and_engine_switches_agree(sess):
+    """The same NET-C scores through (a) the split-concat layout (default), (b) concat as channel slices of one
+    buffer (ALQ_NO_SPLIT) - identical arithmetic per output element, so identical bits - and (c) the fp32-MFMA
+    engines (ALQ_DISABLE_V4 + ALQ_DISABLE_V3: exact fp32 fma chains in another order): fp32-level agreement, with
+    the absolute bar of the tolerance note on top for a ReLU input that lands on the other side of zero."""
+    torch = sess.torch
+    ld, sk = netspec.net_c()
+    in_shape = (16, 16, 16, 1)
+    pars = netspec.he_init(ld, in_shape, seed=31, skips=sk)
+    x = np.random.RandomState(5).randn(9, *in_shape).astype(np.float32)
+    xd = sess.to_device(x.reshape(9, -1), torch.float32)
+
+    def scores(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            m = _device_model(sess, ld, in_shape, sk, pars, max_batch=4)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        r = m.fisher_device(xd, 9, None, 1e-3)
+        out = {k: r[k].cpu().numpy() for k in ('p1', 'g0', 'g1', 'A')}
+        m.close()
+        return out
+
+    a = scores({})
+    b = scores({'ALQ_NO_SPLIT': '1'})
+    c = scores({'ALQ_DISABLE_V4': '1', 'ALQ_DISABLE_V3': '1'})
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    np.testing.assert_allclose(c['p1'], a['p1'], rtol=0, atol=2e-6)
+    for k in ('g0', 'g1'):
+        err = np.abs(c[k] - a[k])
+        assert err.max() <= 5e-4, (k, err.max())
+        big = np.abs(a[k]) > 1e-5
+        assert np.median(err[big] / np.abs(a[k][big])) <= 1e-4, k
+
+
 def test_argument_errors(sess):
     from nnal_amd import device
     from nnal_amd._lib import AlqError

@@ -785,15 +785,112 @@ __global__ __launch_bounds__(256) void boxdot_conv_lds_kernel(const float *dsum,
     if (threadIdx.x == 0) Spart[n * nslab_max + slab] = tot_s;
 }
 
-static int boxdot_zs(int D, int H, int W) {
-    int zs = 2048 / (H * W);
+// Column variant for the usual odd windows on rows that are a multiple of 4 wide: a thread owns 4 x-adjacent voxels
+// of one (y) row and walks z; the KY x KX window sums of a plane are KY rows of 64-bit LDS reads (4 + KX - 1 values,
+// shared by the 4 voxels) and the KZ planes of a window are a rolling register sum, so a voxel costs
+// ~KY * (4 + KX) / 8 LDS reads per plane instead of KZ * KY * KX.  With fewer than 256 columns the threads split the
+// z planes of the slab among them.
+template <int KZ, int KY, int KX>
+__global__ __launch_bounds__(256) void boxdot_conv_col_kernel(const float *dsum, const float *asum, const float *asum2,
+                                                              int D, int H, int W, int lz, int ly, int lx, int ZS,
+                                                              double *Spart, int nslab_max) {
+    extern __shared__ float tile[];
+    __shared__ double sh[4];
+    const long long n = blockIdx.y;
+    const int slab = blockIdx.x;
+    const int z0 = slab * ZS;
+    const int PH = H + KY - 1, PW = W + KX - 1, planes = ZS + KZ - 1;
+    const int vox = D * H * W;
+    const float *an = asum + n * vox;
+    const float *an2 = asum2 ? asum2 + n * vox : nullptr;
+    const int tot = planes * PH * PW;
+    {
+        int r = threadIdx.x;
+        int px = r % PW; r /= PW;
+        int py = r % PH;
+        int pz = r / PH;
+        const int dx = 256 % PW, dy = (256 / PW) % PH, dz = 256 / (PW * PH);
+        for (int i = threadIdx.x; i < tot; i += 256) {
+            const int iz = z0 + pz - lz, iy = py - ly, ix = px - lx;
+            float v = 0.f;
+            if (iz >= 0 && iz < D && iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                const int o = (iz * H + iy) * W + ix;
+                v = an[o];
+                if (an2) v += an2[o];
+            }
+            tile[i] = v;
+            px += dx; py += dy; pz += dz;
+            if (px >= PW) { px -= PW; ++py; }
+            if (py >= PH) { py -= PH; ++pz; }
+        }
+    }
+    __syncthreads();
+    constexpr int NR = (4 + KX) & ~1;                 // values read per row: 4 + KX - 1 rounded up to even
+    const float *dn = dsum + n * vox;
+    const int cols = (H * W) >> 2;
+    const int ceff = cols < 256 ? cols : 256;
+    const int zg = 256 / ceff;                        // thread groups along z
+    const int zper = (ZS + zg - 1) / zg;
+    const int g = threadIdx.x / ceff;
+    const int zb = g * zper;
+    int zend = zb + zper;
+    if (zend > ZS) zend = ZS;
+    if (z0 + zend > D) zend = D - z0;
+    double acc = 0;
+    if (g < zg && zb < zend) {
+        for (int c = threadIdx.x - g * ceff; c < cols; c += ceff) {
+            const int y = (c * 4) / W, x = (c * 4) - y * W;
+            f32x4 s[KZ];
+#pragma unroll
+            for (int q = 0; q < KZ; ++q) s[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int p = zb; p < zend + KZ - 1; ++p) {
+                f32x4 P = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ey = 0; ey < KY; ++ey) {
+                    const float *rowp = tile + (p * PH + (y + ey)) * PW + x;
+                    float r[NR];
+#pragma unroll
+                    for (int j = 0; j < NR; j += 2) {
+                        const f32x2 t = *reinterpret_cast<const f32x2 *>(rowp + j);
+                        r[j] = t.x; r[j + 1] = t.y;
+                    }
+#pragma unroll
+                    for (int ex = 0; ex < KX; ++ex) {
+                        P.x += r[ex]; P.y += r[1 + ex]; P.z += r[2 + ex]; P.w += r[3 + ex];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q + 1 < KZ; ++q) s[q] = s[q + 1];
+                s[KZ - 1] = P;
+                const int zz = p - (KZ - 1);
+                if (zz >= zb) {
+                    f32x4 box = s[0];
+#pragma unroll
+                    for (int q = 1; q < KZ; ++q) { box.x += s[q].x; box.y += s[q].y; box.z += s[q].z; box.w += s[q].w; }
+                    const f32x4 d = *reinterpret_cast<const f32x4 *>(dn + ((z0 + zz) * H + y) * W + x);
+                    acc += (double)d.x * ((double)box.x + 1.0) + (double)d.y * ((double)box.y + 1.0) +
+                           (double)d.z * ((double)box.z + 1.0) + (double)d.w * ((double)box.w + 1.0);
+                }
+            }
+        }
+    }
+    const double tot_s = block_sum256(acc, sh);
+    if (threadIdx.x == 0) Spart[n * nslab_max + slab] = tot_s;
+}
+
+static size_t boxdot_tile_bytes(int zs, int H, int W, const int k[3]) {
+    return (size_t)(zs + k[0] - 1) * (H + k[1] - 1) * (W + k[2] - 1) * sizeof(float);
+}
+// z planes per workgroup: ~4096 voxels, fewer if the padded planes would not fit 48 KB of LDS
+static int boxdot_zs(int D, int H, int W, const int k[3]) {
+    int zs = 4096 / (H * W);
     if (zs < 1) zs = 1;
     if (zs > D) zs = D;
+    while (zs > 1 && boxdot_tile_bytes(zs, H, W, k) > 48 * 1024) --zs;
     return zs;
 }
 static size_t boxdot_lds_bytes(int D, int H, int W, const int k[3]) {
-    const int zs = boxdot_zs(D, H, W);
-    return (size_t)(zs + k[0] - 1) * (H + k[1] - 1) * (W + k[2] - 1) * sizeof(float);
+    return boxdot_tile_bytes(boxdot_zs(D, H, W, k), H, W, k);
 }
 static bool boxdot_use_lds(int D, int H, int W, const int k[3]) {
     return (long long)D * H * W >= 512 && boxdot_lds_bytes(D, H, W, k) <= 48 * 1024;
@@ -801,7 +898,7 @@ static bool boxdot_use_lds(int D, int H, int W, const int k[3]) {
 
 int boxdot_slabs(long long vox) { return (int)((vox + BOX_SLAB - 1) / BOX_SLAB); }
 int boxdot_conv_slabs(int D, int H, int W, const int k[3]) {
-    if (boxdot_use_lds(D, H, W, k)) { const int zs = boxdot_zs(D, H, W); return (D + zs - 1) / zs; }
+    if (boxdot_use_lds(D, H, W, k)) { const int zs = boxdot_zs(D, H, W, k); return (D + zs - 1) / zs; }
     return boxdot_slabs((long long)D * H * W);
 }
 
@@ -809,7 +906,19 @@ int k_boxdot_conv(alq_ctx *ctx, const float *dsum, const float *asum, const floa
                   const int k[3], const int lo[3], int N, double *Spart, int nslab_max) {
     ProfScope ps(ctx, PROF_REDUCE, 0);
     if (boxdot_use_lds(D, H, W, k)) {
-        const int zs = boxdot_zs(D, H, W);
+        const int zs = boxdot_zs(D, H, W, k);
+#define ALQ_BOXCOL(KZ, KY, KX)                                                                                        \
+    if (k[0] == KZ && k[1] == KY && k[2] == KX && (W & 3) == 0) {                                                      \
+        hipLaunchKernelGGL((boxdot_conv_col_kernel<KZ, KY, KX>), dim3((D + zs - 1) / zs, N), dim3(256),               \
+                           boxdot_lds_bytes(D, H, W, k), ctx->stream, dsum, asum, asum2, D, H, W, lo[0], lo[1], lo[2], \
+                           zs, Spart, nslab_max);                                                                      \
+        ALQ_LAUNCH_CHECK();                                                                                            \
+        return ALQ_OK;                                                                                                 \
+    }
+        ALQ_BOXCOL(3, 3, 3)
+        ALQ_BOXCOL(1, 3, 3)
+        ALQ_BOXCOL(1, 5, 5)
+#undef ALQ_BOXCOL
         hipLaunchKernelGGL(boxdot_conv_lds_kernel, dim3((D + zs - 1) / zs, N), dim3(256), boxdot_lds_bytes(D, H, W, k),
                            ctx->stream, dsum, asum, asum2, D, H, W, k[0], k[1], k[2], lo[0], lo[1], lo[2], zs, Spart,
                            nslab_max);

@@ -804,72 +804,97 @@ __global__ __launch_bounds__(256) void boxdot_conv_col_kernel(const float *dsum,
     const float *an = asum + n * vox;
     const float *an2 = asum2 ? asum2 + n * vox : nullptr;
     const int tot = planes * PH * PW;
-    {
-        int r = threadIdx.x;
-        int px = r % PW; r /= PW;
-        int py = r % PH;
-        int pz = r / PH;
-        const int dx = 256 % PW, dy = (256 / PW) % PH, dz = 256 / (PW * PH);
-        for (int i = threadIdx.x; i < tot; i += 256) {
-            const int iz = z0 + pz - lz, iy = py - ly, ix = px - lx;
-            float v = 0.f;
-            if (iz >= 0 && iz < D && iy >= 0 && iy < H && ix >= 0 && ix < W) {
-                const int o = (iz * H + iy) * W + ix;
-                v = an[o];
-                if (an2) v += an2[o];
+    for (int i = threadIdx.x; i < tot; i += 256) tile[i] = 0.f;      // the zero padding (and planes outside the volume)
+    __syncthreads();
+    {   // interior rows as 16-byte loads, 4 (8 with a second source) in flight per thread and trip
+        const int W4 = W >> 2, rowq = H * W4, nq = planes * rowq;
+        constexpr int U = 4;
+        for (int base = threadIdx.x; base < nq; base += 256 * U) {
+            f32x4 v[U];
+            int dst[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = base + u * 256;
+                dst[u] = -1;
+                if (q < nq) {
+                    const int pz = q / rowq, rq = q - pz * rowq;
+                    const int iy = rq / W4, ix = (rq - iy * W4) * 4;
+                    const int iz = z0 + pz - lz;
+                    if (iz >= 0 && iz < D) {
+                        const int o = (iz * H + iy) * W + ix;
+                        v[u] = *reinterpret_cast<const f32x4 *>(an + o);
+                        if (an2) {
+                            const f32x4 w = *reinterpret_cast<const f32x4 *>(an2 + o);
+                            v[u].x += w.x; v[u].y += w.y; v[u].z += w.z; v[u].w += w.w;
+                        }
+                        dst[u] = (pz * PH + iy + ly) * PW + ix + lx;
+                    }
+                }
             }
-            tile[i] = v;
-            px += dx; py += dy; pz += dz;
-            if (px >= PW) { px -= PW; ++py; }
-            if (py >= PH) { py -= PH; ++pz; }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (dst[u] >= 0) {
+                    float *t = tile + dst[u];
+                    t[0] = v[u].x; t[1] = v[u].y; t[2] = v[u].z; t[3] = v[u].w;
+                }
         }
     }
     __syncthreads();
     constexpr int NR = (4 + KX) & ~1;                 // values read per row: 4 + KX - 1 rounded up to even
+    constexpr int ZR = 4;                             // z planes per thread and run
     const float *dn = dsum + n * vox;
     const int cols = (H * W) >> 2;
     const int ceff = cols < 256 ? cols : 256;
     const int zg = 256 / ceff;                        // thread groups along z
-    const int zper = (ZS + zg - 1) / zg;
+    const int nrun = (ZS + ZR - 1) / ZR;
     const int g = threadIdx.x / ceff;
-    const int zb = g * zper;
-    int zend = zb + zper;
-    if (zend > ZS) zend = ZS;
-    if (z0 + zend > D) zend = D - z0;
     double acc = 0;
-    if (g < zg && zb < zend) {
+    if (g < zg) {
         for (int c = threadIdx.x - g * ceff; c < cols; c += ceff) {
             const int y = (c * 4) / W, x = (c * 4) - y * W;
-            f32x4 s[KZ];
+            for (int run = g; run < nrun; run += zg) {
+                const int zb = run * ZR;
+                f32x4 d[ZR];
 #pragma unroll
-            for (int q = 0; q < KZ; ++q) s[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int p = zb; p < zend + KZ - 1; ++p) {
-                f32x4 P = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ey = 0; ey < KY; ++ey) {
-                    const float *rowp = tile + (p * PH + (y + ey)) * PW + x;
-                    float r[NR];
-#pragma unroll
-                    for (int j = 0; j < NR; j += 2) {
-                        const f32x2 t = *reinterpret_cast<const f32x2 *>(rowp + j);
-                        r[j] = t.x; r[j + 1] = t.y;
-                    }
-#pragma unroll
-                    for (int ex = 0; ex < KX; ++ex) {
-                        P.x += r[ex]; P.y += r[1 + ex]; P.z += r[2 + ex]; P.w += r[3 + ex];
-                    }
+                for (int j = 0; j < ZR; ++j) {
+                    const int zz = zb + j;
+                    d[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (zz < ZS && z0 + zz < D) d[j] = *reinterpret_cast<const f32x4 *>(dn + ((z0 + zz) * H + y) * W + x);
                 }
+                f32x4 s[KZ];
 #pragma unroll
-                for (int q = 0; q + 1 < KZ; ++q) s[q] = s[q + 1];
-                s[KZ - 1] = P;
-                const int zz = p - (KZ - 1);
-                if (zz >= zb) {
-                    f32x4 box = s[0];
+                for (int q = 0; q < KZ; ++q) s[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int q = 1; q < KZ; ++q) { box.x += s[q].x; box.y += s[q].y; box.z += s[q].z; box.w += s[q].w; }
-                    const f32x4 d = *reinterpret_cast<const f32x4 *>(dn + ((z0 + zz) * H + y) * W + x);
-                    acc += (double)d.x * ((double)box.x + 1.0) + (double)d.y * ((double)box.y + 1.0) +
-                           (double)d.z * ((double)box.z + 1.0) + (double)d.w * ((double)box.w + 1.0);
+                for (int pp = 0; pp < ZR + KZ - 1; ++pp) {
+                    const int p = zb + pp;
+                    f32x4 P = {0.f, 0.f, 0.f, 0.f};
+                    if (p < planes) {
+#pragma unroll
+                        for (int ey = 0; ey < KY; ++ey) {
+                            const float *rowp = tile + (p * PH + (y + ey)) * PW + x;
+                            float r[NR];
+#pragma unroll
+                            for (int j = 0; j < NR; j += 2) {
+                                const f32x2 t = *reinterpret_cast<const f32x2 *>(rowp + j);
+                                r[j] = t.x; r[j + 1] = t.y;
+                            }
+#pragma unroll
+                            for (int ex = 0; ex < KX; ++ex) {
+                                P.x += r[ex]; P.y += r[1 + ex]; P.z += r[2 + ex]; P.w += r[3 + ex];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q + 1 < KZ; ++q) s[q] = s[q + 1];
+                    s[KZ - 1] = P;
+                    if (pp >= KZ - 1) {
+                        f32x4 box = s[0];
+#pragma unroll
+                        for (int q = 1; q < KZ; ++q) { box.x += s[q].x; box.y += s[q].y; box.z += s[q].z; box.w += s[q].w; }
+                        const f32x4 dd = d[pp - (KZ - 1)];
+                        acc += (double)dd.x * ((double)box.x + 1.0) + (double)dd.y * ((double)box.y + 1.0) +
+                               (double)dd.z * ((double)box.z + 1.0) + (double)dd.w * ((double)box.w + 1.0);
+                    }
                 }
             }
         }
@@ -907,8 +932,9 @@ int k_boxdot_conv(alq_ctx *ctx, const float *dsum, const float *asum, const floa
     ProfScope ps(ctx, PROF_REDUCE, 0);
     if (boxdot_use_lds(D, H, W, k)) {
         const int zs = boxdot_zs(D, H, W, k);
+        const bool al16 = (((uintptr_t)dsum | (uintptr_t)asum | (uintptr_t)asum2) & 15) == 0;
 #define ALQ_BOXCOL(KZ, KY, KX)                                                                                        \
-    if (k[0] == KZ && k[1] == KY && k[2] == KX && (W & 3) == 0) {                                                      \
+    if (k[0] == KZ && k[1] == KY && k[2] == KX && (W & 3) == 0 && al16) {                                              \
         hipLaunchKernelGGL((boxdot_conv_col_kernel<KZ, KY, KX>), dim3((D + zs - 1) / zs, N), dim3(256),               \
                            boxdot_lds_bytes(D, H, W, k), ctx->stream, dsum, asum, asum2, D, H, W, lo[0], lo[1], lo[2], \
                            zs, Spart, nslab_max);                                                                      \

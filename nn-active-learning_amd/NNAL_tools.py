@@ -73,29 +73,11 @@ def sample_query_dstr(q_dstr, k, replacement=True):
     return np.array(picked)
 
 
-def SDP_query_distribution(A, lambda_, X_pool, k, tol=1e-7, max_iter=20000):
-    """Query distribution of Fisher-information AL (reference: NNAL_tools.py:612-659, with
-    `inequality_cvx_matrix` :661-720 and the CVXPY twin `solve_FIAL_SDP` :576-610).
-
-    The reference states, for A-matrices A_i (L x L, positive definite through the diagonal load),
-
-        min  sum_j t_j   s.t.  [[sum_i q_i A_i, e_j], [e_j^T, t_j]] >= 0  (j = 1..L),  q >= 0,  sum q = 1
-
-    and hands it to cvxopt's / MOSEK's SDP solver.  By the Schur complement t_j >= e_j^T M(q)^-1 e_j, so
-    the problem is  min_q tr(M(q)^-1)  over the simplex: an A-optimal design.  cvxopt, cvxpy and
-    MOSEK are absent from this image, so this function solves THAT problem with the classical
-    multiplicative algorithm  q_i <- q_i * sqrt(d_i / tr M^-1),  d_i = <M^-2, A_i>  (monotone for the
-    A-criterion), stopping when the KKT gap  max_i d_i / tr M^-1 - 1  falls below `tol`.
-    PARITY UNPINNED: the optimum is unique in M(q) but the reference solver's iterate, tolerance
-    and therefore the sampled queries cannot be compared here.
-
-    Only the lambda_ = 0 form is built (PW_NNAL.query_multimg passes no features: PW_NNAL.py:596).
-    Returns a dict like cvxopt's: 'x' = concat(q [n], t [L]), 'status', 'primal objective', 'gap'.
-    """
-    if lambda_ and lambda_ > 0:
-        raise NotImplementedError('the feature-regularised SDP (lambda_ > 0, NNAL_tools.py:626-645) is not built')
-    A = np.asarray(A, dtype=np.float64)
-    n, L = A.shape[0], A.shape[1]
+def _aopt_multiplicative(A, tol, max_iter):
+    """q_i <- q_i * sqrt(d_i / tr M^-1): the classical multiplicative algorithm for the A-criterion (monotone;
+    linear convergence, slow once the weights outside the support have to decay).  Kept as the independent
+    cross-check of the Newton solver below."""
+    n = A.shape[0]
     q = np.full(n, 1.0 / n)
     status, gap = 'unknown', np.inf
     for it in range(max_iter):
@@ -109,10 +91,127 @@ def SDP_query_distribution(A, lambda_, X_pool, k, tol=1e-7, max_iter=20000):
             break
         q = q * np.sqrt(d / obj)
         q /= q.sum()
+    return q, status, it + 1
+
+
+def _svec_basis(L):
+    """Orthonormal basis of the symmetric L x L matrices as columns of P [L*L, L(L+1)/2]: <X, Y> = (P^T vec X)(P^T vec Y)."""
+    m = L * (L + 1) // 2
+    P = np.zeros((L * L, m))
+    c = 0
+    for i in range(L):
+        for j in range(i, L):
+            if i == j:
+                P[i * L + i, c] = 1.0
+            else:
+                P[i * L + j, c] = P[j * L + i, c] = np.sqrt(0.5)
+            c += 1
+    return P
+
+
+def _aopt_newton(A, tol, max_iter):
+    """Log-barrier Newton method for  min tr(M(q)^-1),  M(q) = sum q_i A_i,  q in the simplex - the job the
+    reference gives to an interior-point SDP solver, with the structure used instead of a generic cone program:
+    the Hessian of the objective is  V K V^T  with V = [svec A_i] (n x L(L+1)/2) and
+    K = M^-1 (x) M^-2 + M^-2 (x) M^-1 restricted to the symmetric matrices, the barrier adds a diagonal, so a
+    Newton step is one (L(L+1)/2)^2 solve through the Woodbury identity: O(n L^4) per step, ~40 steps,
+    instead of thousands of first-order sweeps.  Duality gap of a centred point = n * mu."""
+    from scipy.linalg import cho_factor, cho_solve
+    n, L = A.shape[0], A.shape[1]
+    P = _svec_basis(L)
+    m = P.shape[1]
+    V = A.reshape(n, L * L) @ P
+
+    def at(q):
+        M = (P @ (q @ V)).reshape(L, L)
+        Mi = np.linalg.inv(M)
+        return Mi, float(np.trace(Mi))
+
+    q = np.full(n, 1.0 / n)
+    Mi, obj = at(q)
+    mu = obj / n
+    status, steps = 'unknown', 0
+    ones = np.ones(n)
+    while steps < max_iter:
+        steps += 1
+        Mi2 = Mi @ Mi
+        d = V @ (P.T @ Mi2.reshape(-1))                        # d_i = <M^-2, A_i> = -df/dq_i
+        if d.max() <= obj * (1.0 + tol):                       # optimality condition d_i <= tr M^-1 for every i
+            status = 'optimal'
+            break
+        g = -d - mu / q
+        K = P.T @ (np.kron(Mi, Mi2) + np.kron(Mi2, Mi)) @ P
+        K = 0.5 * (K + K.T)
+        R = np.linalg.cholesky(K)
+        U = V @ R
+        Dinv = q * q / mu
+        UD = U * Dinv[:, None]
+        S = cho_factor(np.eye(m) + U.T @ UD)
+
+        def Hinv(x):
+            y = Dinv * x
+            return y - UD @ cho_solve(S, U.T @ y)
+        # Newton step on {sum q = 1}: H dq + nu 1 = -g.  g is -(tr M^-1 + n mu) 1 plus a residual that vanishes on
+        # the central path; solving for the residual keeps the step free of the cancellation between the two
+        r = g + (obj + n * mu)
+        a, b = Hinv(r), Hinv(ones)
+        dq = -a + (a.sum() / b.sum()) * b
+        dec = float(-(r @ dq))                                  # Newton decrement squared
+        neg = dq < 0
+        alpha = min(1.0, 0.99 * float(np.min(-q[neg] / dq[neg]))) if neg.any() else 1.0
+        phi0 = obj - mu * np.log(q).sum()
+        slack = 1e-12 * abs(phi0)                               # rounding noise of phi: a decrease below it cannot be tested
+        while True:
+            qn = q + alpha * dq
+            Mn, on = at(qn)
+            if on - mu * np.log(qn).sum() <= phi0 - 0.25 * alpha * dec + slack or alpha < 1e-12:
+                break
+            alpha *= 0.5
+        q, Mi, obj = qn / qn.sum(), Mn, on
+        if dec <= 0.05 * mu * n:                                # centred for this mu: d_i <= tr M^-1 + ~n mu
+            mu = max(0.2 * mu, 0.25 * tol * obj / n)
+    return q, status, steps
+
+
+def SDP_query_distribution(A, lambda_, X_pool, k, tol=1e-7, max_iter=20000, method='newton'):
+    """Query distribution of Fisher-information AL (reference: NNAL_tools.py:612-659, with
+    `inequality_cvx_matrix` :661-720 and the CVXPY twin `solve_FIAL_SDP` :576-610).
+
+    The reference states, for A-matrices A_i (L x L, positive definite through the diagonal load),
+
+        min  sum_j t_j   s.t.  [[sum_i q_i A_i, e_j], [e_j^T, t_j]] >= 0  (j = 1..L),  q >= 0,  sum q = 1
+
+    and hands it to cvxopt's / MOSEK's interior-point SDP solver.  By the Schur complement
+    t_j >= e_j^T M(q)^-1 e_j, so the problem is  min_q tr(M(q)^-1)  over the simplex: an A-optimal design.
+    cvxopt, cvxpy and MOSEK are absent from this image, so this function solves THAT problem itself:
+    `method='newton'` (default) is a log-barrier Newton method on the structure (`_aopt_newton`),
+    `method='multiplicative'` the classical first-order algorithm (`_aopt_multiplicative`); both stop at a
+    relative duality / KKT gap below `tol`.  PARITY UNPINNED: the optimum is unique in M(q) but the reference
+    solver's iterate, tolerance and therefore the sampled queries cannot be compared here.
+
+    Only the lambda_ = 0 form is built (PW_NNAL.query_multimg passes no features: PW_NNAL.py:596).
+    Returns a dict like cvxopt's: 'x' = concat(q [n], t [L]), 'status', 'primal objective', 'gap'
+    (= max_i <M^-2, A_i> / tr M^-1 - 1, the violation of the optimality condition at the returned q).
+    """
+    if lambda_ and lambda_ > 0:
+        raise NotImplementedError('the feature-regularised SDP (lambda_ > 0, NNAL_tools.py:626-645) is not built')
+    A = np.asarray(A, dtype=np.float64)
+    n = A.shape[0]
+    if method == 'newton':
+        q, status, its = _aopt_newton(A, tol, min(max_iter, 500))
+        name = 'log-barrier Newton A-optimal design'
+    elif method == 'multiplicative':
+        q, status, its = _aopt_multiplicative(A, tol, max_iter)
+        name = 'multiplicative A-optimal design'
+    else:
+        raise ValueError('unknown method %r' % (method,))
     M = np.tensordot(q, A, axes=(0, 0))
-    t = np.diag(np.linalg.inv(M)).copy()
-    return {'x': np.concatenate((q, t)), 'status': status + ' (multiplicative A-optimal design; not cvxopt)',
-            'primal objective': float(t.sum()), 'gap': float(gap), 'iterations': it + 1}
+    Minv = np.linalg.inv(M)
+    t = np.diag(Minv).copy()
+    d = np.tensordot(A, Minv @ Minv, axes=([1, 2], [0, 1]))
+    gap = d.max() / t.sum() - 1.0
+    return {'x': np.concatenate((q, t)), 'status': '%s (%s; not cvxopt)' % (status, name),
+            'primal objective': float(t.sum()), 'gap': float(gap), 'iterations': its}
 
 
 def solve_FIAL_SDP(A):

@@ -11,7 +11,8 @@ the volume I/O and the fine-tune itself left out (both outside the hot path): pe
     6. the drawn patches leave the pool                          (PW_AL.py:870-882)
 
 Everything up to the A_i runs on the device through the C ABI; steps 4-5 are host NumPy like the reference's
-(the SDP solver is this build's own: cvxopt is absent, parity unpinned - see NNAL_tools.SDP_query_distribution).
+(the SDP solver is this build's own - a log-barrier Newton method on the A-optimal design the SDP states: cvxopt is
+absent, parity unpinned - see NNAL_tools.SDP_query_distribution).
 """
 import time
 

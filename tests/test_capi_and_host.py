@@ -121,6 +121,26 @@ def test_sdp_query_distribution_is_the_a_optimal_design():
     np.testing.assert_allclose(obj, soln['primal objective'], rtol=1e-12)
 
 
+@pytest.mark.parametrize('n,L', [(1, 2), (3, 8), (60, 4), (700, 8)])
+def test_sdp_newton_and_multiplicative_solvers_agree(n, L):
+    """The two own solvers of the A-optimal design (log-barrier Newton on the diagonal + low-rank Hessian, and
+    the first-order multiplicative algorithm) reach the same optimum: same objective within the stopping
+    tolerance, same information matrix M(q) (unique at the optimum), each with its optimality certificate."""
+    rs = np.random.RandomState(100 + n)
+    G0, G1, p = rs.randn(n, L), rs.randn(n, L), rs.rand(n)
+    A = np.stack([(1 - pp) * np.outer(a, a) + pp * np.outer(b, b) + 1e-3 * np.eye(L) for a, b, pp in zip(G0, G1, p)])
+    sn = NNAL_tools.SDP_query_distribution(A, 0., [], 5, tol=1e-8)
+    sm = NNAL_tools.SDP_query_distribution(A, 0., [], 5, tol=1e-8, max_iter=200000, method='multiplicative')
+    for s_ in (sn, sm):
+        q = s_['x'][:n]
+        assert s_['status'].startswith('optimal') and s_['gap'] <= 1e-8 and abs(q.sum() - 1) < 1e-12 and q.min() >= 0
+    assert sn['iterations'] < 200
+    np.testing.assert_allclose(sn['primal objective'], sm['primal objective'], rtol=3e-8)
+    Mn = np.tensordot(sn['x'][:n], A, axes=(0, 0))
+    Mm = np.tensordot(sm['x'][:n], A, axes=(0, 0))
+    np.testing.assert_allclose(Mn, Mm, rtol=0, atol=2e-3 * np.abs(Mm).max())
+
+
 def test_shard_bounds_cover_the_pool():
     for n in (0, 1, 7, 8, 100000, 1000003):
         for R in (1, 2, 3, 8):

@@ -371,6 +371,7 @@ int k_chansum(alq_ctx *, const View &in, float *field, int N);
 int k_mask_chansum(alq_ctx *, const View &dact, const View *act_or_null, float *field, int N);
 int boxdot_slabs(long long vox);
 int boxdot_conv_slabs(int D, int H, int W, const int k[3]);
+int boxdot_convT_slabs(int ID, int IH, int IW, const int k[3], const int s[3]);
 // asum2 (optional): second channel-sum field added to asum (input = concat of two producers)
 int k_boxdot_conv(alq_ctx *, const float *dsum, const float *asum, const float *asum2, int D, int H, int W,
                   const int k[3], const int lo[3], int N, double *Spart, int nslab_max);

@@ -957,9 +957,101 @@ int k_boxdot_conv(alq_ctx *ctx, const float *dsum, const float *asum, const floa
     return ALQ_OK;
 }
 
+// conv_transpose, output-side form: S[n] = sum_p dsum[n,p] * (1 + sum_{q : p in window(q)} asum[n,q]).  The whole
+// input-grid field asum (+ asum2) of the patch sits in LDS; the large field (dsum, on the s-times finer output
+// grid) is streamed once with 16-byte loads.  Along a dimension the q's of an output point p are
+// (p + lo - t) / s for the taps t = (p + lo) mod s, + s, ... < k: k / s of them on average.
+template <int K, int S>
+__global__ __launch_bounds__(256) void boxdot_convT_out_kernel(const float *dsum, const float *asum, const float *asum2,
+                                                               int ID, int IH, int IW, int kz, int lz, int ly, int lx,
+                                                               int ZS, double *Spart, int nslab_max) {
+    extern __shared__ float tile[];
+    __shared__ double sh[4];
+    const long long n = blockIdx.y;
+    const int slab = blockIdx.x;
+    const int sz = kz == 1 ? 1 : S;                               // 2-D layers: depth 1, window 1, stride 1
+    const int OD = ID * sz, OH = IH * S, OW = IW * S;
+    const int ivox = ID * IH * IW;
+    const float *an = asum + n * ivox;
+    const float *an2 = asum2 ? asum2 + n * ivox : nullptr;
+    const float *dn = dsum + n * (long long)OD * OH * OW;
+    const bool al = (((uintptr_t)dn | (uintptr_t)an | (uintptr_t)an2) & 15) == 0;       // 16-byte loads possible
+    auto ld4 = [al](const float *p) {
+        return al ? *reinterpret_cast<const f32x4 *>(p) : f32x4{p[0], p[1], p[2], p[3]};
+    };
+    for (int i = threadIdx.x * 4; i < ivox; i += 1024) {          // ivox is a multiple of 4 (checked by the launcher)
+        f32x4 v = ld4(an + i);
+        if (an2) {
+            const f32x4 w = ld4(an2 + i);
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        *reinterpret_cast<f32x4 *>(tile + i) = v;
+    }
+    __syncthreads();
+    const int z0 = slab * ZS;
+    const int z1 = min(OD, z0 + ZS);
+    const int OW4 = OW >> 2, ncol = OH * OW4;
+    double acc = 0;
+    const int ceff = ncol < 256 ? ncol : 256, zg = 256 / ceff, g = threadIdx.x / ceff;     // few columns: split the planes
+    for (int c = threadIdx.x - g * ceff; c < ncol && g < zg; c += ceff) {     // a thread owns 4 x-adjacent output points of one row
+        const int py = c / OW4, px = (c - py * OW4) * 4;
+        for (int pz = z0 + g; pz < z1; pz += zg) {
+            const f32x4 d = ld4(dn + ((long long)pz * OH + py) * OW + px);
+            float box[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int tz = (pz + lz) % sz; tz < kz; tz += sz) {
+                const int uz = pz + lz - tz, qz = uz / sz;
+                if (uz < 0 || qz >= ID) continue;
+#pragma unroll
+                for (int iy = 0; iy < (K + S - 1) / S; ++iy) {
+                    const int ty = (py + ly) % S + iy * S, uy = py + ly - ty, qy = uy / S;
+                    if (ty >= K || uy < 0 || qy >= IH) continue;
+                    const float *rowp = tile + (qz * IH + qy) * IW;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int ix = 0; ix < (K + S - 1) / S; ++ix) {
+                            const int tx = (px + j + lx) % S + ix * S, ux = px + j + lx - tx, qx = ux / S;
+                            if (tx < K && ux >= 0 && qx < IW) box[j] += rowp[qx];
+                        }
+                }
+            }
+            acc += (double)d.x * ((double)box[0] + 1.0) + (double)d.y * ((double)box[1] + 1.0) +
+                   (double)d.z * ((double)box[2] + 1.0) + (double)d.w * ((double)box[3] + 1.0);
+        }
+    }
+    const double tot = block_sum256(acc, sh);
+    if (threadIdx.x == 0) Spart[n * nslab_max + slab] = tot;
+}
+
+// window 3, stride 2 in y and x, and either the same in z or a flat (2-D) layer
+static bool boxdot_convT_out_ok(int ID, int IH, int IW, const int k[3], const int s[3]) {
+    const long long ivox = (long long)ID * IH * IW;
+    const bool shape = k[1] == 3 && k[2] == 3 && s[1] == 2 && s[2] == 2 &&
+                       ((k[0] == 3 && s[0] == 2) || (k[0] == 1 && s[0] == 1 && ID == 1));
+    return shape && ivox % 4 == 0 && ivox * 4 <= 48 * 1024;
+}
+static int boxdot_convT_zs(int ID, int IH, int IW, const int s[3]) {
+    int zs = 4096 / (IH * s[1] * IW * s[2]);
+    if (zs < 1) zs = 1;
+    if (zs > ID * s[0]) zs = ID * s[0];
+    return zs;
+}
+int boxdot_convT_slabs(int ID, int IH, int IW, const int k[3], const int s[3]) {
+    if (boxdot_convT_out_ok(ID, IH, IW, k, s)) { const int zs = boxdot_convT_zs(ID, IH, IW, s); return (ID * s[0] + zs - 1) / zs; }
+    return boxdot_slabs((long long)ID * IH * IW);
+}
+
 int k_boxdot_convT(alq_ctx *ctx, const float *dsum, const float *asum, const float *asum2, int ID, int IH, int IW,
                    const int k[3], const int s[3], const int lo[3], int N, double *Spart, int nslab_max) {
     ProfScope ps(ctx, PROF_REDUCE, 0);
+    if (boxdot_convT_out_ok(ID, IH, IW, k, s)) {
+        const int zs = boxdot_convT_zs(ID, IH, IW, s);
+        hipLaunchKernelGGL((boxdot_convT_out_kernel<3, 2>), dim3((ID * s[0] + zs - 1) / zs, N), dim3(256),
+                           (size_t)ID * IH * IW * sizeof(float), ctx->stream, dsum, asum, asum2, ID, IH, IW, k[0], lo[0],
+                           lo[1], lo[2], zs, Spart, nslab_max);
+        ALQ_LAUNCH_CHECK();
+        return ALQ_OK;
+    }
     hipLaunchKernelGGL(boxdot_convT_kernel, dim3(boxdot_slabs((long long)ID * IH * IW), N), dim3(256), 0,
                        ctx->stream, dsum, asum, asum2, ID, IH, IW, k[0], k[1], k[2], s[0], s[1], s[2], lo[0], lo[1], lo[2],
                        Spart, nslab_max);

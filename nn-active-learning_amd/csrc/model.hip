@@ -603,7 +603,8 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
     for (const Layer &ly : m->layers) {
         if (ly.pidx < 0) continue;
         if (ly.spec.type == ALQ_CONV) h_nslab[ly.pidx] = boxdot_conv_slabs(ly.out.D, ly.out.H, ly.out.W, ly.spec.k);
-        else h_nslab[ly.pidx] = boxdot_slabs(ly.spec.type == ALQ_FC ? 1 : ly.in.vox());
+        else if (ly.spec.type == ALQ_CONVT) h_nslab[ly.pidx] = boxdot_convT_slabs(ly.in.D, ly.in.H, ly.in.W, ly.spec.k, ly.spec.s);
+        else h_nslab[ly.pidx] = boxdot_slabs(1);
         m->nslab_max = std::max(m->nslab_max, h_nslab[ly.pidx]);
     }
     ALQ_TRY(m->dalloc(&m->nslab, (size_t)m->L));

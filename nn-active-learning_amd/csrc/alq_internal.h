@@ -207,6 +207,9 @@ struct Igemm2Fuse {
     int store_from = 0;  // columns below this are masked and summed but not stored (igemm4 only)
     int mask_split = 0;  // igemm4 only: the mask source is a split concat (see View): columns >= mask_split at mask + mask_delta
     long long mask_delta = 0;
+    // igemm4 only: the GEMM input is not a stored tensor but in[n, j] = [bit j of patch n] * in_vec[j]
+    const unsigned *in_bits = nullptr;
+    const float *in_vec = nullptr;
 };
 
 extern unsigned long long *g_igemm2_dbg;
@@ -264,6 +267,8 @@ struct Igemm4Args {
     int tt_ints, pd_off, td_off, wbytes, abytes;   // table block in LDS (ints): tap table, then phase, then tile descriptors
     int dbg_repeat;
     unsigned long long *dbg;
+    const unsigned *src_bits;   // BITSRC: `in` is one patch-independent vector, masked per patch by these bits
+    int bits_pstride, bits_bytes;   // floats per patch of the tensor the bits describe; size of the bit field
 };
 
 struct G4Geom {
@@ -377,8 +382,12 @@ int k_boxdot_conv(alq_ctx *, const float *dsum, const float *asum, const float *
                   const int k[3], const int lo[3], int N, double *Spart, int nslab_max);
 int k_boxdot_convT(alq_ctx *, const float *dsum, const float *asum, const float *asum2, int ID, int IH, int IW,
                    const int k[3], const int s[3], const int lo[3], int N, double *Spart, int nslab_max);
+// maskbits (optional, F % 1024 == 0): act > 0 as one bit per element
 int k_fc_small_fwd(alq_ctx *, const float *act, int64_t F, const float *Wp, int nout, int N,
-                   float *partials, int nslices);
+                   float *partials, int nslices, unsigned *maskbits = nullptr);
+// fc head under a patch-independent cotangent: wv = sum_o delta[o] Wp[o, :]; per-voxel sums of [bit] * wv over 8 channels
+int k_fc_small_wvec(alq_ctx *, const float *delta, int nout, const float *Wp, int64_t F, float *wv);
+int k_fc_small_dsum_bits(alq_ctx *, const unsigned *maskbits, const float *wv, int64_t F, int N, float *dsum);
 int k_fc_small_finish(alq_ctx *, const float *partials, int nslices, const float *bias, int nout,
                       int relu, int N, float *out);
 // mask_act / dsum / C (optional): rows are [voxel][C]; masks by act > 0 and emits per-voxel channel sums

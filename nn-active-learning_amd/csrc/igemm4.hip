@@ -76,7 +76,10 @@ __device__ inline unsigned g4_pack2(float a, float b) {
     return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, a), 0x07060302u);
 }
 
-template <int NTW, bool MULTI, bool SUMS>
+// BITSRC: the GEMM input is not a stored tensor: in[n, j] = [bit j of patch n in a.src_bits] * a.in[j] (the cotangent
+// of a fc head's input under a patch-independent head cotangent; one patch per tile).  The staging part loads the
+// vector instead of the tensor plus one mask word per slot and clears the masked elements before the split.
+template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false>
 __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     extern __shared__ __attribute__((aligned(16))) char lds4[];
     const int tid = threadIdx.x;
@@ -224,6 +227,10 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     f32x4 R[G4_NSLOT];
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
+    unsigned Rb[BITSRC ? G4_NSLOT : 1];
+    int s_bsh = 0;                   // BITSRC: (float offset of the fetched phase) mod 32
+    const __amdgpu_buffer_rsrc_t bits_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned *>(a.src_bits), 0, BITSRC ? a.bits_bytes : 0, 0x00020000);
     // the ONE prefetch site: unconditional loads, a slot without work points past the buffer
     auto fetch = [&](int ph) __attribute__((always_inline)) {
         int soff = 0;
@@ -236,12 +243,26 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
 #pragma unroll
         for (int it = 0; it < G4_NSLOT; ++it)
             R[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, goff[it], soff, 0));
+        if constexpr (BITSRC) {
+            const unsigned pbase = (unsigned)f_g * (unsigned)a.bits_pstride;
+#pragma unroll
+            for (int it = 0; it < G4_NSLOT; ++it) {
+                const unsigned e = (unsigned)(goff[it] + soff) >> 2;          // float index inside the patch (huge when parked)
+                Rb[it] = __builtin_amdgcn_raw_buffer_load_b32(bits_rsrc, (int)(((pbase + e) >> 5) << 2), 0, 0);
+            }
+            s_bsh = (soff >> 2) & 31;
+        }
     };
     auto stash = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < G4_NSLOT; ++it) {
             if (s_lds[it] >= 0) {
                 float v0 = R[it].x, v1 = R[it].y, v2 = R[it].z, v3 = R[it].w;
+                if constexpr (BITSRC) {
+                    const unsigned nib = Rb[it] >> ((((unsigned)goff[it] >> 2) + s_bsh) & 31);
+                    v0 = (nib & 1u) ? v0 : 0.f; v1 = (nib & 2u) ? v1 : 0.f;
+                    v2 = (nib & 4u) ? v2 : 0.f; v3 = (nib & 8u) ? v3 : 0.f;
+                }
                 uint2 hi, mid, lo;
                 hi.x = g4_split2(v0, v1);  hi.y = g4_split2(v2, v3);
                 mid.x = g4_split2(v0, v1); mid.y = g4_split2(v2, v3);
@@ -1099,9 +1120,9 @@ void igemm4_pack_weights(Igemm4Plan *plan, const std::vector<float> &Bmat) {
                 }
 }
 
-template <int NTW, bool MULTI, bool SUMS>
+template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false>
 static int launch4_s(alq_ctx *ctx, const Igemm4Plan &plan, const Igemm4Args &a, unsigned grid) {
-    auto kfn = igemm4_kernel<NTW, MULTI, SUMS>;
+    auto kfn = igemm4_kernel<NTW, MULTI, SUMS, BITSRC>;
     if (plan.lds_bytes > 64 * 1024)
         ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)plan.lds_bytes));
@@ -1138,6 +1159,18 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
     a.in_split_ch = in.split / 8; a.in_delta = (int)in.delta;
     a.out_split = out.split; a.out_delta = (int)out.delta;
     a.mask_split = 0; a.mask_delta = 0;
+    a.src_bits = nullptr; a.bits_pstride = 0; a.bits_bytes = 0;
+    if (fuse && fuse->in_bits) {      // masked-vector input: `in` only gives the geometry
+        ALQ_REQUIRE(plan.NTW == 1 && !plan.multi && a.PT == 1 && !in.split && in.c0 == 0 && in.cs == in.C && fuse->in_vec &&
+                        ((long long)in.vox() * in.cs) % 32 == 0,
+                    ALQ_EUNSUPPORTED, "igemm4: masked-vector input needs a one-patch, one-column-tile plan on a dense tensor");
+        a.in = fuse->in_vec;
+        a.in_pstride = 0;
+        a.in_bytes = (int)((long long)in.vox() * in.cs * 4);
+        a.src_bits = fuse->in_bits;
+        a.bits_pstride = (int)((long long)in.vox() * in.cs);
+        a.bits_bytes = (int)((long long)N * in.vox() * in.cs / 8);
+    }
     a.dbg = nullptr;
     if (g_igemm2_dbg) {   // diagnostic: stamp only the launch whose ordinal (since the buffer was set) is ALQ_STAMP_ONLY
         static int want = -2;
@@ -1174,6 +1207,9 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
         if (plan.NTW == 1) return launch4_t<1, true>(ctx, plan, a, grid);
         return launch4_t<2, true>(ctx, plan, a, grid);
     }
+    if (a.src_bits)
+        return (a.osumA || a.osumB) ? launch4_s<1, false, true, true>(ctx, plan, a, grid)
+                                    : launch4_s<1, false, false, true>(ctx, plan, a, grid);
     if (plan.NTW == 1) return launch4_t<1, false>(ctx, plan, a, grid);
     return launch4_t<2, false>(ctx, plan, a, grid);
 }

@@ -1066,9 +1066,12 @@ int k_boxdot_convT(alq_ctx *ctx, const float *dsum, const float *asum, const flo
 constexpr int FC_SLICE = 8192;
 int fc_small_slices(int64_t F) { return (int)((F + FC_SLICE - 1) / FC_SLICE); }
 
-template <int NOUT>
+// BITS: also emits act > 0 as one bit per element (word j / 32, bit j % 32 of the patch's F / 32 words): the
+// backward pass of a fc head on top of a ReLU conv needs nothing else of that tensor (needs F % 1024 == 0: whole
+// waves in every trip)
+template <int NOUT, bool BITS>
 __global__ __launch_bounds__(256) void fc_small_fwd_kernel(const float *act, long long F, const float *Wp,
-                                                           float *partials, int nslices) {
+                                                           float *partials, int nslices, unsigned *maskbits) {
     __shared__ double sh[4];
     const int slice = blockIdx.x;
     const long long n = blockIdx.y;
@@ -1085,6 +1088,14 @@ __global__ __launch_bounds__(256) void fc_small_fwd_kernel(const float *act, lon
             for (int o = 0; o < NOUT; ++o) {
                 const f32x4 wv = *reinterpret_cast<const f32x4 *>(Wp + o * F + f);
                 acc[o] += (av.x * wv.x + av.y * wv.y) + (av.z * wv.z + av.w * wv.w);
+            }
+            if constexpr (BITS) {      // 8 lanes = 32 consecutive elements = one word
+                unsigned nib = (av.x > 0.f ? 1u : 0u) | (av.y > 0.f ? 2u : 0u) | (av.z > 0.f ? 4u : 0u) | (av.w > 0.f ? 8u : 0u);
+                nib <<= 4 * (threadIdx.x & 7);
+                nib |= __shfl_xor(nib, 1, 64);
+                nib |= __shfl_xor(nib, 2, 64);
+                nib |= __shfl_xor(nib, 4, 64);
+                if ((threadIdx.x & 7) == 0) maskbits[(n * F + f) >> 5] = nib;
             }
         }
     } else {
@@ -1114,11 +1125,19 @@ __global__ void fc_small_finish_kernel(const float *partials, int nslices, const
 }
 
 int k_fc_small_fwd(alq_ctx *ctx, const float *act, int64_t F, const float *Wp, int nout, int N,
-                   float *partials, int nslices) {
+                   float *partials, int nslices, unsigned *maskbits) {
     ProfScope ps(ctx, PROF_FC_SMALL, 2.0 * F * nout * N);
     dim3 grid(nslices, N);
-#define ALQ_FC(NO) \
-    case NO: hipLaunchKernelGGL(fc_small_fwd_kernel<NO>, grid, dim3(256), 0, ctx->stream, act, (long long)F, Wp, partials, nslices); break
+    ALQ_REQUIRE(!maskbits || F % 1024 == 0, ALQ_EINVAL, "fc_small: mask bits need F %% 1024 == 0");
+#define ALQ_FC(NO)                                                                                                     \
+    case NO:                                                                                                           \
+        if (maskbits)                                                                                                  \
+            hipLaunchKernelGGL((fc_small_fwd_kernel<NO, true>), grid, dim3(256), 0, ctx->stream, act, (long long)F, Wp, \
+                               partials, nslices, maskbits);                                                           \
+        else                                                                                                           \
+            hipLaunchKernelGGL((fc_small_fwd_kernel<NO, false>), grid, dim3(256), 0, ctx->stream, act, (long long)F,   \
+                               Wp, partials, nslices, maskbits);                                                       \
+        break
     switch (nout) {
         ALQ_FC(1); ALQ_FC(2); ALQ_FC(3); ALQ_FC(4); ALQ_FC(5); ALQ_FC(6); ALQ_FC(7); ALQ_FC(8);
         default: set_error("fc_small: nout=%d unsupported", nout); return ALQ_EUNSUPPORTED;
@@ -1182,6 +1201,53 @@ __global__ void fc_small_bwd_scalar_kernel(const float *delta, int nout, const f
         for (int o = 0; o < nout; ++o) s += delta[n * nout + o] * Wp[o * F + f];
         dact[i] = s;
     }
+}
+
+// The cotangent of a fc head's input when the head's own cotangent is the same for every patch (the unit cotangent of
+// the Fisher pass): dact[n, f] = [act[n, f] > 0] * wv[f] with wv = sum_o delta[o] * Wp[o, :].  It is never stored:
+// wv (fc_small_wvec) and the mask bits of the forward pass are all the consuming contraction needs (igemm4 BITSRC),
+// and the per-voxel channel sums come from the same two (fc_small_dsum_bits, C = 8 channels = one byte of bits).
+__global__ void fc_small_wvec_kernel(const float *delta, int nout, const float *Wp, long long F, float *wv) {
+    const long long f = (blockIdx.x * (long long)blockDim.x + threadIdx.x) * 4;
+    if (f >= F) return;
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int o = 0; o < nout; ++o) s += delta[o] * *reinterpret_cast<const f32x4 *>(Wp + o * F + f);   // same order as fc_small_bwd
+    *reinterpret_cast<f32x4 *>(wv + f) = s;
+}
+__global__ void fc_small_dsum_bits_kernel(const unsigned *maskbits, const float *wv, long long F, int N, float *dsum) {
+    const long long words = F >> 5, total = (long long)N * words;
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;      // one word = 4 voxels x 8 channels
+    if (i >= total) return;
+    const long long n = i / words, w = i - n * words;
+    const unsigned bits = maskbits[i];
+    const float *wp = wv + (w << 5);
+    float out[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(wp + v * 8), b = *reinterpret_cast<const f32x4 *>(wp + v * 8 + 4);
+        const unsigned m = bits >> (v * 8);
+        const float sa = ((m & 1u ? a.x : 0.f) + (m & 2u ? a.y : 0.f)) + ((m & 4u ? a.z : 0.f) + (m & 8u ? a.w : 0.f));
+        const float sb = ((m & 16u ? b.x : 0.f) + (m & 32u ? b.y : 0.f)) + ((m & 64u ? b.z : 0.f) + (m & 128u ? b.w : 0.f));
+        out[v] = sa + sb;
+    }
+    *reinterpret_cast<f32x4 *>(dsum + (n * F >> 3) + (w << 2)) = f32x4{out[0], out[1], out[2], out[3]};
+}
+int k_fc_small_wvec(alq_ctx *ctx, const float *delta, int nout, const float *Wp, int64_t F, float *wv) {
+    ProfScope ps(ctx, PROF_FC_SMALL, 0);
+    ALQ_REQUIRE(F % 4 == 0, ALQ_EINVAL, "fc_small_wvec: F %% 4");
+    hipLaunchKernelGGL(fc_small_wvec_kernel, dim3((unsigned)((F / 4 + 255) / 256)), dim3(256), 0, ctx->stream, delta, nout, Wp,
+                       (long long)F, wv);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+int k_fc_small_dsum_bits(alq_ctx *ctx, const unsigned *maskbits, const float *wv, int64_t F, int N, float *dsum) {
+    ProfScope ps(ctx, PROF_FC_SMALL, 0);
+    ALQ_REQUIRE(F % 32 == 0, ALQ_EINVAL, "fc_small_dsum_bits: F %% 32");
+    const long long total = (long long)N * (F / 32);
+    hipLaunchKernelGGL(fc_small_dsum_bits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, maskbits, wv,
+                       (long long)F, N, dsum);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
 }
 
 int k_fc_small_bwd(alq_ctx *ctx, const float *delta, int nout, const float *Wp, int64_t F, int N,

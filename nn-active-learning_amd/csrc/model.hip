@@ -59,6 +59,12 @@ struct Layer {
     bool delta_ready = false;  // backward: the cotangent of our output is already masked and dsum is filled
     bool dsum_partial = false; // backward, first layer: the skip destination has written its share of dsum
     float *fc_partials = nullptr;
+    // fc head of a Fisher pass on top of a ReLU conv: its input cotangent is [input > 0] * fc_wv for every patch; the
+    // forward pass leaves the bits, the backward pass of the conv below contracts them directly (igemm4 BITSRC)
+    unsigned *fc_maskbits = nullptr;
+    float *fc_wv = nullptr;
+    const unsigned *dout_bits = nullptr;   // set on the conv below for the duration of one backward pass
+    const float *dout_vec = nullptr;
     int fc_slices = 0;
     bool out_is_skip_src = false;
     // convT class tap lists (indices into the k^3 tap enumeration)
@@ -580,6 +586,11 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
                 ly.fc_slices = fc_small_slices(ly.F);
                 ALQ_TRY(m->dalloc(&ly.d_Wp, (size_t)sp.cout * ly.F));
                 ALQ_TRY(m->dalloc(&ly.fc_partials, (size_t)NB * ly.fc_slices * sp.cout));
+                if (ly.F % 1024 == 0 && i == n_layers - 1 && i > 0 && m->layers[i - 1].spec.relu && m->layers[i - 1].pidx > 0 &&
+                    m->layers[i - 1].spec.type == ALQ_CONV && m->layers[i - 1].out.C == 8 && !getenv("ALQ_NO_FC_BITS")) {
+                    ALQ_TRY(m->dalloc(&ly.fc_maskbits, (size_t)NB * (ly.F / 32)));
+                    ALQ_TRY(m->dalloc(&ly.fc_wv, (size_t)ly.F));
+                }
             } else {
                 ConvDesc d;
                 d.ID = d.IH = d.IW = 1; d.Ci = (int)ly.F;
@@ -683,7 +694,8 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums) {
                     else ALQ_TRY(k_chansum(ctx, flat_view(in), ly.asum, N));
                 }
                 if (ly.dense_fc_small) {
-                    ALQ_TRY(k_fc_small_fwd(ctx, in.p, ly.F, ly.d_Wp, ly.spec.cout, N, ly.fc_partials, ly.fc_slices));
+                    ALQ_TRY(k_fc_small_fwd(ctx, in.p, ly.F, ly.d_Wp, ly.spec.cout, N, ly.fc_partials, ly.fc_slices,
+                                           with_sums ? ly.fc_maskbits : nullptr));
                     ALQ_TRY(k_fc_small_finish(ctx, ly.fc_partials, ly.fc_slices, ly.d_bias, ly.spec.cout,
                                               ly.spec.relu, N, ly.out.p));
                 } else {
@@ -704,7 +716,7 @@ static int run_backward(alq_model *m, const float *d_x, int N) {
     const int nl = (int)m->layers.size();
     ALQ_REQUIRE(m->nclass == 2, ALQ_EUNSUPPORTED, "Fisher scoring is binary (PW_NNAL.py:766), got %d classes", m->nclass);
     ALQ_TRY(k_fill_unit_cotangent(ctx, m->dlogits, N));
-    for (Layer &l : m->layers) { l.delta_ready = false; l.dsum_partial = false; }
+    for (Layer &l : m->layers) { l.delta_ready = false; l.dsum_partial = false; l.dout_bits = nullptr; l.dout_vec = nullptr; }
     const bool v4_on = !g_dbg_knobs[4] && !g_dbg_knobs[5];
     // a pool whose producer is the first parameterised layer: 2x2(x2) windows tiling the input exactly
     auto pool_first_ok = [&](const Layer &pl, const Layer &src) {
@@ -763,7 +775,18 @@ static int run_backward(alq_model *m, const float *d_x, int N) {
         bool fused = false;
         if (isfc) {
             ALQ_REQUIRE(!acc, ALQ_EUNSUPPORTED, "layer %d: fc consumer of a skip source", i);
-            if (ly.dense_fc_small) {
+            const bool bits_ok = ly.dense_fc_small && ly.fc_maskbits && prev_param && prev->out.cs == prev->out.C &&
+                                 prev->out.c0 == 0 && v4_on && prev->bwd.p4.ok && prev->bwd.p4.NTW == 1 && !prev->bwd.p4.multi &&
+                                 prev->bwd.p4.a.PT == 1 && !prev->dout.split && !prev_is_src;
+            if (bits_ok) {
+                // every patch has the same head cotangent (the unit cotangent): nothing of the size of the conv's output
+                // is written; the conv's backward contraction reads [bit] * wv (see fc_small_wvec_kernel)
+                ALQ_TRY(k_fc_small_wvec(ctx, ly.dout.p, ly.spec.cout, ly.d_Wp, ly.F, ly.fc_wv));
+                ALQ_TRY(k_fc_small_dsum_bits(ctx, ly.fc_maskbits, ly.fc_wv, ly.F, N, prev->dsum));
+                prev->dout_bits = ly.fc_maskbits;
+                prev->dout_vec = ly.fc_wv;
+                fused = true;
+            } else if (ly.dense_fc_small) {
                 const bool can = prev_param && prev->out.cs == prev->out.C;
                 ALQ_TRY(k_fc_small_bwd(ctx, ly.dout.p, ly.spec.cout, ly.d_Wp, ly.F, N, ly.din.p,
                                        (can && prev->spec.relu) ? prev->out.p : nullptr, can ? prev->dsum : nullptr,
@@ -795,6 +818,13 @@ static int run_backward(alq_model *m, const float *d_x, int N) {
                 }
                 fuse = &fz;
             }
+            if (ly.dout_bits) {       // the cotangent of this layer's output exists only as mask bits and one vector
+                fz.in_bits = ly.dout_bits; fz.in_vec = ly.dout_vec;
+                ly.dout_bits = nullptr; ly.dout_vec = nullptr;
+                const bool honoured = fuse != nullptr;
+                ALQ_TRY(igemm4_launch(ctx, ly.bwd.p4, ly.dout, ly.din, nullptr, 0, acc, N, PROF_IGEMM3_BWD, &fz));
+                fused = honoured;
+            } else
             ALQ_TRY(gemm_launch(ctx, ly.bwd, ly.dout, ly.din, nullptr, 0, acc, N, PROF_IGEMM_BWD, fuse, &fused));
         }
         if (prev_param && fused) prev->delta_ready = true;

@@ -460,7 +460,8 @@ def test_config5_loop_harness(sess):
 
 def test_layout_and_engine_switches_agree(sess):
     """The same NET-C scores through (a) the split-concat layout (default), (b) concat as channel slices of one
-    buffer (ALQ_NO_SPLIT) - identical arithmetic per output element, so identical bits - and (c) the fp32-MFMA
+    buffer (ALQ_NO_SPLIT), (d) the fc head's input cotangent stored as a tensor (ALQ_NO_FC_BITS) instead of mask
+    bits + one vector - identical arithmetic per output element, so identical bits - and (c) the fp32-MFMA
     engines (ALQ_DISABLE_V4 + ALQ_DISABLE_V3: exact fp32 fma chains in another order): fp32-level agreement, with
     the absolute bar of the tolerance note on top for a ReLU input that lands on the other side of zero."""
     torch = sess.torch
@@ -489,8 +490,10 @@ def test_layout_and_engine_switches_agree(sess):
     a = scores({})
     b = scores({'ALQ_NO_SPLIT': '1'})
     c = scores({'ALQ_DISABLE_V4': '1', 'ALQ_DISABLE_V3': '1'})
+    d = scores({'ALQ_NO_FC_BITS': '1'})
     for k in a:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+        np.testing.assert_array_equal(a[k], d[k], err_msg=k)
     np.testing.assert_allclose(c['p1'], a['p1'], rtol=0, atol=2e-6)
     for k in ('g0', 'g1'):
         err = np.abs(c[k] - a[k])

@@ -1214,23 +1214,36 @@ __global__ void fc_small_wvec_kernel(const float *delta, int nout, const float *
     for (int o = 0; o < nout; ++o) s += delta[o] * *reinterpret_cast<const f32x4 *>(Wp + o * F + f);   // same order as fc_small_bwd
     *reinterpret_cast<f32x4 *>(wv + f) = s;
 }
-__global__ void fc_small_dsum_bits_kernel(const unsigned *maskbits, const float *wv, long long F, int N, float *dsum) {
-    const long long words = F >> 5, total = (long long)N * words;
-    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;      // one word = 4 voxels x 8 channels
-    if (i >= total) return;
-    const long long n = i / words, w = i - n * words;
-    const unsigned bits = maskbits[i];
-    const float *wp = wv + (w << 5);
-    float out[4];
+// grid (words / 256, patch groups): a thread keeps the 32 vector values of its word in registers for PG patches
+constexpr int FC_BITS_PG = 8;
+__global__ __launch_bounds__(256) void fc_small_dsum_bits_kernel(const unsigned *maskbits, const float *wv, long long F, int N,
+                                                                 float *dsum) {
+    const long long words = F >> 5;
+    const long long w = blockIdx.x * (long long)blockDim.x + threadIdx.x;      // one word = 4 voxels x 8 channels
+    if (w >= words) return;
+    f32x4 a[4], b[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(wp + v * 8), b = *reinterpret_cast<const f32x4 *>(wp + v * 8 + 4);
-        const unsigned m = bits >> (v * 8);
-        const float sa = ((m & 1u ? a.x : 0.f) + (m & 2u ? a.y : 0.f)) + ((m & 4u ? a.z : 0.f) + (m & 8u ? a.w : 0.f));
-        const float sb = ((m & 16u ? b.x : 0.f) + (m & 32u ? b.y : 0.f)) + ((m & 64u ? b.z : 0.f) + (m & 128u ? b.w : 0.f));
-        out[v] = sa + sb;
+        a[v] = *reinterpret_cast<const f32x4 *>(wv + (w << 5) + v * 8);
+        b[v] = *reinterpret_cast<const f32x4 *>(wv + (w << 5) + v * 8 + 4);
     }
-    *reinterpret_cast<f32x4 *>(dsum + (n * F >> 3) + (w << 2)) = f32x4{out[0], out[1], out[2], out[3]};
+    const int n0 = blockIdx.y * FC_BITS_PG, n1 = min(N, n0 + FC_BITS_PG);
+    unsigned bits[FC_BITS_PG];
+#pragma unroll
+    for (int k = 0; k < FC_BITS_PG; ++k) bits[k] = n0 + k < n1 ? maskbits[(n0 + k) * words + w] : 0u;
+#pragma unroll
+    for (int k = 0; k < FC_BITS_PG; ++k) {
+        if (n0 + k >= n1) break;
+        float out[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const unsigned m = bits[k] >> (v * 8);
+            const float sa = ((m & 1u ? a[v].x : 0.f) + (m & 2u ? a[v].y : 0.f)) + ((m & 4u ? a[v].z : 0.f) + (m & 8u ? a[v].w : 0.f));
+            const float sb = ((m & 16u ? b[v].x : 0.f) + (m & 32u ? b[v].y : 0.f)) + ((m & 64u ? b[v].z : 0.f) + (m & 128u ? b[v].w : 0.f));
+            out[v] = sa + sb;
+        }
+        *reinterpret_cast<f32x4 *>(dsum + ((long long)(n0 + k) * F >> 3) + (w << 2)) = f32x4{out[0], out[1], out[2], out[3]};
+    }
 }
 int k_fc_small_wvec(alq_ctx *ctx, const float *delta, int nout, const float *Wp, int64_t F, float *wv) {
     ProfScope ps(ctx, PROF_FC_SMALL, 0);
@@ -1243,9 +1256,8 @@ int k_fc_small_wvec(alq_ctx *ctx, const float *delta, int nout, const float *Wp,
 int k_fc_small_dsum_bits(alq_ctx *ctx, const unsigned *maskbits, const float *wv, int64_t F, int N, float *dsum) {
     ProfScope ps(ctx, PROF_FC_SMALL, 0);
     ALQ_REQUIRE(F % 32 == 0, ALQ_EINVAL, "fc_small_dsum_bits: F %% 32");
-    const long long total = (long long)N * (F / 32);
-    hipLaunchKernelGGL(fc_small_dsum_bits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, maskbits, wv,
-                       (long long)F, N, dsum);
+    hipLaunchKernelGGL(fc_small_dsum_bits_kernel, dim3((unsigned)((F / 32 + 255) / 256), (unsigned)((N + FC_BITS_PG - 1) / FC_BITS_PG)),
+                       dim3(256), 0, ctx->stream, maskbits, wv, (long long)F, N, dsum);
     ALQ_LAUNCH_CHECK();
     return ALQ_OK;
 }

@@ -210,6 +210,13 @@ struct Igemm2Fuse {
     // igemm4 only: the GEMM input is not a stored tensor but in[n, j] = [bit j of patch n] * in_vec[j]
     const unsigned *in_bits = nullptr;
     const float *in_vec = nullptr;
+    // igemm4 only (pair form, 8 output channels, one patch per tile): the output feeds nothing but a 2-output fc head -
+    // the epilogue emits per (tile, wave) partials of the logit difference against fc_W [fc_F] = W0 - W1
+    // (activation-memory order) and the sign byte of every voxel instead of storing the tensor
+    const float *fc_W = nullptr;
+    long long fc_F = 0;
+    float *fc_part = nullptr;
+    unsigned *fc_bits = nullptr;
 };
 
 extern unsigned long long *g_igemm2_dbg;
@@ -269,6 +276,10 @@ struct Igemm4Args {
     unsigned long long *dbg;
     const unsigned *src_bits;   // BITSRC: `in` is one patch-independent vector, masked per patch by these bits
     int bits_pstride, bits_bytes;   // floats per patch of the tensor the bits describe; size of the bit field
+    const float *fc_W;          // FCF: fused 2-output fc head (see Igemm2Fuse)
+    float *fc_part;
+    unsigned char *fc_bits;
+    int fc_F;
 };
 
 struct G4Geom {
@@ -390,6 +401,8 @@ int k_fc_small_wvec(alq_ctx *, const float *delta, int nout, const float *Wp, in
 int k_fc_small_dsum_bits(alq_ctx *, const unsigned *maskbits, const float *wv, int64_t F, int N, float *dsum);
 int k_fc_small_finish(alq_ctx *, const float *partials, int nslices, const float *bias, int nout,
                       int relu, int N, float *out);
+// two-class head from partials of the logit DIFFERENCE z0 - z1: out[n] = (sum + b0 - b1, 0) - the same posteriors
+int k_fc_small_finish_diff(alq_ctx *, const float *partials, int nslices, const float *bias, int N, float *out);
 // mask_act / dsum / C (optional): rows are [voxel][C]; masks by act > 0 and emits per-voxel channel sums
 int k_fc_small_bwd(alq_ctx *, const float *delta, int nout, const float *Wp, int64_t F, int N,
                    float *dact, const float *mask_act = nullptr, float *dsum = nullptr, int C = 0,

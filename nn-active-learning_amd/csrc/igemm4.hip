@@ -79,7 +79,28 @@ __device__ inline unsigned g4_pack2(float a, float b) {
 // BITSRC: the GEMM input is not a stored tensor: in[n, j] = [bit j of patch n in a.src_bits] * a.in[j] (the cotangent
 // of a fc head's input under a patch-independent head cotangent; one patch per tile).  The staging part loads the
 // vector instead of the tensor plus one mask word per slot and clears the masked elements before the split.
-template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false>
+// FCF: the output tensor is consumed only by a 2-output fc head (pair form, one patch per tile): the epilogue
+// multiplies the finished values with the head's weight difference W0 - W1 (same memory order as the output: the
+// posteriors of two classes depend on the logit difference only), reduces them to one partial per (tile, wave) -
+// summed in fixed order by fc_small_finish_diff - and writes the sign byte of every voxel (8 channels) for the
+// backward pass; nothing else of the tensor is stored (store_from = Co).
+// (a.x b.x + a.y b.y) + (a.z b.z + a.w b.w) in single-width VALU instructions: inline asm so that the compiler cannot
+// fuse pairs into v_pk_mul_f32 / v_pk_fma_f32.  Measured on gfx950: with the packed forms (op_sel swizzles) in the
+// epilogue of a tile that is written back INSIDE the tick loop - i.e. while the other half's waves run MFMAs on the
+// same SIMDs - the logit partials were wrong by ~1e-2 and different from run to run; the same code after the loop
+// (other half idle), and single-width multiplies in either place, are exact and repeatable
+// (tests/test_gpu_parity.py::test_writeback_inside_and_after_the_tick_loop_agree).  The v_pk_add_f32 of the split
+// is not affected (bit-stable in every run of the suite).
+__device__ inline float g4_dot4(const f32x4 &a, const f32x4 &b) {
+    float t0, t1;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(t0) : "v"(a.x), "v"(b.x));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(a.y), "v"(b.y), "v"(t0));
+    asm("v_mul_f32 %0, %1, %2" : "=v"(t1) : "v"(a.z), "v"(b.z));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t1) : "v"(a.w), "v"(b.w), "v"(t1));
+    return t0 + t1;
+}
+
+template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false, bool FCF = false>
 __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     extern __shared__ __attribute__((aligned(16))) char lds4[];
     const int tid = threadIdx.x;
@@ -310,6 +331,30 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         }
         }
     };
+    // FCF: the head's weight difference for the 4 row blocks of the pending tile, loaded before the split + stage work
+    // of the tick that writes the tile back (their L2 latency, exposed, cost as much as the fusion saved)
+    f32x4 fwv[FCF ? 4 : 1];
+    auto fcw_prefetch = [&](int q_out, int q_full, int q_l, int q_g) __attribute__((always_inline)) {
+        if constexpr (FCF) {
+            int mz0 = 0, my0 = 0, mx0 = 0;
+            if (!q_full) {
+                const i32x4 t1 = ld4(a.td_off + q_l * 8 + 4);
+                mz0 = t1.y & 255; my0 = (t1.y >> 8) & 255; mx0 = (t1.y >> 16) & 255;
+            }
+            const int jb = (q_out - q_g * a.out_pstride) * a.out_cs;
+#pragma unroll
+            for (int ms = 0; ms < 4; ++ms) {
+                bool live = erow_ok;
+                if (!q_full) {
+                    const int e = vpk[ms];
+                    const int z = (e >> 16) & 255, y = (e >> 8) & 255, x = e & 255;
+                    live = e >= 0 && q_g < a.N && mz0 + z < a.MD && my0 + y < a.MH && mx0 + x < a.MW;
+                }
+                fwv[ms] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (live) fwv[ms] = *reinterpret_cast<const f32x4 *>(a.fc_W + (jb + eoff[ms] + coff[0]));
+            }
+        }
+    };
     auto flush = [&](int q_out, int q_full, int q_l, int q_g) __attribute__((always_inline)) {
         const int obase_e = q_out * a.out_cs;
         int mz0 = 0, my0 = 0, mx0 = 0;
@@ -323,6 +368,10 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         // 16-lane ones (those, each waiting on its own MFMA, were 4 % of a pass).
         f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f};
         bool livem[4];
+        float fs0 = 0.f;
+        unsigned fbyte[FCF ? 4 : 1];
+        bool fon[FCF ? 4 : 1];
+        const int jbase = (q_out - q_g * a.out_pstride) * a.out_cs;      // FCF: float offset of the tile inside its patch
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms) {
             bool live = erow_ok;
@@ -362,6 +411,17 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                     }
                     if (c >= a.store_from) *dst = val;
                 }
+                if constexpr (FCF) {
+                    // the sign bytes go out after the loop: no store between the weight loads above and their use
+                    unsigned nib = 0;
+                    if (on) {
+                        fs0 += g4_dot4(val, fwv[ms]);
+                        nib = (val.x > 0.f ? 1u : 0u) | (val.y > 0.f ? 2u : 0u) | (val.z > 0.f ? 4u : 0u) | (val.w > 0.f ? 8u : 0u);
+                    }
+                    const unsigned oth = __shfl_xor(nib, 16, 64);      // the lane with the other 4 channels of the voxel
+                    fbyte[ms] = nib | (oth << 4);
+                    fon[ms] = on;
+                }
                 if constexpr (SUMS) {
                     if (!on) val = f32x4{0.f, 0.f, 0.f, 0.f};
                     // selector MFMA: result row 0 = sum over the lane groups of set A, row 1 = set B
@@ -386,6 +446,26 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 if (l0) base[q_out + ev0 - fix] = sacc.x;
                 if (l1) base[q_out + ev1 - fix] = sacc.y;
             }
+        }
+        if constexpr (FCF) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ms = 0; ms < 4; ++ms)
+                if (fon[ms] && (lq & 1) == 0)
+                    a.fc_bits[(size_t)q_g * (a.fc_F >> 3) + ((jbase + eoff[ms]) >> 3)] = (unsigned char)fbyte[ms];
+            // wave sum without the LDS crossbar (six dependent ds_bpermute round trips were ~1 k cycles per tile): prefix
+            // sums inside each row of 16 lanes with DPP shifts, then the four row totals through scalar registers
+            int v = __builtin_bit_cast(int, fs0);
+#define G4_ROW_SHR_ADD(n)                                                                                              \
+    v = __builtin_bit_cast(int, __builtin_bit_cast(float, v) +                                                         \
+                                    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, v, 0x110 + (n), 0xf, 0xf, true)))
+            G4_ROW_SHR_ADD(1); G4_ROW_SHR_ADD(2); G4_ROW_SHR_ADD(4); G4_ROW_SHR_ADD(8);
+#undef G4_ROW_SHR_ADD
+            const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 15));
+            const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 31));
+            const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 47));
+            const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 63));
+            if (lane == 0) a.fc_part[(size_t)(q_g * a.tpg + q_l) * 4 + hw] = (r0 + r1) + (r2 + r3);
         }
     };
 
@@ -505,6 +585,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         int nph = 0;
         if (a_i < n_ph) {
             if (a_ph == 0) { c_out = f_out; c_full = f_full; c_l = f_l; c_g = f_g; c_pdb = f_pdb; }
+            if constexpr (FCF) { if (a_ph == 0 && have_pend) fcw_prefetch(p_out, p_full, p_l, p_g); }
             stash();
             PHASE4_END(0);
             if (a_ph == 0 && have_pend) {
@@ -572,6 +653,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     }
     if (h == 0) __syncthreads();
     if (have_pend) {
+        fcw_prefetch(p_out, p_full, p_l, p_g);
         flush(p_out, p_full, p_l, p_g);
     }
 #ifdef ALQ_STAMPS
@@ -1120,9 +1202,9 @@ void igemm4_pack_weights(Igemm4Plan *plan, const std::vector<float> &Bmat) {
                 }
 }
 
-template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false>
+template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false, bool FCF = false>
 static int launch4_s(alq_ctx *ctx, const Igemm4Plan &plan, const Igemm4Args &a, unsigned grid) {
-    auto kfn = igemm4_kernel<NTW, MULTI, SUMS, BITSRC>;
+    auto kfn = igemm4_kernel<NTW, MULTI, SUMS, BITSRC, FCF>;
     if (plan.lds_bytes > 64 * 1024)
         ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)plan.lds_bytes));
@@ -1160,6 +1242,7 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
     a.out_split = out.split; a.out_delta = (int)out.delta;
     a.mask_split = 0; a.mask_delta = 0;
     a.src_bits = nullptr; a.bits_pstride = 0; a.bits_bytes = 0;
+    a.fc_W = nullptr; a.fc_part = nullptr; a.fc_bits = nullptr; a.fc_F = 0;
     if (fuse && fuse->in_bits) {      // masked-vector input: `in` only gives the geometry
         ALQ_REQUIRE(plan.NTW == 1 && !plan.multi && a.PT == 1 && !in.split && in.c0 == 0 && in.cs == in.C && fuse->in_vec &&
                         ((long long)in.vox() * in.cs) % 32 == 0,
@@ -1198,6 +1281,15 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
         a.store_from = fuse->store_from;
         ALQ_REQUIRE(a.store_from % 4 == 0 && (a.store_from == 0 || !accumulate), ALQ_EUNSUPPORTED,
                     "igemm4: store_from needs a 4-aligned column and no accumulation");
+        if (fuse->fc_W) {
+            ALQ_REQUIRE(plan.NTW == 1 && !plan.multi && a.pair && a.PT == 1 && out.C == 8 && out.cs == 8 && out.c0 == 0 && !out.split &&
+                            !accumulate && !fuse->mask && fuse->osumA && fuse->fc_part && fuse->fc_bits &&
+                            fuse->fc_F == (long long)out.vox() * 8,
+                        ALQ_EUNSUPPORTED, "igemm4: fused fc head needs the pair form on a dense 8-channel output");
+            a.fc_W = fuse->fc_W; a.fc_F = (int)fuse->fc_F; a.fc_part = fuse->fc_part;
+            a.fc_bits = reinterpret_cast<unsigned char *>(fuse->fc_bits);
+            a.store_from = out.C;
+        }
     }
     const int pgroups = (N + a.PT - 1) / a.PT;
     const long long total = (long long)pgroups * a.tpg;
@@ -1210,6 +1302,7 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
     if (a.src_bits)
         return (a.osumA || a.osumB) ? launch4_s<1, false, true, true>(ctx, plan, a, grid)
                                     : launch4_s<1, false, false, true>(ctx, plan, a, grid);
+    if (a.fc_W) return launch4_s<1, false, true, false, true>(ctx, plan, a, grid);
     if (plan.NTW == 1) return launch4_t<1, false>(ctx, plan, a, grid);
     return launch4_t<2, false>(ctx, plan, a, grid);
 }

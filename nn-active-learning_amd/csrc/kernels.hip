@@ -1124,6 +1124,26 @@ __global__ void fc_small_finish_kernel(const float *partials, int nslices, const
     out[i] = v;
 }
 
+// one 64-lane wave per patch: lane l sums partials l, l + 64, ... in fp64, then a fixed butterfly
+__global__ __launch_bounds__(64) void fc_small_finish_diff_kernel(const float *partials, int nslices, const float *bias, int N,
+                                                                  float *out) {
+    const int n = blockIdx.x;
+    double s = 0;
+    for (int k = threadIdx.x; k < nslices; k += 64) s += (double)partials[(long long)n * nslices + k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (threadIdx.x == 0) {
+        out[2 * n] = (float)s + (bias ? bias[0] - bias[1] : 0.f);
+        out[2 * n + 1] = 0.f;
+    }
+}
+int k_fc_small_finish_diff(alq_ctx *ctx, const float *partials, int nslices, const float *bias, int N, float *out) {
+    ProfScope ps(ctx, PROF_FC_SMALL, 0);
+    hipLaunchKernelGGL(fc_small_finish_diff_kernel, dim3(N), dim3(64), 0, ctx->stream, partials, nslices, bias, N, out);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
 int k_fc_small_fwd(alq_ctx *ctx, const float *act, int64_t F, const float *Wp, int nout, int N,
                    float *partials, int nslices, unsigned *maskbits) {
     ProfScope ps(ctx, PROF_FC_SMALL, 2.0 * F * nout * N);

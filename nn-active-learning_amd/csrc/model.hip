@@ -63,6 +63,8 @@ struct Layer {
     // forward pass leaves the bits, the backward pass of the conv below contracts them directly (igemm4 BITSRC)
     unsigned *fc_maskbits = nullptr;
     float *fc_wv = nullptr;
+    float *fc_part2 = nullptr;         // partial logits per (tile, wave) when the conv below computes them in its epilogue
+    int fc_slices2 = 0;
     const unsigned *dout_bits = nullptr;   // set on the conv below for the duration of one backward pass
     const float *dout_vec = nullptr;
     int fc_slices = 0;
@@ -590,6 +592,15 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
                     m->layers[i - 1].spec.type == ALQ_CONV && m->layers[i - 1].out.C == 8 && !getenv("ALQ_NO_FC_BITS")) {
                     ALQ_TRY(m->dalloc(&ly.fc_maskbits, (size_t)NB * (ly.F / 32)));
                     ALQ_TRY(m->dalloc(&ly.fc_wv, (size_t)ly.F));
+                    const Layer &cv = m->layers[i - 1];
+                    const Igemm4Plan &fp = cv.fwd[0].p4;
+                    if (sp.cout == 2 && !sp.relu && fp.ok && fp.NTW == 1 && !fp.multi && fp.a.pair && fp.a.PT == 1 && cv.out.cs == 8 &&
+                        cv.out.c0 == 0 && !cv.out.split && cv.osum && !cv.out_is_skip_src && !getenv("ALQ_NO_FC_FUSE") &&
+                        // the backward pass must be able to work from the bits alone (bits_ok in run_backward)
+                        cv.bwd.p4.ok && cv.bwd.p4.NTW == 1 && !cv.bwd.p4.multi && cv.bwd.p4.a.PT == 1 && !cv.dout.split) {
+                        ly.fc_slices2 = fp.a.tpg * 4;
+                        ALQ_TRY(m->dalloc(&ly.fc_part2, (size_t)NB * ly.fc_slices2));
+                    }
                 }
             } else {
                 ConvDesc d;
@@ -636,6 +647,7 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums) {
     alq_ctx *ctx = m->ctx;
     const int nl = (int)m->layers.size();
     bool skip_next = false;      // this layer's outputs were produced by the previous layer's kernel
+    bool fc_head_fused = false;  // the logits partials of the fc head came out of the previous conv's epilogue
     for (int i = 0; i < nl; ++i) {
         Layer &ly = m->layers[i];
         ALQ_REQUIRE(ly.pidx < 0 || ly.weights_set, ALQ_EINVAL, "weights of parameterised layer %d not set", ly.pidx);
@@ -663,6 +675,17 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums) {
                                                     ly.fwd[0].pd.flops_per_patch));
                     fused = true;
                     skip_next = true;
+                    break;
+                }
+                if (fuse && nx && i + 2 == nl && nx->fc_part2 && !g_dbg_knobs[4] && !g_dbg_knobs[5]) {
+                    // the fc head is this layer's only consumer in a Fisher pass: logits partials + sign bytes from the
+                    // epilogue, the tensor itself is not stored
+                    ALQ_TRY(k_fill_unit_cotangent(ctx, m->dlogits, 1));
+                    ALQ_TRY(k_fc_small_wvec(ctx, m->dlogits, 2, nx->d_Wp, nx->F, nx->fc_wv));       // W0 - W1
+                    fz.fc_W = nx->fc_wv; fz.fc_F = nx->F; fz.fc_part = nx->fc_part2; fz.fc_bits = nx->fc_maskbits;
+                    ALQ_TRY(igemm4_launch(ctx, ly.fwd[0].p4, in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM3_FWD, &fz));
+                    fused = true;
+                    fc_head_fused = true;
                     break;
                 }
                 ALQ_TRY(gemm_launch(ctx, ly.fwd[0], in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM_FWD, fuse, &fused));
@@ -693,7 +716,9 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums) {
                     if (prev_spatial) ALQ_TRY(k_rowsum_field(ctx, m->layers[i - 1].osum, m->layers[i - 1].out.vox(), N, ly.asum));
                     else ALQ_TRY(k_chansum(ctx, flat_view(in), ly.asum, N));
                 }
-                if (ly.dense_fc_small) {
+                if (ly.dense_fc_small && fc_head_fused) {
+                    ALQ_TRY(k_fc_small_finish_diff(ctx, ly.fc_part2, ly.fc_slices2, ly.d_bias, N, ly.out.p));
+                } else if (ly.dense_fc_small) {
                     ALQ_TRY(k_fc_small_fwd(ctx, in.p, ly.F, ly.d_Wp, ly.spec.cout, N, ly.fc_partials, ly.fc_slices,
                                            with_sums ? ly.fc_maskbits : nullptr));
                     ALQ_TRY(k_fc_small_finish(ctx, ly.fc_partials, ly.fc_slices, ly.d_bias, ly.spec.cout,

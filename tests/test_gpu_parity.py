@@ -458,10 +458,40 @@ def test_config5_loop_harness(sess):
     model.close()
 
 
+def test_writeback_inside_and_after_the_tick_loop_agree(sess):
+    """A half of the two-slot engine writes a tile back either inside its tick loop (while the other half's waves
+    contract on the same SIMDs) or after it (its last tile).  With 16 patches of NET-C 32^3 every half owns two tiles
+    of the last conv: patches 0-7 are written back inside the loop, 8-15 after it.  The second eight are copies of
+    the first eight, so every score of patch i and patch i + 8 must be bit-identical - and stay so from run to run
+    (this caught packed fp32 multiplies in the fused fc-head epilogue going wrong under concurrent MFMAs)."""
+    import ctypes as C
+    from nnal_amd._lib import check
+    torch = sess.torch
+    ld, sk = netspec.net_c()
+    in_shape = (32, 32, 32, 1)
+    pars = netspec.he_init(ld, in_shape, seed=14, skips=sk)
+    x = sess.empty((16, 32 ** 3), torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, 8, 32 ** 3, C.c_void_p(x.data_ptr())))
+    x[8:] = x[:8]
+    m = _device_model(sess, ld, in_shape, sk, pars, max_batch=16)
+    first = None
+    for _ in range(4):
+        r = m.fisher_device(x, 16, None, 1e-3)
+        out = {k: r[k].cpu().numpy() for k in ('p1', 'g0', 'g1', 'A', 'trace')}
+        for k, v in out.items():
+            np.testing.assert_array_equal(v[:8], v[8:], err_msg=k)
+        if first is None:
+            first = out
+        for k, v in out.items():
+            np.testing.assert_array_equal(v, first[k], err_msg=k)
+    m.close()
+
+
 def test_layout_and_engine_switches_agree(sess):
     """The same NET-C scores through (a) the split-concat layout (default), (b) concat as channel slices of one
-    buffer (ALQ_NO_SPLIT), (d) the fc head's input cotangent stored as a tensor (ALQ_NO_FC_BITS) instead of mask
-    bits + one vector - identical arithmetic per output element, so identical bits - and (c) the fp32-MFMA
+    buffer (ALQ_NO_SPLIT): identical arithmetic per output element, so identical bits; (e) the fc head as its own
+    kernels (ALQ_NO_FC_FUSE) against (d) additionally its input cotangent as a tensor (ALQ_NO_FC_BITS): identical
+    bits; fused head (a) against (e): another summation order of the two logits; and (c) the fp32-MFMA
     engines (ALQ_DISABLE_V4 + ALQ_DISABLE_V3: exact fp32 fma chains in another order): fp32-level agreement, with
     the absolute bar of the tolerance note on top for a ReLU input that lands on the other side of zero."""
     torch = sess.torch
@@ -491,9 +521,14 @@ def test_layout_and_engine_switches_agree(sess):
     b = scores({'ALQ_NO_SPLIT': '1'})
     c = scores({'ALQ_DISABLE_V4': '1', 'ALQ_DISABLE_V3': '1'})
     d = scores({'ALQ_NO_FC_BITS': '1'})
+    e = scores({'ALQ_NO_FC_FUSE': '1'})
     for k in a:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
-        np.testing.assert_array_equal(a[k], d[k], err_msg=k)
+        np.testing.assert_array_equal(e[k], d[k], err_msg=k)       # bits vs tensor: the same numbers
+    # the head's logits summed per (tile, wave) in the last conv's epilogue instead of per slice of the stored tensor
+    np.testing.assert_allclose(a['p1'], e['p1'], rtol=0, atol=1e-6)
+    for k in ('g0', 'g1', 'A'):
+        np.testing.assert_allclose(a[k], e[k], rtol=1e-5, atol=1e-9 + 1e-6 * np.abs(e[k]).max())
     np.testing.assert_allclose(c['p1'], a['p1'], rtol=0, atol=2e-6)
     for k in ('g0', 'g1'):
         err = np.abs(c[k] - a[k])

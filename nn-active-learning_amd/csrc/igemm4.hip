@@ -76,14 +76,15 @@ __device__ inline unsigned g4_pack2(float a, float b) {
     return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, a), 0x07060302u);
 }
 
-// BITSRC: the GEMM input is not a stored tensor: in[n, j] = [bit j of patch n in a.src_bits] * a.in[j] (the cotangent
+// BITSRC: the GEMM input is not a stored tensor: in[n, j] = [sign of element j of patch n in a.src_bits: one byte per 4
+// channels, bit c of byte j / 4 for element j = 4 (j / 4) + c] * a.in[j] (the cotangent
 // of a fc head's input under a patch-independent head cotangent; one patch per tile).  The staging part loads the
 // vector instead of the tensor plus one mask word per slot and clears the masked elements before the split.
 // FCF: the output tensor is consumed only by a 2-output fc head (pair form, one patch per tile): the epilogue
 // multiplies the finished values with the head's weight difference W0 - W1 (same memory order as the output: the
 // posteriors of two classes depend on the logit difference only), reduces them to one partial per (tile, wave) -
-// summed in fixed order by fc_small_finish_diff - and writes the sign byte of every voxel (8 channels) for the
-// backward pass; nothing else of the tensor is stored (store_from = Co).
+// summed in fixed order by fc_small_finish_diff - and writes the signs of its 4 channels as one byte for the
+// backward pass (each lane its own byte: 4 channels, no cross-lane step); nothing else of the tensor is stored.
 // (a.x b.x + a.y b.y) + (a.z b.z + a.w b.w) in single-width VALU instructions: inline asm so that the compiler cannot
 // fuse pairs into v_pk_mul_f32 / v_pk_fma_f32.  Measured on gfx950: with the packed forms (op_sel swizzles) in the
 // epilogue of a tile that is written back INSIDE the tick loop - i.e. while the other half's waves run MFMAs on the
@@ -249,7 +250,6 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
     unsigned Rb[BITSRC ? G4_NSLOT : 1];
-    int s_bsh = 0;                   // BITSRC: (float offset of the fetched phase) mod 32
     const __amdgpu_buffer_rsrc_t bits_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned *>(a.src_bits), 0, BITSRC ? a.bits_bytes : 0, 0x00020000);
     // the ONE prefetch site: unconditional loads, a slot without work points past the buffer
@@ -269,9 +269,8 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
 #pragma unroll
             for (int it = 0; it < G4_NSLOT; ++it) {
                 const unsigned e = (unsigned)(goff[it] + soff) >> 2;          // float index inside the patch (huge when parked)
-                Rb[it] = __builtin_amdgcn_raw_buffer_load_b32(bits_rsrc, (int)(((pbase + e) >> 5) << 2), 0, 0);
+                Rb[it] = (unsigned char)__builtin_amdgcn_raw_buffer_load_b8(bits_rsrc, (int)((pbase + e) >> 2), 0, 0);
             }
-            s_bsh = (soff >> 2) & 31;
         }
     };
     auto stash = [&]() __attribute__((always_inline)) {
@@ -280,7 +279,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             if (s_lds[it] >= 0) {
                 float v0 = R[it].x, v1 = R[it].y, v2 = R[it].z, v3 = R[it].w;
                 if constexpr (BITSRC) {
-                    const unsigned nib = Rb[it] >> ((((unsigned)goff[it] >> 2) + s_bsh) & 31);
+                    const unsigned nib = Rb[it];       // one sign byte (low nibble) per 4 channels
                     v0 = (nib & 1u) ? v0 : 0.f; v1 = (nib & 2u) ? v1 : 0.f;
                     v2 = (nib & 4u) ? v2 : 0.f; v3 = (nib & 8u) ? v3 : 0.f;
                 }
@@ -418,8 +417,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                         fs0 += g4_dot4(val, fwv[ms]);
                         nib = (val.x > 0.f ? 1u : 0u) | (val.y > 0.f ? 2u : 0u) | (val.z > 0.f ? 4u : 0u) | (val.w > 0.f ? 8u : 0u);
                     }
-                    const unsigned oth = __shfl_xor(nib, 16, 64);      // the lane with the other 4 channels of the voxel
-                    fbyte[ms] = nib | (oth << 4);
+                    fbyte[ms] = nib;
                     fon[ms] = on;
                 }
                 if constexpr (SUMS) {
@@ -451,8 +449,8 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ms = 0; ms < 4; ++ms)
-                if (fon[ms] && (lq & 1) == 0)
-                    a.fc_bits[(size_t)q_g * (a.fc_F >> 3) + ((jbase + eoff[ms]) >> 3)] = (unsigned char)fbyte[ms];
+                if (fon[ms])
+                    a.fc_bits[(size_t)q_g * (a.fc_F >> 2) + ((jbase + eoff[ms] + coff[0]) >> 2)] = (unsigned char)fbyte[ms];
             // wave sum without the LDS crossbar (six dependent ds_bpermute round trips were ~1 k cycles per tile): prefix
             // sums inside each row of 16 lanes with DPP shifts, then the four row totals through scalar registers
             int v = __builtin_bit_cast(int, fs0);
@@ -1252,7 +1250,7 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
         a.in_bytes = (int)((long long)in.vox() * in.cs * 4);
         a.src_bits = fuse->in_bits;
         a.bits_pstride = (int)((long long)in.vox() * in.cs);
-        a.bits_bytes = (int)((long long)N * in.vox() * in.cs / 8);
+        a.bits_bytes = (int)((long long)N * in.vox() * in.cs / 4);
     }
     a.dbg = nullptr;
     if (g_igemm2_dbg) {   // diagnostic: stamp only the launch whose ordinal (since the buffer was set) is ALQ_STAMP_ONLY

@@ -1066,9 +1066,8 @@ int k_boxdot_convT(alq_ctx *ctx, const float *dsum, const float *asum, const flo
 constexpr int FC_SLICE = 8192;
 int fc_small_slices(int64_t F) { return (int)((F + FC_SLICE - 1) / FC_SLICE); }
 
-// BITS: also emits act > 0 as one bit per element (word j / 32, bit j % 32 of the patch's F / 32 words): the
-// backward pass of a fc head on top of a ReLU conv needs nothing else of that tensor (needs F % 1024 == 0: whole
-// waves in every trip)
+// BITS: also emits the signs act > 0, one byte (low nibble) per 4 consecutive elements: the backward pass of a fc head
+// on top of a ReLU conv needs nothing else of that tensor
 template <int NOUT, bool BITS>
 __global__ __launch_bounds__(256) void fc_small_fwd_kernel(const float *act, long long F, const float *Wp,
                                                            float *partials, int nslices, unsigned *maskbits) {
@@ -1089,13 +1088,9 @@ __global__ __launch_bounds__(256) void fc_small_fwd_kernel(const float *act, lon
                 const f32x4 wv = *reinterpret_cast<const f32x4 *>(Wp + o * F + f);
                 acc[o] += (av.x * wv.x + av.y * wv.y) + (av.z * wv.z + av.w * wv.w);
             }
-            if constexpr (BITS) {      // 8 lanes = 32 consecutive elements = one word
-                unsigned nib = (av.x > 0.f ? 1u : 0u) | (av.y > 0.f ? 2u : 0u) | (av.z > 0.f ? 4u : 0u) | (av.w > 0.f ? 8u : 0u);
-                nib <<= 4 * (threadIdx.x & 7);
-                nib |= __shfl_xor(nib, 1, 64);
-                nib |= __shfl_xor(nib, 2, 64);
-                nib |= __shfl_xor(nib, 4, 64);
-                if ((threadIdx.x & 7) == 0) maskbits[(n * F + f) >> 5] = nib;
+            if constexpr (BITS) {
+                const unsigned nib = (av.x > 0.f ? 1u : 0u) | (av.y > 0.f ? 2u : 0u) | (av.z > 0.f ? 4u : 0u) | (av.w > 0.f ? 8u : 0u);
+                reinterpret_cast<unsigned char *>(maskbits)[(n * F + f) >> 2] = (unsigned char)nib;
             }
         }
     } else {
@@ -1234,12 +1229,13 @@ __global__ void fc_small_wvec_kernel(const float *delta, int nout, const float *
     for (int o = 0; o < nout; ++o) s += delta[o] * *reinterpret_cast<const f32x4 *>(Wp + o * F + f);   // same order as fc_small_bwd
     *reinterpret_cast<f32x4 *>(wv + f) = s;
 }
-// grid (words / 256, patch groups): a thread keeps the 32 vector values of its word in registers for PG patches
+// grid (groups of 4 voxels / 256, patch groups): a thread keeps the 32 vector values of its 4 voxels (8 channels each, 8
+// sign bytes) in registers for PG patches
 constexpr int FC_BITS_PG = 8;
 __global__ __launch_bounds__(256) void fc_small_dsum_bits_kernel(const unsigned *maskbits, const float *wv, long long F, int N,
                                                                  float *dsum) {
     const long long words = F >> 5;
-    const long long w = blockIdx.x * (long long)blockDim.x + threadIdx.x;      // one word = 4 voxels x 8 channels
+    const long long w = blockIdx.x * (long long)blockDim.x + threadIdx.x;      // 32 elements = 4 voxels x 8 channels = 8 bytes
     if (w >= words) return;
     f32x4 a[4], b[4];
 #pragma unroll
@@ -1248,18 +1244,20 @@ __global__ __launch_bounds__(256) void fc_small_dsum_bits_kernel(const unsigned 
         b[v] = *reinterpret_cast<const f32x4 *>(wv + (w << 5) + v * 8 + 4);
     }
     const int n0 = blockIdx.y * FC_BITS_PG, n1 = min(N, n0 + FC_BITS_PG);
-    unsigned bits[FC_BITS_PG];
+    uint2 bits[FC_BITS_PG];
 #pragma unroll
-    for (int k = 0; k < FC_BITS_PG; ++k) bits[k] = n0 + k < n1 ? maskbits[(n0 + k) * words + w] : 0u;
+    for (int k = 0; k < FC_BITS_PG; ++k)
+        bits[k] = n0 + k < n1 ? reinterpret_cast<const uint2 *>(maskbits)[(n0 + k) * words + w] : uint2{0u, 0u};
 #pragma unroll
     for (int k = 0; k < FC_BITS_PG; ++k) {
         if (n0 + k >= n1) break;
         float out[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const unsigned m = bits[k] >> (v * 8);
+            const unsigned two = (v < 2 ? bits[k].x : bits[k].y) >> ((v & 1) * 16);     // bytes 2v (channels 0-3), 2v + 1 (4-7)
+            const unsigned m = two, m2 = two >> 8;
             const float sa = ((m & 1u ? a[v].x : 0.f) + (m & 2u ? a[v].y : 0.f)) + ((m & 4u ? a[v].z : 0.f) + (m & 8u ? a[v].w : 0.f));
-            const float sb = ((m & 16u ? b[v].x : 0.f) + (m & 32u ? b[v].y : 0.f)) + ((m & 64u ? b[v].z : 0.f) + (m & 128u ? b[v].w : 0.f));
+            const float sb = ((m2 & 1u ? b[v].x : 0.f) + (m2 & 2u ? b[v].y : 0.f)) + ((m2 & 4u ? b[v].z : 0.f) + (m2 & 8u ? b[v].w : 0.f));
             out[v] = sa + sb;
         }
         *reinterpret_cast<f32x4 *>(dsum + ((long long)(n0 + k) * F >> 3) + (w << 2)) = f32x4{out[0], out[1], out[2], out[3]};

@@ -60,7 +60,8 @@ struct Layer {
     bool dsum_partial = false; // backward, first layer: the skip destination has written its share of dsum
     float *fc_partials = nullptr;
     // fc head of a Fisher pass on top of a ReLU conv: its input cotangent is [input > 0] * fc_wv for every patch; the
-    // forward pass leaves the bits, the backward pass of the conv below contracts them directly (igemm4 BITSRC)
+    // forward pass leaves the signs (one byte per 4 elements), the backward pass of the conv below contracts them
+    // directly (igemm4 BITSRC)
     unsigned *fc_maskbits = nullptr;
     float *fc_wv = nullptr;
     float *fc_part2 = nullptr;         // partial logits per (tile, wave) when the conv below computes them in its epilogue
@@ -590,7 +591,7 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
                 ALQ_TRY(m->dalloc(&ly.fc_partials, (size_t)NB * ly.fc_slices * sp.cout));
                 if (ly.F % 1024 == 0 && i == n_layers - 1 && i > 0 && m->layers[i - 1].spec.relu && m->layers[i - 1].pidx > 0 &&
                     m->layers[i - 1].spec.type == ALQ_CONV && m->layers[i - 1].out.C == 8 && !getenv("ALQ_NO_FC_BITS")) {
-                    ALQ_TRY(m->dalloc(&ly.fc_maskbits, (size_t)NB * (ly.F / 32)));
+                    ALQ_TRY(m->dalloc(&ly.fc_maskbits, (size_t)NB * (ly.F / 16)));      // one sign byte per 4 elements
                     ALQ_TRY(m->dalloc(&ly.fc_wv, (size_t)ly.F));
                     const Layer &cv = m->layers[i - 1];
                     const Igemm4Plan &fp = cv.fwd[0].p4;

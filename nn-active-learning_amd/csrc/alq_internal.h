@@ -299,6 +299,7 @@ struct Igemm4Plan {
     Igemm4Args a;
     int NTW = 1;
     bool multi = false;
+    bool fic = false;         // issue the prefetch from the contracting side (stage-bound plans)
     size_t lds_bytes = 0;
     double flops_per_patch = 0;
     int Ci = 0, Co = 0;

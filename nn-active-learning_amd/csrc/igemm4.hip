@@ -101,7 +101,7 @@ __device__ inline float g4_dot4(const f32x4 &a, const f32x4 &b) {
     return t0 + t1;
 }
 
-template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false, bool FCF = false>
+template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false, bool FCF = false, bool FIC = false>
 __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     extern __shared__ __attribute__((aligned(16))) char lds4[];
     const int tid = threadIdx.x;
@@ -246,6 +246,12 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         }
     };
 
+    // Where the prefetch of the next phase is issued (FIC).  A tick is max(stage of one half, contraction of the other);
+    // with short contractions (1-2 k-steps per phase: conv_transpose classes; 8 input channels and a heavy epilogue:
+    // the last conv's backward) the staging part is the longer one (phase stamps: 465 k vs 353 k cycles per half,
+    // 47 % vs 20 % for the first conv_transpose), so its ~1 k cycles of load issue per phase move to the start of the
+    // contraction - still ONE site per kernel: the loads then have the contraction to land in.
+    constexpr bool FETCH_IN_CONTRACT = BITSRC || FIC;
     f32x4 R[G4_NSLOT];
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
@@ -330,8 +336,9 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         }
         }
     };
-    // FCF: the head's weight difference for the 4 row blocks of the pending tile, loaded before the split + stage work
-    // of the tick that writes the tile back (their L2 latency, exposed, cost as much as the fusion saved)
+    // FCF: the head's weight difference for the 4 row blocks of a tile, loaded at the start of the tile's last
+    // contraction like the ReLU-grad mask values (their L2 latency, exposed in the epilogue, cost as much as the
+    // fusion saved)
     f32x4 fwv[FCF ? 4 : 1];
     auto fcw_prefetch = [&](int q_out, int q_full, int q_l, int q_g) __attribute__((always_inline)) {
         if constexpr (FCF) {
@@ -583,7 +590,6 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         int nph = 0;
         if (a_i < n_ph) {
             if (a_ph == 0) { c_out = f_out; c_full = f_full; c_l = f_l; c_g = f_g; c_pdb = f_pdb; }
-            if constexpr (FCF) { if (a_ph == 0 && have_pend) fcw_prefetch(p_out, p_full, p_l, p_g); }
             stash();
             PHASE4_END(0);
             if (a_ph == 0 && have_pend) {
@@ -600,17 +606,22 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             a_ph = nph;
             ++a_i;
         }
-        fetch(nph);                      // unconditional: parked slots read nothing
+        if constexpr (!FETCH_IN_CONTRACT) fetch(nph);       // unconditional: parked slots read nothing
         PHASE4_END(2);
     };
     auto contract = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_s_setprio(3);       // the contracting wave goes first on its SIMD; staging fills the gaps
         PHASE4_END(4);
+        // still the ONE prefetch site of the kernel, on the side that has the slack (see FETCH_IN_CONTRACT)
+        if constexpr (FETCH_IN_CONTRACT) fetch(a_i < n_ph ? a_ph : 0);
         if (b_i < a_i) {
             if constexpr (!MULTI) {
                 const i32x4 pdA = ld4(a.pd_off + (c_pdb + b_ph) * 8), pdB = ld4(a.pd_off + (c_pdb + b_ph) * 8 + 4);
                 const int pd[5] = {0, 0, __builtin_amdgcn_readfirstlane(pdA.z), pdA.w, pdB.x};
                 if constexpr (MASK_PF) { if (b_ph == a.nph - 1 && a.mask) load_mask(c_out, c_full, c_l, c_g); }
+                // the contracting side has the slack (phase stamps: with the prefetch in the staging part that part was
+                // the longer one and the other half waited for it at the barrier)
+                if constexpr (FCF) { if (b_ph == a.nph - 1) fcw_prefetch(c_out, c_full, c_l, c_g); }
                 if (b_ph == 0) init_acc();
                 for (int rep = 0; rep <= a.dbg_repeat; ++rep)
                     unit(pd[2], Wl + pd[3] + lane * 16, Al, pd[4]);
@@ -651,7 +662,6 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     }
     if (h == 0) __syncthreads();
     if (have_pend) {
-        fcw_prefetch(p_out, p_full, p_l, p_g);
         flush(p_out, p_full, p_l, p_g);
     }
 #ifdef ALQ_STAMPS
@@ -1148,6 +1158,7 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
     a.tt_ints = (int)plan->h_ttab.size();
     plan->NTW = NTW;
     plan->multi = multi;
+    plan->fic = NTW == 1 && (g.kind == 4 || g.kind == 1) && !getenv("ALQ_NO_FIC");       // short contractions per phase: see FIC in the kernel
     plan->Ci = g.Ci; plan->Co = g.Co;
     plan->lds_bytes = (size_t)a.tt_ints * 4 + wbytes + 2 * (size_t)a.abytes;
     if (plan->lds_bytes > 160 * 1024) return ALQ_OK;
@@ -1200,9 +1211,9 @@ void igemm4_pack_weights(Igemm4Plan *plan, const std::vector<float> &Bmat) {
                 }
 }
 
-template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false, bool FCF = false>
+template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false, bool FCF = false, bool FIC = false>
 static int launch4_s(alq_ctx *ctx, const Igemm4Plan &plan, const Igemm4Args &a, unsigned grid) {
-    auto kfn = igemm4_kernel<NTW, MULTI, SUMS, BITSRC, FCF>;
+    auto kfn = igemm4_kernel<NTW, MULTI, SUMS, BITSRC, FCF, FIC>;
     if (plan.lds_bytes > 64 * 1024)
         ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)plan.lds_bytes));
@@ -1301,6 +1312,9 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
         return (a.osumA || a.osumB) ? launch4_s<1, false, true, true>(ctx, plan, a, grid)
                                     : launch4_s<1, false, false, true>(ctx, plan, a, grid);
     if (a.fc_W) return launch4_s<1, false, true, false, true>(ctx, plan, a, grid);
+    if (plan.NTW == 1 && plan.fic)
+        return (a.osumA || a.osumB) ? launch4_s<1, false, true, false, false, true>(ctx, plan, a, grid)
+                                    : launch4_s<1, false, false, false, false, true>(ctx, plan, a, grid);
     if (plan.NTW == 1) return launch4_t<1, false>(ctx, plan, a, grid);
     return launch4_t<2, false>(ctx, plan, a, grid);
 }

@@ -81,6 +81,7 @@ using namespace alq;
 struct alq_model {
     alq_ctx *ctx = nullptr;
     int max_batch = 0;
+    bool last_call_fisher = false;   // what alq_model_debug_copy may read
     int in_dims[4] = {1, 1, 1, 1};
     int nclass = 0;
     int L = 0;
@@ -1084,6 +1085,7 @@ int alq_forward(alq_model *m, const float *d_x, int N, float *d_post, int64_t *d
     ALQ_REQUIRE(N >= 0 && N <= m->max_batch, ALQ_EINVAL, "alq_forward: N=%d exceeds max_batch=%d", N, m->max_batch);
     if (N == 0) return ALQ_OK;
     ALQ_HIP(hipSetDevice(m->ctx->device));
+    m->last_call_fisher = false;
     ALQ_TRY(run_forward(m, d_x, N, false));
     ALQ_TRY(k_softmax(m->ctx, m->logits, m->nclass, N, d_post ? d_post : m->post, d_pred));
     if (d_feat) {
@@ -1124,6 +1126,7 @@ int alq_fisher(alq_model *m, const float *d_x, int N, const float *d_p1_in, doub
         explicit SkipGuard(alq_ctx *ctx) : c(ctx) { c->prof_skip = c->prof_on && (c->prof_pass++ % c->prof_every) != 0; }
         ~SkipGuard() { c->prof_skip = false; }
     } guard(m->ctx);
+    m->last_call_fisher = true;
     ALQ_TRY(run_forward(m, d_x, N, true));
     ALQ_TRY(k_softmax(m->ctx, m->logits, m->nclass, N, m->post, nullptr));
     ALQ_TRY(run_backward(m, d_x, N));
@@ -1191,6 +1194,12 @@ int alq_model_debug_copy(alq_model *m, int layer_idx, int what, int N, float *d_
     ALQ_REQUIRE(layer_idx >= 0 && layer_idx < (int)m->layers.size(), ALQ_EINVAL, "bad layer index");
     const Layer &ly = m->layers[layer_idx];
     if (what == 0 || what == 1) {
+        // the last conv under a fused fc head: a Fisher pass stores neither its output nor the cotangent of it
+        const Layer &head = m->layers.back();
+        ALQ_REQUIRE(!(m->last_call_fisher && layer_idx + 2 == (int)m->layers.size() && head.spec.type == ALQ_FC &&
+                      (what == 0 ? head.fc_part2 != nullptr : head.fc_maskbits != nullptr) && !g_dbg_knobs[4] && !g_dbg_knobs[5]),
+                    ALQ_EUNSUPPORTED, "layer %d: this tensor is not materialised in a Fisher pass (fc head fused into the layer: "
+                    "create the model under ALQ_NO_FC_BITS=1 to keep it)", layer_idx);
         const View &v = what == 0 ? ly.out : ly.dout;
         if (elems_out) *elems_out = (int64_t)N * v.elems();
         return debug_view_copy(m->ctx, v, N, d_out);

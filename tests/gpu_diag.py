@@ -11,6 +11,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# every activation and cotangent is read back below: keep the fc head as its own kernels (a fused head leaves the last
+# conv's output and its cotangent unmaterialised in a Fisher pass and alq_model_debug_copy refuses them)
+os.environ.setdefault('ALQ_NO_FC_BITS', '1')
 
 import torch  # noqa: E402
 

@@ -23,6 +23,14 @@
 //    dimension, fragment reads are bank-conflict-free (host-built row permutation + padded pitches),
 //    the prefetch is unconditional at one site of a straight-line loop body (see the tick loop), and the
 //    two producers of a concat may hand over two dense tensors (split views).
+//  * variants of the same kernel (template flags, one instantiation per combination in use):
+//      SUMS    channel sums of the output in the epilogue (selector MFMA);
+//      FIC     the prefetch is issued at the start of the contraction instead of the end of the staging part, for
+//              plans whose staging part is the longer one (a tick is max(stage of one half, contraction of the other));
+//      BITSRC  the input is [sign byte] * one patch-independent vector instead of a tensor (backward of the conv under
+//              a fc head in a Fisher pass);
+//      FCF     the output feeds only a 2-output fc head: the epilogue reduces it against W0 - W1 and writes sign bytes
+//              instead of the tensor.
 #include "alq_internal.h"
 
 #include <algorithm>

@@ -210,6 +210,7 @@ struct Igemm2Fuse {
     // igemm4 only: the GEMM input is not a stored tensor but in[n, j] = [bit j of patch n] * in_vec[j]
     const unsigned *in_bits = nullptr;
     const float *in_vec = nullptr;
+    float in_vec_amax = 0.f;   // max |in_vec| when the host knows it (> 0 enables the fp16x2 contraction of that launch)
     // igemm4 only (pair form, 8 output channels, one patch per tile): the output feeds nothing but a 2-output fc head -
     // the epilogue emits per (tile, wave) partials of the logit difference against fc_W [fc_F] = W0 - W1
     // (activation-memory order) and the sign byte of every voxel instead of storing the tensor
@@ -280,6 +281,8 @@ struct Igemm4Args {
     float *fc_part;
     unsigned char *fc_bits;
     int fc_F;
+    int f16_ein;                // F16: the staged input is scaled by 2^f16_ein before the fp16 split
+    float f16_inv;              // F16: 2^-(f16_ein + weight scale exponent), applied to the accumulators
 };
 
 struct G4Geom {
@@ -309,6 +312,10 @@ struct Igemm4Plan {
     int *d_tdesc = nullptr, *d_sdesc = nullptr, *d_pdesc = nullptr, *d_ttab = nullptr, *d_vdesc = nullptr;
     std::vector<unsigned short> h_W;
     void *d_W = nullptr;
+    // the same weights as fp16 pairs (h, l * 2^11) of W * 2^w16_exp, for the F16 variant (one column tile, not MULTI)
+    std::vector<unsigned short> h_W16;
+    void *d_W16 = nullptr;
+    int w16_exp = 0;
 };
 int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan);
 void igemm4_pack_weights(Igemm4Plan *plan, const std::vector<float> &Bmat /* [(enum tap, ci)][co] */);

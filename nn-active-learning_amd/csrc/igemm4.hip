@@ -48,6 +48,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #ifdef ALQ_STAMPS
 #define STAMP4(var) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
@@ -109,7 +110,21 @@ __device__ inline float g4_dot4(const f32x4 &a, const f32x4 &b) {
     return t0 + t1;
 }
 
-template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false, bool FCF = false, bool FIC = false>
+// F16 (one column tile): fp16x2 split instead of bf16x3 - x * 2^e = h + l * 2^-11 with fp16 h, l (weights alike, packed
+// by the host), h.h into `acc`, h.l + l.h into `accl`, result (acc + accl * 2^-11) * 2^-(e_in + e_w): THREE MFMAs and
+// two LDS pieces per operand instead of six and three, at the accuracy of a plain fp32 GEMM for operands within 2^28 of
+// the scale (tests/study_split_precision.py).  Needs max |x| of the input ahead of the launch: available for free
+// where the input is [sign] * one host-known vector (BITSRC).
+__device__ inline float g4_fma(float a, float b, float c) {      // single-width on purpose, see g4_dot4
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ inline unsigned g4_pack_h2(_Float16 a, _Float16 b) {
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false, bool FCF = false, bool FIC = false, bool F16 = false>
 __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     extern __shared__ __attribute__((aligned(16))) char lds4[];
     const int tid = threadIdx.x;
@@ -297,6 +312,17 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                     v0 = (nib & 1u) ? v0 : 0.f; v1 = (nib & 2u) ? v1 : 0.f;
                     v2 = (nib & 4u) ? v2 : 0.f; v3 = (nib & 8u) ? v3 : 0.f;
                 }
+                if constexpr (F16) {
+                    v0 = __builtin_ldexpf(v0, a.f16_ein); v1 = __builtin_ldexpf(v1, a.f16_ein);       // exact: a power of two
+                    v2 = __builtin_ldexpf(v2, a.f16_ein); v3 = __builtin_ldexpf(v3, a.f16_ein);
+                    const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1, h2 = (_Float16)v2, h3 = (_Float16)v3;     // round to nearest
+                    const _Float16 l0 = (_Float16)__builtin_ldexpf(v0 - (float)h0, 11), l1 = (_Float16)__builtin_ldexpf(v1 - (float)h1, 11);
+                    const _Float16 l2 = (_Float16)__builtin_ldexpf(v2 - (float)h2, 11), l3 = (_Float16)__builtin_ldexpf(v3 - (float)h3, 11);
+                    char *dst = Al + s_lds[it];
+                    *reinterpret_cast<uint2 *>(dst) = uint2{g4_pack_h2(h0, h1), g4_pack_h2(h2, h3)};
+                    *reinterpret_cast<uint2 *>(dst + 16) = uint2{g4_pack_h2(l0, l1), g4_pack_h2(l2, l3)};
+                    continue;
+                }
                 uint2 hi, mid, lo;
                 hi.x = g4_split2(v0, v1);  hi.y = g4_split2(v2, v3);
                 mid.x = g4_split2(v0, v1); mid.y = g4_split2(v2, v3);
@@ -311,6 +337,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
 
     // ---------------- epilogue of one tile (bias already in the accumulators) --------------------------
     f32x4 acc[4][NTW];
+    f32x4 accl[F16 ? 4 : 1][NTW];      // F16: the h.l + l.h products (weight 2^-11)
     char *outb = reinterpret_cast<char *>(a.out);
     const char *maskb = reinterpret_cast<const char *>(a.mask);
     // ReLU-grad mask values of the pending tile: loaded before the staging work of the same tick so that their
@@ -367,6 +394,23 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 fwv[ms] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (live) fwv[ms] = *reinterpret_cast<const f32x4 *>(a.fc_W + (jb + eoff[ms] + coff[0]));
             }
+        }
+    };
+    // F16: the two scaled accumulators of a finished tile -> its fp32 result (+ bias).  Runs at the end of the tile's
+    // last contraction: with three products the contracting side is the shorter one (phase stamps)
+    auto f16_combine = [&]() __attribute__((always_inline)) {
+        if constexpr (F16) {
+#pragma unroll
+            for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    f32x4 &c = acc[ms][nt];
+                    const f32x4 d = accl[ms][nt], b4 = bias4[nt];
+                    c.x = g4_fma(g4_fma(d.x, 0x1p-11f, c.x), a.f16_inv, b4.x);
+                    c.y = g4_fma(g4_fma(d.y, 0x1p-11f, c.y), a.f16_inv, b4.y);
+                    c.z = g4_fma(g4_fma(d.z, 0x1p-11f, c.z), a.f16_inv, b4.z);
+                    c.w = g4_fma(g4_fma(d.w, 0x1p-11f, c.w), a.f16_inv, b4.w);
+                }
         }
     };
     auto flush = [&](int q_out, int q_full, int q_l, int q_g) __attribute__((always_inline)) {
@@ -569,7 +613,68 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms)
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) acc[ms][nt] = bias4[nt];
+            for (int nt = 0; nt < NTW; ++nt) {
+                if constexpr (F16) {      // scaled sums: the bias joins in the epilogue
+                    acc[ms][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    accl[ms][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                } else {
+                    acc[ms][nt] = bias4[nt];
+                }
+            }
+    };
+    // F16 twin of `unit` (one column tile): two fragment pieces per operand, three products
+    auto unit16 = [&](int S, const char *Wc, const char *Ab, int trow) __attribute__((always_inline)) {
+        if constexpr (F16) {
+            const int *tt = Tl + trow * (G4_MAXS * 4) + lq;
+            f16x8 Wa[2], Wb[2], Xa[2][2], Xb[2][2];
+            auto rdW = [&](f16x8 (&Wf)[2], int s) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    Wf[p] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(Wc + (s * 3 + p) * 1024));
+            };
+            auto rdX = [&](f16x8 (&X)[2][2], int mh, int to) {
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2) {
+                    const char *row = Ab + vbase[mh + m2] + to;
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        X[p][m2] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(row + 16 * p));
+                }
+            };
+            auto mm = [&](const f16x8 (&Wf)[2], const f16x8 (&X)[2][2], int mh) {
+                f32x4 c0 = acc[mh][0], c1 = acc[mh + 1][0], d0 = accl[mh][0], d1 = accl[mh + 1][0];
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[1], X[0][0], d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[1], X[0][1], d1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[0], X[0][0], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[0], X[0][1], c1, 0, 0, 0);
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[0], X[1][0], d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[0], X[1][1], d1, 0, 0, 0);
+                acc[mh][0] = c0; acc[mh + 1][0] = c1; accl[mh][0] = d0; accl[mh + 1][0] = d1;
+            };
+            int t_cur = tt[0];
+            rdX(Xa, 0, t_cur);
+            rdW(Wa, 0);
+            auto kstep = [&](const f16x8 (&Wc_)[2], f16x8 (&Wn_)[2], int s) {
+                const int s1 = s + 1 < S ? s + 1 : s;
+                const int t_nxt = tt[s1 * 4];
+                rdX(Xb, 2, t_cur);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(Wc_, Xa, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                rdW(Wn_, s1);
+                rdX(Xa, 0, t_nxt);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(Wc_, Xb, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                t_cur = t_nxt;
+            };
+            int s = 0;
+            for (; s + 1 < S; s += 2) {
+                kstep(Wa, Wb, s);
+                kstep(Wb, Wa, s + 1);
+            }
+            if (s < S) kstep(Wa, Wb, s);
+        }
     };
 
     // ---------------- tick loop --------------------------------------------------------------------------
@@ -631,9 +736,12 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 // the longer one and the other half waited for it at the barrier)
                 if constexpr (FCF) { if (b_ph == a.nph - 1) fcw_prefetch(c_out, c_full, c_l, c_g); }
                 if (b_ph == 0) init_acc();
-                for (int rep = 0; rep <= a.dbg_repeat; ++rep)
-                    unit(pd[2], Wl + pd[3] + lane * 16, Al, pd[4]);
+                for (int rep = 0; rep <= a.dbg_repeat; ++rep) {
+                    if constexpr (F16) unit16(pd[2], Wl + pd[3] + lane * 16, Al, pd[4]);
+                    else unit(pd[2], Wl + pd[3] + lane * 16, Al, pd[4]);
+                }
                 if (b_ph == a.nph - 1) {
+                    f16_combine();
                     have_pend = true;
                     p_out = c_out; p_full = c_full; p_l = c_l; p_g = c_g;
                 }
@@ -1199,6 +1307,13 @@ void igemm4_pack_weights(Igemm4Plan *plan, const std::vector<float> &Bmat) {
     const int NTW = plan->NTW, Ci = plan->Ci, Co = plan->Co;
     const bool pair = plan->a.pair != 0;
     plan->h_W.assign((size_t)plan->a.wbytes / 2, 0);
+    const bool w16 = NTW == 1 && !plan->multi;
+    float amax = 0.f;
+    for (float w : Bmat) amax = std::max(amax, std::fabs(w));
+    int ex = 0;
+    if (amax > 0.f) (void)std::frexp(amax, &ex);       // amax < 2^ex
+    plan->w16_exp = 14 - ex;
+    if (w16) plan->h_W16.assign((size_t)plan->a.wbytes / 2, 0);
     for (const Igemm4Plan::Unit &u : plan->units)
         for (int s = 0; s < u.S; ++s)
             for (int nt = 0; nt < NTW; ++nt)
@@ -1210,6 +1325,16 @@ void igemm4_pack_weights(Igemm4Plan *plan, const std::vector<float> &Bmat) {
                     for (int j = 0; j < 8; ++j) {
                         float w = 0.f;
                         if (tap >= 0 && co < Co) w = Bmat[((size_t)tap * Ci + u.chunk * 8 + j) * Co + co];
+                        if (w16) {      // fp16 pair of w * 2^w16_exp: h, then the remainder times 2^11 (both round to nearest)
+                            const float ws = std::ldexp(w, plan->w16_exp);
+                            const _Float16 h = (_Float16)ws;
+                            const _Float16 l = (_Float16)std::ldexp(ws - (float)h, 11);
+                            unsigned short hb, lb;
+                            std::memcpy(&hb, &h, 2);
+                            std::memcpy(&lb, &l, 2);
+                            plan->h_W16[(size_t)u.w_off / 2 + ((((size_t)s * 3 + 0) * NTW + nt) * 64 + lane) * 8 + j] = hb;
+                            plan->h_W16[(size_t)u.w_off / 2 + ((((size_t)s * 3 + 1) * NTW + nt) * 64 + lane) * 8 + j] = lb;
+                        }
                         for (int p = 0; p < 3; ++p) {
                             const unsigned short hb = g4_bf16_rne(w);
                             w -= g4_bf16_to_f(hb);
@@ -1219,9 +1344,9 @@ void igemm4_pack_weights(Igemm4Plan *plan, const std::vector<float> &Bmat) {
                 }
 }
 
-template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false, bool FCF = false, bool FIC = false>
+template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false, bool FCF = false, bool FIC = false, bool F16 = false>
 static int launch4_s(alq_ctx *ctx, const Igemm4Plan &plan, const Igemm4Args &a, unsigned grid) {
-    auto kfn = igemm4_kernel<NTW, MULTI, SUMS, BITSRC, FCF, FIC>;
+    auto kfn = igemm4_kernel<NTW, MULTI, SUMS, BITSRC, FCF, FIC, F16>;
     if (plan.lds_bytes > 64 * 1024)
         ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)plan.lds_bytes));
@@ -1259,6 +1384,8 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
     a.out_split = out.split; a.out_delta = (int)out.delta;
     a.mask_split = 0; a.mask_delta = 0;
     a.src_bits = nullptr; a.bits_pstride = 0; a.bits_bytes = 0;
+    a.f16_ein = 0; a.f16_inv = 1.f;
+    bool f16 = false;
     a.fc_W = nullptr; a.fc_part = nullptr; a.fc_bits = nullptr; a.fc_F = 0;
     if (fuse && fuse->in_bits) {      // masked-vector input: `in` only gives the geometry
         ALQ_REQUIRE(plan.NTW == 1 && !plan.multi && a.PT == 1 && !in.split && in.c0 == 0 && in.cs == in.C && fuse->in_vec &&
@@ -1270,6 +1397,15 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
         a.src_bits = fuse->in_bits;
         a.bits_pstride = (int)((long long)in.vox() * in.cs);
         a.bits_bytes = (int)((long long)N * in.vox() * in.cs / 4);
+        static const bool no16 = getenv("ALQ_NO_F16X2") != nullptr;
+        if (fuse->in_vec_amax > 0.f && plan.d_W16 && !no16) {       // scales known ahead of the launch: fp16x2 contraction
+            int ex = 0;
+            (void)std::frexp(fuse->in_vec_amax, &ex);
+            a.f16_ein = 14 - ex;
+            a.f16_inv = std::ldexp(1.f, -(a.f16_ein + plan.w16_exp));
+            a.W = plan.d_W16;
+            f16 = true;
+        }
     }
     a.dbg = nullptr;
     if (g_igemm2_dbg) {   // diagnostic: stamp only the launch whose ordinal (since the buffer was set) is ALQ_STAMP_ONLY
@@ -1316,6 +1452,9 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
         if (plan.NTW == 1) return launch4_t<1, true>(ctx, plan, a, grid);
         return launch4_t<2, true>(ctx, plan, a, grid);
     }
+    if (a.src_bits && f16)
+        return (a.osumA || a.osumB) ? launch4_s<1, false, true, true, false, false, true>(ctx, plan, a, grid)
+                                    : launch4_s<1, false, false, true, false, false, true>(ctx, plan, a, grid);
     if (a.src_bits)
         return (a.osumA || a.osumB) ? launch4_s<1, false, true, true>(ctx, plan, a, grid)
                                     : launch4_s<1, false, false, true>(ctx, plan, a, grid);

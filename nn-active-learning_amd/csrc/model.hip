@@ -64,6 +64,8 @@ struct Layer {
     // directly (igemm4 BITSRC)
     unsigned *fc_maskbits = nullptr;
     float *fc_wv = nullptr;
+    float fc_wv_amax = 0.f;            // max |W0 - W1| of a two-output head (host side, set with the weights)
+    float dout_vec_amax = 0.f;
     float *fc_part2 = nullptr;         // partial logits per (tile, wave) when the conv below computes them in its epilogue
     int fc_slices2 = 0;
     const unsigned *dout_bits = nullptr;   // set on the conv below for the duration of one backward pass
@@ -201,8 +203,15 @@ static int set4(alq_model *m, Igemm4Plan *p4, const std::vector<float> &Bmat) {
     if (!dw) ALQ_TRY(m->dalloc(&dw, p4->h_W.size()));
     p4->d_W = dw;
     ALQ_HIP(hipMemcpyAsync(dw, p4->h_W.data(), p4->h_W.size() * sizeof(unsigned short), hipMemcpyHostToDevice, st));
+    if (!p4->h_W16.empty()) {
+        unsigned short *dw16 = reinterpret_cast<unsigned short *>(p4->d_W16);
+        if (!dw16) ALQ_TRY(m->dalloc(&dw16, p4->h_W16.size()));
+        p4->d_W16 = dw16;
+        ALQ_HIP(hipMemcpyAsync(dw16, p4->h_W16.data(), p4->h_W16.size() * sizeof(unsigned short), hipMemcpyHostToDevice, st));
+    }
     ALQ_HIP(hipStreamSynchronize(st));
     std::vector<unsigned short>().swap(p4->h_W);
+    std::vector<unsigned short>().swap(p4->h_W16);
     return ALQ_OK;
 }
 
@@ -812,6 +821,7 @@ static int run_backward(alq_model *m, const float *d_x, int N) {
                 ALQ_TRY(k_fc_small_dsum_bits(ctx, ly.fc_maskbits, ly.fc_wv, ly.F, N, prev->dsum));
                 prev->dout_bits = ly.fc_maskbits;
                 prev->dout_vec = ly.fc_wv;
+                prev->dout_vec_amax = ly.spec.cout == 2 ? ly.fc_wv_amax : 0.f;
                 fused = true;
             } else if (ly.dense_fc_small) {
                 const bool can = prev_param && prev->out.cs == prev->out.C;
@@ -846,7 +856,7 @@ static int run_backward(alq_model *m, const float *d_x, int N) {
                 fuse = &fz;
             }
             if (ly.dout_bits) {       // the cotangent of this layer's output exists only as mask bits and one vector
-                fz.in_bits = ly.dout_bits; fz.in_vec = ly.dout_vec;
+                fz.in_bits = ly.dout_bits; fz.in_vec = ly.dout_vec; fz.in_vec_amax = ly.dout_vec_amax;
                 ly.dout_bits = nullptr; ly.dout_vec = nullptr;
                 const bool honoured = fuse != nullptr;
                 ALQ_TRY(igemm4_launch(ctx, ly.bwd.p4, ly.dout, ly.din, nullptr, 0, acc, N, PROF_IGEMM3_BWD, &fz));
@@ -1034,6 +1044,9 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
                         for (int o = 0; o < Co; ++o) Wp[(size_t)o * F + fm] = W[(size_t)o * F + ft];
                     }
         if (ly.dense_fc_small) {
+            ly.fc_wv_amax = 0.f;
+            if (Co == 2)
+                for (int64_t f = 0; f < F; ++f) ly.fc_wv_amax = std::max(ly.fc_wv_amax, std::fabs((0.f + Wp[(size_t)f]) - Wp[(size_t)F + f]));
             ALQ_HIP(hipMemcpyAsync(ly.d_Wp, Wp.data(), Wp.size() * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
             ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
         } else {

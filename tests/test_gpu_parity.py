@@ -524,7 +524,11 @@ def test_layout_and_engine_switches_agree(sess):
     e = scores({'ALQ_NO_FC_FUSE': '1'})
     for k in a:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
-        np.testing.assert_array_equal(e[k], d[k], err_msg=k)       # bits vs tensor: the same numbers
+    # (e) contracts [sign] * (W0 - W1) in the last conv's backward with the fp16x2 split (three products), (d) the stored
+    # tensor with bf16x3 (six): both at fp32-level accuracy, another rounding pattern
+    np.testing.assert_array_equal(e['p1'], d['p1'])
+    for k in ('g0', 'g1', 'A'):
+        np.testing.assert_allclose(e[k], d[k], rtol=2e-5, atol=1e-9 + 2e-6 * np.abs(d[k]).max())
     # the head's logits summed per (tile, wave) in the last conv's epilogue instead of per slice of the stored tensor
     np.testing.assert_allclose(a['p1'], e['p1'], rtol=0, atol=1e-6)
     for k in ('g0', 'g1', 'A'):

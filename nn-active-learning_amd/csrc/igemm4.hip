@@ -39,6 +39,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <type_traits>
 
 namespace alq {
 
@@ -115,6 +116,7 @@ __device__ inline float g4_dot4(const f32x4 &a, const f32x4 &b) {
 // two LDS pieces per operand instead of six and three, at the accuracy of a plain fp32 GEMM for operands within 2^28 of
 // the scale (tests/study_split_precision.py).  Needs max |x| of the input ahead of the launch: available for free
 // where the input is [sign] * one host-known vector (BITSRC).
+template <int V> using IC = std::integral_constant<int, V>;
 __device__ inline float g4_fma(float a, float b, float c) {      // single-width on purpose, see g4_dot4
     float r;
     asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -275,6 +277,9 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     // 47 % vs 20 % for the first conv_transpose), so its ~1 k cycles of load issue per phase move to the start of the
     // contraction - still ONE site per kernel: the loads then have the contraction to land in.
     constexpr bool FETCH_IN_CONTRACT = BITSRC || FIC;
+    // row blocks of a tile written back by the contracting side: with three products instead of six the contraction of
+    // the F16 kernel is the shorter part again (phase stamps: 302 k vs 445 k cycles per half)
+    constexpr int EPI_SPLIT = (BITSRC && F16) ? 1 : 0;
     f32x4 R[G4_NSLOT];
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
@@ -413,7 +418,12 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 }
         }
     };
-    auto flush = [&](int q_out, int q_full, int q_l, int q_g) __attribute__((always_inline)) {
+    // Row blocks [MS0, MS1) of a finished tile (compile-time range).  The whole tile is normally written back by the
+    // staging part of the next tick; a kernel whose staging part is the longer one writes its first EPI_SPLIT row
+    // blocks at the end of the contraction instead (the channel-sum accumulator travels in sacc_k).
+    f32x4 sacc_k = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto flush = [&](int q_out, int q_full, int q_l, int q_g, auto MS0, auto MS1) __attribute__((always_inline)) {
+        constexpr int m0 = decltype(MS0)::value, m1 = decltype(MS1)::value;
         const int obase_e = q_out * a.out_cs;
         int mz0 = 0, my0 = 0, mx0 = 0;
         if (!q_full) {
@@ -424,7 +434,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         // into MFMA rows (0, 4), (1, 5), (8, 12), (9, 13), i.e. lane group q ends up with  .x / .y = the sum of
         // set (q & 1) for row blocks 2 * (q >> 1) and 2 * (q >> 1) + 1:  two 64-lane stores instead of eight
         // 16-lane ones (those, each waiting on its own MFMA, were 4 % of a pass).
-        f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 sacc = m0 == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sacc_k;
         bool livem[4];
         float fs0 = 0.f;
         unsigned fbyte[FCF ? 4 : 1];
@@ -439,6 +449,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 live = e >= 0 && q_g * a.PT + pt < a.N && mz0 + z < a.MD && my0 + y < a.MH && mx0 + x < a.MW;
             }
             livem[ms] = live;
+            if (ms < m0 || ms >= m1) continue;
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 const int c = nt * 16 + cl;
@@ -488,6 +499,10 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                     sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, (val.x + val.y) + (val.z + val.w), sacc, 0, 0, 0);
                 }
             }
+        }
+        if constexpr (m1 < 4) {       // the rest of the tile follows in the staging part
+            sacc_k = sacc;
+            return;
         }
         if constexpr (SUMS) {
             // lane group q: set (q & 1), row blocks m0 = 2 * (q >> 1) (in .x) and m0 + 1 (in .y)
@@ -706,7 +721,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             stash();
             PHASE4_END(0);
             if (a_ph == 0 && have_pend) {
-                flush(p_out, p_full, p_l, p_g);
+                flush(p_out, p_full, p_l, p_g, IC<EPI_SPLIT>{}, IC<4>{});
                 have_pend = false;
             }
             PHASE4_END(1);
@@ -742,6 +757,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 }
                 if (b_ph == a.nph - 1) {
                     f16_combine();
+                    if constexpr (EPI_SPLIT > 0) flush(c_out, c_full, c_l, c_g, IC<0>{}, IC<EPI_SPLIT>{});
                     have_pend = true;
                     p_out = c_out; p_full = c_full; p_l = c_l; p_g = c_g;
                 }
@@ -756,7 +772,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                         for (int p = 0; p < a.NP; ++p)
                             unit(gd[2], Wl + gd[3] + p * ub + lane * 16, Al + p * a.plane_bytes, gd[4]);
                     if (g + 1 < a.ngr) {
-                        flush(c_out + gd[5], c_full, c_l, c_g);
+                        flush(c_out + gd[5], c_full, c_l, c_g, IC<0>{}, IC<4>{});
                     } else {
                         have_pend = true;
                         p_out = c_out + gd[5]; p_full = c_full; p_l = c_l; p_g = c_g;
@@ -778,7 +794,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     }
     if (h == 0) __syncthreads();
     if (have_pend) {
-        flush(p_out, p_full, p_l, p_g);
+        flush(p_out, p_full, p_l, p_g, IC<EPI_SPLIT>{}, IC<4>{});
     }
 #ifdef ALQ_STAMPS
     PHASE4_END(6);

@@ -116,11 +116,18 @@ def main():
         # dominant kernel = igemm4_kernel (conv / conv_transpose fwd + bwd-data on the bf16 matrix cores
         # with the 3-way operand split: 6 bf16 MFMA MACs per fp32-accurate MAC, so the matrix-core bound
         # on ALGORITHMIC fp32 flops is the dense bf16 peak / 6)
-        ig_ms = prof['igemm3_fwd']['ms'] + prof['igemm3_bwd']['ms']
-        ig_fl = prof['igemm3_fwd']['flops'] + prof['igemm3_bwd']['flops']
-        ig_n = prof['igemm3_fwd']['launches'] + prof['igemm3_bwd']['launches']
+        # One launch per pass (the last conv's backward, whose input scale is host-known) runs the fp16x2 split:
+        # 3 fp16 MFMA MACs per fp32-accurate MAC, bound = dense fp16 peak (= the bf16 one) / 3.  The bound of the mix
+        # is the flop-weighted harmonic mean of the two.
+        f16 = prof.get('igemm_f16x2', {'ms': 0.0, 'flops': 0.0, 'launches': 0})
+        bf_fl = prof['igemm3_fwd']['flops'] + prof['igemm3_bwd']['flops']
+        ig_ms = prof['igemm3_fwd']['ms'] + prof['igemm3_bwd']['ms'] + f16['ms']
+        ig_fl = bf_fl + f16['flops']
+        ig_n = prof['igemm3_fwd']['launches'] + prof['igemm3_bwd']['launches'] + f16['launches']
         achieved = ig_fl / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
-        peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
+        peak_bf, peak_f16 = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS, PEAK_BF16_MFMA_TFLOPS / 3
+        peak = ig_fl / (bf_fl / peak_bf + f16['flops'] / peak_f16) if ig_fl > 0 else peak_bf
+        executed = (bf_fl * SPLIT_PRODUCTS + f16['flops'] * 3) / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
         conv_ms = ig_ms + sum(prof[k]['ms'] for k in ('igemm_fwd', 'igemm_bwd', 'direct_conv'))
         conv_fl = ig_fl + sum(prof[k]['flops'] for k in ('igemm_fwd', 'igemm_bwd', 'direct_conv'))
         traffic = None                       # PMC passes are separate runs (profiles/pmc_traffic.json)
@@ -134,7 +141,8 @@ def main():
             'metric': 'patches/sec Fisher-scored (32^3, 2-class)',
             'value': value, 'unit': 'patches/s', 'n_gpus': ws, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32 (bf16x3 operand split on the bf16 MFMA, fp32 accumulate; everything else fp32 / fp64)',
+            'dtype': 'f32 (bf16x3 operand split on the bf16 MFMA - fp16x2 split in one launch per pass -, fp32 accumulate; '
+                     'everything else fp32 / fp64)',
             'data': 'synthetic',
             'config': {'workload': 'configs[2]: Fisher scoring, NET-C patch-wise 3-D U-Net (fc head), '
                                    '%d synthetic 32^3 2-class patches per GPU, random-init weights seed 14'
@@ -143,11 +151,14 @@ def main():
                        'parallelism': 'pool sharded over %d GPU(s), RCCL top-B merge + 8x8 Fisher all-reduce' % ws},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic,
-                         'kernel': 'igemm4_kernel (+ igemm3_kernel for unfused conv_transpose classes): conv / conv_transpose '
-                                   'fwd + bwd-data, bf16x3 split',
-                         'peak_note': 'algorithmic fp32 flops; peak = %.0f dense bf16 / %d split products'
-                                      % (PEAK_BF16_MFMA_TFLOPS, SPLIT_PRODUCTS),
-                         'executed_bf16_tflops': achieved * SPLIT_PRODUCTS, 'peak_bf16_tflops': PEAK_BF16_MFMA_TFLOPS,
+                         'kernel': 'igemm4_kernel: conv / conv_transpose fwd + bwd-data, bf16x3 split (fp16x2 in the last '
+                                   'conv\'s backward)',
+                         'peak_note': 'algorithmic fp32 flops; peak = flop-weighted harmonic mean of %.0f dense 16-bit MFMA / %d '
+                                      'products (bf16x3 launches, %.0f %% of the flops) and / 3 (the fp16x2 launch)'
+                                      % (PEAK_BF16_MFMA_TFLOPS, SPLIT_PRODUCTS, 100.0 * bf_fl / max(ig_fl, 1.0)),
+                         'executed_bf16_tflops': executed, 'peak_bf16_tflops': PEAK_BF16_MFMA_TFLOPS,
+                         'f16x2_launch': {'tflops': f16['flops'] / (f16['ms'] * 1e-3) / 1e12 if f16['ms'] > 0 else 0.0,
+                                          'avg_launch_ms': f16['ms'] / max(f16['launches'], 1), 'bound_tflops': peak_f16},
                          'frac_of_f32_mfma_peak': achieved / PEAK_F32_MFMA_TFLOPS,
                          'launches': ig_n, 'avg_launch_ms': ig_ms / max(ig_n, 1), 'timed_every_kth_pass': args.prof_every,
                          'all_conv_engines_tflops': conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,

@@ -53,7 +53,8 @@ struct View {
 
 // igemm_* = the fp32 engines (v1 / v2), igemm3_* = the bf16x3 matrix-core engine, direct = the VALU first-layer conv
 enum ProfClass { PROF_IGEMM_FWD = 0, PROF_IGEMM_BWD = 1, PROF_ELEMWISE = 2, PROF_REDUCE = 3,
-                 PROF_FC_SMALL = 4, PROF_IGEMM3_FWD = 5, PROF_IGEMM3_BWD = 6, PROF_DIRECT = 7, PROF_NUM = 8 };
+                 PROF_FC_SMALL = 4, PROF_IGEMM3_FWD = 5, PROF_IGEMM3_BWD = 6, PROF_DIRECT = 7,
+                 PROF_IGEMM_F16 = 8 /* igemm4 launches on the fp16x2 split (3 products) */, PROF_NUM = 9 };
 
 struct ProfSlot {
     double ms = 0;

@@ -1463,7 +1463,7 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
     const int pgroups = (N + a.PT - 1) / a.PT;
     const long long total = (long long)pgroups * a.tpg;
     const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((total + 1) / 2, 256));
-    ProfScope ps(ctx, prof_cls, plan.flops_per_patch * N);
+    ProfScope ps(ctx, f16 ? (int)PROF_IGEMM_F16 : prof_cls, plan.flops_per_patch * N);
     if (plan.multi) {
         if (plan.NTW == 1) return launch4_t<1, true>(ctx, plan, a, grid);
         return launch4_t<2, true>(ctx, plan, a, grid);

@@ -1166,7 +1166,7 @@ int alq_topk_merge(const double *h_keys, const int64_t *h_idx, int64_t n, int64_
 }
 
 static const char *kProfNames[PROF_NUM] = {"igemm_fwd", "igemm_bwd", "elementwise", "reduce", "fc_small",
-                                           "igemm3_fwd", "igemm3_bwd", "direct_conv"};
+                                           "igemm3_fwd", "igemm3_bwd", "direct_conv", "igemm_f16x2"};
 
 int alq_prof_enable(alq_ctx *ctx, int on) {
     ALQ_REQUIRE(ctx != nullptr, ALQ_EINVAL, "null ctx");

@@ -272,6 +272,7 @@ struct Igemm4Args {
     int nslots, plane_bytes;
     int in_pstride, out_pstride, in_bytes;
     int relu, accumulate, pair, store_from;
+    int cls_ok;             // halo validity by tile class (sdesc[1] = one bit per class) instead of by coordinate ranges
     int in_split_ch, in_delta, out_split, out_delta, mask_split, mask_delta;   // split-concat views (floats)
     int tt_ints, pd_off, td_off, wbytes, abytes;   // table block in LDS (ints): tap table, then phase, then tile descriptors
     int dbg_repeat;

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
 #pragma unroll
     for (int it = 0; it < G4_NSLOT; ++it) {
         const int slot = ht + it * 256;
-        int rel = 0x20000000, pk = 0x00ff0000, ld = -1; // unused slot: past the buffer on the fast path, hz = 255 on the checked one
+        int rel = 0x20000000, pk = a.cls_ok ? 0 : 0x00ff0000, ld = -1; // unused slot: past the buffer on the fast path; no class bit / hz = 255 on the checked ones
         if (slot < a.nslots) {
             const int4 sd = *reinterpret_cast<const int4 *>(a.sdesc + slot * 4);
             rel = sd.x * a.in_cs + a.in_c0 + sd.w;
@@ -255,6 +255,14 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         if ((tflags & 2) && (fpg + 1) * a.PT <= a.N) {      // whole halo inside the tensor: no per-slot checks
 #pragma unroll
             for (int it = 0; it < G4_NSLOT; ++it) goff[it] = (org + s_rel[it]) * 4;
+            return;
+        }
+        if (a.cls_ok) {         // one patch per tile, <= 3 validity classes per dimension: s_pk holds a bit per class
+            const int cls = __builtin_amdgcn_readfirstlane(t1.w);
+            const bool pin = fpg < a.N;
+#pragma unroll
+            for (int it = 0; it < G4_NSLOT; ++it)
+                goff[it] = (pin && (((unsigned)s_pk[it] >> cls) & 1u)) ? (org + s_rel[it]) * 4 : G4_OOB;
             return;
         }
         const unsigned zy = (unsigned)t0.w, xx = (unsigned)t1.x;
@@ -1233,7 +1241,10 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
             }
         }
     }
-    // tiles
+    // tiles.  Halo validity classes: along every dimension the tiles' valid index ranges [lo, hi) usually take at most
+    // three values (first tile, interior, last tile); then a tile is one of 27 classes and a staging slot carries one
+    // validity bit per class instead of its halo coordinates (locate(): one bit test per slot instead of six compares).
+    std::vector<std::pair<int, int>> dcls[3];
     plan->h_tdesc.assign((size_t)a.tpg * 8, 0);
     if (dg[0].M > 255 || dg[1].M > 255 || dg[2].M > 255) return ALQ_OK;       // tile origins are packed in bytes
     for (int cl = 0; cl < ncls; ++cl)
@@ -1263,9 +1274,19 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
                 td[4] = lohi[2][0] | (lohi[2][1] << 8);
                 td[5] = m0[0] | (m0[1] << 8) | (m0[2] << 16);
                 td[6] = g.kind == 4 ? cl * NCH : 0;          // first phase descriptor of this tile
-                td[7] = 0;
+                int cls = 0;
+                for (int d = 0; d < 3; ++d) {
+                    const std::pair<int, int> pr(lohi[d][0], lohi[d][1]);
+                    size_t k = 0;
+                    while (k < dcls[d].size() && dcls[d][k] != pr) ++k;
+                    if (k == dcls[d].size()) dcls[d].push_back(pr);
+                    cls = cls * 3 + (int)k;
+                }
+                td[7] = cls;                                 // meaningful when every dimension has <= 3 classes
             }
     // staging slots
+    const bool cls_ok = PT == 1 && dcls[0].size() <= 3 && dcls[1].size() <= 3 && dcls[2].size() <= 3 && !getenv("ALQ_NO_HALO_CLASSES");
+    a.cls_ok = cls_ok ? 1 : 0;
     plan->h_sdesc.assign((size_t)a.nslots * 4, 0);
     for (int pl = 0; pl < NPs; ++pl)
         for (int pt = 0; pt < PT; ++pt)
@@ -1278,6 +1299,18 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
                             int *sd = &plan->h_sdesc[(((size_t)pl * nhv + hv) * 2 + half) * 4];
                             sd[0] = ((pt * I[0] + hz * dg[0].hs) * I[1] + hy * dg[1].hs) * I[2] + hx * dg[2].hs;
                             sd[1] = (pt << 24) | (hz << 16) | (hy << 8) | hx;
+                            if (cls_ok) {       // bit ((cz * 3 + cy) * 3 + cx): the slot is inside the tensor for tiles of that class
+                                const int hh[3] = {hz, hy, hx};
+                                int mask = 0;
+                                for (int c = 0; c < 27; ++c) {
+                                    const int cc[3] = {c / 9, (c / 3) % 3, c % 3};
+                                    bool ok = true;
+                                    for (int d = 0; d < 3; ++d)
+                                        ok = ok && cc[d] < (int)dcls[d].size() && hh[d] >= dcls[d][cc[d]].first && hh[d] < dcls[d][cc[d]].second;
+                                    if (ok) mask |= 1 << c;
+                                }
+                                sd[1] = mask;
+                            }
                             sd[2] = (pl * plane_rows + lrow) * G4_ROWB + half * 8;
                             sd[3] = pl * 8 + half * 4;
                         }

@@ -212,6 +212,12 @@ struct Igemm2Fuse {
     const unsigned *in_bits = nullptr;
     const float *in_vec = nullptr;
     float in_vec_amax = 0.f;   // max |in_vec| when the host knows it (> 0 enables the fp16x2 contraction of that launch)
+    // igemm4 only: max |x| of tensors as float bits (non-negative, so unsigned order = float order).  out_amax
+    // [N][tiles per patch * groups * 4] receives the maxima of the STORED output columns per (tile, group, wave)
+    // (k_rowmax_u32 folds them per patch); in_amax / in_amax2 [N] describe the (two parts of the) input tensor and
+    // enable the fp16x2 contraction with one scale per patch.
+    unsigned *out_amax = nullptr;
+    const unsigned *in_amax = nullptr, *in_amax2 = nullptr;
     // igemm4 only (pair form, 8 output channels, one patch per tile): the output feeds nothing but a 2-output fc head -
     // the epilogue emits per (tile, wave) partials of the logit difference against fc_W [fc_F] = W0 - W1
     // (activation-memory order) and the sign byte of every voxel instead of storing the tensor
@@ -223,6 +229,7 @@ struct Igemm2Fuse {
 
 extern unsigned long long *g_igemm2_dbg;
 extern int g_dbg_knobs[8];
+extern int g_no_f16x2;        // ALQ_NO_F16X2, read when a model is created: bf16x3 split in every launch
 int igemm2_build_plan(const IgemmPlan &p1, Igemm2Plan *p2);
 void igemm2_pack_weights(Igemm2Plan *p2, const std::vector<float> &Bmat);
 int igemm2_launch(alq_ctx *ctx, const Igemm2Plan &plan, const View &in, const View &out, const float *bias,
@@ -283,8 +290,10 @@ struct Igemm4Args {
     float *fc_part;
     unsigned char *fc_bits;
     int fc_F;
-    int f16_ein;                // F16: the staged input is scaled by 2^f16_ein before the fp16 split
-    float f16_inv;              // F16: 2^-(f16_ein + weight scale exponent), applied to the accumulators
+    int f16_ein;                // F16: the staged input is scaled by 2^f16_ein before the fp16 split (launch-wide scale)
+    int f16_ew;                 // F16: scale exponent of the packed weights
+    const unsigned *in_amax, *in_amax2;   // F16: per-patch max |x| of the input part(s), float bits -> one scale per tile
+    unsigned *out_amax;         // any variant: max |stored output| per (tile, group, wave), float bits
 };
 
 struct G4Geom {
@@ -355,7 +364,7 @@ int direct_launch(alq_ctx *ctx, const DirectPlan &dp, const View &in, const View
 // first conv (1 -> 8 channels, 3x3x3) fused with the 2x2x2 max-pool behind it: both outputs, arg-max, both sums
 int direct_conv_pool_launch(alq_ctx *ctx, const float *d_W, const View &in, const View &out, const View &pout,
                             const float *bias, int relu, uint8_t *argmax, float *osum, float *posum, int N,
-                            double flops_per_patch);
+                            double flops_per_patch, unsigned *amax = nullptr);
 
 // ------------------------------------------------------------------ wide fc layers (fcgemm.hip)
 struct FcGemmPlan {
@@ -418,6 +427,7 @@ int k_fc_small_bwd(alq_ctx *, const float *delta, int nout, const float *Wp, int
                    float *dact, const float *mask_act = nullptr, float *dsum = nullptr, int C = 0,
                    bool *fused = nullptr);
 int k_rowsum_field(alq_ctx *, const float *field, int64_t len, int N, float *out);
+int k_rowmax_u32(alq_ctx *, const unsigned *in, int len, int N, unsigned *out);      // out[n] = max_k in[n][k]
 int k_softmax(alq_ctx *, const float *logits, int c, int N, float *post_cN, int64_t *pred);
 int k_fill_unit_cotangent(alq_ctx *, float *dlogits, int N);
 int k_fisher_finalize(alq_ctx *, const double *Spart, const int *nslab, int nslab_max, int max_batch, double *S,

@@ -106,6 +106,7 @@ struct DirectPoolArgs {
     float *pout;               // pooled output view
     unsigned *argmax;          // [N * pooled voxels][2] packed window indices (4 channels per word)
     float *osum, *posum;       // channel sums of the conv output / pooled output (or null)
+    unsigned *amax;            // [N] max |conv output| per patch as float bits (atomic max; zeroed by the caller) or null
     const float *W;            // [27][8]
     const float *bias;
     int out_cs, out_c0, po_cs, po_c0;
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(256, 2) void direct_conv_pool_kernel(const DirectPo
     if (wlive && a.posum) a.posum[pvox0] = psum;
     __syncthreads();
     // voxel-consecutive lanes: 32 B per lane, 2 KB contiguous per wave along x
+    float amx = 0.f;
     for (int lv = tid; lv < 2 * TWZ * 2 * TWY * 2 * TWX; lv += 256) {
         const int lx = lv % (2 * TWX), ly = (lv / (2 * TWX)) % (2 * TWY), lz = lv / (2 * TWX * 2 * TWY);
         const int z = z0 + lz, y = y0 + ly, x = x0 + lx;
@@ -238,20 +240,31 @@ __global__ __launch_bounds__(256, 2) void direct_conv_pool_kernel(const DirectPo
             sum += (g1.x + g1.y) + (g1.z + g1.w);
             a.osum[vox] = sum;
         }
+        if (a.amax)
+            amx = fmaxf(amx, fmaxf(fmaxf(fmaxf(__builtin_fabsf(g0.x), __builtin_fabsf(g0.y)), fmaxf(__builtin_fabsf(g0.z), __builtin_fabsf(g0.w))),
+                                   fmaxf(fmaxf(__builtin_fabsf(g1.x), __builtin_fabsf(g1.y)), fmaxf(__builtin_fabsf(g1.z), __builtin_fabsf(g1.w)))));
+    }
+    if (a.amax) {      // 16 workgroups per 32^3 patch: one atomic each
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) amx = fmaxf(amx, __shfl_xor(amx, off, 64));
+        __syncthreads();                 // Ol is read no more: its first words carry the four wave maxima
+        if ((tid & 63) == 0) Ol[tid >> 6] = amx;
+        __syncthreads();
+        if (tid == 0) atomicMax(a.amax + n, __builtin_bit_cast(unsigned, fmaxf(fmaxf(Ol[0], Ol[1]), fmaxf(Ol[2], Ol[3]))));
     }
 }
 
 // eligibility is checked by the caller (model.hip): 3x3x3 SAME conv of one channel into 8, 2x2x2 pool, even dims
 int direct_conv_pool_launch(alq_ctx *ctx, const float *d_W, const View &in, const View &out, const View &pout,
                             const float *bias, int relu, uint8_t *argmax, float *osum, float *posum, int N,
-                            double flops_per_patch) {
+                            double flops_per_patch, unsigned *amax) {
     ALQ_REQUIRE(in.C == 1 && in.cs == 1 && in.c0 == 0 && out.C == 8 && pout.C == 8 && d_W, ALQ_EINVAL, "direct conv+pool: bad views");
     ALQ_REQUIRE(((out.cs | out.c0 | pout.cs | pout.c0) & 3) == 0 && in.D % 2 == 0 && in.H % 2 == 0 && in.W % 2 == 0 &&
                     pout.D * 2 == in.D && pout.H * 2 == in.H && pout.W * 2 == in.W,
                 ALQ_EUNSUPPORTED, "direct conv+pool: unsupported geometry");
     DirectPoolArgs a;
     a.in = in.p; a.out = out.p; a.pout = pout.p; a.argmax = reinterpret_cast<unsigned *>(argmax);
-    a.osum = osum; a.posum = posum; a.W = d_W; a.bias = bias;
+    a.osum = osum; a.posum = posum; a.W = d_W; a.bias = bias; a.amax = amax;
     a.out_cs = out.cs; a.out_c0 = out.c0; a.po_cs = pout.cs; a.po_c0 = pout.c0;
     a.D = in.D; a.H = in.H; a.Wd = in.W; a.N = N; a.relu = relu;
     a.tilesZ = (pout.D + 3) / 4; a.tilesY = (pout.H + 7) / 8; a.tilesX = (pout.W + 7) / 8;

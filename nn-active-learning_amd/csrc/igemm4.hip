@@ -235,6 +235,8 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     int f_out = 0, f_full = 0, f_l = 0, f_g = 0;      // tile the prefetch cursor points at
     int c_out = 0, c_full = 0, c_l = 0, c_g = 0;      // tile being contracted
     int f_pdb = 0, c_pdb = 0;                         // first phase descriptor of that tile (several tap sets in one launch)
+    unsigned f_m = 0;                                 // F16 with per-patch scales: max |x| (float bits) of the cursor tile's patch
+    int c_e = a.f16_ein;                              // F16: scale exponent of the tile being staged / contracted
     int p_out = 0, p_full = 0, p_l = 0, p_g = 0;      // tile whose results wait in registers
     bool have_pend = false;
 
@@ -252,6 +254,13 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         f_pdb = __builtin_amdgcn_readfirstlane(t1.z);
         f_full = (tflags & 1) && (fpg + 1) * a.PT <= a.N;
         f_l = fl; f_g = fpg;
+        if constexpr (F16) {       // consumed one tick later (stage, a_ph == 0)
+            if (a.in_amax) {
+                const int pn = fpg < a.N ? fpg : 0;
+                f_m = a.in_amax[pn];
+                if (a.in_amax2) f_m = max(f_m, a.in_amax2[pn]);
+            }
+        }
         if ((tflags & 2) && (fpg + 1) * a.PT <= a.N) {      // whole halo inside the tensor: no per-slot checks
 #pragma unroll
             for (int it = 0; it < G4_NSLOT; ++it) goff[it] = (org + s_rel[it]) * 4;
@@ -326,8 +335,8 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                     v2 = (nib & 4u) ? v2 : 0.f; v3 = (nib & 8u) ? v3 : 0.f;
                 }
                 if constexpr (F16) {
-                    v0 = __builtin_ldexpf(v0, a.f16_ein); v1 = __builtin_ldexpf(v1, a.f16_ein);       // exact: a power of two
-                    v2 = __builtin_ldexpf(v2, a.f16_ein); v3 = __builtin_ldexpf(v3, a.f16_ein);
+                    v0 = __builtin_ldexpf(v0, c_e); v1 = __builtin_ldexpf(v1, c_e);       // exact: a power of two
+                    v2 = __builtin_ldexpf(v2, c_e); v3 = __builtin_ldexpf(v3, c_e);
                     const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1, h2 = (_Float16)v2, h3 = (_Float16)v3;     // round to nearest
                     const _Float16 l0 = (_Float16)__builtin_ldexpf(v0 - (float)h0, 11), l1 = (_Float16)__builtin_ldexpf(v1 - (float)h1, 11);
                     const _Float16 l2 = (_Float16)__builtin_ldexpf(v2 - (float)h2, 11), l3 = (_Float16)__builtin_ldexpf(v3 - (float)h3, 11);
@@ -413,16 +422,17 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     // last contraction: with three products the contracting side is the shorter one (phase stamps)
     auto f16_combine = [&]() __attribute__((always_inline)) {
         if constexpr (F16) {
+            const float inv = __builtin_ldexpf(1.f, -(c_e + a.f16_ew));
 #pragma unroll
             for (int ms = 0; ms < 4; ++ms)
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt) {
                     f32x4 &c = acc[ms][nt];
                     const f32x4 d = accl[ms][nt], b4 = bias4[nt];
-                    c.x = g4_fma(g4_fma(d.x, 0x1p-11f, c.x), a.f16_inv, b4.x);
-                    c.y = g4_fma(g4_fma(d.y, 0x1p-11f, c.y), a.f16_inv, b4.y);
-                    c.z = g4_fma(g4_fma(d.z, 0x1p-11f, c.z), a.f16_inv, b4.z);
-                    c.w = g4_fma(g4_fma(d.w, 0x1p-11f, c.w), a.f16_inv, b4.w);
+                    c.x = g4_fma(g4_fma(d.x, 0x1p-11f, c.x), inv, b4.x);
+                    c.y = g4_fma(g4_fma(d.y, 0x1p-11f, c.y), inv, b4.y);
+                    c.z = g4_fma(g4_fma(d.z, 0x1p-11f, c.z), inv, b4.z);
+                    c.w = g4_fma(g4_fma(d.w, 0x1p-11f, c.w), inv, b4.w);
                 }
         }
     };
@@ -430,6 +440,8 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     // staging part of the next tick; a kernel whose staging part is the longer one writes its first EPI_SPLIT row
     // blocks at the end of the contraction instead (the channel-sum accumulator travels in sacc_k).
     f32x4 sacc_k = f32x4{0.f, 0.f, 0.f, 0.f};
+    float amx_k = 0.f;                // a.out_amax: max |stored value| of the row blocks written so far
+    int flush_grp = 0;                // a.out_amax: output group of the running flush (MULTI)
     auto flush = [&](int q_out, int q_full, int q_l, int q_g, auto MS0, auto MS1) __attribute__((always_inline)) {
         constexpr int m0 = decltype(MS0)::value, m1 = decltype(MS1)::value;
         const int obase_e = q_out * a.out_cs;
@@ -443,6 +455,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         // set (q & 1) for row blocks 2 * (q >> 1) and 2 * (q >> 1) + 1:  two 64-lane stores instead of eight
         // 16-lane ones (those, each waiting on its own MFMA, were 4 % of a pass).
         f32x4 sacc = m0 == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sacc_k;
+        float amx = m0 == 0 ? 0.f : amx_k;
         bool livem[4];
         float fs0 = 0.f;
         unsigned fbyte[FCF ? 4 : 1];
@@ -486,7 +499,12 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                         val.x = mk.x > 0.f ? val.x : 0.f; val.y = mk.y > 0.f ? val.y : 0.f;
                         val.z = mk.z > 0.f ? val.z : 0.f; val.w = mk.w > 0.f ? val.w : 0.f;
                     }
-                    if (c >= a.store_from) *dst = val;
+                    if (c >= a.store_from) {
+                        *dst = val;
+                        if (a.out_amax)
+                            amx = fmaxf(fmaxf(amx, fmaxf(__builtin_fabsf(val.x), __builtin_fabsf(val.y))),
+                                        fmaxf(__builtin_fabsf(val.z), __builtin_fabsf(val.w)));
+                    }
                 }
                 if constexpr (FCF) {
                     // the sign bytes go out after the loop: no store between the weight loads above and their use
@@ -510,7 +528,24 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         }
         if constexpr (m1 < 4) {       // the rest of the tile follows in the staging part
             sacc_k = sacc;
+            amx_k = amx;
             return;
+        }
+        if (a.out_amax) {      // one plain store per wave, tile and group; k_rowmax_u32 folds the slots of a patch
+            int v = __builtin_bit_cast(int, amx);
+#define G4_ROW_SHR_MAX(n)                                                                                              \
+    v = __builtin_bit_cast(int, fmaxf(__builtin_bit_cast(float, v),                                                    \
+                                      __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, v, 0x110 + (n), 0xf, 0xf, true))))
+            G4_ROW_SHR_MAX(1); G4_ROW_SHR_MAX(2); G4_ROW_SHR_MAX(4); G4_ROW_SHR_MAX(8);
+#undef G4_ROW_SHR_MAX
+            const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 15));
+            const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 31));
+            const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 47));
+            const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 63));
+            const int ngr = MULTI ? a.ngr : 1;
+            if (lane == 0)
+                a.out_amax[((size_t)(q_g * a.tpg + q_l) * ngr + flush_grp) * 4 + hw] =
+                    __builtin_bit_cast(unsigned, fmaxf(fmaxf(r0, r1), fmaxf(r2, r3)));
         }
         if constexpr (SUMS) {
             // lane group q: set (q & 1), row blocks m0 = 2 * (q >> 1) (in .x) and m0 + 1 (in .y)
@@ -725,7 +760,15 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         PHASE4_END(5);
         int nph = 0;
         if (a_i < n_ph) {
-            if (a_ph == 0) { c_out = f_out; c_full = f_full; c_l = f_l; c_g = f_g; c_pdb = f_pdb; }
+            if (a_ph == 0) {
+                c_out = f_out; c_full = f_full; c_l = f_l; c_g = f_g; c_pdb = f_pdb;
+                if constexpr (F16) {
+                    if (a.in_amax) {      // max |x| < 2^ex  ->  scale 2^(14 - ex); an all-zero patch keeps 0
+                        const int ex = (int)((f_m >> 23) & 255u) - 126;
+                        c_e = f_m ? 14 - ex : 0;
+                    }
+                }
+            }
             stash();
             PHASE4_END(0);
             if (a_ph == 0 && have_pend) {
@@ -780,7 +823,9 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                         for (int p = 0; p < a.NP; ++p)
                             unit(gd[2], Wl + gd[3] + p * ub + lane * 16, Al + p * a.plane_bytes, gd[4]);
                     if (g + 1 < a.ngr) {
+                        flush_grp = g;
                         flush(c_out + gd[5], c_full, c_l, c_g, IC<0>{}, IC<4>{});
+                        flush_grp = a.ngr - 1;       // the group left pending
                     } else {
                         have_pend = true;
                         p_out = c_out + gd[5]; p_full = c_full; p_l = c_l; p_g = c_g;
@@ -1433,8 +1478,13 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
     a.out_split = out.split; a.out_delta = (int)out.delta;
     a.mask_split = 0; a.mask_delta = 0;
     a.src_bits = nullptr; a.bits_pstride = 0; a.bits_bytes = 0;
-    a.f16_ein = 0; a.f16_inv = 1.f;
+    a.f16_ein = 0; a.f16_ew = plan.w16_exp; a.in_amax = nullptr; a.in_amax2 = nullptr; a.out_amax = nullptr;
     bool f16 = false;
+    const bool no16 = g_no_f16x2 != 0;
+    if (fuse && fuse->out_amax) {
+        ALQ_REQUIRE(a.PT == 1, ALQ_EUNSUPPORTED, "igemm4: output maxima need one patch per tile");
+        a.out_amax = fuse->out_amax;
+    }
     a.fc_W = nullptr; a.fc_part = nullptr; a.fc_bits = nullptr; a.fc_F = 0;
     if (fuse && fuse->in_bits) {      // masked-vector input: `in` only gives the geometry
         ALQ_REQUIRE(plan.NTW == 1 && !plan.multi && a.PT == 1 && !in.split && in.c0 == 0 && in.cs == in.C && fuse->in_vec &&
@@ -1446,12 +1496,10 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
         a.src_bits = fuse->in_bits;
         a.bits_pstride = (int)((long long)in.vox() * in.cs);
         a.bits_bytes = (int)((long long)N * in.vox() * in.cs / 4);
-        static const bool no16 = getenv("ALQ_NO_F16X2") != nullptr;
-        if (fuse->in_vec_amax > 0.f && plan.d_W16 && !no16) {       // scales known ahead of the launch: fp16x2 contraction
+        if (fuse->in_vec_amax > 0.f && plan.d_W16 && !no16) {       // scale known ahead of the launch: fp16x2 contraction
             int ex = 0;
             (void)std::frexp(fuse->in_vec_amax, &ex);
             a.f16_ein = 14 - ex;
-            a.f16_inv = std::ldexp(1.f, -(a.f16_ein + plan.w16_exp));
             a.W = plan.d_W16;
             f16 = true;
         }
@@ -1496,6 +1544,11 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
     const int pgroups = (N + a.PT - 1) / a.PT;
     const long long total = (long long)pgroups * a.tpg;
     const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((total + 1) / 2, 256));
+    if (a.fc_W && fuse->in_amax && plan.d_W16 && !no16) {       // the fused-head conv with per-patch input maxima: fp16x2
+        a.in_amax = fuse->in_amax; a.in_amax2 = fuse->in_amax2;
+        a.W = plan.d_W16;
+        f16 = true;
+    }
     ProfScope ps(ctx, f16 ? (int)PROF_IGEMM_F16 : prof_cls, plan.flops_per_patch * N);
     if (plan.multi) {
         if (plan.NTW == 1) return launch4_t<1, true>(ctx, plan, a, grid);
@@ -1507,6 +1560,7 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
     if (a.src_bits)
         return (a.osumA || a.osumB) ? launch4_s<1, false, true, true>(ctx, plan, a, grid)
                                     : launch4_s<1, false, false, true>(ctx, plan, a, grid);
+    if (a.fc_W && f16) return launch4_s<1, false, true, false, true, false, true>(ctx, plan, a, grid);
     if (a.fc_W) return launch4_s<1, false, true, false, true>(ctx, plan, a, grid);
     if (plan.NTW == 1 && plan.fic)
         return (a.osumA || a.osumB) ? launch4_s<1, false, true, false, false, true>(ctx, plan, a, grid)

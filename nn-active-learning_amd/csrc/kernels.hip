@@ -1263,6 +1263,22 @@ __global__ __launch_bounds__(256) void fc_small_dsum_bits_kernel(const unsigned 
         *reinterpret_cast<f32x4 *>(dsum + ((long long)(n0 + k) * F >> 3) + (w << 2)) = f32x4{out[0], out[1], out[2], out[3]};
     }
 }
+// out[n] = max_k in[n, k] (unsigned order; one 64-lane wave per row)
+__global__ __launch_bounds__(64) void rowmax_u32_kernel(const unsigned *in, int len, unsigned *out) {
+    const int n = blockIdx.x;
+    unsigned m = 0;
+    for (int k = threadIdx.x; k < len; k += 64) m = max(m, in[(long long)n * len + k]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+    if (threadIdx.x == 0) out[n] = m;
+}
+int k_rowmax_u32(alq_ctx *ctx, const unsigned *in, int len, int N, unsigned *out) {
+    ProfScope ps(ctx, PROF_REDUCE, 0);
+    hipLaunchKernelGGL(rowmax_u32_kernel, dim3(N), dim3(64), 0, ctx->stream, in, len, out);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
 int k_fc_small_wvec(alq_ctx *ctx, const float *delta, int nout, const float *Wp, int64_t F, float *wv) {
     ProfScope ps(ctx, PROF_FC_SMALL, 0);
     ALQ_REQUIRE(F % 4 == 0, ALQ_EINVAL, "fc_small_wvec: F %% 4");

@@ -84,6 +84,9 @@ struct alq_model {
     alq_ctx *ctx = nullptr;
     int max_batch = 0;
     bool last_call_fisher = false;   // what alq_model_debug_copy may read
+    // per-patch max |x| (float bits) of the two producers of the fused-head conv's input, for its fp16x2 contraction
+    unsigned *amax_a = nullptr, *amax_b = nullptr, *amax_tiles = nullptr;
+    size_t amax_tiles_len = 0;
     int in_dims[4] = {1, 1, 1, 1};
     int nclass = 0;
     int L = 0;
@@ -659,6 +662,21 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums) {
     const int nl = (int)m->layers.size();
     bool skip_next = false;      // this layer's outputs were produced by the previous layer's kernel
     bool fc_head_fused = false;  // the logits partials of the fc head came out of the previous conv's epilogue
+    // The fused-head conv can contract with the fp16x2 split if it knows max |x| per patch of both parts of its split
+    // input ahead of its launch: the first conv (+ pool) kernel and the conv_transpose in front of it report them.
+    const bool no16 = g_no_f16x2 != 0;
+    int f16_conv = -1;
+    bool amax_a_ok = false, amax_b_ok = false;
+    if (with_sums && nl >= 4 && !no16 && !g_dbg_knobs[3] && !g_dbg_knobs[4] && !g_dbg_knobs[5]) {
+        const Layer &cv = m->layers[nl - 2], &fcl = m->layers[nl - 1], &up = m->layers[nl - 3];
+        if (fcl.fc_part2 && cv.spec.type == ALQ_CONV && cv.in.split && cv.spec.skip_src == 0 && cv.fwd[0].p4.ok && cv.fwd[0].p4.d_W16 &&
+            up.spec.type == ALQ_CONVT && up.fwd_all.ok && up.fwd_all.a.PT == 1 && up.osum) {
+            f16_conv = nl - 2;
+            const size_t len = (size_t)up.fwd_all.a.tpg * up.fwd_all.a.ngr * 4;
+            if (!m->amax_a) { ALQ_TRY(m->dalloc(&m->amax_a, (size_t)m->max_batch)); ALQ_TRY(m->dalloc(&m->amax_b, (size_t)m->max_batch)); }
+            if (m->amax_tiles_len < len) { ALQ_TRY(m->dalloc(&m->amax_tiles, (size_t)m->max_batch * len)); m->amax_tiles_len = len; }
+        }
+    }
     for (int i = 0; i < nl; ++i) {
         Layer &ly = m->layers[i];
         ALQ_REQUIRE(ly.pidx < 0 || ly.weights_set, ALQ_EINVAL, "weights of parameterised layer %d not set", ly.pidx);
@@ -681,9 +699,13 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums) {
                     nx->spec.k[0] == 2 && nx->spec.k[1] == 2 && nx->spec.k[2] == 2 && nx->lo[0] == 0 && nx->lo[1] == 0 && nx->lo[2] == 0 &&
                     in.D % 2 == 0 && in.H % 2 == 0 && in.W % 2 == 0 && nx->out.D * 2 == in.D && nx->out.H * 2 == in.H &&
                     nx->out.W * 2 == in.W && ((ly.out.cs | ly.out.c0 | nx->out.cs | nx->out.c0) & 3) == 0 && !g_dbg_knobs[7]) {
+                    if (f16_conv >= 0) {
+                        ALQ_HIP(hipMemsetAsync(m->amax_a, 0, (size_t)N * sizeof(unsigned), ctx->stream));
+                        amax_a_ok = true;
+                    }
                     ALQ_TRY(direct_conv_pool_launch(ctx, ly.fwd[0].pd.d_W, in, ly.out, nx->out, ly.d_bias, sp.relu, nx->argmax,
                                                     with_sums ? ly.osum : nullptr, with_sums ? nx->osum : nullptr, N,
-                                                    ly.fwd[0].pd.flops_per_patch));
+                                                    ly.fwd[0].pd.flops_per_patch, amax_a_ok ? m->amax_a : nullptr));
                     fused = true;
                     skip_next = true;
                     break;
@@ -694,6 +716,7 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums) {
                     ALQ_TRY(k_fill_unit_cotangent(ctx, m->dlogits, 1));
                     ALQ_TRY(k_fc_small_wvec(ctx, m->dlogits, 2, nx->d_Wp, nx->F, nx->fc_wv));       // W0 - W1
                     fz.fc_W = nx->fc_wv; fz.fc_F = nx->F; fz.fc_part = nx->fc_part2; fz.fc_bits = nx->fc_maskbits;
+                    if (i == f16_conv && amax_a_ok && amax_b_ok) { fz.in_amax = m->amax_a; fz.in_amax2 = m->amax_b; }
                     ALQ_TRY(igemm4_launch(ctx, ly.fwd[0].p4, in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM3_FWD, &fz));
                     fused = true;
                     fc_head_fused = true;
@@ -704,7 +727,13 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums) {
             }
             case ALQ_CONVT: {
                 if (ly.fwd_all.ok && !g_dbg_knobs[4] && !g_dbg_knobs[5]) {
+                    const bool want_amax = fuse && i + 1 == f16_conv;
+                    if (want_amax) fz.out_amax = m->amax_tiles;
                     ALQ_TRY(igemm4_launch(ctx, ly.fwd_all, in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM3_FWD, fuse));
+                    if (want_amax) {
+                        ALQ_TRY(k_rowmax_u32(ctx, m->amax_tiles, ly.fwd_all.a.tpg * ly.fwd_all.a.ngr * 4, N, m->amax_b));
+                        amax_b_ok = true;
+                    }
                     fused = fuse != nullptr;
                     break;
                 }
@@ -933,6 +962,7 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
         const char *e = getenv("ALQ_DISABLE_V2");   // diagnostics: force the general GEMM kernel
         g_use_v2 = !(e && e[0] == '1');
         g_knobs_init = true;
+        g_no_f16x2 = getenv("ALQ_NO_F16X2") != nullptr;
         static const char *names[8] = {"ALQ_DEBUG_REPEAT", "ALQ_DEBUG_FLAGS", "ALQ_NO_BWD_FUSE", "ALQ_NO_FWD_FUSE", "ALQ_NO_V3", "ALQ_NO_V4",
                                        "ALQ_NO_POOL_FIRST", "ALQ_NO_CONV_POOL"};
         for (int k = 0; k < 8; ++k) {

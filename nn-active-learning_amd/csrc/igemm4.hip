@@ -1560,7 +1560,8 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
     if (a.src_bits)
         return (a.osumA || a.osumB) ? launch4_s<1, false, true, true>(ctx, plan, a, grid)
                                     : launch4_s<1, false, false, true>(ctx, plan, a, grid);
-    if (a.fc_W && f16) return launch4_s<1, false, true, false, true, false, true>(ctx, plan, a, grid);
+    // with three products its contraction is the shorter side: the prefetch is issued from there (FIC)
+    if (a.fc_W && f16) return launch4_s<1, false, true, false, true, true, true>(ctx, plan, a, grid);
     if (a.fc_W) return launch4_s<1, false, true, false, true>(ctx, plan, a, grid);
     if (plan.NTW == 1 && plan.fic)
         return (a.osumA || a.osumB) ? launch4_s<1, false, true, false, false, true>(ctx, plan, a, grid)

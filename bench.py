@@ -116,9 +116,9 @@ def main():
         # dominant kernel = igemm4_kernel (conv / conv_transpose fwd + bwd-data on the bf16 matrix cores
         # with the 3-way operand split: 6 bf16 MFMA MACs per fp32-accurate MAC, so the matrix-core bound
         # on ALGORITHMIC fp32 flops is the dense bf16 peak / 6)
-        # One launch per pass (the last conv's backward, whose input scale is host-known) runs the fp16x2 split:
-        # 3 fp16 MFMA MACs per fp32-accurate MAC, bound = dense fp16 peak (= the bf16 one) / 3.  The bound of the mix
-        # is the flop-weighted harmonic mean of the two.
+        # The launches whose input maxima are known ahead of time (the last conv's forward and backward) run the fp16x2
+        # split: 3 fp16 MFMA MACs per fp32-accurate MAC, bound = dense fp16 peak (= the bf16 one) / 3.  The bound of
+        # the mix is the flop-weighted harmonic mean of the two.
         f16 = prof.get('igemm_f16x2', {'ms': 0.0, 'flops': 0.0, 'launches': 0})
         bf_fl = prof['igemm3_fwd']['flops'] + prof['igemm3_bwd']['flops']
         ig_ms = prof['igemm3_fwd']['ms'] + prof['igemm3_bwd']['ms'] + f16['ms']
@@ -141,7 +141,7 @@ def main():
             'metric': 'patches/sec Fisher-scored (32^3, 2-class)',
             'value': value, 'unit': 'patches/s', 'n_gpus': ws, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32 (bf16x3 operand split on the bf16 MFMA - fp16x2 split in one launch per pass -, fp32 accumulate; '
+            'dtype': 'f32 (bf16x3 operand split on the bf16 MFMA - fp16x2 split in the two launches of the last conv -, fp32 accumulate; '
                      'everything else fp32 / fp64)',
             'data': 'synthetic',
             'config': {'workload': 'configs[2]: Fisher scoring, NET-C patch-wise 3-D U-Net (fc head), '
@@ -152,12 +152,12 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic,
                          'kernel': 'igemm4_kernel: conv / conv_transpose fwd + bwd-data, bf16x3 split (fp16x2 in the last '
-                                   'conv\'s backward)',
+                                   'conv\'s forward and backward)',
                          'peak_note': 'algorithmic fp32 flops; peak = flop-weighted harmonic mean of %.0f dense 16-bit MFMA / %d '
-                                      'products (bf16x3 launches, %.0f %% of the flops) and / 3 (the fp16x2 launch)'
+                                      'products (bf16x3 launches, %.0f %% of the flops) and / 3 (the fp16x2 launches)'
                                       % (PEAK_BF16_MFMA_TFLOPS, SPLIT_PRODUCTS, 100.0 * bf_fl / max(ig_fl, 1.0)),
                          'executed_bf16_tflops': executed, 'peak_bf16_tflops': PEAK_BF16_MFMA_TFLOPS,
-                         'f16x2_launch': {'tflops': f16['flops'] / (f16['ms'] * 1e-3) / 1e12 if f16['ms'] > 0 else 0.0,
+                         'f16x2_launches': {'tflops': f16['flops'] / (f16['ms'] * 1e-3) / 1e12 if f16['ms'] > 0 else 0.0,
                                           'avg_launch_ms': f16['ms'] / max(f16['launches'], 1), 'bound_tflops': peak_f16},
                          'frac_of_f32_mfma_peak': achieved / PEAK_F32_MFMA_TFLOPS,
                          'launches': ig_n, 'avg_launch_ms': ig_ms / max(ig_n, 1), 'timed_every_kth_pass': args.prof_every,

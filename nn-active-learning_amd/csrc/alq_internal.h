@@ -217,6 +217,7 @@ struct Igemm2Fuse {
     // (k_rowmax_u32 folds them per patch); in_amax / in_amax2 [N] describe the (two parts of the) input tensor and
     // enable the fp16x2 contraction with one scale per patch.
     unsigned *out_amax = nullptr;
+    int amax_from = 0;         // only columns >= amax_from count for out_amax (the slice the next launch reads)
     const unsigned *in_amax = nullptr, *in_amax2 = nullptr;
     // igemm4 only (pair form, 8 output channels, one patch per tile): the output feeds nothing but a 2-output fc head -
     // the epilogue emits per (tile, wave) partials of the logit difference against fc_W [fc_F] = W0 - W1
@@ -294,6 +295,7 @@ struct Igemm4Args {
     int f16_ew;                 // F16: scale exponent of the packed weights
     const unsigned *in_amax, *in_amax2;   // F16: per-patch max |x| of the input part(s), float bits -> one scale per tile
     unsigned *out_amax;         // any variant: max |stored output| per (tile, group, wave), float bits
+    int amax_from;
 };
 
 struct G4Geom {

@@ -501,7 +501,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                     }
                     if (c >= a.store_from) {
                         *dst = val;
-                        if (a.out_amax)
+                        if (a.out_amax && c >= a.amax_from)
                             amx = fmaxf(fmaxf(amx, fmaxf(__builtin_fabsf(val.x), __builtin_fabsf(val.y))),
                                         fmaxf(__builtin_fabsf(val.z), __builtin_fabsf(val.w)));
                     }
@@ -684,11 +684,13 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     auto unit16 = [&](int S, const char *Wc, const char *Ab, int trow) __attribute__((always_inline)) {
         if constexpr (F16) {
             const int *tt = Tl + trow * (G4_MAXS * 4) + lq;
-            f16x8 Wa[2], Wb[2], Xa[2][2], Xb[2][2];
-            auto rdW = [&](f16x8 (&Wf)[2], int s) {
+            f16x8 Wa[2][NTW], Wb[NTW >= 2 ? 1 : 2][NTW], Xa[2][2], Xb[2][2];
+            auto rdW = [&](f16x8 (&Wf)[2][NTW], int s) {
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
-                    Wf[p] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(Wc + (s * 3 + p) * 1024));
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt)
+                        Wf[p][nt] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(Wc + ((s * 3 + p) * NTW + nt) * 1024));
             };
             auto rdX = [&](f16x8 (&X)[2][2], int mh, int to) {
 #pragma unroll
@@ -699,39 +701,59 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                         X[p][m2] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(row + 16 * p));
                 }
             };
-            auto mm = [&](const f16x8 (&Wf)[2], const f16x8 (&X)[2][2], int mh) {
-                f32x4 c0 = acc[mh][0], c1 = acc[mh + 1][0], d0 = accl[mh][0], d1 = accl[mh + 1][0];
-                d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[1], X[0][0], d0, 0, 0, 0);
-                d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[1], X[0][1], d1, 0, 0, 0);
-                c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[0], X[0][0], c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[0], X[0][1], c1, 0, 0, 0);
-                d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[0], X[1][0], d0, 0, 0, 0);
-                d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[0], X[1][1], d1, 0, 0, 0);
-                acc[mh][0] = c0; acc[mh + 1][0] = c1; accl[mh][0] = d0; accl[mh + 1][0] = d1;
+            auto mm = [&](const f16x8 (&Wf)[2][NTW], const f16x8 (&X)[2][2], int mh) {
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    f32x4 c0 = acc[mh][nt], c1 = acc[mh + 1][nt], d0 = accl[mh][nt], d1 = accl[mh + 1][nt];
+                    d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[1][nt], X[0][0], d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[1][nt], X[0][1], d1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[0][nt], X[0][0], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[0][nt], X[0][1], c1, 0, 0, 0);
+                    d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[0][nt], X[1][0], d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[0][nt], X[1][1], d1, 0, 0, 0);
+                    acc[mh][nt] = c0; acc[mh + 1][nt] = c1; accl[mh][nt] = d0; accl[mh + 1][nt] = d1;
+                }
             };
             int t_cur = tt[0];
             rdX(Xa, 0, t_cur);
-            rdW(Wa, 0);
-            auto kstep = [&](const f16x8 (&Wc_)[2], f16x8 (&Wn_)[2], int s) {
-                const int s1 = s + 1 < S ? s + 1 : s;
-                const int t_nxt = tt[s1 * 4];
-                rdX(Xb, 2, t_cur);
-                __builtin_amdgcn_sched_barrier(0);
-                mm(Wc_, Xa, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                rdW(Wn_, s1);
-                rdX(Xa, 0, t_nxt);
-                __builtin_amdgcn_sched_barrier(0);
-                mm(Wc_, Xb, 2);
-                __builtin_amdgcn_sched_barrier(0);
-                t_cur = t_nxt;
-            };
-            int s = 0;
-            for (; s + 1 < S; s += 2) {
-                kstep(Wa, Wb, s);
-                kstep(Wb, Wa, s + 1);
+            if constexpr (NTW >= 2) {       // one weight fragment set, as in `unit`
+                for (int s = 0; s < S; ++s) {
+                    const int s1 = s + 1 < S ? s + 1 : s;
+                    const int t_nxt = tt[s1 * 4];
+                    rdW(Wa, s);
+                    rdX(Xb, 2, t_cur);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(Wa, Xa, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    rdX(Xa, 0, t_nxt);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(Wa, Xb, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    t_cur = t_nxt;
+                }
+            } else {
+                rdW(Wa, 0);
+                auto kstep = [&](const f16x8 (&Wc_)[2][NTW], f16x8 (&Wn_)[2][NTW], int s) {
+                    const int s1 = s + 1 < S ? s + 1 : s;
+                    const int t_nxt = tt[s1 * 4];
+                    rdX(Xb, 2, t_cur);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(Wc_, Xa, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    rdW(Wn_, s1);
+                    rdX(Xa, 0, t_nxt);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(Wc_, Xb, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    t_cur = t_nxt;
+                };
+                int s = 0;
+                for (; s + 1 < S; s += 2) {
+                    kstep(Wa, Wb, s);
+                    kstep(Wb, Wa, s + 1);
+                }
+                if (s < S) kstep(Wa, Wb, s);
             }
-            if (s < S) kstep(Wa, Wb, s);
         }
     };
 
@@ -1401,7 +1423,7 @@ void igemm4_pack_weights(Igemm4Plan *plan, const std::vector<float> &Bmat) {
     const int NTW = plan->NTW, Ci = plan->Ci, Co = plan->Co;
     const bool pair = plan->a.pair != 0;
     plan->h_W.assign((size_t)plan->a.wbytes / 2, 0);
-    const bool w16 = NTW == 1 && !plan->multi;
+    const bool w16 = !plan->multi;
     float amax = 0.f;
     for (float w : Bmat) amax = std::max(amax, std::fabs(w));
     int ex = 0;
@@ -1481,9 +1503,18 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
     a.f16_ein = 0; a.f16_ew = plan.w16_exp; a.in_amax = nullptr; a.in_amax2 = nullptr; a.out_amax = nullptr;
     bool f16 = false;
     const bool no16 = g_no_f16x2 != 0;
+    a.amax_from = 0;
     if (fuse && fuse->out_amax) {
         ALQ_REQUIRE(a.PT == 1, ALQ_EUNSUPPORTED, "igemm4: output maxima need one patch per tile");
         a.out_amax = fuse->out_amax;
+        a.amax_from = fuse->amax_from;
+    }
+    // a stored input tensor with per-patch maxima: fp16x2 where a variant of the plan's shape exists
+    if (fuse && fuse->in_amax && !fuse->in_bits && !fuse->fc_W && plan.d_W16 && !plan.multi && a.PT == 1 && !in.split && !no16 &&
+        ((plan.NTW == 1 && plan.fic) || plan.NTW == 2)) {
+        a.in_amax = fuse->in_amax; a.in_amax2 = fuse->in_amax2;
+        a.W = plan.d_W16;
+        f16 = true;
     }
     a.fc_W = nullptr; a.fc_part = nullptr; a.fc_bits = nullptr; a.fc_F = 0;
     if (fuse && fuse->in_bits) {      // masked-vector input: `in` only gives the geometry
@@ -1563,6 +1594,13 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
     // with three products its contraction is the shorter side: the prefetch is issued from there (FIC)
     if (a.fc_W && f16) return launch4_s<1, false, true, false, true, true, true>(ctx, plan, a, grid);
     if (a.fc_W) return launch4_s<1, false, true, false, true>(ctx, plan, a, grid);
+    if (f16 && !a.src_bits && !a.fc_W) {
+        if (plan.NTW == 2)
+            return (a.osumA || a.osumB) ? launch4_s<2, false, true, false, false, false, true>(ctx, plan, a, grid)
+                                        : launch4_s<2, false, false, false, false, false, true>(ctx, plan, a, grid);
+        return (a.osumA || a.osumB) ? launch4_s<1, false, true, false, false, true, true>(ctx, plan, a, grid)
+                                    : launch4_s<1, false, false, false, false, true, true>(ctx, plan, a, grid);
+    }
     if (plan.NTW == 1 && plan.fic)
         return (a.osumA || a.osumB) ? launch4_s<1, false, true, false, false, true>(ctx, plan, a, grid)
                                     : launch4_s<1, false, false, false, false, true>(ctx, plan, a, grid);

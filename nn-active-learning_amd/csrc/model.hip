@@ -65,6 +65,7 @@ struct Layer {
     unsigned *fc_maskbits = nullptr;
     float *fc_wv = nullptr;
     float fc_wv_amax = 0.f;            // max |W0 - W1| of a two-output head (host side, set with the weights)
+    const unsigned *dout_amax = nullptr;   // per-patch max |cotangent of this layer's output| of the running backward pass, or null
     float dout_vec_amax = 0.f;
     float *fc_part2 = nullptr;         // partial logits per (tile, wave) when the conv below computes them in its epilogue
     int fc_slices2 = 0;
@@ -781,7 +782,7 @@ static int run_backward(alq_model *m, const float *d_x, int N) {
     const int nl = (int)m->layers.size();
     ALQ_REQUIRE(m->nclass == 2, ALQ_EUNSUPPORTED, "Fisher scoring is binary (PW_NNAL.py:766), got %d classes", m->nclass);
     ALQ_TRY(k_fill_unit_cotangent(ctx, m->dlogits, N));
-    for (Layer &l : m->layers) { l.delta_ready = false; l.dsum_partial = false; l.dout_bits = nullptr; l.dout_vec = nullptr; }
+    for (Layer &l : m->layers) { l.delta_ready = false; l.dsum_partial = false; l.dout_bits = nullptr; l.dout_vec = nullptr; l.dout_amax = nullptr; }
     const bool v4_on = !g_dbg_knobs[4] && !g_dbg_knobs[5];
     // a pool whose producer is the first parameterised layer: 2x2(x2) windows tiling the input exactly
     auto pool_first_ok = [&](const Layer &pl, const Layer &src) {
@@ -890,8 +891,33 @@ static int run_backward(alq_model *m, const float *d_x, int N) {
                 const bool honoured = fuse != nullptr;
                 ALQ_TRY(igemm4_launch(ctx, ly.bwd.p4, ly.dout, ly.din, nullptr, 0, acc, N, PROF_IGEMM3_BWD, &fz));
                 fused = honoured;
-            } else
-            ALQ_TRY(gemm_launch(ctx, ly.bwd, ly.dout, ly.din, nullptr, 0, acc, N, PROF_IGEMM_BWD, fuse, &fused));
+            } else {
+                // Hand the per-patch maxima of what this launch stores to the backward launch below it when that one has
+                // an fp16x2 variant (two column tiles, or one with the prefetch on the contracting side).  Not from the
+                // mask-bit launch above: its staging side is the critical one and the maxima cost more than they gave.
+                const bool p4_here = fuse && v4_on && ly.bwd.p4.ok && !ly.bwd.p4.multi && ly.bwd.p4.a.PT == 1 && !g_no_f16x2;
+                bool hand = false;
+                if (p4_here && prev_param && !acc && prev->pidx > 0 && prev->bwd.p4.ok && !prev->bwd.p4.multi && prev->bwd.p4.a.PT == 1 &&
+                    prev->bwd.p4.d_W16 && !prev->dout.split &&
+                    ((prev->bwd.p4.NTW == 1 && prev->bwd.p4.fic) || prev->bwd.p4.NTW == 2)) {
+                    const size_t len = (size_t)ly.bwd.p4.a.tpg * 4;
+                    if (!m->amax_a) { ALQ_TRY(m->dalloc(&m->amax_a, (size_t)m->max_batch)); ALQ_TRY(m->dalloc(&m->amax_b, (size_t)m->max_batch)); }
+                    if (m->amax_tiles_len < len) { ALQ_TRY(m->dalloc(&m->amax_tiles, (size_t)m->max_batch * len)); m->amax_tiles_len = len; }
+                    fz.out_amax = m->amax_tiles;
+                    fz.amax_from = fz.split > 0 && fz.split < (1 << 29) ? fz.split : 0;       // the slice the layer below reads
+                    hand = true;
+                }
+                if (p4_here && ly.dout_amax) fz.in_amax = ly.dout_amax;
+                const unsigned *mine = ly.dout_amax;
+                ly.dout_amax = nullptr;
+                ALQ_TRY(gemm_launch(ctx, ly.bwd, ly.dout, ly.din, nullptr, 0, acc, N, PROF_IGEMM_BWD, fuse, &fused));
+                if (hand) {
+                    // two buffers alternate down the chain: this launch may have read the other one
+                    unsigned *dst = mine == m->amax_a ? m->amax_b : m->amax_a;
+                    ALQ_TRY(k_rowmax_u32(ctx, m->amax_tiles, ly.bwd.p4.a.tpg * 4, N, dst));
+                    prev->dout_amax = dst;
+                }
+            }
         }
         if (prev_param && fused) prev->delta_ready = true;
     }

@@ -1510,8 +1510,8 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
         a.amax_from = fuse->amax_from;
     }
     // a stored input tensor with per-patch maxima: fp16x2 where a variant of the plan's shape exists
-    if (fuse && fuse->in_amax && !fuse->in_bits && !fuse->fc_W && plan.d_W16 && !plan.multi && a.PT == 1 && !in.split && !no16 &&
-        ((plan.NTW == 1 && plan.fic) || plan.NTW == 2)) {
+    if (fuse && fuse->in_amax && !fuse->in_bits && !fuse->fc_W && plan.d_W16 && !plan.multi && a.PT == 1 && !no16 &&
+        (!in.split || fuse->in_amax2) && plan.NTW <= 2) {
         a.in_amax = fuse->in_amax; a.in_amax2 = fuse->in_amax2;
         a.W = plan.d_W16;
         f16 = true;
@@ -1598,8 +1598,11 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
         if (plan.NTW == 2)
             return (a.osumA || a.osumB) ? launch4_s<2, false, true, false, false, false, true>(ctx, plan, a, grid)
                                         : launch4_s<2, false, false, false, false, false, true>(ctx, plan, a, grid);
-        return (a.osumA || a.osumB) ? launch4_s<1, false, true, false, false, true, true>(ctx, plan, a, grid)
-                                    : launch4_s<1, false, false, false, false, true, true>(ctx, plan, a, grid);
+        if (plan.fic)
+            return (a.osumA || a.osumB) ? launch4_s<1, false, true, false, false, true, true>(ctx, plan, a, grid)
+                                        : launch4_s<1, false, false, false, false, true, true>(ctx, plan, a, grid);
+        return (a.osumA || a.osumB) ? launch4_s<1, false, true, false, false, false, true>(ctx, plan, a, grid)
+                                    : launch4_s<1, false, false, false, false, false, true>(ctx, plan, a, grid);
     }
     if (plan.NTW == 1 && plan.fic)
         return (a.osumA || a.osumB) ? launch4_s<1, false, true, false, false, true>(ctx, plan, a, grid)

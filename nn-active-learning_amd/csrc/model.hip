@@ -66,6 +66,7 @@ struct Layer {
     float *fc_wv = nullptr;
     float fc_wv_amax = 0.f;            // max |W0 - W1| of a two-output head (host side, set with the weights)
     const unsigned *dout_amax = nullptr;   // per-patch max |cotangent of this layer's output| of the running backward pass, or null
+    unsigned *amax_fwd = nullptr;          // [max_batch] per-patch max |output| of a forward pass that asked for it
     float dout_vec_amax = 0.f;
     float *fc_part2 = nullptr;         // partial logits per (tile, wave) when the conv below computes them in its epilogue
     int fc_slices2 = 0;
@@ -663,21 +664,66 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums) {
     const int nl = (int)m->layers.size();
     bool skip_next = false;      // this layer's outputs were produced by the previous layer's kernel
     bool fc_head_fused = false;  // the logits partials of the fc head came out of the previous conv's epilogue
-    // The fused-head conv can contract with the fp16x2 split if it knows max |x| per patch of both parts of its split
-    // input ahead of its launch: the first conv (+ pool) kernel and the conv_transpose in front of it report them.
+    // A conv / conv_transpose launch contracts with the fp16x2 split if it knows max |x| per patch of (every part of)
+    // its input ahead of time: the launches that produce those tensors report them (`prod`), the consumers (`cons`)
+    // read one scale per tile.  Producers: the first conv + pool kernel and one-patch-per-tile igemm4 launches.
     const bool no16 = g_no_f16x2 != 0;
-    int f16_conv = -1;
-    bool amax_a_ok = false, amax_b_ok = false;
-    if (with_sums && nl >= 4 && !no16 && !g_dbg_knobs[3] && !g_dbg_knobs[4] && !g_dbg_knobs[5]) {
-        const Layer &cv = m->layers[nl - 2], &fcl = m->layers[nl - 1], &up = m->layers[nl - 3];
-        if (fcl.fc_part2 && cv.spec.type == ALQ_CONV && cv.in.split && cv.spec.skip_src == 0 && cv.fwd[0].p4.ok && cv.fwd[0].p4.d_W16 &&
-            up.spec.type == ALQ_CONVT && up.fwd_all.ok && up.fwd_all.a.PT == 1 && up.osum) {
-            f16_conv = nl - 2;
-            const size_t len = (size_t)up.fwd_all.a.tpg * up.fwd_all.a.ngr * 4;
-            if (!m->amax_a) { ALQ_TRY(m->dalloc(&m->amax_a, (size_t)m->max_batch)); ALQ_TRY(m->dalloc(&m->amax_b, (size_t)m->max_batch)); }
-            if (m->amax_tiles_len < len) { ALQ_TRY(m->dalloc(&m->amax_tiles, (size_t)m->max_batch * len)); m->amax_tiles_len = len; }
+    auto use_dcp = [&](int i) {      // layer i = first conv, fused with the pool behind it (direct_conv_pool_launch)
+        if (i != 0 || nl < 2) return false;
+        const Layer &ly = m->layers[0], &nx = m->layers[1];
+        const alq_layer_t &sp = ly.spec;
+        const View &in = ly.in;
+        return ly.spec.type == ALQ_CONV && nx.spec.type == ALQ_POOL && ly.fwd[0].pd.ok && ly.fwd[0].pd.d_W && in.C == 1 && in.cs == 1 &&
+               sp.cout == 8 && sp.k[0] == 3 && sp.k[1] == 3 && sp.k[2] == 3 && ly.lo[0] == 1 && ly.lo[1] == 1 && ly.lo[2] == 1 &&
+               nx.spec.k[0] == 2 && nx.spec.k[1] == 2 && nx.spec.k[2] == 2 && nx.lo[0] == 0 && nx.lo[1] == 0 && nx.lo[2] == 0 &&
+               in.D % 2 == 0 && in.H % 2 == 0 && in.W % 2 == 0 && nx.out.D * 2 == in.D && nx.out.H * 2 == in.H &&
+               nx.out.W * 2 == in.W && ((ly.out.cs | ly.out.c0 | nx.out.cs | nx.out.c0) & 3) == 0 && !g_dbg_knobs[7];
+    };
+    std::vector<char> prod(nl, 0), cons(nl, 0);
+    if (with_sums && !no16 && !g_dbg_knobs[3] && !g_dbg_knobs[4] && !g_dbg_knobs[5]) {
+        auto prod_ok = [&](int p) {
+            if (p < 0) return false;
+            const Layer &l = m->layers[p];
+            if (p == 0 && use_dcp(0)) return true;
+            if (!l.osum) return false;
+            if (l.spec.type == ALQ_CONV) return l.fwd[0].p4.ok && !l.fwd[0].pd.ok && !l.fwd[0].pfc.ok && l.fwd[0].p4.a.PT == 1;
+            if (l.spec.type == ALQ_CONVT) return l.fwd_all.ok && l.fwd_all.a.PT == 1;
+            return false;
+        };
+        size_t need = 0;
+        for (int j = 1; j < nl; ++j) {
+            const Layer &l = m->layers[j];
+            const Igemm4Plan *pl = l.spec.type == ALQ_CONV ? &l.fwd[0].p4 : (l.spec.type == ALQ_CONVT ? &l.fwd_all : nullptr);
+            if (!pl || !pl->ok || !pl->d_W16 || pl->multi || pl->a.PT != 1 || !l.osum) continue;
+            if (l.spec.type == ALQ_CONV && (l.fwd[0].pd.ok || l.fwd[0].pfc.ok)) continue;
+            // Forward launches: only the conv under the fused fc head.  The fp16x2 split rounds at 2^-22 instead of 2^-24; in
+            // the forward pass that noise reaches ReLU decisions (measured: with dec1 or up1 on the split one patch in ~12
+            // had a ReLU input of a later layer land on the other side of zero, moving two layer scores by 1 % - the same
+            // event any two fp32 implementations produce, four times as often).  The head conv has one ReLU behind it;
+            // backward launches have none (the masks are fixed by then), so they take the split wherever a variant exists.
+            if (!(j == nl - 2 && m->layers[nl - 1].fc_part2 && l.spec.type == ALQ_CONV) && !getenv("ALQ_F16_FWD_MASK")) continue;
+            if (l.spec.type == ALQ_CONVT && !pl->fic) continue;                 // MULTI has no F16 variant
+            const int s_ = l.spec.skip_src;
+            if (!prod_ok(j - 1) || (s_ >= 0 && !prod_ok(s_))) continue;
+            if ((s_ >= 0) != (l.in.split != 0)) continue;                       // two parts <-> a split view
+            if (const char *e = getenv("ALQ_F16_FWD_MASK")) { if (!((atoi(e) >> j) & 1)) continue; }      // diagnostics: consumers by layer bit
+            cons[j] = 1; prod[j - 1] = 1;
+            if (s_ >= 0) prod[s_] = 1;
         }
+        for (int p = 0; p < nl; ++p) {
+            if (!prod[p]) continue;
+            Layer &l = m->layers[p];
+            if (!l.amax_fwd) ALQ_TRY(m->dalloc(&l.amax_fwd, (size_t)m->max_batch));
+            if (l.spec.type == ALQ_CONV && !(p == 0 && use_dcp(0))) need = std::max(need, (size_t)l.fwd[0].p4.a.tpg * 4);
+            if (l.spec.type == ALQ_CONVT) need = std::max(need, (size_t)l.fwd_all.a.tpg * (l.fwd_all.multi ? l.fwd_all.a.ngr : 1) * 4);
+        }
+        if (need > m->amax_tiles_len) { ALQ_TRY(m->dalloc(&m->amax_tiles, (size_t)m->max_batch * need)); m->amax_tiles_len = need; }
     }
+    auto take_amax = [&](Igemm2Fuse &fz, int j) {      // the input maxima of consumer j
+        if (!cons[j]) return;
+        fz.in_amax = m->layers[j - 1].amax_fwd;
+        if (m->layers[j].spec.skip_src >= 0) fz.in_amax2 = m->layers[m->layers[j].spec.skip_src].amax_fwd;
+    };
     for (int i = 0; i < nl; ++i) {
         Layer &ly = m->layers[i];
         ALQ_REQUIRE(ly.pidx < 0 || ly.weights_set, ALQ_EINVAL, "weights of parameterised layer %d not set", ly.pidx);
@@ -695,18 +741,11 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums) {
                 // first conv + the pool behind it in one kernel (one input channel, 3x3x3 -> 8, 2x2x2 windows)
                 Layer *nx = i + 1 < nl ? &m->layers[i + 1] : nullptr;
                 const alq_layer_t &sp = ly.spec;
-                if (i == 0 && nx && nx->spec.type == ALQ_POOL && ly.fwd[0].pd.ok && ly.fwd[0].pd.d_W && in.C == 1 && in.cs == 1 &&
-                    sp.cout == 8 && sp.k[0] == 3 && sp.k[1] == 3 && sp.k[2] == 3 && ly.lo[0] == 1 && ly.lo[1] == 1 && ly.lo[2] == 1 &&
-                    nx->spec.k[0] == 2 && nx->spec.k[1] == 2 && nx->spec.k[2] == 2 && nx->lo[0] == 0 && nx->lo[1] == 0 && nx->lo[2] == 0 &&
-                    in.D % 2 == 0 && in.H % 2 == 0 && in.W % 2 == 0 && nx->out.D * 2 == in.D && nx->out.H * 2 == in.H &&
-                    nx->out.W * 2 == in.W && ((ly.out.cs | ly.out.c0 | nx->out.cs | nx->out.c0) & 3) == 0 && !g_dbg_knobs[7]) {
-                    if (f16_conv >= 0) {
-                        ALQ_HIP(hipMemsetAsync(m->amax_a, 0, (size_t)N * sizeof(unsigned), ctx->stream));
-                        amax_a_ok = true;
-                    }
+                if (use_dcp(i)) {
+                    if (prod[i]) ALQ_HIP(hipMemsetAsync(ly.amax_fwd, 0, (size_t)N * sizeof(unsigned), ctx->stream));
                     ALQ_TRY(direct_conv_pool_launch(ctx, ly.fwd[0].pd.d_W, in, ly.out, nx->out, ly.d_bias, sp.relu, nx->argmax,
                                                     with_sums ? ly.osum : nullptr, with_sums ? nx->osum : nullptr, N,
-                                                    ly.fwd[0].pd.flops_per_patch, amax_a_ok ? m->amax_a : nullptr));
+                                                    ly.fwd[0].pd.flops_per_patch, prod[i] ? ly.amax_fwd : nullptr));
                     fused = true;
                     skip_next = true;
                     break;
@@ -717,24 +756,26 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums) {
                     ALQ_TRY(k_fill_unit_cotangent(ctx, m->dlogits, 1));
                     ALQ_TRY(k_fc_small_wvec(ctx, m->dlogits, 2, nx->d_Wp, nx->F, nx->fc_wv));       // W0 - W1
                     fz.fc_W = nx->fc_wv; fz.fc_F = nx->F; fz.fc_part = nx->fc_part2; fz.fc_bits = nx->fc_maskbits;
-                    if (i == f16_conv && amax_a_ok && amax_b_ok) { fz.in_amax = m->amax_a; fz.in_amax2 = m->amax_b; }
+                    take_amax(fz, i);
                     ALQ_TRY(igemm4_launch(ctx, ly.fwd[0].p4, in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM3_FWD, &fz));
                     fused = true;
                     fc_head_fused = true;
                     break;
                 }
+                if (fuse) take_amax(fz, i);
+                if (fuse && prod[i]) fz.out_amax = m->amax_tiles;
                 ALQ_TRY(gemm_launch(ctx, ly.fwd[0], in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM_FWD, fuse, &fused));
+                if (fuse && prod[i]) ALQ_TRY(k_rowmax_u32(ctx, m->amax_tiles, ly.fwd[0].p4.a.tpg * 4, N, ly.amax_fwd));
                 break;
             }
             case ALQ_CONVT: {
                 if (ly.fwd_all.ok && !g_dbg_knobs[4] && !g_dbg_knobs[5]) {
-                    const bool want_amax = fuse && i + 1 == f16_conv;
+                    const bool want_amax = fuse && prod[i];
+                    if (fuse) take_amax(fz, i);
                     if (want_amax) fz.out_amax = m->amax_tiles;
                     ALQ_TRY(igemm4_launch(ctx, ly.fwd_all, in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM3_FWD, fuse));
-                    if (want_amax) {
-                        ALQ_TRY(k_rowmax_u32(ctx, m->amax_tiles, ly.fwd_all.a.tpg * ly.fwd_all.a.ngr * 4, N, m->amax_b));
-                        amax_b_ok = true;
-                    }
+                    if (want_amax)
+                        ALQ_TRY(k_rowmax_u32(ctx, m->amax_tiles, ly.fwd_all.a.tpg * (ly.fwd_all.multi ? ly.fwd_all.a.ngr : 1) * 4, N, ly.amax_fwd));
                     fused = fuse != nullptr;
                     break;
                 }

@@ -116,8 +116,8 @@ def main():
         # dominant kernel = igemm4_kernel (conv / conv_transpose fwd + bwd-data on the bf16 matrix cores
         # with the 3-way operand split: 6 bf16 MFMA MACs per fp32-accurate MAC, so the matrix-core bound
         # on ALGORITHMIC fp32 flops is the dense bf16 peak / 6)
-        # The launches whose input maxima are known ahead of time (the last conv's forward and backward) run the fp16x2
-        # split: 3 fp16 MFMA MACs per fp32-accurate MAC, bound = dense fp16 peak (= the bf16 one) / 3.  The bound of
+        # The launches whose input maxima are known ahead of time (the last conv's forward and backward, the backward
+        # launches of the two layers below it) run the fp16x2 split: 3 fp16 MFMA MACs per fp32-accurate MAC, bound = dense fp16 peak (= the bf16 one) / 3.  The bound of
         # the mix is the flop-weighted harmonic mean of the two.
         f16 = prof.get('igemm_f16x2', {'ms': 0.0, 'flops': 0.0, 'launches': 0})
         bf_fl = prof['igemm3_fwd']['flops'] + prof['igemm3_bwd']['flops']
@@ -141,7 +141,7 @@ def main():
             'metric': 'patches/sec Fisher-scored (32^3, 2-class)',
             'value': value, 'unit': 'patches/s', 'n_gpus': ws, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32 (bf16x3 operand split on the bf16 MFMA - fp16x2 split in the two launches of the last conv -, fp32 accumulate; '
+            'dtype': 'f32 (bf16x3 operand split on the bf16 MFMA - fp16x2 split in the launches whose input maxima are known ahead -, fp32 accumulate; '
                      'everything else fp32 / fp64)',
             'data': 'synthetic',
             'config': {'workload': 'configs[2]: Fisher scoring, NET-C patch-wise 3-D U-Net (fc head), '
@@ -151,8 +151,8 @@ def main():
                        'parallelism': 'pool sharded over %d GPU(s), RCCL top-B merge + 8x8 Fisher all-reduce' % ws},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic,
-                         'kernel': 'igemm4_kernel: conv / conv_transpose fwd + bwd-data, bf16x3 split (fp16x2 in the last '
-                                   'conv\'s forward and backward)',
+                         'kernel': 'igemm4_kernel: conv / conv_transpose fwd + bwd-data, bf16x3 split (fp16x2 where the input '
+                                   'maxima are known ahead: 4 of the 12 launches of a pass)',
                          'peak_note': 'algorithmic fp32 flops; peak = flop-weighted harmonic mean of %.0f dense 16-bit MFMA / %d '
                                       'products (bf16x3 launches, %.0f %% of the flops) and / 3 (the fp16x2 launches)'
                                       % (PEAK_BF16_MFMA_TFLOPS, SPLIT_PRODUCTS, 100.0 * bf_fl / max(ig_fl, 1.0)),

@@ -566,7 +566,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ms = 0; ms < 4; ++ms)
-                if (fon[ms])
+                if (fon[ms] && a.fc_bits)
                     a.fc_bits[(size_t)q_g * (a.fc_F >> 2) + ((jbase + eoff[ms] + coff[0]) >> 2)] = (unsigned char)fbyte[ms];
             // wave sum without the LDS crossbar (six dependent ds_bpermute round trips were ~1 k cycles per tile): prefix
             // sums inside each row of 16 lanes with DPP shifts, then the four row totals through scalar registers
@@ -1564,7 +1564,7 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
                     "igemm4: store_from needs a 4-aligned column and no accumulation");
         if (fuse->fc_W) {
             ALQ_REQUIRE(plan.NTW == 1 && !plan.multi && a.pair && a.PT == 1 && out.C == 8 && out.cs == 8 && out.c0 == 0 && !out.split &&
-                            !accumulate && !fuse->mask && fuse->osumA && fuse->fc_part && fuse->fc_bits &&
+                            !accumulate && !fuse->mask && fuse->fc_part &&
                             fuse->fc_F == (long long)out.vox() * 8,
                         ALQ_EUNSUPPORTED, "igemm4: fused fc head needs the pair form on a dense 8-channel output");
             a.fc_W = fuse->fc_W; a.fc_F = (int)fuse->fc_F; a.fc_part = fuse->fc_part;
@@ -1592,8 +1592,12 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
         return (a.osumA || a.osumB) ? launch4_s<1, false, true, true>(ctx, plan, a, grid)
                                     : launch4_s<1, false, false, true>(ctx, plan, a, grid);
     // with three products its contraction is the shorter side: the prefetch is issued from there (FIC)
-    if (a.fc_W && f16) return launch4_s<1, false, true, false, true, true, true>(ctx, plan, a, grid);
-    if (a.fc_W) return launch4_s<1, false, true, false, true>(ctx, plan, a, grid);
+    if (a.fc_W && f16)
+        return a.osumA ? launch4_s<1, false, true, false, true, true, true>(ctx, plan, a, grid)
+                       : launch4_s<1, false, false, false, true, true, true>(ctx, plan, a, grid);
+    if (a.fc_W)
+        return a.osumA ? launch4_s<1, false, true, false, true>(ctx, plan, a, grid)
+                       : launch4_s<1, false, false, false, true>(ctx, plan, a, grid);
     if (f16 && !a.src_bits && !a.fc_W) {
         if (plan.NTW == 2)
             return (a.osumA || a.osumB) ? launch4_s<2, false, true, false, false, false, true>(ctx, plan, a, grid)

@@ -86,6 +86,7 @@ struct alq_model {
     alq_ctx *ctx = nullptr;
     int max_batch = 0;
     bool last_call_fisher = false;   // what alq_model_debug_copy may read
+    bool last_head_fused = false;    // the last forward pass did not store the last conv's output
     // per-patch max |x| (float bits) of the two producers of the fused-head conv's input, for its fp16x2 contraction
     unsigned *amax_a = nullptr, *amax_b = nullptr, *amax_tiles = nullptr;
     size_t amax_tiles_len = 0;
@@ -659,11 +660,14 @@ static View flat_view(const View &v) {
 }
 
 // ------------------------------------------------------------------------------------------
-static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums) {
+// keep_all (forward-only calls): every activation stays readable (a feature layer was asked for); otherwise the fc
+// head of a two-class net is fused into the last conv in forward-only calls too (no channel sums, no sign bytes)
+static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bool keep_all = false) {
     alq_ctx *ctx = m->ctx;
     const int nl = (int)m->layers.size();
     bool skip_next = false;      // this layer's outputs were produced by the previous layer's kernel
     bool fc_head_fused = false;  // the logits partials of the fc head came out of the previous conv's epilogue
+    m->last_head_fused = false;
     // A conv / conv_transpose launch contracts with the fp16x2 split if it knows max |x| per patch of (every part of)
     // its input ahead of time: the launches that produce those tensors report them (`prod`), the consumers (`cons`)
     // read one scale per tile.  Producers: the first conv + pool kernel and one-patch-per-tile igemm4 launches.
@@ -680,7 +684,8 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums) {
                nx.out.W * 2 == in.W && ((ly.out.cs | ly.out.c0 | nx.out.cs | nx.out.c0) & 3) == 0 && !g_dbg_knobs[7];
     };
     std::vector<char> prod(nl, 0), cons(nl, 0);
-    if (with_sums && !no16 && !g_dbg_knobs[3] && !g_dbg_knobs[4] && !g_dbg_knobs[5]) {
+    const bool light = !with_sums && !keep_all;       // forward-only: fuse objects only for the launches of the fused head
+    if ((with_sums || light) && !no16 && !g_dbg_knobs[3] && !g_dbg_knobs[4] && !g_dbg_knobs[5]) {
         auto prod_ok = [&](int p) {
             if (p < 0) return false;
             const Layer &l = m->layers[p];
@@ -733,8 +738,10 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums) {
         // channel sums of every spatial layer's output ride on the producing kernel's epilogue when it
         // can; they are the `asum` fields of the layers that consume it
         Igemm2Fuse fz;
-        fz.osumA = ly.osum;
-        const Igemm2Fuse *fuse = (with_sums && ly.osum && !g_dbg_knobs[3]) ? &fz : nullptr;
+        fz.osumA = with_sums ? ly.osum : nullptr;
+        const bool head_conv = i + 2 == nl && m->layers[nl - 1].fc_part2 && ly.spec.type == ALQ_CONV;
+        const bool light_here = light && (prod[i] || cons[i] || head_conv);
+        const Igemm2Fuse *fuse = ((with_sums || light_here) && ly.osum && !g_dbg_knobs[3]) ? &fz : nullptr;
         bool fused = false;
         switch (ly.spec.type) {
             case ALQ_CONV: {
@@ -755,11 +762,12 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums) {
                     // epilogue, the tensor itself is not stored
                     ALQ_TRY(k_fill_unit_cotangent(ctx, m->dlogits, 1));
                     ALQ_TRY(k_fc_small_wvec(ctx, m->dlogits, 2, nx->d_Wp, nx->F, nx->fc_wv));       // W0 - W1
-                    fz.fc_W = nx->fc_wv; fz.fc_F = nx->F; fz.fc_part = nx->fc_part2; fz.fc_bits = nx->fc_maskbits;
+                    fz.fc_W = nx->fc_wv; fz.fc_F = nx->F; fz.fc_part = nx->fc_part2; fz.fc_bits = with_sums ? nx->fc_maskbits : nullptr;
                     take_amax(fz, i);
                     ALQ_TRY(igemm4_launch(ctx, ly.fwd[0].p4, in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM3_FWD, &fz));
                     fused = true;
                     fc_head_fused = true;
+                    m->last_head_fused = true;
                     break;
                 }
                 if (fuse) take_amax(fz, i);
@@ -1196,7 +1204,7 @@ int alq_forward(alq_model *m, const float *d_x, int N, float *d_post, int64_t *d
     if (N == 0) return ALQ_OK;
     ALQ_HIP(hipSetDevice(m->ctx->device));
     m->last_call_fisher = false;
-    ALQ_TRY(run_forward(m, d_x, N, false));
+    ALQ_TRY(run_forward(m, d_x, N, false, /*keep_all=*/d_feat != nullptr));
     ALQ_TRY(k_softmax(m->ctx, m->logits, m->nclass, N, d_post ? d_post : m->post, d_pred));
     if (d_feat) {
         ALQ_REQUIRE(feature_layer_idx >= 0 && feature_layer_idx < (int)m->layers.size(), ALQ_EINVAL, "bad feature layer");
@@ -1306,8 +1314,9 @@ int alq_model_debug_copy(alq_model *m, int layer_idx, int what, int N, float *d_
     if (what == 0 || what == 1) {
         // the last conv under a fused fc head: a Fisher pass stores neither its output nor the cotangent of it
         const Layer &head = m->layers.back();
-        ALQ_REQUIRE(!(m->last_call_fisher && layer_idx + 2 == (int)m->layers.size() && head.spec.type == ALQ_FC &&
-                      (what == 0 ? head.fc_part2 != nullptr : head.fc_maskbits != nullptr) && !g_dbg_knobs[4] && !g_dbg_knobs[5]),
+        ALQ_REQUIRE(!(layer_idx + 2 == (int)m->layers.size() && head.spec.type == ALQ_FC &&
+                      (what == 0 ? m->last_head_fused
+                                 : (m->last_call_fisher && head.fc_maskbits != nullptr && !g_dbg_knobs[4] && !g_dbg_knobs[5]))),
                     ALQ_EUNSUPPORTED, "layer %d: this tensor is not materialised in a Fisher pass (fc head fused into the layer: "
                     "create the model under ALQ_NO_FC_BITS=1 to keep it)", layer_idx);
         const View &v = what == 0 ? ly.out : ly.dout;

@@ -605,7 +605,7 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
                 ly.fc_slices = fc_small_slices(ly.F);
                 ALQ_TRY(m->dalloc(&ly.d_Wp, (size_t)sp.cout * ly.F));
                 ALQ_TRY(m->dalloc(&ly.fc_partials, (size_t)NB * ly.fc_slices * sp.cout));
-                if (ly.F % 1024 == 0 && i == n_layers - 1 && i > 0 && m->layers[i - 1].spec.relu && m->layers[i - 1].pidx > 0 &&
+                if (sp.cout == 2 && ly.F % 1024 == 0 && i == n_layers - 1 && i > 0 && m->layers[i - 1].spec.relu && m->layers[i - 1].pidx > 0 &&
                     m->layers[i - 1].spec.type == ALQ_CONV && m->layers[i - 1].out.C == 8 && !getenv("ALQ_NO_FC_BITS")) {
                     ALQ_TRY(m->dalloc(&ly.fc_maskbits, (size_t)NB * (ly.F / 16)));      // one sign byte per 4 elements
                     ALQ_TRY(m->dalloc(&ly.fc_wv, (size_t)ly.F));
@@ -760,8 +760,6 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                 if (fuse && nx && i + 2 == nl && nx->fc_part2 && !g_dbg_knobs[4] && !g_dbg_knobs[5]) {
                     // the fc head is this layer's only consumer in a Fisher pass: logits partials + sign bytes from the
                     // epilogue, the tensor itself is not stored
-                    ALQ_TRY(k_fill_unit_cotangent(ctx, m->dlogits, 1));
-                    ALQ_TRY(k_fc_small_wvec(ctx, m->dlogits, 2, nx->d_Wp, nx->F, nx->fc_wv));       // W0 - W1
                     fz.fc_W = nx->fc_wv; fz.fc_F = nx->F; fz.fc_part = nx->fc_part2; fz.fc_bits = with_sums ? nx->fc_maskbits : nullptr;
                     take_amax(fz, i);
                     ALQ_TRY(igemm4_launch(ctx, ly.fwd[0].p4, in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM3_FWD, &fz));
@@ -896,7 +894,6 @@ static int run_backward(alq_model *m, const float *d_x, int N) {
             if (bits_ok) {
                 // every patch has the same head cotangent (the unit cotangent): nothing of the size of the conv's output
                 // is written; the conv's backward contraction reads [bit] * wv (see fc_small_wvec_kernel)
-                ALQ_TRY(k_fc_small_wvec(ctx, ly.dout.p, ly.spec.cout, ly.d_Wp, ly.F, ly.fc_wv));
                 ALQ_TRY(k_fc_small_dsum_bits(ctx, ly.fc_maskbits, ly.fc_wv, ly.F, N, prev->dsum));
                 prev->dout_bits = ly.fc_maskbits;
                 prev->dout_vec = ly.fc_wv;
@@ -1150,8 +1147,15 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
                     }
         if (ly.dense_fc_small) {
             ly.fc_wv_amax = 0.f;
-            if (Co == 2)
-                for (int64_t f = 0; f < F; ++f) ly.fc_wv_amax = std::max(ly.fc_wv_amax, std::fabs((0.f + Wp[(size_t)f]) - Wp[(size_t)F + f]));
+            if (Co == 2 && ly.fc_wv) {      // the head's input cotangent under the unit cotangent (+1, -1): W0 - W1, set with the weights
+                std::vector<float> wv((size_t)F);
+                for (int64_t f = 0; f < F; ++f) {
+                    wv[(size_t)f] = (0.f + Wp[(size_t)f]) - Wp[(size_t)F + f];
+                    ly.fc_wv_amax = std::max(ly.fc_wv_amax, std::fabs(wv[(size_t)f]));
+                }
+                ALQ_HIP(hipMemcpyAsync(ly.fc_wv, wv.data(), wv.size() * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
+                ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
+            }
             ALQ_HIP(hipMemcpyAsync(ly.d_Wp, Wp.data(), Wp.size() * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
             ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
         } else {

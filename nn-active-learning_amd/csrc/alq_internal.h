@@ -417,8 +417,7 @@ int k_boxdot_convT(alq_ctx *, const float *dsum, const float *asum, const float 
 // maskbits (optional, F % 1024 == 0): act > 0 as one bit per element
 int k_fc_small_fwd(alq_ctx *, const float *act, int64_t F, const float *Wp, int nout, int N,
                    float *partials, int nslices, unsigned *maskbits = nullptr);
-// fc head under a patch-independent cotangent: wv = sum_o delta[o] Wp[o, :]; per-voxel sums of [bit] * wv over 8 channels
-int k_fc_small_wvec(alq_ctx *, const float *delta, int nout, const float *Wp, int64_t F, float *wv);
+// fc head under the unit cotangent: per-voxel sums of [sign] * wv over 8 channels (wv = W0 - W1)
 int k_fc_small_dsum_bits(alq_ctx *, const unsigned *maskbits, const float *wv, int64_t F, int N, float *dsum);
 int k_fc_small_finish(alq_ctx *, const float *partials, int nslices, const float *bias, int nout,
                       int relu, int N, float *out);

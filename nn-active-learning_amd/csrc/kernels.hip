@@ -1220,15 +1220,8 @@ __global__ void fc_small_bwd_scalar_kernel(const float *delta, int nout, const f
 
 // The cotangent of a fc head's input when the head's own cotangent is the same for every patch (the unit cotangent of
 // the Fisher pass): dact[n, f] = [act[n, f] > 0] * wv[f] with wv = sum_o delta[o] * Wp[o, :].  It is never stored:
-// wv (fc_small_wvec) and the mask bits of the forward pass are all the consuming contraction needs (igemm4 BITSRC),
+// wv (set with the weights) and the sign bytes of the forward pass are all the consuming contraction needs (igemm4 BITSRC),
 // and the per-voxel channel sums come from the same two (fc_small_dsum_bits, C = 8 channels = one byte of bits).
-__global__ void fc_small_wvec_kernel(const float *delta, int nout, const float *Wp, long long F, float *wv) {
-    const long long f = (blockIdx.x * (long long)blockDim.x + threadIdx.x) * 4;
-    if (f >= F) return;
-    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int o = 0; o < nout; ++o) s += delta[o] * *reinterpret_cast<const f32x4 *>(Wp + o * F + f);   // same order as fc_small_bwd
-    *reinterpret_cast<f32x4 *>(wv + f) = s;
-}
 // grid (groups of 4 voxels / 256, patch groups): a thread keeps the 32 vector values of its 4 voxels (8 channels each, 8
 // sign bytes) in registers for PG patches
 constexpr int FC_BITS_PG = 8;
@@ -1279,14 +1272,6 @@ int k_rowmax_u32(alq_ctx *ctx, const unsigned *in, int len, int N, unsigned *out
     return ALQ_OK;
 }
 
-int k_fc_small_wvec(alq_ctx *ctx, const float *delta, int nout, const float *Wp, int64_t F, float *wv) {
-    ProfScope ps(ctx, PROF_FC_SMALL, 0);
-    ALQ_REQUIRE(F % 4 == 0, ALQ_EINVAL, "fc_small_wvec: F %% 4");
-    hipLaunchKernelGGL(fc_small_wvec_kernel, dim3((unsigned)((F / 4 + 255) / 256)), dim3(256), 0, ctx->stream, delta, nout, Wp,
-                       (long long)F, wv);
-    ALQ_LAUNCH_CHECK();
-    return ALQ_OK;
-}
 int k_fc_small_dsum_bits(alq_ctx *ctx, const unsigned *maskbits, const float *wv, int64_t F, int N, float *dsum) {
     ProfScope ps(ctx, PROF_FC_SMALL, 0);
     ALQ_REQUIRE(F % 32 == 0, ALQ_EINVAL, "fc_small_dsum_bits: F %% 32");

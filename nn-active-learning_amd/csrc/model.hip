@@ -893,7 +893,7 @@ static int run_backward(alq_model *m, const float *d_x, int N) {
                                  prev->bwd.p4.a.PT == 1 && !prev->dout.split && !prev_is_src;
             if (bits_ok) {
                 // every patch has the same head cotangent (the unit cotangent): nothing of the size of the conv's output
-                // is written; the conv's backward contraction reads [bit] * wv (see fc_small_wvec_kernel)
+                // is written; the conv's backward contraction reads [sign] * wv (wv = W0 - W1, set with the weights)
                 ALQ_TRY(k_fc_small_dsum_bits(ctx, ly.fc_maskbits, ly.fc_wv, ly.F, N, prev->dsum));
                 prev->dout_bits = ly.fc_maskbits;
                 prev->dout_vec = ly.fc_wv;

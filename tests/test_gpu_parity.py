@@ -487,6 +487,49 @@ def test_writeback_inside_and_after_the_tick_loop_agree(sess):
     m.close()
 
 
+def test_fp16x2_scales_follow_the_data(sess):
+    """The fp16x2 launches take one power-of-two scale per patch from the maxima their producers report.  Patches whose
+    input is scaled by 1e4, 1e-5 and 300, and an all-zero patch, must come out finite, agree with the bf16x3 path at
+    fp32 level, and not depend on what else is in the batch (max_batch 1 and 5: identical bits)."""
+    import ctypes as C
+    from nnal_amd._lib import check
+    torch = sess.torch
+    ld, sk = netspec.net_c()
+    in_shape = (32, 32, 32, 1)
+    pars = netspec.he_init(ld, in_shape, seed=14, skips=sk)
+    x = sess.empty((5, 32 ** 3), torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, 5, 32 ** 3, C.c_void_p(x.data_ptr())))
+    x[1] *= 1e4
+    x[2] *= 1e-5
+    x[3] = 0
+    x[4] *= 300.0
+
+    def run(env, nb):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            m = _device_model(sess, ld, in_shape, sk, pars, max_batch=nb)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        r = m.fisher_device(x, 5, None, 1e-3)
+        out = {k: r[k].cpu().numpy() for k in ('p1', 'g0', 'g1', 'A')}
+        m.close()
+        return out
+
+    a1, a5, b5 = run({}, 1), run({}, 5), run({'ALQ_NO_F16X2': '1'}, 5)
+    for k in a5:
+        assert np.isfinite(a5[k]).all(), k
+        np.testing.assert_array_equal(a1[k], a5[k], err_msg=k)
+    np.testing.assert_allclose(a5['p1'], b5['p1'], rtol=0, atol=1e-6)
+    for k in ('g0', 'g1'):
+        scale = np.abs(b5[k]).max(axis=1, keepdims=True)
+        assert (np.abs(a5[k] - b5[k]) <= 1e-3 * scale + 1e-12).all(), k       # near-saturated patches: tiny g, fp32 noise
+
+
 def test_layout_and_engine_switches_agree(sess):
     """The same NET-C scores through (a) the split-concat layout (default), (b) concat as channel slices of one
     buffer (ALQ_NO_SPLIT): identical arithmetic per output element, so identical bits; (e) the fc head as its own

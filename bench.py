@@ -8,11 +8,16 @@ patch ids = global positions so shards are reproducible), weights He-normal seed
 One "step" = one Fisher-scoring pass over the whole pool: per patch p1, |p1-.5| top-B
 candidates, g0, g1, A_i (8x8), tr(A_i), and the pool sum of A_i.
 
-  python bench.py --gpus N --steps K --warmup W     (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
 
-N > 1 is weak scaling: every rank scores its own 100,000-patch shard of an N*100,000 pool
-(config 4's sharding), with the top-B merge and the 8x8 Fisher-sum all-reduce over RCCL inside
-the timed region.  Prints ONE JSON line on rank 0.
+N > 1: one process per GPU.  Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (the
+driver's form: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) this process IS one rank.  From a bare shell
+(`python bench.py --gpus N`, no WORLD_SIZE) it is the PARENT: before anything touches the GPU it starts N fresh rank
+processes of itself (pool_shard.spawn_ranks), relays rank 0's JSON line and exits non-zero if any rank failed.
+
+Default = weak scaling: every rank scores its own `--pool` (100,000) patches of an N*100,000 pool (config 4's sharding).
+`--pool-global G` = strong scaling: ONE pool of G patches (configs[3]: 1,000,000) in contiguous blocks of ceil(G/N).
+Either way the top-B merge and the 8x8 Fisher-sum all-reduce (RCCL) are inside the timed region.  ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -41,7 +46,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--pool', type=int, default=100000, help='patches per GPU')
+    ap.add_argument('--pool', type=int, default=100000, help='patches per GPU (weak scaling)')
+    ap.add_argument('--pool-global', type=int, default=0, help='strong scaling: one pool of this many patches over all GPUs')
+    ap.add_argument('--netb-pool', type=int, default=8192, help='patches of the NET-B side measurement at N = 1 (0 = skip)')
     ap.add_argument('--batch', type=int, default=512, help='patches per device pass')
     ap.add_argument('--topB', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -49,17 +56,27 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=128, help='patches the CPU baseline scores (~15 s on 16 cores)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # Bare-shell launch: this process only starts the ranks (it never imports torch.cuda or touches HIP).
+        import nnal_amd  # noqa: F401
+        from nnal_amd import pool_shard
+        rc, out0 = pool_shard.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+        sys.exit(rc)
+
     import torch
     import torch.distributed as dist
     ws = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if ws != args.gpus:
+        sys.exit('bench.py: WORLD_SIZE=%d but --gpus %d' % (ws, args.gpus))
     if ws > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', rank=rank, world_size=ws,
                                 device_id=torch.device('cuda', local_rank))
-    assert ws == args.gpus, 'WORLD_SIZE=%d but --gpus %d' % (ws, args.gpus)
 
     import ctypes as C
     import nnal_amd  # noqa: F401
@@ -74,10 +91,20 @@ def main():
     model = device.DeviceModel(sess, ld, in_shape, sk, max_batch=args.batch)
     model.set_weights(pars)
 
-    n_local = args.pool
-    n_global = n_local * ws
+    strong = args.pool_global > 0
+    n_global = args.pool_global if strong else args.pool * ws
     a0, b0 = pool_shard.shard_bounds(n_global, ws, rank)
-    assert b0 - a0 == n_local
+    n_local = b0 - a0
+    assert strong or n_local == args.pool
+    comm = 'torch.distributed (world 1: identity)'
+    if ws > 1:
+        # the Fisher-sum all-reduce goes through the C ABI (alq_allreduce_sum, the library's own RCCL communicator)
+        try:
+            pool_shard.attach_comm(sess)
+            comm = 'alq_allreduce_sum (RCCL communicator of the libalq context)'
+        except Exception as e:      # a transport choice, not a compute fallback: torch.distributed's RCCL group does the same sum
+            comm = 'torch.distributed nccl (alq_comm_init failed: %s)' % (e,)
+            print('[bench] rank %d: %s' % (rank, comm), file=sys.stderr, flush=True)
     epp = 32 ** 3
     x = sess.empty((n_local, epp), torch.float32)      # 13.1 GB per GPU at the default pool
     check(sess.lib.alq_synth_patches(sess.ctx, 1004, a0, n_local, epp, C.c_void_p(x.data_ptr())))
@@ -140,15 +167,17 @@ def main():
         line = {
             'metric': 'patches/sec Fisher-scored (32^3, 2-class)',
             'value': value, 'unit': 'patches/s', 'n_gpus': ws, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
             'dtype': 'f32 (bf16x3 operand split on the bf16 MFMA - fp16x2 split in the launches whose input maxima are known ahead -, fp32 accumulate; '
                      'everything else fp32 / fp64)',
             'data': 'synthetic',
-            'config': {'workload': 'configs[2]: Fisher scoring, NET-C patch-wise 3-D U-Net (fc head), '
-                                   '%d synthetic 32^3 2-class patches per GPU, random-init weights seed 14'
-                                   % n_local,
-                       'pool_per_gpu': n_local, 'batch': args.batch, 'topB': args.topB,
-                       'parallelism': 'pool sharded over %d GPU(s), RCCL top-B merge + 8x8 Fisher all-reduce' % ws},
+            'config': {'workload': ('configs[3]: Fisher scoring, NET-C patch-wise 3-D U-Net (fc head), ONE pool of %d synthetic 32^3 '
+                                    '2-class patches in contiguous blocks over the GPUs, random-init weights seed 14' % n_global) if strong else
+                                   ('configs[2]: Fisher scoring, NET-C patch-wise 3-D U-Net (fc head), '
+                                    '%d synthetic 32^3 2-class patches per GPU, random-init weights seed 14' % n_local),
+                       'outputs_per_patch': 'p1, |p1-.5| (top-B keys), H, g0[8], g1[8], A[8x8], tr A stored; sum A over the pool',
+                       'pool_global': n_global, 'pool_per_gpu': n_local, 'batch': args.batch, 'topB': args.topB,
+                       'parallelism': 'pool sharded over %d GPU(s), top-B merge (all-gather) + 8x8 Fisher all-reduce: %s' % (ws, comm)},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic,
                          'kernel': 'igemm4_kernel: conv / conv_transpose fwd + bwd-data, bf16x3 split (fp16x2 where the input '
@@ -167,13 +196,40 @@ def main():
                          'hbm_algorithmic_GBps': B_ALG * value / ws / 1e9,
                          'time_share_ms_sampled': {k: v['ms'] for k, v in prof.items()}},
         }
-        note('GPU: %.1f patches/s; timing the CPU baseline' % value)
+        note('GPU: %.1f patches/s' % value)
+        if ws == 1 and args.netb_pool > 0:
+            line['netb'] = netb_rate(sess, args.netb_pool, x)
         if not args.no_cpu_baseline:
+            note('timing the CPU baseline')
             line['cpu_baseline'] = cpu_baseline(x[:args.cpu_sample].cpu().numpy(), ld, sk, in_shape, pars)
         print(json.dumps(line))
     if ws > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def netb_rate(sess, n, x):
+    """"NET-B at [n,32,32,32] reported alongside" - the reference's literal patch net
+    (NN.create_PW1: 42.05 M parameters, the 32 slices of a patch as channels) Fisher-scored on the first n pool
+    patches, same outputs per patch; one warm-up pass, then one timed pass.  Not part of `value`."""
+    import torch
+    from nnal_amd import device, netspec
+    ld = netspec.net_b()
+    in_shape = (32, 32, 32)
+    model = device.DeviceModel(sess, ld, in_shape, (), max_batch=256)
+    model.set_weights(netspec.he_init(ld, in_shape, seed=13))
+    want = ('p1', 'H', 'g0', 'g1', 'A', 'trace', 'Asum')
+    n = min(n, int(x.shape[0]))
+    model.fisher_device(x, min(n, 512), None, 1e-3, want=want)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model.fisher_device(x, n, None, 1e-3, want=want)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    model.close()
+    return {'value': n / dt, 'unit': 'patches/s', 'net': 'NET-B = NN.create_PW1 (NN.py:1328-1336), input [N,32,32,32], 7 parameterised layers',
+            'patches': n, 'batch': 256, 'flops_per_patch_executed': 190.9e6 + 151.5e6,
+            'tflops_executed': (190.9e6 + 151.5e6) * n / dt / 1e12}
 
 
 def cpu_baseline(xs, ld, sk, in_shape, pars):

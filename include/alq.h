@@ -99,6 +99,12 @@ int alq_gather_normalize(alq_ctx *ctx, const void *const *d_vols, int m, int vol
 int alq_forward(alq_model *m, const float *d_x, int N, float *d_post, int64_t *d_pred,
                 float *d_feat, int feature_layer_idx);
 
+/* Same, on rows of a resident pool: patch i of the batch is d_pool[d_rows[i]] (d_pool: [n_pool, D,H,W,C] fp32,
+ * d_rows: int64 [N] device).  Replaces the `inds[batches[j]]` indirection of PW_NN.batch_eval (PW_NN.py:447-451,
+ * :498-501) for pools that live in HBM: the caller passes positions instead of gathering a copy of the patches. */
+int alq_forward_rows(alq_model *m, const float *d_pool, const int64_t *d_rows, int N, float *d_post,
+                     int64_t *d_pred, float *d_feat, int feature_layer_idx);
+
 /* ---- uncertainty scores ----------------------------------------------------------------- */
 /* Replaces: np.abs(posts - .5) (PW_NNAL.py:64,109,728) and NNAL_tools.compute_entropy
  * (NNAL_tools.py:71-85).  d_p1: float [n] (row 1 of the posteriors); d_absdev: double [n]
@@ -116,12 +122,24 @@ int alq_topk_uncertain(alq_ctx *ctx, const double *d_keys, int64_t n, int64_t B,
 /* Multi-GPU top-B merge step (no reference counterpart: the reference is one process).
  * Host function: merges the candidate (key, GLOBAL index) pairs gathered from all ranks
  * (torch.distributed all_gather over RCCL in pool_shard.merge_topB; entries with index < 0 are padding)
- * into the global top-B, ascending key, ties -> lower global index: the rule of alq_topk_uncertain,
- * so the result is identical on every rank.  out_idx: int64 [B]; returns the count in *n_out.
- * The L x L Fisher-sum all-reduce needs a communicator and stays in torch.distributed
- * (pool_shard.allreduce_sum).                                                                    */
+ * into the global top-B, ascending key (compared by bit pattern, so a NaN key sorts behind every number),
+ * ties -> lower global index: the rule of alq_topk_uncertain, so the result is identical on every rank.
+ * out_idx: int64 [B]; returns the count in *n_out.                                               */
 int alq_topk_merge(const double *h_keys, const int64_t *h_idx, int64_t n, int64_t B, int64_t *h_out_idx,
                    int64_t *n_out);
+
+/* The other multi-GPU exchange (no reference counterpart): all-reduce(sum) of the L x L fp64
+ * Fisher sum  sum_i A_i  over the ranks that share one pool, on RCCL over xGMI, enqueued on the context's
+ * stream.  One communicator per context: rank 0 calls alq_comm_unique_id (128 bytes, host), the host side
+ * distributes the id (pool_shard.attach_comm broadcasts it through torch.distributed) and every rank calls
+ * alq_comm_init (collective: returns when all `world` ranks have joined).  alq_allreduce_sum reduces d_buf
+ * [count] doubles IN PLACE; stream-ordered, does not synchronise.  librccl.so.1 is resolved at run time
+ * (dlopen): a process without RCCL gets ALQ_EUNSUPPORTED from these three calls and nothing else changes. */
+#define ALQ_COMM_ID_BYTES 128
+int alq_comm_unique_id(void *h_id);
+int alq_comm_init(alq_ctx *ctx, const void *h_id, int rank, int world);
+int alq_comm_destroy(alq_ctx *ctx);
+int alq_allreduce_sum(alq_ctx *ctx, double *d_buf, int64_t count);
 
 /* ---- Fisher scoring --------------------------------------------------------------------- */
 /* Replaces: the per-sample loop of PW_NNAL.gen_A_matrices (PW_NNAL.py:757-814): up to two
@@ -135,6 +153,12 @@ int alq_topk_merge(const double *h_keys, const int64_t *h_idx, int64_t n, int64_
 int alq_fisher(alq_model *m, const float *d_x, int N, const float *d_p1_in, double diag_load,
                float *d_p1_out, double *d_g0, double *d_g1, double *d_A, double *d_trace,
                double *d_Asum);
+
+/* Same, on rows of a resident pool (see alq_forward_rows): the B filtered candidates `sel_inds` of
+ * PW_NNAL.py:108-129 / :549-559 are passed as positions, not as a gathered copy.  d_p1_in, outputs: per row. */
+int alq_fisher_rows(alq_model *m, const float *d_pool, const int64_t *d_rows, int N, const float *d_p1_in,
+                    double diag_load, float *d_p1_out, double *d_g0, double *d_g1, double *d_A,
+                    double *d_trace, double *d_Asum);
 
 /* ---- measurement hooks (bench.py only) -------------------------------------------------- */
 /* Per-kernel-class HIP-event timing on the context's stream.  alq_prof_enable(ctx, 1) makes

@@ -17,6 +17,7 @@ def device_uncertainty_filter(sess, posts, B):
     import ctypes as C
     from ._lib import check
     torch = sess.torch
+    sess.bind_stream()
     n = int(posts.numel())
     B = min(int(B), n)
     keys = sess.empty((n,), torch.float64)

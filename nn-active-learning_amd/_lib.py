@@ -43,6 +43,12 @@ _SIGNATURES = {
     'alq_topk_uncertain': (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P]),
     'alq_topk_merge': (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P]),
     'alq_fisher': (C.c_int, [_P, _P, C.c_int, _P, C.c_double, _P, _P, _P, _P, _P, _P]),
+    'alq_forward_rows': (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, C.c_int]),
+    'alq_fisher_rows': (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_double, _P, _P, _P, _P, _P, _P]),
+    'alq_comm_unique_id': (C.c_int, [_P]),
+    'alq_comm_init': (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    'alq_comm_destroy': (C.c_int, [_P]),
+    'alq_allreduce_sum': (C.c_int, [_P, _P, C.c_int64]),
     'alq_prof_enable': (C.c_int, [_P, C.c_int]),
     'alq_prof_reset': (C.c_int, [_P]),
     'alq_prof_num_classes': (C.c_int, []),

@@ -1,89 +1,148 @@
-"""Query rounds of the reference's active-learning loop at the patch-tensor level.
+"""Query rounds of the reference's active-learning loop at the patch-tensor level, on one GPU or
+sharded over the ranks of a torch.distributed process group (one process per GPU).
 
-Control flow of `PW_AL.Experiment_MultiImg.run_method` (PW_AL.py:690-898) between two fine-tunes, with
-the volume I/O and the fine-tune itself left out (both outside the hot path): per round
+Control flow of `PW_AL.Experiment_MultiImg.run_method` (PW_AL.py:690-898) between two fine-tunes: per round
 
     1. posteriors of every patch still in the pool               (PW_NNAL.bin_uncertainty_filter_multimg -> batch_eval)
     2. the B most uncertain ones, |p - .5| ascending             (PW_NNAL.py:729-730)
     3. their conditional Fisher matrices A_i                     (PW_NNAL.gen_A_matrices, diag_load 1e-3: PW_NNAL.py:578)
-    4. the query distribution over the B candidates              (NNAL_tools.SDP_query_distribution, lambda = 0: PW_NNAL.py:596-604)
+    4. the query distribution over the B candidates              (NNAL_tools.SDP_query_distribution: PW_NNAL.py:596-604)
     5. k draws from it with the global NumPy RNG                 (NNAL_tools.sample_query_dstr: PW_NNAL.py:617-620)
     6. the drawn patches leave the pool                          (PW_AL.py:870-882)
+    7. (optional) `after_round(r, queries)`: the caller's fine-tune on the queried patches (PW_AL.py:890-898)
 
-Everything up to the A_i runs on the device through the C ABI; steps 4-5 are host NumPy like the reference's
-(the SDP solver is this build's own - a log-barrier Newton method on the A-optimal design the SDP states: cvxopt is
-absent, parity unpinned - see NNAL_tools.SDP_query_distribution).
+Sharding (no counterpart in the reference, which is one process): the pool is the concatenation of the ranks'
+contiguous blocks (the "concatenated sets" model of patch_utils.global2local_inds, patch_utils.py:855-864;
+pool_shard.shard_bounds) and a patch never moves: rank r scores the patches of ITS block that are still in the pool
+(step 1), offers its best B to the top-B merge (step 2: pool_shard.merge_topB, identical result on every rank),
+computes the A_i of the candidates it owns (step 3) and the B x L x L block is assembled on every rank by one
+all-reduce of owner-filled rows (pool_shard.allgather_rows); steps 4-6 are then the same deterministic host code on
+the same bits on every rank, so no further exchange is needed.  At world size 1 every exchange is the identity.
+
+Everything up to the A_i runs on the device through the C ABI (row lists into the resident pool: alq_forward_rows /
+alq_fisher_rows, no gathered copies); steps 4-5 are host NumPy like the reference's (the SDP solver is this build's
+own - cvxopt is absent, parity unpinned - see NNAL_tools.SDP_query_distribution).
 """
 import time
 
 import numpy as np
 
-from . import NNAL_tools
-from .PW_NNAL import device_uncertainty_filter
+from . import NNAL_tools, pool_shard
 
 
-def run_rounds(model, sess, pool, rounds, B, k, diag_load=1e-3, seed=15, chunk=8192):
-    """pool: device fp32 tensor [n, ...] of normalised patches.  Returns a list with one dict per round:
-    'queries' (positions into `pool`, sorted), 'candidates' (the B filtered positions), 'posts' of the candidates,
-    'A' [B, L, L], 'q' the query distribution, 'sdp' solver report and wall times per stage."""
+def run_rounds(model, sess, pool, rounds, B, k, diag_load=1e-3, seed=15, n_global=None, lambda_=0., after_round=None):
+    """pool: this rank's block of the pool, device fp32 tensor [n_local, ...] of normalised patches = global positions
+    pool_shard.shard_bounds(n_global, world, rank) (n_global defaults to n_local: one process).  Returns a list with
+    one dict per round, identical on every rank except 'seconds': 'queries' (GLOBAL positions, sorted), 'candidates'
+    (the B filtered positions, most uncertain first), 'posts' of the candidates, 'A' [B, L, L], 'q' the query
+    distribution, 'sdp' solver report, wall times per stage, 'pool_left' (global)."""
     torch = sess.torch
-    n = int(pool.shape[0])
-    flat = pool.reshape(n, -1)
-    remaining = np.arange(n, dtype=np.int64)
+    rank, ws = pool_shard.world()
+    n_local = int(pool.shape[0])
+    if n_global is None:
+        n_global = n_local
+    off, end = pool_shard.shard_bounds(n_global, ws, rank)
+    if end - off != n_local:
+        raise ValueError('rank %d holds %d patches, its block of a %d-patch pool over %d ranks has %d' %
+                         (rank, n_local, n_global, ws, end - off))
+    flat = pool.reshape(n_local, -1)
+    remaining = np.arange(n_local, dtype=np.int64)          # LOCAL positions of this rank's patches still in the pool
+    left_global = int(n_global)
     out = []
     for r in range(rounds):
         t0 = time.perf_counter()
         nr = len(remaining)
         rem_dev = sess.to_device(remaining, torch.int64)
-        p1 = sess.empty((nr,), torch.float32)
-        for a in range(0, nr, chunk):                      # gather a chunk of the remaining patches, score it
-            b = min(nr, a + chunk)
-            x = flat.index_select(0, rem_dev[a:b])
-            post, _, _ = model.forward_device(x, b - a)
-            p1[a:b] = post[1]
-        Bq = min(int(B), nr)
-        cand_local = device_uncertainty_filter(sess, p1, Bq)           # positions into `remaining`
-        torch.cuda.synchronize()
+        if nr > 0:
+            post, _, _ = model.forward_device(flat, nr, rows=rem_dev)
+            p1 = post[1].contiguous()
+            Bl = min(int(B), nr)
+            loc = sess.uncertainty_filter(p1, Bl)                           # positions into `remaining`
+            p_loc = p1.index_select(0, loc)
+            keys = (p_loc.double() - 0.5).abs().cpu().numpy()
+            loc_h = loc.cpu().numpy()
+            gidx = remaining[loc_h] + off
+        else:
+            keys, gidx, loc_h = np.zeros(0), np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+            p_loc = sess.empty((0,), torch.float32)
+        Bq = min(int(B), left_global)
+        cand = pool_shard.merge_topB(keys, gidx, Bq)                        # global positions, same on every rank
+        if hasattr(sess, 'synchronize'):
+            sess.synchronize()
         t1 = time.perf_counter()
-        xc = flat.index_select(0, rem_dev.index_select(0, cand_local))
-        res = model.fisher_device(xc, Bq, p1.index_select(0, cand_local), diag_load, want=('A',))
-        A = res['A'].cpu().numpy()
+        mine = np.nonzero((cand >= off) & (cand < end))[0]                 # the candidates this rank owns
+        if len(mine):
+            # a candidate of ours is one of our local top-B: find it there to reuse its posterior
+            order = np.argsort(gidx, kind='stable')
+            at = order[np.searchsorted(gidx[order], cand[mine])]
+            rows_dev = sess.to_device(cand[mine] - off, torch.int64)
+            p_mine = p_loc.index_select(0, sess.to_device(at, torch.int64)).contiguous()
+            res = model.fisher_device(flat, len(mine), p_mine, diag_load, want=('A',), rows=rows_dev)
+            A_mine = res['A'].cpu().numpy()
+            posts_mine = p_mine.cpu().numpy().astype(np.float64)
+        else:
+            A_mine = np.zeros((0, model.L, model.L))
+            posts_mine = np.zeros(0)
+        A = pool_shard.allgather_rows(len(cand), mine, A_mine, sess)
+        posts = pool_shard.allgather_rows(len(cand), mine, posts_mine, sess).astype(np.float32)
         t2 = time.perf_counter()
-        soln = NNAL_tools.SDP_query_distribution(A, 0, None, k)
-        q = np.array(soln['x'][:Bq], dtype=np.float64)
+        soln = NNAL_tools.SDP_query_distribution(A, lambda_, None, k)
+        q = np.array(soln['x'][:len(cand)], dtype=np.float64)
         np.random.seed(seed + r)
         draws = NNAL_tools.sample_query_dstr(q, k, replacement=True)
         t3 = time.perf_counter()
-        cand = remaining[cand_local.cpu().numpy()]
         queries = np.sort(cand[draws])
-        remaining = np.setdiff1d(remaining, queries, assume_unique=True)
-        out.append(dict(queries=queries, candidates=cand, posts=p1.index_select(0, cand_local).cpu().numpy(), A=A, q=q,
+        own = queries[(queries >= off) & (queries < end)] - off
+        remaining = np.setdiff1d(remaining, own, assume_unique=True)
+        left_global -= len(queries)
+        out.append(dict(queries=queries, candidates=cand, posts=posts, A=A, q=q,
                         sdp={kk: soln[kk] for kk in ('status', 'primal objective', 'gap', 'iterations')},
-                        seconds=dict(filter=t1 - t0, fisher=t2 - t1, sdp_and_sampling=t3 - t2), pool_left=len(remaining)))
+                        seconds=dict(filter=t1 - t0, fisher=t2 - t1, sdp_and_sampling=t3 - t2), pool_left=left_global))
+        if after_round is not None:
+            after_round(r, queries)
     return out
 
 
 def main():
-    """python -m nnal_amd.al_loop [pool] [rounds]: NET-C, synthetic 32^3 pool (seed 1005), weights seed 15."""
+    """python -m nnal_amd.al_loop [pool] [rounds]: NET-C, synthetic 32^3 pool (seed 1005), weights seed 15.
+    Under torch.distributed.run (WORLD_SIZE > 1) the pool is sharded over the ranks."""
     import ctypes as C
+    import os
     import sys
     from . import device
     from ._lib import check
     from . import netspec
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-    sess = device.DeviceSession(0)
+    ws = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if ws > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=ws, device_id=torch.device('cuda', local_rank))
+    sess = device.DeviceSession(local_rank)
     ld, sk = netspec.net_c()
     in_shape = (32, 32, 32, 1)
     model = device.DeviceModel(sess, ld, in_shape, sk, max_batch=512)
     model.set_weights(netspec.he_init(ld, in_shape, seed=15, skips=sk))
-    pool = sess.empty((n, 32 ** 3), sess.torch.float32)
-    check(sess.lib.alq_synth_patches(sess.ctx, 1005, 0, n, 32 ** 3, C.c_void_p(pool.data_ptr())))
-    for r, rd in enumerate(run_rounds(model, sess, pool, rounds, 4096, 100)):
-        print('round %d: %d queries, pool left %d, filter %.2f s, fisher %.2f s, sdp+sampling %.2f s (%s, %d iterations)' %
-              (r, len(rd['queries']), rd['pool_left'], rd['seconds']['filter'], rd['seconds']['fisher'],
-               rd['seconds']['sdp_and_sampling'], rd['sdp']['status'], rd['sdp']['iterations']))
+    a, b = pool_shard.shard_bounds(n, ws, rank)
+    pool = sess.empty((b - a, 32 ** 3), sess.torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1005, a, b - a, 32 ** 3, C.c_void_p(pool.data_ptr())))
+    if ws > 1:
+        pool_shard.attach_comm(sess)
+    for r, rd in enumerate(run_rounds(model, sess, pool, rounds, 4096, 100, n_global=n)):
+        if rank == 0:
+            print('round %d: %d queries, pool left %d, filter %.2f s, fisher %.2f s, sdp+sampling %.2f s (%s, %d iterations)' %
+                  (r, len(rd['queries']), rd['pool_left'], rd['seconds']['filter'], rd['seconds']['fisher'],
+                   rd['seconds']['sdp_and_sampling'], rd['sdp']['status'], rd['sdp']['iterations']))
     model.close()
+    if ws > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -76,6 +76,8 @@ struct alq_ctx {
     long long prof_pass = 0;
     bool prof_skip = false;    // this pass is not sampled
     void *param_block = nullptr;   // small device buffer for per-call parameters (gather)
+    void *comm = nullptr;          // RCCL communicator of this rank (comm.hip), or null
+    int comm_rank = 0, comm_world = 1;
     alq::ProfSlot prof[alq::PROF_NUM];
     int prof_begin(int cls, hipEvent_t *e0, hipEvent_t *e1);
     void prof_end(int cls, hipEvent_t e0, hipEvent_t e1, double flops);

@@ -1504,6 +1504,32 @@ int score_entropy_impl(alq_ctx *ctx, const float *d_p1, int64_t n, double *d_abs
     return ALQ_OK;
 }
 
+// =========================================================================== row gather (index-list entry points)
+// out[i, :] = pool[rows[i], :]  (epp floats per row; 16-byte copies when the row length allows)
+__global__ void gather_rows_kernel(const float *pool, const long long *rows, long long n, long long epp, float *out) {
+    if ((epp & 3) == 0) {
+        const long long q = epp >> 2, total = n * q;
+        for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+            const long long r = i / q, e = i - r * q;
+            reinterpret_cast<float4 *>(out)[i] = reinterpret_cast<const float4 *>(pool + rows[r] * epp)[e];
+        }
+    } else {
+        const long long total = n * epp;
+        for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+            const long long r = i / epp, e = i - r * epp;
+            out[i] = pool[rows[r] * epp + e];
+        }
+    }
+}
+
+int gather_rows_impl(alq_ctx *ctx, const float *d_pool, const int64_t *d_rows, int64_t n, int64_t epp, float *d_out) {
+    ProfScope ps(ctx, PROF_ELEMWISE, 0);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n * epp / 4 + 1)), dim3(256), 0, ctx->stream, d_pool,
+                       reinterpret_cast<const long long *>(d_rows), (long long)n, (long long)epp, d_out);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
 // =========================================================================== debug copies
 __global__ void view_to_dense_kernel(const float *t, int cs, int c0, int C, long long nvox, float *out) {
     const long long total = nvox * C;

@@ -23,6 +23,7 @@ int gather_normalize_impl(alq_ctx *, const void *const *, int, int, const int64_
                           const int64_t *, int64_t, const int32_t[3], const double *, int, int, void *);
 int score_entropy_impl(alq_ctx *, const float *, int64_t, double *, float *);
 int synth_impl(alq_ctx *, uint64_t, int64_t, int64_t, int64_t, float *);
+int gather_rows_impl(alq_ctx *, const float *, const int64_t *, int64_t, int64_t, float *);
 int debug_view_copy(alq_ctx *, const View &, int, float *);
 int debug_f64_copy(alq_ctx *, const double *, long long, float *);
 size_t topk_work_bytes_impl(int64_t n);
@@ -100,7 +101,13 @@ struct alq_model {
     double *Spart = nullptr;       // [L][max_batch][nslab_max] box-dot slab partials
     int *nslab = nullptr;          // [L] slabs actually written per layer
     int nslab_max = 1;
-    float *x_stage = nullptr;
+    float *x_stage = nullptr;      // [max_batch, elems per patch]: rows gathered by the *_rows entry points
+    int64_t epp = 0;               // elements per patch
+    // Engine-selection knobs, read from the environment ONCE, when this model is created; every call applies the
+    // model's own snapshot (alq_debug_set overrides a key for all models until it is set back to -1 / re-set).
+    int knobs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int no_f16x2 = 0;
+    int f16_fwd_mask = -1;         // ALQ_F16_FWD_MASK (diagnostics): forward fp16x2 consumers by layer bit, -1 = default rule
 
     template <typename T>
     int dalloc(T **p, size_t count) {
@@ -171,7 +178,14 @@ static int upload1(alq_model *m, IgemmPlan *p) {
 }
 
 static bool g_use_v2 = true;
-static bool g_knobs_init = false;
+static int g_knob_override[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // alq_debug_set: >= 0 overrides every model's snapshot
+
+// The kernels' launch helpers read the process-wide g_dbg_knobs / g_no_f16x2; each entry point loads them from the
+// model it was called on, so creating another model (or its environment) never changes a live one.
+static void apply_knobs(const alq_model *m) {
+    for (int k = 0; k < 8; ++k) g_dbg_knobs[k] = g_knob_override[k] >= 0 ? g_knob_override[k] : m->knobs[k];
+    g_no_f16x2 = m->no_f16x2;
+}
 
 static int gemm_build(const ConvDesc &d, int max_batch, Gemm *g, const G4Geom *g4 = nullptr) {
     ALQ_TRY(igemm_build_plan(d, max_batch, &g->p1));
@@ -706,12 +720,12 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
             // had a ReLU input of a later layer land on the other side of zero, moving two layer scores by 1 % - the same
             // event any two fp32 implementations produce, four times as often).  The head conv has one ReLU behind it;
             // backward launches have none (the masks are fixed by then), so they take the split wherever a variant exists.
-            if (!(j == nl - 2 && m->layers[nl - 1].fc_part2 && l.spec.type == ALQ_CONV) && !getenv("ALQ_F16_FWD_MASK")) continue;
+            if (!(j == nl - 2 && m->layers[nl - 1].fc_part2 && l.spec.type == ALQ_CONV) && m->f16_fwd_mask < 0) continue;
             if (l.spec.type == ALQ_CONVT && !pl->fic) continue;                 // MULTI has no F16 variant
             const int s_ = l.spec.skip_src;
             if (!prod_ok(j - 1) || (s_ >= 0 && !prod_ok(s_))) continue;
             if ((s_ >= 0) != (l.in.split != 0)) continue;                       // two parts <-> a split view
-            if (const char *e = getenv("ALQ_F16_FWD_MASK")) { if (!((atoi(e) >> j) & 1)) continue; }      // diagnostics: consumers by layer bit
+            if (m->f16_fwd_mask >= 0 && !((m->f16_fwd_mask >> j) & 1)) continue;      // diagnostics: consumers by layer bit
             cons[j] = 1; prod[j - 1] = 1;
             if (s_ >= 0) prod[s_] = 1;
         }
@@ -1001,6 +1015,7 @@ int alq_ctx_create(int device, void *stream, alq_ctx **out) {
 int alq_ctx_destroy(alq_ctx *ctx) {
     if (!ctx) return ALQ_OK;
     (void)hipStreamSynchronize(ctx->stream);
+    (void)alq_comm_destroy(ctx);
     for (int c = 0; c < PROF_NUM; ++c) {
         for (auto &pr : ctx->prof[c].pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
         for (auto e : ctx->prof[c].pool) (void)hipEventDestroy(e);
@@ -1031,18 +1046,19 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
     m->ctx = ctx;
     m->max_batch = max_batch;
     {
-        const char *e = getenv("ALQ_DISABLE_V2");   // diagnostics: force the general GEMM kernel
+        const char *e = getenv("ALQ_DISABLE_V2");   // diagnostics: force the general GEMM kernel (plan-time only)
         g_use_v2 = !(e && e[0] == '1');
-        g_knobs_init = true;
-        g_no_f16x2 = getenv("ALQ_NO_F16X2") != nullptr;
+        m->no_f16x2 = getenv("ALQ_NO_F16X2") != nullptr;
+        if (const char *f = getenv("ALQ_F16_FWD_MASK")) m->f16_fwd_mask = atoi(f);
         static const char *names[8] = {"ALQ_DEBUG_REPEAT", "ALQ_DEBUG_FLAGS", "ALQ_NO_BWD_FUSE", "ALQ_NO_FWD_FUSE", "ALQ_NO_V3", "ALQ_NO_V4",
                                        "ALQ_NO_POOL_FIRST", "ALQ_NO_CONV_POOL"};
         for (int k = 0; k < 8; ++k) {
             const char *v = getenv(names[k]);
-            if (v) g_dbg_knobs[k] = atoi(v);
+            if (v) m->knobs[k] = atoi(v);
         }
     }
     for (int i = 0; i < 4; ++i) m->in_dims[i] = in_dims[i];
+    m->epp = (int64_t)in_dims[0] * in_dims[1] * in_dims[2] * in_dims[3];
     const int rc = build_model(m, layers, n_layers);
     if (rc != ALQ_OK) {
         alq_model_destroy(m);
@@ -1208,6 +1224,7 @@ int alq_forward(alq_model *m, const float *d_x, int N, float *d_post, int64_t *d
     if (N == 0) return ALQ_OK;
     ALQ_HIP(hipSetDevice(m->ctx->device));
     m->last_call_fisher = false;
+    apply_knobs(m);
     ALQ_TRY(run_forward(m, d_x, N, false, /*keep_all=*/d_feat != nullptr));
     ALQ_TRY(k_softmax(m->ctx, m->logits, m->nclass, N, d_post ? d_post : m->post, d_pred));
     if (d_feat) {
@@ -1249,6 +1266,7 @@ int alq_fisher(alq_model *m, const float *d_x, int N, const float *d_p1_in, doub
         ~SkipGuard() { c->prof_skip = false; }
     } guard(m->ctx);
     m->last_call_fisher = true;
+    apply_knobs(m);
     ALQ_TRY(run_forward(m, d_x, N, true));
     ALQ_TRY(k_softmax(m->ctx, m->logits, m->nclass, N, m->post, nullptr));
     ALQ_TRY(run_backward(m, d_x, N));
@@ -1259,15 +1277,49 @@ int alq_fisher(alq_model *m, const float *d_x, int N, const float *d_p1_in, doub
     return ALQ_OK;
 }
 
+// rows of a resident pool -> the model's staging buffer (one 16-byte-wide copy kernel, no caller-side temporary)
+static int stage_rows(alq_model *m, const float *d_pool, const int64_t *d_rows, int N) {
+    ALQ_REQUIRE(d_pool && d_rows, ALQ_EINVAL, "null pool / row list");
+    if (!m->x_stage) ALQ_TRY(m->dalloc(&m->x_stage, (size_t)m->max_batch * m->epp));
+    return gather_rows_impl(m->ctx, d_pool, d_rows, N, m->epp, m->x_stage);
+}
+
+int alq_forward_rows(alq_model *m, const float *d_pool, const int64_t *d_rows, int N, float *d_post, int64_t *d_pred,
+                     float *d_feat, int feature_layer_idx) {
+    ALQ_REQUIRE(m != nullptr, ALQ_EINVAL, "alq_forward_rows: null model");
+    ALQ_REQUIRE(N >= 0 && N <= m->max_batch, ALQ_EINVAL, "alq_forward_rows: N=%d exceeds max_batch=%d", N, m->max_batch);
+    if (N == 0) return ALQ_OK;
+    ALQ_HIP(hipSetDevice(m->ctx->device));
+    ALQ_TRY(stage_rows(m, d_pool, d_rows, N));
+    return alq_forward(m, m->x_stage, N, d_post, d_pred, d_feat, feature_layer_idx);
+}
+
+int alq_fisher_rows(alq_model *m, const float *d_pool, const int64_t *d_rows, int N, const float *d_p1_in, double diag_load,
+                    float *d_p1_out, double *d_g0, double *d_g1, double *d_A, double *d_trace, double *d_Asum) {
+    ALQ_REQUIRE(m != nullptr, ALQ_EINVAL, "alq_fisher_rows: null model");
+    ALQ_REQUIRE(N >= 0 && N <= m->max_batch, ALQ_EINVAL, "alq_fisher_rows: N=%d exceeds max_batch=%d", N, m->max_batch);
+    ALQ_HIP(hipSetDevice(m->ctx->device));
+    if (N > 0) ALQ_TRY(stage_rows(m, d_pool, d_rows, N));
+    return alq_fisher(m, N > 0 ? m->x_stage : d_pool, N, d_p1_in, diag_load, d_p1_out, d_g0, d_g1, d_A, d_trace, d_Asum);
+}
+
 int alq_topk_merge(const double *h_keys, const int64_t *h_idx, int64_t n, int64_t B, int64_t *h_out_idx,
                    int64_t *n_out) {
     ALQ_REQUIRE(n >= 0 && B >= 0 && (n == 0 || (h_keys && h_idx)) && (B == 0 || h_out_idx) && n_out, ALQ_EINVAL,
                 "alq_topk_merge: bad argument");
-    std::vector<std::pair<double, int64_t>> v;
+    // Keys are compared by BIT PATTERN, like the device top-B (topk.hip): |p - .5| is non-negative, so the unsigned
+    // order of the bits is the numeric order, and a NaN key (NaN posterior of a NaN / inf patch on some rank) sorts
+    // deterministically behind every number instead of breaking the strict weak ordering of operator<.
+    std::vector<std::pair<uint64_t, int64_t>> v;
     v.reserve((size_t)n);
     for (int64_t i = 0; i < n; ++i)
-        if (h_idx[i] >= 0) v.emplace_back(h_keys[i], h_idx[i]);
-    std::sort(v.begin(), v.end());          // key, then global index
+        if (h_idx[i] >= 0) {
+            double k = h_keys[i] == 0.0 ? 0.0 : h_keys[i];      // -0.0 -> +0.0
+            uint64_t b;
+            std::memcpy(&b, &k, sizeof(b));
+            v.emplace_back(b, h_idx[i]);
+        }
+    std::sort(v.begin(), v.end());          // key bits, then global index
     const int64_t m = std::min<int64_t>(B, (int64_t)v.size());
     for (int64_t i = 0; i < m; ++i) h_out_idx[i] = v[(size_t)i].second;
     *n_out = m;
@@ -1338,6 +1390,9 @@ int alq_model_debug_copy(alq_model *m, int layer_idx, int what, int N, float *d_
 
 int alq_debug_set(int key, int value) {
     ALQ_REQUIRE(key >= 0 && key < 8, ALQ_EINVAL, "alq_debug_set: bad key");
+    // an explicit override of every model's snapshot; 0 restores "whatever the model was created with" for the keys
+    // whose environment default is 0 (all of them unless the ALQ_* diagnostics variables were set at creation)
+    g_knob_override[key] = value > 0 ? value : -1;
     g_dbg_knobs[key] = value;
     return ALQ_OK;
 }

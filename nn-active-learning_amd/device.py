@@ -82,11 +82,47 @@ class DeviceSession(object):
         self._ctx = C.c_void_p()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         check(self.lib.alq_ctx_create(device, C.c_void_p(stream), C.byref(self._ctx)))
+        self._stream = stream
+        self.comm_world = 0          # > 0 once pool_shard.attach_comm gave this context an RCCL communicator
         _track(self)
 
     @property
     def ctx(self):
         return self._ctx
+
+    def bind_stream(self):
+        """Points the library at torch's CURRENT stream on this device.  Every device call interleaves libalq
+        launches with torch ops and caching-allocator frees, which are ordered on torch's current stream; a
+        caller inside `torch.cuda.stream(s)` would otherwise have the library race with torch's reuse of the
+        buffers it was handed.  One pointer compare per call when nothing changed."""
+        s = self.torch.cuda.current_stream(self.device).cuda_stream
+        if s != self._stream:
+            check(self.lib.alq_ctx_set_stream(self._ctx, C.c_void_p(s)))
+            self._stream = s
+
+    def uncertainty_filter(self, posts, B):
+        """The B positions of `posts` (device fp32 [n]) closest to 0.5, ascending |p - .5|, ties -> lower position
+        (alq_score_entropy + alq_topk_uncertain); int64 device tensor [min(B, n)]."""
+        from .PW_NNAL import device_uncertainty_filter
+        return device_uncertainty_filter(self, posts, B)
+
+    # -- RCCL communicator of the sharded pool (pool_shard.attach_comm) --------------------
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128)
+        check(self.lib.alq_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, uid, rank, world):
+        self.bind_stream()
+        check(self.lib.alq_comm_init(self._ctx, C.c_char_p(uid), int(rank), int(world)))
+        self.comm_world = int(world)
+
+    def allreduce_sum_(self, t):
+        """In-place all-reduce(sum) of a float64 device tensor over the context's RCCL communicator."""
+        assert t.dtype == self.torch.float64 and t.is_contiguous()
+        self.bind_stream()
+        check(self.lib.alq_allreduce_sum(self._ctx, C.c_void_p(t.data_ptr()), t.numel()))
+        return t
 
     def synchronize(self):
         check(self.lib.alq_ctx_synchronize(self._ctx))
@@ -389,21 +425,29 @@ class DeviceModel(object):
             raise ValueError('batch of %d elements is not a multiple of the patch size %d' % (t.numel(), self.elems_per_patch))
         return t, n
 
-    def forward_device(self, t, n, want_pred=False, want_feat=False):
-        """t: device fp32 tensor of n patches.  Returns device tensors (post [c,n], pred, feat)."""
+    def forward_device(self, t, n, want_pred=False, want_feat=False, rows=None):
+        """t: device fp32 tensor of n patches - or, with `rows` (int64 device tensor [n]), a resident pool whose
+        rows `rows` are the patches (alq_forward_rows: no gathered copy on the caller's side).
+        Returns device tensors (post [c,n], pred, feat)."""
         torch = self.sess.torch
+        self.sess.bind_stream()
         post = self.sess.empty((self.nclass, n), torch.float32)
         pred = self.sess.empty((n,), torch.int64) if want_pred else None
         feat = self.sess.empty((n, self.feature_dim), torch.float32) if want_feat else None
+        if rows is not None:
+            assert rows.dtype == torch.int64 and rows.is_contiguous() and int(rows.numel()) == n
         for a in range(0, n, self.max_batch):
             b = min(n, a + self.max_batch)
             pb = self.sess.empty((self.nclass, b - a), torch.float32)
-            check(self.lib.alq_forward(
-                self._m, C.c_void_p(t.data_ptr() + a * self.elems_per_patch * 4), b - a,
-                C.c_void_p(pb.data_ptr()),
-                C.c_void_p(pred.data_ptr() + a * 8) if want_pred else None,
-                C.c_void_p(feat.data_ptr() + a * self.feature_dim * 4) if want_feat else None,
-                self.feature_idx if want_feat else -1))
+            outs = (C.c_void_p(pb.data_ptr()),
+                    C.c_void_p(pred.data_ptr() + a * 8) if want_pred else None,
+                    C.c_void_p(feat.data_ptr() + a * self.feature_dim * 4) if want_feat else None,
+                    self.feature_idx if want_feat else -1)
+            if rows is None:
+                check(self.lib.alq_forward(self._m, C.c_void_p(t.data_ptr() + a * self.elems_per_patch * 4), b - a, *outs))
+            else:
+                check(self.lib.alq_forward_rows(self._m, C.c_void_p(t.data_ptr()), C.c_void_p(rows.data_ptr() + a * 8),
+                                                b - a, *outs))
             post[:, a:b] = pb
         return post, pred, feat
 
@@ -420,10 +464,14 @@ class DeviceModel(object):
             res['feature_layer'] = np.ascontiguousarray(f.T)       # [F, n] like the reference
         return res
 
-    def fisher_device(self, t, n, p1_in=None, diag_load=1e-5, want=('p1', 'g0', 'g1', 'A', 'trace', 'Asum')):
-        """Device-resident Fisher scoring of n patches (t: device fp32).  Returns device tensors;
-        'Asum' is the sum over the n patches (fixed summation order per launch)."""
+    def fisher_device(self, t, n, p1_in=None, diag_load=1e-5, want=('p1', 'g0', 'g1', 'A', 'trace', 'Asum'), rows=None):
+        """Device-resident Fisher scoring of n patches (t: device fp32; with `rows`, rows of the resident pool `t`:
+        alq_fisher_rows).  Returns device tensors; 'Asum' is the sum over the n patches (fixed summation order per
+        launch).  'H' (Shannon entropy of the posteriors, alq_score_entropy) is produced on request."""
         torch = self.sess.torch
+        self.sess.bind_stream()
+        if rows is not None:
+            assert rows.dtype == torch.int64 and rows.is_contiguous() and int(rows.numel()) == n
         L = self.L
         out = {}
         out['p1'] = self.sess.empty((n,), torch.float32) if 'p1' in want else None
@@ -439,14 +487,24 @@ class DeviceModel(object):
 
         for a in range(0, n, self.max_batch):
             b = min(n, a + self.max_batch)
-            check(self.lib.alq_fisher(
-                self._m, C.c_void_p(t.data_ptr() + a * self.elems_per_patch * 4), b - a,
-                ptr(p1_in, a, 4), float(diag_load), ptr(out['p1'], a, 4), ptr(out['g0'], a * L, 8),
-                ptr(out['g1'], a * L, 8), ptr(out['A'], a * L * L, 8), ptr(out['trace'], a, 8),
-                C.c_void_p(part.data_ptr()) if part is not None else None))
+            outs = (ptr(p1_in, a, 4), float(diag_load), ptr(out['p1'], a, 4), ptr(out['g0'], a * L, 8),
+                    ptr(out['g1'], a * L, 8), ptr(out['A'], a * L * L, 8), ptr(out['trace'], a, 8),
+                    C.c_void_p(part.data_ptr()) if part is not None else None)
+            if rows is None:
+                check(self.lib.alq_fisher(self._m, C.c_void_p(t.data_ptr() + a * self.elems_per_patch * 4), b - a, *outs))
+            else:
+                check(self.lib.alq_fisher_rows(self._m, C.c_void_p(t.data_ptr()), C.c_void_p(rows.data_ptr() + a * 8),
+                                               b - a, *outs))
             if asum is not None:
                 asum += part
         out['Asum'] = asum
+        if 'H' in want or 'absdev' in want:
+            if out['p1'] is None:
+                raise ValueError("'H' / 'absdev' need 'p1' in `want`")
+            out['H'] = self.sess.empty((n,), torch.float32) if 'H' in want else None
+            out['absdev'] = self.sess.empty((n,), torch.float64) if 'absdev' in want else None
+            check(self.lib.alq_score_entropy(self.sess.ctx, C.c_void_p(out['p1'].data_ptr()), n,
+                                             ptr(out['absdev'], 0, 8), ptr(out['H'], 0, 4)))
         return out
 
     def fisher(self, x, p1=None, diag_load=1e-5):

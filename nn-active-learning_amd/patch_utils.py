@@ -44,6 +44,7 @@ class DeviceVolumes(object):
         orig = [self.pad_dims[a] - 2 * r[a] for a in range(3)]
         if inds.min() < 0 or inds.max() >= orig[0] * orig[1] * orig[2]:
             raise IndexError('voxel index outside the un-padded volume %r' % (orig,))
+        sess.bind_stream()
         d_inds = sess.to_device(inds, torch.int64)
         ptrs = (C.c_void_p * self.m)(*[t.data_ptr() for t in self.tensors])
         pd = (C.c_int64 * 3)(*self.pad_dims)

@@ -36,9 +36,36 @@ def _comm_device():
     return torch.device('cpu')
 
 
-def allreduce_sum(mat):
-    """Sum of a small float64 array over all ranks (the Fisher-matrix sum); identity at world 1."""
+def attach_comm(sess):
+    """Gives the session's libalq context its own RCCL communicator over the ranks of the process group
+    (alq_comm_unique_id on rank 0 -> broadcast of the 128-byte id through torch.distributed -> alq_comm_init on
+    every rank), so that the Fisher-sum all-reduce is the C ABI's alq_allreduce_sum on the library's stream.
+    Returns True when the communicator exists afterwards.  Needs a GPU session; world 1 works (RCCL accepts a
+    one-rank communicator), which is how the GPU test exercises it."""
+    if getattr(sess, 'comm_world', 0) > 0:
+        return True
     rank, ws = world()
+    uid = [sess.comm_unique_id() if rank == 0 else None]
+    if ws > 1:
+        _dist().broadcast_object_list(uid, src=0)
+    sess.comm_init(uid[0], rank, ws)
+    return True
+
+
+def allreduce_sum(mat, sess=None):
+    """Sum of a small float64 array over all ranks (the Fisher-matrix sum); identity at world 1.
+    With a session that holds an RCCL communicator (attach_comm) the reduction is alq_allreduce_sum on the device;
+    otherwise torch.distributed (gloo in the CPU tests)."""
+    rank, ws = world()
+    if sess is not None and getattr(sess, 'comm_world', 0) == ws and ws >= 1 and getattr(sess, 'comm_world', 0) > 0:
+        torch = sess.torch
+        if isinstance(mat, torch.Tensor):
+            t = mat.to(dtype=torch.float64).contiguous().clone()
+        else:
+            t = sess.to_device(np.asarray(mat, dtype=np.float64), torch.float64)
+        return sess.allreduce_sum_(t).cpu().numpy()
+    if hasattr(mat, 'cpu'):
+        mat = mat.cpu().numpy()
     mat = np.asarray(mat, dtype=np.float64)
     if ws == 1:
         return mat.copy()
@@ -46,6 +73,21 @@ def allreduce_sum(mat):
     t = torch.as_tensor(mat.copy()).to(_comm_device())
     _dist().all_reduce(t, op=_dist().ReduceOp.SUM)
     return t.cpu().numpy()
+
+
+def allgather_rows(total, positions, rows, sess=None):
+    """Every rank contributes `rows[i]` (float64) for the global row `positions[i]` of a [total, ...] array; all
+    ranks receive the assembled array.  Realised as ONE all-reduce(sum) of an array that is zero outside a rank's
+    own rows: x + 0.0 is exact, each row has exactly one owner, so the result is bit-identical to the owner's
+    values (the all-gather of a ragged partition without a size exchange)."""
+    rows = np.asarray(rows, dtype=np.float64)
+    full = np.zeros((int(total),) + rows.shape[1:], dtype=np.float64)
+    if len(positions):
+        full[np.asarray(positions, dtype=np.int64)] = rows
+    rank, ws = world()
+    if ws == 1:
+        return full
+    return allreduce_sum(full, sess)
 
 
 def _topk_merge(keys, gidx, B):
@@ -107,26 +149,87 @@ def barrier():
         _dist().barrier()
 
 
-def score_pool(model, sess, local_patches, n_global, B, diag_load=1e-5, fisher_on='all'):
-    """Scores this rank's shard of a pool of `n_global` patches.
+def score_pool(model, sess, local_patches, n_global, B, diag_load=1e-5,
+               want=('p1', 'H', 'g0', 'g1', 'A', 'trace', 'Asum')):
+    """Scores this rank's shard of a pool of `n_global` patches ("Fisher-scored", SURVEY.md 8d: per patch p1,
+    |p1-.5| (through the top-B keys), H, g0, g1, A_i, tr A_i, and the pool sum of A_i).
 
     local_patches: device fp32 tensor [n_local, ...] = patches shard_bounds(n_global, R, rank).
     Returns dict: 'sel' global top-B most-uncertain positions (same on all ranks), 'Asum' the
-    all-reduced sum of A_i over the pool (fisher_on='all') and the local per-patch outputs."""
+    all-reduced sum of A_i over the pool and the local per-patch outputs as device tensors."""
     torch = sess.torch
     rank, ws = world()
     a, b = shard_bounds(n_global, ws, rank)
     n_local = b - a
     assert int(local_patches.shape[0]) == n_local
-    out = model.fisher_device(local_patches, n_local, None, diag_load, want=('p1', 'trace', 'Asum'))
-    from .PW_NNAL import device_uncertainty_filter
+    out = model.fisher_device(local_patches, n_local, None, diag_load, want=want)
     Bl = min(B, n_local)
     if Bl > 0:
-        loc = device_uncertainty_filter(sess, out['p1'], Bl)
+        loc = sess.uncertainty_filter(out['p1'], Bl)
         keys = (out['p1'][loc].double() - 0.5).abs().cpu().numpy()
         gidx = loc.cpu().numpy() + a
     else:
         keys, gidx = np.zeros(0), np.zeros(0, dtype=np.int64)
     sel = merge_topB(keys, gidx, min(B, n_global))
-    Asum = allreduce_sum(out['Asum'].cpu().numpy())
-    return dict(sel=sel, Asum=Asum, p1=out['p1'], trace=out['trace'], offset=a)
+    Asum = allreduce_sum(out['Asum'], sess)
+    out.update(sel=sel, Asum=Asum, offset=a)
+    return out
+
+
+# ------------------------------------------------------------------------------------------ rank launcher
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(argv, n, env=None, timeout=None):
+    """Starts `n` rank processes of `argv` (a command list) on this node - RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT in the environment, one process per GPU - relays rank 0's stdout and every
+    rank's stderr, and returns (exit code, rank 0's stdout text).  The exit code is non-zero when ANY rank failed;
+    the others are then terminated (a rank that died leaves its peers blocked in a collective).
+
+    The caller must not have initialised the GPU: children are fresh processes (never an exec of a process that
+    touched HIP).  This is what `python bench.py --gpus N` does from a bare shell."""
+    import os
+    import subprocess
+    import sys
+    import time
+    base = dict(os.environ if env is None else env)
+    base.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    import tempfile
+    procs = []
+    out0_file = tempfile.TemporaryFile(mode='w+')        # a file, not a pipe: nothing blocks however much rank 0 prints
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(list(argv), env=e, stdout=out0_file if r == 0 else subprocess.DEVNULL,
+                                      stderr=None, text=True))
+    t0 = time.time()
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            pending.discard(r)
+            if c != 0 and rc == 0:
+                rc = c
+                print('[spawn_ranks] rank %d exited with code %d; stopping the others' % (r, c), file=sys.stderr, flush=True)
+                for q in pending:
+                    procs[q].terminate()
+        if pending:
+            if timeout is not None and time.time() - t0 > timeout:
+                rc = rc or 124
+                for q in pending:
+                    procs[q].kill()
+                timeout = None
+            time.sleep(0.05)
+    out0_file.seek(0)
+    out0 = out0_file.read()
+    out0_file.close()
+    return rc, out0

@@ -1,0 +1,51 @@
+"""CPU stand-ins for device.DeviceSession / device.DeviceModel, backed by the oracle: they give the host logic above
+the C ABI (al_loop's sharded rounds, pool_shard) something to run on in the world_size-2 gloo tests, where no GPU and
+no libalq compute exist.  TEST INFRASTRUCTURE: per-patch results are pure functions of the patch (as on the device,
+whose engines are batch-invariant), which is the property the sharded-equals-single test rests on."""
+import numpy as np
+import torch
+
+from oracle import alpath
+from oracle.model import OracleModel, OracleSession
+
+
+class FakeSession(object):
+    torch = torch
+    comm_world = 0
+
+    def to_device(self, arr, dtype):
+        return torch.as_tensor(np.ascontiguousarray(arr)).to(dtype)
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype)
+
+    def uncertainty_filter(self, posts, B):
+        key = np.abs(posts.numpy().astype(np.float64) - 0.5)
+        return torch.as_tensor(np.argsort(key, kind='stable')[:B].astype(np.int64))
+
+    def bind_stream(self):
+        pass
+
+
+class FakeModel(object):
+    def __init__(self, ld, in_shape, pars, skips=()):
+        self.om = OracleModel(ld, in_shape, pars, skips=skips)
+        self.osess = OracleSession(self.om)
+        self.in_shape = tuple(in_shape)
+        self.L = self.om.nlayers_par
+
+    def forward_device(self, t, n, want_pred=False, want_feat=False, rows=None):
+        x = t.numpy() if rows is None else t.numpy()[rows.numpy()]
+        post = self.om.forward(x.reshape((-1,) + self.in_shape)[:n])['posteriors']
+        return torch.as_tensor(post), None, None
+
+    def fisher_device(self, t, n, p1_in=None, diag_load=1e-5, want=('A',), rows=None):
+        x = t.numpy() if rows is None else t.numpy()[rows.numpy()]
+        x = x.reshape((-1,) + self.in_shape)[:n]
+
+        class E(object):
+            pars = {'patch_shape': self.in_shape[:3]}
+            nclass = 2
+        p = p1_in.numpy().astype(np.float64) if p1_in is not None else self.om.forward(x)['posteriors'][1].astype(np.float64)
+        A = np.stack(alpath.gen_A_matrices(E(), self.om, self.osess, x, p, diag_load)) if n else np.zeros((0, self.L, self.L))
+        return {'A': torch.as_tensor(A)}

@@ -57,3 +57,130 @@ def test_world2_merge_and_allreduce():
         np.testing.assert_array_equal(sel, want)            # identical on every rank, ties -> lower index
         np.testing.assert_allclose(Asum, A.sum(0), rtol=1e-12)
         assert mx == 2.0
+
+
+# ---------------------------------------------------------------------------------------------- sharded AL loop
+def _loop_setup():
+    from oracle import netspec
+    ld = netspec.net_a()
+    in_shape = (12, 12, 1)
+    pars = netspec.he_init(ld, in_shape, seed=21)
+    x = np.random.RandomState(77).randn(240, *in_shape).astype(np.float32)
+    return ld, in_shape, pars, x
+
+
+def _loop_worker(rank, ws, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    if ws > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=ws)
+    import nnal_amd  # noqa: F401
+    from nnal_amd import al_loop, pool_shard
+    from tests.fake_device import FakeModel, FakeSession
+    ld, in_shape, pars, x = _loop_setup()
+    a, b = pool_shard.shard_bounds(len(x), ws, rank)
+    sess = FakeSession()
+    model = FakeModel(ld, in_shape, pars)
+    pool = torch.as_tensor(x[a:b].reshape(b - a, -1))
+    rounds = al_loop.run_rounds(model, sess, pool, 3, 20, 6, seed=5, n_global=len(x))
+    q.put((rank, [{k: r[k] for k in ('queries', 'candidates', 'posts', 'A', 'q', 'pool_left')} for r in rounds]))
+    if ws > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run_loop(ws):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loop_worker, args=(r, ws, port, q)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(ws))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_sharded_loop_equals_single_process_bit_for_bit():
+    """al_loop.run_rounds over two gloo ranks (each holding its contiguous block of the pool, a fake device backed by
+    the oracle) against the same loop in one process: candidates, posteriors, A matrices, query distribution and the
+    drawn queries of every round are identical bit for bit, on both ranks."""
+    single = _run_loop(1)[0]
+    both = _run_loop(2)
+    assert len(single) == 3
+    taken = []
+    for rank in (0, 1):
+        for r, (s, d) in enumerate(zip(single, both[rank])):
+            for k in ('queries', 'candidates', 'posts', 'A', 'q'):
+                np.testing.assert_array_equal(s[k], d[k], err_msg='round %d, %s, rank %d' % (r, k, rank))
+            assert s['pool_left'] == d['pool_left']
+    for s in single:
+        assert 1 <= len(s['queries']) <= 6 and not np.isin(s['queries'], taken).any()
+        assert not np.isin(s['candidates'], taken).any()            # queried patches have left the pool
+        taken += list(s['queries'])
+    # queries span both blocks over the rounds (otherwise the test would not exercise the ownership logic)
+    cand = np.concatenate([s['candidates'] for s in single])
+    assert (cand < 120).any() and (cand >= 120).any()
+
+
+# ---------------------------------------------------------------------------------------------- rank launcher
+_CHILD = '''
+import json, os, sys
+sys.path.insert(0, %r)
+import torch.distributed as dist
+import nnal_amd
+from nnal_amd import pool_shard
+rank, ws = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=ws)
+if len(sys.argv) > 1 and sys.argv[1] == 'fail' and rank == 1:
+    sys.exit(7)                                     # dies before the collective: rank 0 would wait for ever
+tot = pool_shard.allreduce_sum([float(rank + 1)])
+if rank == 0:
+    print(json.dumps({'sum': float(tot[0]), 'world': ws, 'local_rank': os.environ['LOCAL_RANK']}))
+dist.destroy_process_group()
+'''
+
+
+def test_spawn_ranks_relays_rank0_and_propagates_failure(tmp_path):
+    """The parent leg of `python bench.py --gpus N` from a bare shell (pool_shard.spawn_ranks), on CPU."""
+    import json
+    import sys
+    import nnal_amd  # noqa: F401
+    from nnal_amd import pool_shard
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = tmp_path / 'child.py'
+    child.write_text(_CHILD % root)
+    rc, out = pool_shard.spawn_ranks([sys.executable, str(child)], 2, timeout=120)
+    assert rc == 0
+    assert json.loads(out.strip().splitlines()[-1]) == {'sum': 3.0, 'world': 2, 'local_rank': '0'}
+    rc, out = pool_shard.spawn_ranks([sys.executable, str(child), 'fail'], 2, timeout=120)
+    assert rc == 7 and '"sum"' not in out            # rank 0 never got to its JSON line (gloo itself may print a banner)
+
+
+def test_bench_parent_mode_is_chosen_before_any_gpu_use(monkeypatch):
+    """`python bench.py --gpus 2` without WORLD_SIZE must go through spawn_ranks with its own argv and exit with the
+    ranks' code, without importing torch.cuda-touching code first."""
+    import importlib
+    import sys
+    import nnal_amd  # noqa: F401
+    from nnal_amd import pool_shard
+    bench = importlib.import_module('bench')
+    seen = {}
+
+    def fake_spawn(argv, n, **kw):
+        seen['argv'], seen['n'] = list(argv), n
+        return 3, '{"metric": "x"}\n'
+    monkeypatch.setattr(pool_shard, 'spawn_ranks', fake_spawn)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '2', '--steps', '1', '--pool-global', '1000'])
+    try:
+        bench.main()
+        raise AssertionError('bench.main() returned in parent mode')
+    except SystemExit as e:
+        assert e.code == 3
+    assert seen['n'] == 2 and seen['argv'][1].endswith('bench.py') and seen['argv'][2:] == ['--gpus', '2', '--steps', '1', '--pool-global', '1000']

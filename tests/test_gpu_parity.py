@@ -66,32 +66,66 @@ FISHER = [('fisher_neta.npz', 'a'), ('fisher_neta_saturated.npz', 'a'),
           ('fisher_netc2d.npz', 'c2'), ('fisher_netc_8cube.npz', 'c'), ('fisher_netc_32cube.npz', 'c')]
 
 
+def _clean_patches_vs_fp64(g, ld, skips, in_shape, pars, torch, diag_load):
+    """Which patches of a golden are free of ReLU-mask flips in the GOLDEN itself: the fp32 torch oracle that stood
+    behind the reference's loop lands a near-zero ReLU input on the other side of zero in some 32^3 patches, which moves
+    the affected layer sums by O(1e-3) relative.  A patch is clean when the golden's g0, g1 agree with an fp64
+    evaluation of the same network to 5e-4 relative.  Returns (clean mask [n], g0_64, g1_64, A_64)."""
+    pars64 = {k: [v[0].astype(np.float64), v[1].astype(np.float64)] for k, v in pars.items()}
+    om64 = OracleModel(ld, in_shape, pars64, skips=skips, dtype=torch.float64)
+    p64, S64, sizes = factored_ref.factored_unit_scores(om64, g['x'].astype(np.float64))
+    g64, h64, A64 = factored_ref.fisher_from_unit(p64[1], S64, sizes, diag_load)
+    clean = np.ones(len(g['x']), bool)
+    for gold, ref in ((g['g0'], g64), (g['g1'], h64)):
+        big = np.abs(ref) > 1e-5
+        rel = np.where(big, np.abs(gold - ref) / np.maximum(np.abs(ref), 1e-300), 0.)
+        clean &= rel.max(axis=1) <= 5e-4
+    return clean, g64, h64, A64
+
+
 @pytest.mark.parametrize('fname,kind', FISHER)
 def test_gen_A_matrices_vs_golden(sess, golden_dir, fname, kind):
-    """A-matrices produced by the REFERENCE's gen_A_matrices (golden) vs the device path."""
+    """A-matrices produced by the REFERENCE's gen_A_matrices (golden) vs the device path.  Same bars for every
+    fixture (A p90-relative 2e-3, g 1e-3, medians 1e-4).  The 32^3 fixture holds 3 patches of ~0.7M ReLU inputs each
+    and the fp32 oracle behind the golden flips a mask bit in some of them (its own rounding, visible against fp64):
+    those patches are held to the same relative bars against the fp64 evaluation instead, every patch to the
+    absolute bars against the golden."""
     from nnal_amd import PW_NNAL
     g = _load(golden_dir, fname)
-    # the 32^3 fixture holds 3 patches of ~0.7M ReLU inputs each: one mask flip (see above) in one
-    # patch already puts a third of its entries at the 1e-3 level, so its percentile bar is wider
-    A_RTOL, G_RTOL = (1e-2, 5e-3) if '32cube' in fname else (2e-3, 1e-3)
-    sum_med = 5e-3 if '32cube' in fname else 1e-4    # the 3-patch sum inherits the flipped patch
     ld, skips, in_shape, pars = build_fisher_model(g, kind)
     model = _device_model(sess, ld, in_shape, skips, pars, max_batch=16)
     x, p1 = g['x'], g['p1']
-    A = PW_NNAL.gen_A_matrices(Expr({'patch_shape': in_shape[:3]}), model, sess, x, p1, float(g['diag_load']))
+    dl = float(g['diag_load'])
+    A = PW_NNAL.gen_A_matrices(Expr({'patch_shape': in_shape[:3]}), model, sess, x, p1, dl)
     A = np.stack(A)
     assert A.shape == g['A'].shape and A.dtype == np.float64
-    assert_scores_close(A, g['A'], SCORE_ATOL * 0.1, A_RTOL, 1e-6)
-    res = model.fisher(x, p1, float(g['diag_load']))
+    res = model.fisher(x, p1, dl)
     np.testing.assert_allclose(res['p1'], p1, rtol=0, atol=P_ATOL)
     # goldens hold both class gradients for every sample; the device zeroes the skipped branch
     lo, hi = p1 < 1e-6, p1 > 1 - 1e-6
     g0 = np.where(hi[:, None], 0., g['g0'])
     g1 = np.where(lo[:, None], 0., g['g1'])
-    assert_scores_close(res['g0'], g0, SCORE_ATOL, G_RTOL, 1e-5)
-    assert_scores_close(res['g1'], g1, SCORE_ATOL, G_RTOL, 1e-5)
-    assert_scores_close(res['trace'], np.trace(g['A'], axis1=1, axis2=2), SCORE_ATOL, A_RTOL, 1e-6)
-    assert_scores_close(res['Asum'], g['A'].sum(0), SCORE_ATOL, 5 * A_RTOL, 1e-6, med=sum_med)
+    clean = np.ones(len(x), bool)
+    if '32cube' in fname:
+        clean, g64, h64, A64 = _clean_patches_vs_fp64(g, ld, skips, in_shape, pars, sess.torch, dl)
+        # absolute bars for every patch against the golden, whatever the oracle's own flips
+        for dev, ref in ((A, g['A']), (res['g0'], g0), (res['g1'], g1)):
+            assert np.abs(dev - ref).max() <= SCORE_ATOL
+        d = ~clean
+        if d.any():      # the golden's flipped patches: the device against the exact values
+            assert_scores_close(A[d], A64[d], SCORE_ATOL * 0.1, A_RTOL, 1e-6)
+            assert_scores_close(res['g0'][d], g64[d], SCORE_ATOL, G_RTOL, 1e-5)
+            assert_scores_close(res['g1'][d], h64[d], SCORE_ATOL, G_RTOL, 1e-5)
+        Asum_ref = np.where(clean[:, None, None], g['A'], A64).sum(0)
+    else:
+        Asum_ref = g['A'].sum(0)
+    c = clean
+    if c.any():
+        assert_scores_close(A[c], g['A'][c], SCORE_ATOL * 0.1, A_RTOL, 1e-6)
+        assert_scores_close(res['g0'][c], g0[c], SCORE_ATOL, G_RTOL, 1e-5)
+        assert_scores_close(res['g1'][c], g1[c], SCORE_ATOL, G_RTOL, 1e-5)
+        assert_scores_close(res['trace'][c], np.trace(g['A'], axis1=1, axis2=2)[c], SCORE_ATOL, A_RTOL, 1e-6)
+    assert_scores_close(res['Asum'], Asum_ref, SCORE_ATOL, 5 * A_RTOL, 1e-6)
     model.close()
 
 
@@ -292,15 +326,21 @@ def test_config2_neta_live_oracle(sess):
     p_dev = model.forward(x)['posteriors'][1]
     np.testing.assert_allclose(p_dev, p_ref, rtol=0, atol=P_ATOL)
     want = alpath.binary_uncertainty_filter(p_ref.astype(np.float64), 500)
-    # index parity is defined for tie-free, well-separated scores: drop pairs closer than the tolerance
+    got = PW_NNAL.device_uncertainty_filter(sess, sess.to_device(p_dev, sess.torch.float32), 500).cpu().numpy()
+    # Index parity at config-2 scale.  The device's posteriors differ from the oracle's by dmax (measured here, ~1e-6);
+    # two patches whose oracle keys lie closer than 2 * dmax may legitimately swap places, nothing else may: every
+    # position where the lists differ must pair two patches inside that window, and with ~1e-4 mean key spacing in the
+    # top 500 only a handful of pairs are that close.
+    dmax = float(np.abs(p_dev.astype(np.float64) - p_ref.astype(np.float64)).max())
+    assert dmax <= 5e-6, dmax
     key = np.abs(p_ref.astype(np.float64) - .5)
-    gaps = np.diff(np.sort(key)[:520])
-    if gaps.min() > 4 * P_ATOL:
-        got = PW_NNAL.device_uncertainty_filter(sess, sess.to_device(p_dev, sess.torch.float32), 500).cpu().numpy()
-        np.testing.assert_array_equal(got, want)
-    else:   # same ordering of the device's own scores + same SET up to near-ties
-        got = PW_NNAL.device_uncertainty_filter(sess, sess.to_device(p_dev, sess.torch.float32), 500).cpu().numpy()
-        assert len(set(got) ^ set(want)) <= 2 * int((gaps <= 4 * P_ATOL).sum())
+    diff = np.nonzero(got != want)[0]
+    assert len(diff) <= 6, '%d of 500 positions differ (dmax %.2e)' % (len(diff), dmax)
+    for i in diff:
+        assert abs(key[got[i]] - key[want[i]]) <= 2 * dmax, (i, got[i], want[i], key[got[i]], key[want[i]], dmax)
+    assert len(set(got) ^ set(want)) <= 2          # at most the pair straddling the cut at position 500
+    # and the device orders ITS OWN posteriors exactly like the host rule
+    np.testing.assert_array_equal(got, PW_NNAL.binary_uncertainty_filter(p_dev.astype(np.float64), 500))
     osess = OracleSession(om)
     n = 256
     A_ref = np.stack(alpath.gen_A_matrices(Expr({'patch_shape': in_shape}), om, osess, x[:n],
@@ -603,3 +643,130 @@ def test_argument_errors(sess):
     m.close()
     with pytest.raises(NotImplementedError):
         device.translate_layers({'a': ['conv', [4, [3, 3]], 'MBA'], 'f': ['fc', [2]]}, (8, 8, 1))
+
+
+def test_rows_entry_points_equal_gathered_copies(sess):
+    """alq_forward_rows / alq_fisher_rows (positions into a resident pool) against the same patches gathered by the
+    caller: identical bits, for a row list with repeats, out of order, spanning several device passes."""
+    torch = sess.torch
+    ld, sk = netspec.net_c()
+    in_shape = (16, 16, 16, 1)
+    pars = netspec.he_init(ld, in_shape, seed=33, skips=sk)
+    model = _device_model(sess, ld, in_shape, sk, pars, max_batch=8)
+    x = np.random.RandomState(9).randn(40, *in_shape).astype(np.float32)
+    pool = sess.to_device(x.reshape(40, -1), torch.float32)
+    rows = np.array([39, 0, 7, 7, 21, 3, 38, 12, 5, 30, 1, 2, 2, 19, 8, 27, 11, 33, 4], dtype=np.int64)
+    rd = sess.to_device(rows, torch.int64)
+    gathered = pool.index_select(0, rd)
+    pa, _, _ = model.forward_device(gathered, len(rows))
+    pb, _, _ = model.forward_device(pool, len(rows), rows=rd)
+    assert torch.equal(pa, pb)
+    ra = model.fisher_device(gathered, len(rows), None, 1e-3)
+    rb = model.fisher_device(pool, len(rows), None, 1e-3, rows=rd)
+    for k in ('p1', 'g0', 'g1', 'A', 'trace', 'Asum'):
+        assert torch.equal(ra[k], rb[k]), k
+    model.close()
+
+
+def test_models_keep_their_own_engine_knobs(sess):
+    """Engine knobs are snapshotted per model at creation: a second model created under other ALQ_* settings must not
+    change the kernels of one that is already live (they were process globals rewritten by every alq_model_create)."""
+    torch = sess.torch
+    ld, sk = netspec.net_c()
+    in_shape = (16, 16, 16, 1)
+    pars = netspec.he_init(ld, in_shape, seed=34, skips=sk)
+    x = sess.to_device(np.random.RandomState(10).randn(6, 16 ** 3).astype(np.float32), torch.float32)
+    m1 = _device_model(sess, ld, in_shape, sk, pars, max_batch=8)
+    before = m1.fisher_device(x, 6, None, 1e-3)
+    os.environ['ALQ_NO_F16X2'] = '1'
+    os.environ['ALQ_NO_FWD_FUSE'] = '1'
+    try:
+        m2 = _device_model(sess, ld, in_shape, sk, pars, max_batch=8)
+    finally:
+        os.environ.pop('ALQ_NO_F16X2')
+        os.environ.pop('ALQ_NO_FWD_FUSE')
+    other = m2.fisher_device(x, 6, None, 1e-3)
+    after = m1.fisher_device(x, 6, None, 1e-3)
+    for k in ('p1', 'g0', 'g1', 'A'):
+        assert torch.equal(before[k], after[k]), k
+    assert not torch.equal(before['g0'], other['g0'])        # the second model really ran other engines
+    np.testing.assert_allclose(other['g0'].cpu().numpy(), before['g0'].cpu().numpy(), rtol=1e-3, atol=1e-7)
+    m1.close()
+    m2.close()
+
+
+def test_calls_follow_torchs_current_stream(sess):
+    """The library is bound to torch's CURRENT stream at every call (DeviceSession.bind_stream): the same scores
+    inside `torch.cuda.stream(s)` as on the default stream, and the result is ordered on `s`."""
+    torch = sess.torch
+    ld = netspec.net_a()
+    in_shape = (32, 32, 1)
+    pars = netspec.he_init(ld, in_shape, seed=35)
+    model = _device_model(sess, ld, in_shape, (), pars, max_batch=64)
+    x = sess.to_device(np.random.RandomState(11).randn(200, 32 * 32).astype(np.float32), torch.float32)
+    r0 = model.fisher_device(x, 200, None, 1e-5)
+    s = torch.cuda.Stream(device=sess.device)
+    s.wait_stream(torch.cuda.current_stream(sess.device))
+    with torch.cuda.stream(s):
+        r1 = model.fisher_device(x, 200, None, 1e-5)
+        got = {k: r1[k].cpu() for k in ('p1', 'A', 'Asum')}       # .cpu() synchronises `s`
+    for k in got:
+        assert torch.equal(got[k], r0[k].cpu()), k
+    torch.cuda.current_stream(sess.device).wait_stream(s)
+    r2 = model.fisher_device(x, 200, None, 1e-5)                  # back on the default stream
+    assert torch.equal(r2['A'], r0['A'])
+    model.close()
+
+
+def test_rccl_allreduce_through_the_c_abi_world1(sess):
+    """alq_comm_unique_id / alq_comm_init / alq_allreduce_sum with a one-rank RCCL communicator (the GPU box has one
+    GPU): the sum over one rank is the identity, stream-ordered on the library's stream."""
+    from nnal_amd import pool_shard
+    torch = sess.torch
+    assert pool_shard.attach_comm(sess) and sess.comm_world == 1
+    m = np.random.RandomState(12).randn(8, 8)
+    out = pool_shard.allreduce_sum(m, sess)
+    np.testing.assert_array_equal(out, m)
+    t = sess.to_device(m, torch.float64)
+    np.testing.assert_array_equal(pool_shard.allreduce_sum(t, sess), m)
+    np.testing.assert_array_equal(t.cpu().numpy(), m)             # the caller's tensor is not reduced in place
+    full = pool_shard.allgather_rows(5, [1, 3], np.ones((2, 2, 2)), sess)
+    assert full.shape == (5, 2, 2) and full[1].sum() == 4 and full[0].sum() == 0
+
+
+def test_sharded_loop_world1_under_nccl(sess):
+    """The sharded AL loop (al_loop.run_rounds + pool_shard) at world size 1 under the `nccl` backend - the code path
+    of the 8-GPU run with every exchange through RCCL - equals the loop without a process group, bit for bit."""
+    import torch.distributed as dist
+    from nnal_amd import al_loop, pool_shard
+    from tests.test_dist_gloo import _free_port
+    torch = sess.torch
+    ld, sk = netspec.net_c()
+    in_shape = (16, 16, 16, 1)
+    pars = netspec.he_init(ld, in_shape, seed=15, skips=sk)
+    model = _device_model(sess, ld, in_shape, sk, pars, max_batch=128)
+    n, B, k = 700, 64, 8
+    pool = sess.to_device(np.random.RandomState(1006).randn(n, 16 ** 3).astype(np.float32), torch.float32)
+    plain = al_loop.run_rounds(model, sess, pool, 2, B, k, seed=3)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(_free_port())
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=sess.device)
+    try:
+        pool_shard.attach_comm(sess)
+        assert pool_shard.world() == (0, 1)
+        shard = al_loop.run_rounds(model, sess, pool, 2, B, k, seed=3, n_global=n)
+        sc = pool_shard.score_pool(model, sess, pool, n, B, 1e-3)
+    finally:
+        dist.destroy_process_group()
+    for a, b in zip(plain, shard):
+        for key in ('queries', 'candidates', 'posts', 'A', 'q'):
+            np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    # score_pool stores what "Fisher-scored" names (SURVEY.md 8d): p1, H, g0, g1, A, trace per patch + the pool sum
+    for key in ('p1', 'H', 'g0', 'g1', 'A', 'trace'):
+        assert sc[key] is not None and int(sc[key].shape[0]) == n, key
+    np.testing.assert_array_equal(sc['sel'], plain[0]['candidates'])
+    np.testing.assert_allclose(sc['Asum'], sc['A'].cpu().numpy().sum(0), rtol=1e-10)
+    p = sc['p1'].cpu().numpy().astype(np.float64)
+    pm = np.stack([1 - p, p]).astype(np.float32)
+    np.testing.assert_allclose(sc['H'].cpu().numpy(), alpath.compute_entropy(pm), rtol=1e-5, atol=1e-6)
+    model.close()

@@ -176,7 +176,8 @@ int alq_prof_read(alq_ctx *ctx, int cls, double *ms, int64_t *launches, double *
  * dense device buffer.  what: 0 = activation of layer `layer_idx` [N, vox, C], 1 = its cotangent
  * (after the ReLU mask), 2 = channel-sum field of the layer's INPUT [N, vox_in], 3 = channel-sum
  * field of its masked cotangent [N, vox_out], 4 = the unit-cotangent layer sums S [N, L] (as
- * float; layer_idx ignored).  *elems_out receives the element count.  Tests only.             */
+ * float; layer_idx ignored), 5 = the fused fc head's logit-difference partials [N, tiles * 4] (one per
+ * (tile, wave) of the last conv's launch).  *elems_out receives the element count.  Tests only.  */
 int alq_model_debug_copy(alq_model *m, int layer_idx, int what, int N, float *d_out,
                          int64_t *elems_out);
 

@@ -95,20 +95,37 @@ __device__ inline unsigned g4_pack2(float a, float b) {
 // posteriors of two classes depend on the logit difference only), reduces them to one partial per (tile, wave) -
 // summed in fixed order by fc_small_finish_diff - and writes the signs of its 4 channels as one byte for the
 // backward pass (each lane its own byte: 4 channels, no cross-lane step); nothing else of the tensor is stored.
-// (a.x b.x + a.y b.y) + (a.z b.z + a.w b.w) in single-width VALU instructions: inline asm so that the compiler cannot
-// fuse pairs into v_pk_mul_f32 / v_pk_fma_f32.  Measured on gfx950: with the packed forms (op_sel swizzles) in the
-// epilogue of a tile that is written back INSIDE the tick loop - i.e. while the other half's waves run MFMAs on the
-// same SIMDs - the logit partials were wrong by ~1e-2 and different from run to run; the same code after the loop
-// (other half idle), and single-width multiplies in either place, are exact and repeatable
-// (tests/test_gpu_parity.py::test_writeback_inside_and_after_the_tick_loop_agree).  The v_pk_add_f32 of the split
-// is not affected (bit-stable in every run of the suite).
+// The dot product of the FCF epilogue is plain C++ (the compiler forms v_pk_mul_f32 / v_pk_add_f32 from it).  Round 1
+// shipped single-width inline asm here after seeing logit partials "wrong by ~1e-2 and different from run to run" with
+// packed multiplies in a tile written back inside the tick loop.  That does not reproduce: compiler-formed and
+// hand-written packed builds of this kernel AND of the kernel of the commit that introduced the workaround give
+// bit-identical partials inside and after the loop, pass after pass (tests/gpu_fcf_diag.py, profiles/r02_fcf_diag.txt);
+// the observation belonged to an uncommitted intermediate state, not to packed math under concurrent MFMAs.  Plain
+// C++ also keeps every read of an MFMA result (f16_combine) under the compiler's hazard recognizer, which inline asm
+// operands are not.  tests/test_gpu_parity.py::test_writeback_inside_and_after_the_tick_loop_agree stays as the guard.
 __device__ inline float g4_dot4(const f32x4 &a, const f32x4 &b) {
+#if defined(ALQ_PK_DOT) && (ALQ_PK_DOT == 3 || ALQ_PK_DOT == 4)                     // diagnostics: hand-written packed math
+    f32x2 p0, p1, q;
+    const f32x2 a0 = {a.x, a.y}, a1 = {a.z, a.w}, b0 = {b.x, b.y}, b1 = {b.z, b.w};
+#if ALQ_PK_DOT == 4
+#define G4_PAD "\n\ts_nop 7\n\ts_nop 7"
+#else
+#define G4_PAD ""
+#endif
+    asm volatile("v_pk_mul_f32 %0, %1, %2" G4_PAD : "=v"(p0) : "v"(a0), "v"(b0));
+    asm volatile("v_pk_mul_f32 %0, %1, %2" G4_PAD : "=v"(p1) : "v"(a1), "v"(b1));
+    asm volatile("v_pk_add_f32 %0, %1, %2" G4_PAD : "=v"(q) : "v"(p0), "v"(p1));
+    return q.x + q.y;
+#elif defined(ALQ_PK_DOT) && ALQ_PK_DOT == 6                                         // diagnostics: round 1's single-width asm
     float t0, t1;
     asm("v_mul_f32 %0, %1, %2" : "=v"(t0) : "v"(a.x), "v"(b.x));
     asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(a.y), "v"(b.y), "v"(t0));
     asm("v_mul_f32 %0, %1, %2" : "=v"(t1) : "v"(a.z), "v"(b.z));
     asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t1) : "v"(a.w), "v"(b.w), "v"(t1));
     return t0 + t1;
+#else
+    return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+#endif
 }
 
 // F16 (one column tile): fp16x2 split instead of bf16x3 - x * 2^e = h + l * 2^-11 with fp16 h, l (weights alike, packed
@@ -117,11 +134,7 @@ __device__ inline float g4_dot4(const f32x4 &a, const f32x4 &b) {
 // the scale (tests/study_split_precision.py).  Needs max |x| of the input ahead of the launch: available for free
 // where the input is [sign] * one host-known vector (BITSRC).
 template <int V> using IC = std::integral_constant<int, V>;
-__device__ inline float g4_fma(float a, float b, float c) {      // single-width on purpose, see g4_dot4
-    float r;
-    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
+__device__ inline float g4_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ inline unsigned g4_pack_h2(_Float16 a, _Float16 b) {
     return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
 }
@@ -509,6 +522,12 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 if constexpr (FCF) {
                     // the sign bytes go out after the loop: no store between the weight loads above and their use
                     unsigned nib = 0;
+#if defined(ALQ_PK_DOT) && ALQ_PK_DOT == 2
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+#endif
+#if defined(ALQ_PK_DOT) && ALQ_PK_DOT == 5
+                    __builtin_amdgcn_s_setprio(3);
+#endif
                     if (on) {
                         fs0 += g4_dot4(val, fwv[ms]);
                         nib = (val.x > 0.f ? 1u : 0u) | (val.y > 0.f ? 2u : 0u) | (val.z > 0.f ? 4u : 0u) | (val.w > 0.f ? 8u : 0u);

@@ -1365,6 +1365,14 @@ int alq_model_debug_copy(alq_model *m, int layer_idx, int what, int N, float *d_
         if (elems_out) *elems_out = (int64_t)N * m->L;
         return debug_f64_copy(m->ctx, m->S, (long long)N * m->L, d_out);
     }
+    if (what == 5) {       // per (tile, wave) partials of the logit difference from the fused fc head (last pass)
+        const Layer &head = m->layers.back();
+        ALQ_REQUIRE(head.fc_part2 && m->last_head_fused, ALQ_EUNSUPPORTED, "the last pass did not run the fused fc head");
+        if (elems_out) *elems_out = (int64_t)N * head.fc_slices2;
+        ALQ_HIP(hipMemcpyAsync(d_out, head.fc_part2, (size_t)N * head.fc_slices2 * sizeof(float), hipMemcpyDeviceToDevice,
+                               m->ctx->stream));
+        return ALQ_OK;
+    }
     ALQ_REQUIRE(layer_idx >= 0 && layer_idx < (int)m->layers.size(), ALQ_EINVAL, "bad layer index");
     const Layer &ly = m->layers[layer_idx];
     if (what == 0 || what == 1) {

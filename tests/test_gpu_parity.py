@@ -502,8 +502,9 @@ def test_writeback_inside_and_after_the_tick_loop_agree(sess):
     """A half of the two-slot engine writes a tile back either inside its tick loop (while the other half's waves
     contract on the same SIMDs) or after it (its last tile).  With 16 patches of NET-C 32^3 every half owns two tiles
     of the last conv: patches 0-7 are written back inside the loop, 8-15 after it.  The second eight are copies of
-    the first eight, so every score of patch i and patch i + 8 must be bit-identical - and stay so from run to run
-    (this caught packed fp32 multiplies in the fused fc-head epilogue going wrong under concurrent MFMAs)."""
+    the first eight, so every score of patch i and patch i + 8 must be bit-identical - and stay so from run to run.
+    (Round 1 blamed packed fp32 multiplies under concurrent MFMAs for a failure of this property; A/B builds refuted
+    that - profiles/r02_fcf_diag.txt - and the epilogue is plain C++ with compiler-formed packed math again.)"""
     import ctypes as C
     from nnal_amd._lib import check
     torch = sess.torch
@@ -515,7 +516,7 @@ def test_writeback_inside_and_after_the_tick_loop_agree(sess):
     x[8:] = x[:8]
     m = _device_model(sess, ld, in_shape, sk, pars, max_batch=16)
     first = None
-    for _ in range(4):
+    for _ in range(12):
         r = m.fisher_device(x, 16, None, 1e-3)
         out = {k: r[k].cpu().numpy() for k in ('p1', 'g0', 'g1', 'A', 'trace')}
         for k, v in out.items():

@@ -160,6 +160,41 @@ int alq_fisher_rows(alq_model *m, const float *d_pool, const int64_t *d_rows, in
                     double diag_load, float *d_p1_out, double *d_g0, double *d_g1, double *d_A,
                     double *d_trace, double *d_Asum);
 
+/* ---- parameter gradients, dropout passes, optimiser steps ------------------------------- */
+/* Total number of parameters P = sum_t (w_elems + b_elems); the flat parameter / gradient vector of this API is
+ * [W_0, b_0, W_1, b_1, ...] in variable-creation order and TF layouts (see alq_model_set_weights).            */
+int64_t alq_model_num_params(const alq_model *m);
+
+/* Replaces: sess.run(model.posteriors, {keep_prob: p < 1}) of the MC strategies (PW_NNAL.py:232-282: MC-entropy,
+ * BALD).  Dropout (x * keep / keep_prob, NN.py:169-171) on the OUTPUT of the listed layers with a counter-based mask
+ * keyed (seed, layer, first_sample + n, element): reproducible and independent of the batch split; TF's own random
+ * stream is not reproducible outside TF, so the mask is this library's (the oracle restates the generator).     */
+int alq_forward_dropout(alq_model *m, const float *d_x, int N, float keep_prob, uint64_t seed, int64_t first_sample,
+                        const int32_t *h_drop_layers, int n_drop_layers, float *d_post, int64_t *d_pred);
+
+/* Replaces: sess.run(model.grad_posts[str(cls)], ...) = tf.gradients(tf.log(posteriors[cls, 0]), variables)
+ * (NN.py:639-645; mode 0: one full gradient per sample, the reference feeds batches of one, PW_NNAL.py:773-807) and
+ * the gradient half of sess.run(model.train_step, {x, y_, keep_prob}) (NN.py:583-615; mode 1: gradient of
+ * loss_scale * sum_n CE(softmax(z_n), label_n), loss_scale = 1 / batch for the reference's reduce_mean; d_labels
+ * int32 [N], a label outside [0, c) contributes nothing).  per_sample = 1: d_grads [N, P]; 0: [P] summed over the
+ * batch (fixed order, fp64).  d_post [c, N] and d_loss (mean CE of the batch, mode 1) optional.  Dropout as above
+ * (keep_prob = 1: none).  Never on the 'sum'-shrink scoring path, which forms no weight gradient (alq_fisher).  */
+int alq_param_grads(alq_model *m, const float *d_x, int N, int mode, int cls, const int32_t *d_labels,
+                    float loss_scale, float keep_prob, uint64_t seed, int64_t first_sample,
+                    const int32_t *h_drop_layers, int n_drop_layers, int per_sample, float *d_grads,
+                    float *d_post, double *d_loss);
+
+/* Replaces: tf.train.GradientDescentOptimizer / AdamOptimizer .minimize (NN.py:591-615) on flat device vectors:
+ * theta -= lr g;  Adam (TF-1.x defaults are the caller's: beta1 .9, beta2 .999, eps 1e-8), step count t >= 1:
+ * lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t), m = b1 m + (1-b1) g, v = b2 v + (1-b2) g^2,
+ * theta -= lr_t m / (sqrt(v) + eps).  The updated vector goes back through alq_model_set_weights.              */
+int alq_sgd_step(alq_ctx *ctx, float *d_theta, const float *d_grad, int64_t n, float lr);
+int alq_adam_step(alq_ctx *ctx, float *d_theta, const float *d_grad, float *d_m, float *d_v, int64_t n, float lr,
+                  float beta1, float beta2, float eps, int64_t t);
+/* Replaces: the accumulation loop of model_utils.diagonal_Fisher (model_utils.py:294-330):
+ * d_acc[i] += sum_n d_grads[n, i]^2 (fp64).                                                                    */
+int alq_sq_accum(alq_ctx *ctx, const float *d_grads, int64_t per_sample_len, int N, double *d_acc);
+
 /* ---- measurement hooks (bench.py only) -------------------------------------------------- */
 /* Per-kernel-class HIP-event timing on the context's stream.  alq_prof_enable(ctx, 1) makes
  * every launch of an instrumented kernel class record start/stop events; on = k > 1 samples the

@@ -16,16 +16,6 @@ class CNN(DeviceModel):
                                   dropout, max_batch, name)
         self.probes = list(probes)
 
-    def get_optimizer(self, *a, **k):
-        raise NotImplementedError('training (get_optimizer, NN.py:557-619) is outside the scored path')
-
-    def get_gradients(self, grad_layers=[]):
-        """NN.py:621-645.  Gradients of the log-posteriors w.r.t. ALL layers are what the device
-        Fisher pass reduces; a layer subset would change L and is not supported."""
-        if len(grad_layers) not in (0, self.L):
-            raise NotImplementedError('grad_layers subsets are outside the scored path')
-        self.grad_layers = grad_layers
-
 
 def pw1_layer_dict(nclass):
     """The layer dict of create_PW1 (NN.py:1328-1336)."""
@@ -41,7 +31,8 @@ def create_PW1(nclass, dropout_rate, learning_rate, optimizer_name, patch_shape,
     (index len-2, :1346); dropout on layers 6-8 is identity at keep_prob = 1."""
     d = pw1_layer_dict(nclass)
     model = CNN(tuple(patch_shape), d, 'PatchWise', len(d) - 2, [[6, 7, 8], dropout_rate], [5], sess, max_batch)
-    model.get_gradients()
+    model.get_optimizer(learning_rate, [], optimizer_name)      # NN.py:1354
+    model.get_gradients()                                        # NN.py:1357
     return model
 
 
@@ -50,4 +41,5 @@ def create_model(model_name, dropout_rate, nclass, learning_rate, grad_layers=[]
     """NN.create_model (NN.py:1217-1245), 'PW' only."""
     if model_name != 'PW':
         raise NotImplementedError("model %r: only the patch-wise 'PW' net is on the scored path" % model_name)
+    # like the reference's 'PW' branch (NN.py:1238-1243), grad_layers / train_layers are not forwarded: all layers
     return create_PW1(nclass, dropout_rate, learning_rate, optimizer_name, patch_shape, sess, max_batch)

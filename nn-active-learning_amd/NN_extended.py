@@ -15,9 +15,3 @@ class CNN(DeviceModel):
                 raise NotImplementedError('hyper-parameter %r belongs to training, outside the scored path' % key)
         super(CNN, self).__init__(sess or default_session(), layer_dict, in_shape, skips, feature_layer,
                                   dropout, max_batch, name)
-
-    def get_gradients(self, grad_layers=[]):
-        """NN_extended.py:1011-1035."""
-        if len(grad_layers) not in (0, self.L):
-            raise NotImplementedError('grad_layers subsets are outside the scored path')
-        self.grad_layers = grad_layers

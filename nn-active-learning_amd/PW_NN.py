@@ -14,6 +14,7 @@ def batch_eval(model, sess, img_dat, inds, patch_shape, batch_size, stats, varna
     Returns a list of float64 arrays: 'posteriors' -> [n] probability of class 1
     (PW_NN.py:526-529), 'prediction' -> [n], 'feature_layer' -> [fdim, n].  Patches are
     normalised with the channel-index rule of PW_NN.py:503-506 (channel j < m with stats[j]).
+    `x_feed_dict = {model.keep_prob: p}` (PW_NN.py:516-521) evaluates with dropout on the model's dropout layers.
     `batch_size` only bounds the reference's feed size; samples are independent, so the device
     path walks the same index order in larger chunks.
     """
@@ -22,9 +23,15 @@ def batch_eval(model, sess, img_dat, inds, patch_shape, batch_size, stats, varna
     for v in varnames:
         if v not in ('posteriors', 'prediction', 'feature_layer'):
             raise NotImplementedError("batch_eval variable %r (training-time graph) is outside the scored path" % v)
-    for k, val in x_feed_dict.items():
-        if k is getattr(model, 'keep_prob', None) and float(val) != 1.:
-            raise NotImplementedError('dropout at keep_prob < 1 is outside the scored path')
+    keep_prob = 1.
+    for k, val in x_feed_dict.items():            # PW_NN.py:516-521: x_feed_dict overrides keep_prob = 1 (MC dropout)
+        if k is getattr(model, 'keep_prob', None):
+            keep_prob = float(val)
+    mc = keep_prob < 1. and len(model.dropout_layers) > 0
+    if mc and 'feature_layer' in varnames:
+        raise NotImplementedError('feature_layer at keep_prob < 1')
+    # one dropout seed per call from the global NumPy stream; masks are keyed by the sample's position in `inds`
+    seed = int(np.random.randint(0, 2 ** 31 - 1)) if mc else 0
     if not isinstance(img_dat[0], np.ndarray):
         raise NotImplementedError('volume paths need pynrrd (absent): pass the padded arrays (PW_NN.py:429-444)')
     if int(batch_size) < 1:
@@ -42,7 +49,11 @@ def batch_eval(model, sess, img_dat, inds, patch_shape, batch_size, stats, varna
     for a in range(0, n, _CHUNK):
         b = min(n, a + _CHUNK)
         t = vols.gather(inds[a:b], patch_shape, st, quirk=1)
-        post, pred, feat = model.forward_device(t, b - a, want_pred, want_feat)
+        if mc:
+            post, pred = model.forward_dropout_device(t, b - a, keep_prob, seed=seed, first_sample=a, want_pred=want_pred)
+            feat = None
+        else:
+            post, pred, feat = model.forward_device(t, b - a, want_pred, want_feat)
         posts[a:b] = post[1].cpu().numpy()
         if want_pred:
             preds[a:b] = pred.cpu().numpy()

@@ -63,7 +63,15 @@ def gen_A_matrices(expr, model, sess, sel_patches, sel_posts, diag_load=1e-5):
         return []
     x = np.asarray(sel_patches)
     res = model.fisher(x.reshape((n,) + model.in_shape), p1=sel_posts, diag_load=diag_load)
-    return [res['A'][i] for i in range(n)]
+    idx = list(getattr(model, 'grad_layer_idx', range(model.L)))
+    if idx == list(range(model.L)):
+        return [res['A'][i] for i in range(n)]
+    # `grad_layers` subset (NN.py:627-633): A_size = len(grad_posts['1'])/2 (:751), the shrunk gradients of those layers
+    # only; the same host formula as the reference (:810-814) on the device's g0, g1
+    p = np.where(sel_posts < 1e-6, 0., np.where(sel_posts > 1 - 1e-6, 1., sel_posts))
+    g0, g1 = res['g0'][:, idx], res['g1'][:, idx]
+    eye = np.eye(len(idx)) * diag_load
+    return [(1. - p[i]) * np.outer(g0[i], g0[i]) + p[i] * np.outer(g1[i], g1[i]) + eye for i in range(n)]
 
 
 def _entropy_query_single(expr, model, sess, padded_imgs, pool_inds):
@@ -103,6 +111,17 @@ def CNN_query(expr, model, sess, padded_imgs, pool_inds, tr_inds, method_name):
         return np.random.permutation(len(pool_inds))[:expr.pars['k']]
     if method_name == 'entropy':
         return _entropy_query_single(expr, model, sess, padded_imgs, pool_inds)
+    if method_name == 'MC-entropy':
+        # PW_NNAL.py:66-87.  The reference passes x_feed_dict as batch_eval's NINTH positional argument, which is
+        # `mask` (PW_NN.py:365-366): the keep probability never reaches the feed and every iteration evaluates the
+        # same deterministic posteriors.  Mirrored: MC_iters evaluations at keep_prob = 1, running average.
+        x_feed_dict = {model.keep_prob: model.dropout_rate}
+        total_posts = 0
+        for i in range(expr.pars['MC_iters']):
+            posts = PW_NN.batch_eval(model, sess, padded_imgs, pool_inds, expr.pars['patch_shape'], expr.pars['ntb'],
+                                     expr.pars['stats'], 'posteriors', x_feed_dict)[0]
+            total_posts = (posts + i * total_posts) / (i + 1)
+        return np.argsort(np.abs(total_posts - .5), kind='stable')[:expr.pars['k']]
     if method_name == 'fi':
         sel_inds, sel_posts, A = fisher_candidates(expr, model, sess, padded_imgs, pool_inds)
         F = PW_NN.batch_eval(model, sess, padded_imgs, pool_inds[sel_inds], expr.pars['patch_shape'],
@@ -125,6 +144,34 @@ def query_multimg(expr, model, sess, all_padded_imgs, pool_inds, labeled_inds, m
         return patch_utils.global2local_inds(inds, sizes)
     if method_name == 'entropy':
         return bin_uncertainty_filter_multimg(expr, model, sess, all_padded_imgs, pool_inds, k)[0]
+    if method_name == 'MC-entropy':
+        # PW_NNAL.py:232-247: running average of MC_iters dropout passes, then the k closest to 0.5
+        x_feed_dict = {model.keep_prob: model.dropout_rate}
+        av_posts = 0
+        for i in range(expr.pars['MC_iters']):
+            posts = bin_uncertainty_filter_multimg(expr, model, sess, all_padded_imgs, pool_inds, k, x_feed_dict)
+            av_posts = (posts + i * av_posts) / (i + 1)
+        inds = np.argsort(np.abs(av_posts - .5), kind='stable')[:k]
+        return patch_utils.global2local_inds(inds, sizes)
+    if method_name == 'BALD':
+        # PW_NNAL.py:249-282: entropy of the average posterior minus the average entropy (mutual information)
+        x_feed_dict = {model.keep_prob: model.dropout_rate}
+        av_posts, av_ents = 0, 0
+        for i in range(expr.pars['MC_iters']):
+            posts = bin_uncertainty_filter_multimg(expr, model, sess, all_padded_imgs, pool_inds, k, x_feed_dict)
+            av_posts = (posts + i * av_posts) / (i + 1)
+            neg_posts = 1 - posts
+            posts[posts == 0] += 1e-6
+            neg_posts[neg_posts == 0] += 1e-6
+            ents = -posts * np.log(posts) - neg_posts * np.log(neg_posts)
+            av_ents = (ents + i * av_ents) / (i + 1)
+        av_neg_posts = 1 - av_posts
+        av_posts[av_posts == 0] += 1e-6
+        av_neg_posts[av_neg_posts == 0] += 1e-6
+        ent_av_posts = -av_posts * np.log(av_posts) - av_neg_posts * np.log(av_neg_posts)
+        scores = ent_av_posts - av_ents
+        inds = np.argsort(-scores, kind='stable')[:k]
+        return patch_utils.global2local_inds(inds, sizes)
     if method_name == 'fi':
         sel_inds, sel_posts = bin_uncertainty_filter_multimg(expr, model, sess, all_padded_imgs, pool_inds, B)
         m = len(all_padded_imgs[0]) - 1

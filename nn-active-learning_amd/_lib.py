@@ -45,6 +45,13 @@ _SIGNATURES = {
     'alq_fisher': (C.c_int, [_P, _P, C.c_int, _P, C.c_double, _P, _P, _P, _P, _P, _P]),
     'alq_forward_rows': (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, C.c_int]),
     'alq_fisher_rows': (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_double, _P, _P, _P, _P, _P, _P]),
+    'alq_model_num_params': (C.c_int64, [_P]),
+    'alq_forward_dropout': (C.c_int, [_P, _P, C.c_int, C.c_float, C.c_uint64, C.c_int64, C.POINTER(C.c_int32), C.c_int, _P, _P]),
+    'alq_param_grads': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_float, C.c_float, C.c_uint64, C.c_int64,
+                                  C.POINTER(C.c_int32), C.c_int, C.c_int, _P, _P, _P]),
+    'alq_sgd_step': (C.c_int, [_P, _P, _P, C.c_int64, C.c_float]),
+    'alq_adam_step': (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64]),
+    'alq_sq_accum': (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     'alq_comm_unique_id': (C.c_int, [_P]),
     'alq_comm_init': (C.c_int, [_P, _P, C.c_int, C.c_int]),
     'alq_comm_destroy': (C.c_int, [_P]),

@@ -233,6 +233,7 @@ struct Igemm2Fuse {
 extern unsigned long long *g_igemm2_dbg;
 extern int g_dbg_knobs[8];
 extern int g_no_f16x2;        // ALQ_NO_F16X2, read when a model is created: bf16x3 split in every launch
+extern int g_no_xcd_order;    // ALQ_NO_XCD_ORDER (A/B runs): igemm4 tiles in dispatch order
 int igemm2_build_plan(const IgemmPlan &p1, Igemm2Plan *p2);
 void igemm2_pack_weights(Igemm2Plan *p2, const std::vector<float> &Bmat);
 int igemm2_launch(alq_ctx *ctx, const Igemm2Plan &plan, const View &in, const View &out, const float *bias,
@@ -298,6 +299,7 @@ struct Igemm4Args {
     const unsigned *in_amax, *in_amax2;   // F16: per-patch max |x| of the input part(s), float bits -> one scale per tile
     unsigned *out_amax;         // any variant: max |stored output| per (tile, group, wave), float bits
     int amax_from;
+    int xcd_order;              // 1: logical workgroup id = (XCD, slot) instead of the dispatch id (see the kernel)
 };
 
 struct G4Geom {
@@ -439,5 +441,19 @@ int k_fisher_finalize(alq_ctx *, const double *Spart, const int *nslab, int nsla
                       double *Apart, int *nblocks_out);
 int k_reduce_Asum(alq_ctx *, const double *Apart, int nblocks, int LL, double *Asum);
 int fc_small_slices(int64_t F);
+
+// ------------------------------------------------------------------ parameter gradients / training (train.hip)
+int k_dropout(alq_ctx *, const View &t, int N, long long first_sample, unsigned long long seed, int layer, float keep_prob);
+int k_logit_cotangent(alq_ctx *, const float *post_cN, int c, int N, int mode, int cls, const int *labels, float scale,
+                      float *dlogits);
+int k_ce_loss(alq_ctx *, const float *post_cN, int c, int N, const int *labels, double *d_out);
+long long wgrad_partial_floats(const View &U, const View &V, const int k[3]);
+int k_wgrad(alq_ctx *, const View &U, const View &V, const int k[3], const int s[3], const int lo[3], int N, int sum_n,
+            float *partial, float *d_out, long long out_stride);
+int k_bgrad(alq_ctx *, const View &delta, int N, int sum_n, float *d_out, long long out_stride);
+int k_fc_wgrad(alq_ctx *, const float *delta, const View &a, int nout, int N, int sum_n, float *d_out, long long out_stride);
+int k_sgd(alq_ctx *, float *theta, const float *g, long long n, float lr);
+int k_adam(alq_ctx *, float *theta, const float *g, float *m, float *v, long long n, float lr_t, float b1, float b2, float eps);
+int k_sq_accum(alq_ctx *, const float *g, long long per, int N, double *acc);
 
 }  // namespace alq

@@ -232,7 +232,17 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     const int pgroups = (a.N + a.PT - 1) / a.PT;
     const int total = pgroups * a.tpg;
     const int nwork = gridDim.x * 2;
-    const int me = blockIdx.x * 2 + h;
+    // XCD-aware work order: consecutive workgroup ids land on different XCDs (8 of them, each with its own L2), so with
+    // me = 2 * blockIdx.x + h the tiles of one patch - which share halo planes - were spread over all eight L2s.
+    // Logical id = (XCD, slot within the XCD): at every step an XCD owns a run of gridDim.x / 4 consecutive tiles
+    // (dec2 at 32^3: exactly one patch's 64 tiles), so a halo re-read hits the L2 that already holds it.
+    // Placement-independent for correctness (a bijection of the block ids); the id -> XCD map is only assumed for speed.
+    int bx = blockIdx.x;
+    if (a.xcd_order) {
+        const int per = gridDim.x >> 3;
+        bx = (bx & 7) * per + (bx >> 3);
+    }
+    const int me = bx * 2 + h;
     const int n_mine = me < total ? (total - me + nwork - 1) / nwork : 0;
     const int oth = me ^ 1;
     const int n_oth = oth < total ? (total - oth + nwork - 1) / nwork : 0;
@@ -893,7 +903,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
 #ifdef ALQ_STAMPS
     PHASE4_END(6);
     if (a.dbg && (tid & 255) == 0)
-        for (int i = 0; i < 8; ++i) a.dbg[(blockIdx.x * 2 + h) * 8 + i] = ph[i];
+        for (int i = 0; i < 8; ++i) a.dbg[(bx * 2 + h) * 8 + i] = ph[i];
 #endif
 }
 
@@ -1594,6 +1604,7 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
     const int pgroups = (N + a.PT - 1) / a.PT;
     const long long total = (long long)pgroups * a.tpg;
     const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((total + 1) / 2, 256));
+    a.xcd_order = (grid % 8 == 0 && !g_no_xcd_order) ? 1 : 0;
     if (a.fc_W && fuse->in_amax && plan.d_W16 && !no16) {       // the fused-head conv with per-patch input maxima: fp16x2
         a.in_amax = fuse->in_amax; a.in_amax2 = fuse->in_amax2;
         a.W = plan.d_W16;

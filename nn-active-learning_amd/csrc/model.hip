@@ -101,12 +101,15 @@ struct alq_model {
     double *Spart = nullptr;       // [L][max_batch][nslab_max] box-dot slab partials
     int *nslab = nullptr;          // [L] slabs actually written per layer
     int nslab_max = 1;
+    float *wg_partial = nullptr;   // slab partials of the weight-gradient kernels (grown on demand)
+    size_t wg_partial_len = 0;
     float *x_stage = nullptr;      // [max_batch, elems per patch]: rows gathered by the *_rows entry points
     int64_t epp = 0;               // elements per patch
     // Engine-selection knobs, read from the environment ONCE, when this model is created; every call applies the
     // model's own snapshot (alq_debug_set overrides a key for all models until it is set back to -1 / re-set).
     int knobs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int no_f16x2 = 0;
+    int no_xcd_order = 0;
     int f16_fwd_mask = -1;         // ALQ_F16_FWD_MASK (diagnostics): forward fp16x2 consumers by layer bit, -1 = default rule
 
     template <typename T>
@@ -185,6 +188,7 @@ static int g_knob_override[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // alq_debug
 static void apply_knobs(const alq_model *m) {
     for (int k = 0; k < 8; ++k) g_dbg_knobs[k] = g_knob_override[k] >= 0 ? g_knob_override[k] : m->knobs[k];
     g_no_f16x2 = m->no_f16x2;
+    g_no_xcd_order = m->no_xcd_order;
 }
 
 static int gemm_build(const ConvDesc &d, int max_batch, Gemm *g, const G4Geom *g4 = nullptr) {
@@ -666,6 +670,15 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
     return ALQ_OK;
 }
 
+// dropout of a training / MC forward pass: layers whose OUTPUT is dropped (NN.py:169-171), one keep probability
+struct DropSpec {
+    unsigned long long layers = 0;     // bit i = layer i
+    float keep_prob = 1.f;
+    unsigned long long seed = 0;
+    long long first_sample = 0;        // id of patch 0 of this call: masks are keyed by sample id, not by batch position
+    bool on(int i) const { return keep_prob < 1.f && i < 64 && ((layers >> i) & 1ull); }
+};
+
 static View flat_view(const View &v) {
     View f;
     f.p = v.p; f.D = f.H = f.W = 1;
@@ -676,7 +689,7 @@ static View flat_view(const View &v) {
 // ------------------------------------------------------------------------------------------
 // keep_all (forward-only calls): every activation stays readable (a feature layer was asked for); otherwise the fc
 // head of a two-class net is fused into the last conv in forward-only calls too (no channel sums, no sign bytes)
-static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bool keep_all = false) {
+static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bool keep_all = false, const DropSpec *drop = nullptr) {
     alq_ctx *ctx = m->ctx;
     const int nl = (int)m->layers.size();
     bool skip_next = false;      // this layer's outputs were produced by the previous layer's kernel
@@ -695,7 +708,8 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                sp.cout == 8 && sp.k[0] == 3 && sp.k[1] == 3 && sp.k[2] == 3 && ly.lo[0] == 1 && ly.lo[1] == 1 && ly.lo[2] == 1 &&
                nx.spec.k[0] == 2 && nx.spec.k[1] == 2 && nx.spec.k[2] == 2 && nx.lo[0] == 0 && nx.lo[1] == 0 && nx.lo[2] == 0 &&
                in.D % 2 == 0 && in.H % 2 == 0 && in.W % 2 == 0 && nx.out.D * 2 == in.D && nx.out.H * 2 == in.H &&
-               nx.out.W * 2 == in.W && ((ly.out.cs | ly.out.c0 | nx.out.cs | nx.out.c0) & 3) == 0 && !g_dbg_knobs[7];
+               nx.out.W * 2 == in.W && ((ly.out.cs | ly.out.c0 | nx.out.cs | nx.out.c0) & 3) == 0 && !g_dbg_knobs[7] &&
+               !(drop && (drop->on(0) || drop->on(1)));       // a dropped layer 0 output cannot share a kernel with the pool
     };
     std::vector<char> prod(nl, 0), cons(nl, 0);
     const bool light = !with_sums && !keep_all;       // forward-only: fuse objects only for the launches of the fused head
@@ -830,6 +844,10 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                                         PROF_IGEMM_FWD));
                 }
                 break;
+        }
+        if (drop && drop->on(i)) {
+            ALQ_REQUIRE(keep_all && !with_sums, ALQ_EINVAL, "dropout only in passes that keep every activation");
+            ALQ_TRY(k_dropout(ctx, ly.spec.type == ALQ_FC ? flat_view(ly.out) : ly.out, N, drop->first_sample, drop->seed, i, drop->keep_prob));
         }
         if (with_sums && ly.osum && !fused) ALQ_TRY(k_chansum(ctx, ly.out, ly.osum, N));
         if (with_sums && i == 0 && ly.pidx == 0 && ly.spec.type != ALQ_FC && in.C > 1)
@@ -984,8 +1002,162 @@ static int run_backward(alq_model *m, const float *d_x, int N) {
     return ALQ_OK;
 }
 
+// General backward-data pass for a cotangent already in m->dlogits ([N, c], w.r.t. the logits as the forward pass left
+// them): every layer's masked pre-activation cotangent ends up in its `dout` view (what the weight gradients need), no
+// shortcut of the Fisher pass is taken (no unit cotangent, no sign-byte input, every tensor stored).  The forward pass
+// must have kept every activation (run_forward(..., keep_all = true)).
+static int run_backward_general(alq_model *m, int N, const DropSpec *drop) {
+    alq_ctx *ctx = m->ctx;
+    const int nl = (int)m->layers.size();
+    for (int i = nl - 1; i >= 0; --i) {
+        Layer &ly = m->layers[i];
+        const bool isfc = ly.spec.type == ALQ_FC;
+        const bool prev_is_src = (i > 0 && m->layers[i - 1].out_is_skip_src && ly.spec.skip_src < 0);
+        if (drop && drop->on(i))       // out = act * keep / keep_prob: the cotangent takes the same factor
+            ALQ_TRY(k_dropout(ctx, isfc ? flat_view(ly.dout) : ly.dout, N, drop->first_sample, drop->seed, i, drop->keep_prob));
+        if (ly.spec.type == ALQ_POOL) {
+            if (i == 0) break;
+            bool fused = false;
+            ALQ_TRY(k_pool_bwd(ctx, ly.dout, ly.din, ly.argmax, ly.spec.k, ly.lo, N, prev_is_src ? 1 : 0, nullptr, nullptr, &fused, 1));
+            continue;
+        }
+        View dv = isfc ? flat_view(ly.dout) : ly.dout;
+        View av = isfc ? flat_view(ly.out) : ly.out;
+        ALQ_TRY(k_mask_chansum(ctx, dv, ly.spec.relu ? &av : nullptr, ly.dsum, N));      // ReLU-grad mask in place (+ sums, unused)
+        if (ly.pidx == 0) break;      // the first parameterised layer: nothing below needs a cotangent
+        const int acc = prev_is_src ? 1 : 0;
+        if (isfc) {
+            ALQ_REQUIRE(!acc, ALQ_EUNSUPPORTED, "layer %d: fc consumer of a skip source", i);
+            if (ly.dense_fc_small) {
+                bool fused = false;
+                ALQ_TRY(k_fc_small_bwd(ctx, ly.dout.p, ly.spec.cout, ly.d_Wp, ly.F, N, ly.din.p, nullptr, nullptr, 0, &fused));
+            } else {
+                ALQ_TRY(gemm_launch(ctx, ly.bwd, ly.dout, flat_view(ly.din), nullptr, 0, 0, N, PROF_IGEMM_BWD));
+            }
+        } else {
+            ALQ_TRY(gemm_launch(ctx, ly.bwd, ly.dout, ly.din, nullptr, 0, acc, N, PROF_IGEMM_BWD));
+        }
+    }
+    return ALQ_OK;
+}
+
+// Weight + bias gradients of every parameterised layer from the tensors a general backward pass left behind, written as
+// one flat vector per sample (or one for the batch): [W_0, b_0, W_1, b_1, ...] in the reference's variable order and
+// TF layouts (conv [k.., ci, co], conv_transpose [k.., co, ci], fc [out, in] with `in` in flatten order, NN.py:272-318).
+static int run_param_grads(alq_model *m, const float *d_x, int N, int sum_n, float *d_out, long long P) {
+    alq_ctx *ctx = m->ctx;
+    long long need = 0;
+    for (Layer &ly : m->layers) {
+        if (ly.pidx < 0 || ly.spec.type == ALQ_FC) continue;
+        const bool convt = ly.spec.type == ALQ_CONVT;
+        need = std::max(need, wgrad_partial_floats(convt ? ly.in : ly.dout, convt ? ly.dout : ly.in, ly.spec.k) * N);
+    }
+    if ((size_t)need > m->wg_partial_len) {
+        ALQ_TRY(m->dalloc(&m->wg_partial, (size_t)need));
+        m->wg_partial_len = (size_t)need;
+    }
+    long long off = 0;
+    const long long stride = sum_n ? 0 : P;
+    for (size_t i = 0; i < m->layers.size(); ++i) {
+        Layer &ly = m->layers[i];
+        if (ly.pidx < 0) continue;
+        View in = ly.in;
+        if (i == 0) in.p = const_cast<float *>(d_x);
+        const int one[3] = {1, 1, 1};
+        if (ly.spec.type == ALQ_CONV) {
+            ALQ_TRY(k_wgrad(ctx, ly.dout, in, ly.spec.k, one, ly.lo, N, sum_n, m->wg_partial, d_out + off, stride));
+            ALQ_TRY(k_bgrad(ctx, ly.dout, N, sum_n, d_out + off + ly.w_elems, stride));
+        } else if (ly.spec.type == ALQ_CONVT) {
+            ALQ_TRY(k_wgrad(ctx, in, ly.dout, ly.spec.k, ly.spec.s, ly.lo, N, sum_n, m->wg_partial, d_out + off, stride));
+            ALQ_TRY(k_bgrad(ctx, ly.dout, N, sum_n, d_out + off + ly.w_elems, stride));
+        } else {
+            ALQ_TRY(k_fc_wgrad(ctx, ly.dout.p, in, ly.spec.cout, N, sum_n, d_out + off, stride));
+            ALQ_TRY(k_bgrad(ctx, flat_view(ly.dout), N, sum_n, d_out + off + ly.w_elems, stride));
+        }
+        off += ly.w_elems + ly.b_elems;
+    }
+    ALQ_REQUIRE(off == P, ALQ_EINVAL, "parameter count mismatch");
+    return ALQ_OK;
+}
+
+static int make_drop(const alq_model *m, float keep_prob, uint64_t seed, int64_t first_sample, const int32_t *h_layers, int n_layers,
+                     DropSpec *d) {
+    ALQ_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f, ALQ_EINVAL, "keep_prob %g outside (0, 1]", (double)keep_prob);
+    ALQ_REQUIRE(n_layers == 0 || h_layers, ALQ_EINVAL, "dropout layer list missing");
+    d->keep_prob = keep_prob; d->seed = seed; d->first_sample = first_sample; d->layers = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        ALQ_REQUIRE(h_layers[i] >= 0 && h_layers[i] < (int)m->layers.size() && h_layers[i] < 64, ALQ_EINVAL, "dropout layer %d", h_layers[i]);
+        d->layers |= 1ull << h_layers[i];
+    }
+    return ALQ_OK;
+}
+
 // =========================================================================================== C ABI
 extern "C" {
+
+int64_t alq_model_num_params(const alq_model *m) {
+    if (!m) return ALQ_EINVAL;
+    int64_t p = 0;
+    for (const Layer &ly : m->layers)
+        if (ly.pidx >= 0) p += ly.w_elems + ly.b_elems;
+    return p;
+}
+
+int alq_forward_dropout(alq_model *m, const float *d_x, int N, float keep_prob, uint64_t seed, int64_t first_sample,
+                        const int32_t *h_drop_layers, int n_drop_layers, float *d_post, int64_t *d_pred) {
+    ALQ_REQUIRE(m && d_x, ALQ_EINVAL, "alq_forward_dropout: null argument");
+    ALQ_REQUIRE(N >= 0 && N <= m->max_batch, ALQ_EINVAL, "alq_forward_dropout: N=%d exceeds max_batch=%d", N, m->max_batch);
+    if (N == 0) return ALQ_OK;
+    ALQ_HIP(hipSetDevice(m->ctx->device));
+    DropSpec ds;
+    ALQ_TRY(make_drop(m, keep_prob, seed, first_sample, h_drop_layers, n_drop_layers, &ds));
+    m->last_call_fisher = false;
+    apply_knobs(m);
+    ALQ_TRY(run_forward(m, d_x, N, false, /*keep_all=*/true, &ds));
+    ALQ_TRY(k_softmax(m->ctx, m->logits, m->nclass, N, d_post ? d_post : m->post, d_pred));
+    return ALQ_OK;
+}
+
+int alq_param_grads(alq_model *m, const float *d_x, int N, int mode, int cls, const int32_t *d_labels, float loss_scale,
+                    float keep_prob, uint64_t seed, int64_t first_sample, const int32_t *h_drop_layers, int n_drop_layers,
+                    int per_sample, float *d_grads, float *d_post, double *d_loss) {
+    ALQ_REQUIRE(m && d_x && d_grads, ALQ_EINVAL, "alq_param_grads: null argument");
+    ALQ_REQUIRE(N >= 1 && N <= m->max_batch, ALQ_EINVAL, "alq_param_grads: N=%d outside [1, max_batch=%d]", N, m->max_batch);
+    ALQ_REQUIRE(mode == 0 || (mode == 1 && d_labels), ALQ_EINVAL, "alq_param_grads: mode %d / labels", mode);
+    ALQ_REQUIRE(mode != 0 || (cls >= 0 && cls < m->nclass), ALQ_EINVAL, "alq_param_grads: class %d", cls);
+    ALQ_HIP(hipSetDevice(m->ctx->device));
+    DropSpec ds;
+    ALQ_TRY(make_drop(m, keep_prob, seed, first_sample, h_drop_layers, n_drop_layers, &ds));
+    m->last_call_fisher = false;
+    apply_knobs(m);
+    ALQ_TRY(run_forward(m, d_x, N, false, /*keep_all=*/true, &ds));
+    float *post = d_post ? d_post : m->post;
+    ALQ_TRY(k_softmax(m->ctx, m->logits, m->nclass, N, post, nullptr));
+    if (d_loss && mode == 1) ALQ_TRY(k_ce_loss(m->ctx, post, m->nclass, N, d_labels, d_loss));
+    ALQ_TRY(k_logit_cotangent(m->ctx, post, m->nclass, N, mode, cls, d_labels, loss_scale, m->dlogits));
+    ALQ_TRY(run_backward_general(m, N, &ds));
+    return run_param_grads(m, d_x, N, per_sample ? 0 : 1, d_grads, alq_model_num_params(m));
+}
+
+int alq_sgd_step(alq_ctx *ctx, float *d_theta, const float *d_grad, int64_t n, float lr) {
+    ALQ_REQUIRE(ctx && (n == 0 || (d_theta && d_grad)) && n >= 0, ALQ_EINVAL, "alq_sgd_step: bad argument");
+    ALQ_HIP(hipSetDevice(ctx->device));
+    return n ? k_sgd(ctx, d_theta, d_grad, n, lr) : ALQ_OK;
+}
+
+int alq_adam_step(alq_ctx *ctx, float *d_theta, const float *d_grad, float *d_m, float *d_v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int64_t t) {
+    ALQ_REQUIRE(ctx && (n == 0 || (d_theta && d_grad && d_m && d_v)) && n >= 0 && t >= 1, ALQ_EINVAL, "alq_adam_step: bad argument");
+    ALQ_HIP(hipSetDevice(ctx->device));
+    const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, (double)t)) / (1.0 - std::pow((double)beta1, (double)t));
+    return n ? k_adam(ctx, d_theta, d_grad, d_m, d_v, n, (float)lr_t, beta1, beta2, eps) : ALQ_OK;
+}
+
+int alq_sq_accum(alq_ctx *ctx, const float *d_grads, int64_t per_sample_len, int N, double *d_acc) {
+    ALQ_REQUIRE(ctx && d_grads && d_acc && per_sample_len >= 1 && N >= 1, ALQ_EINVAL, "alq_sq_accum: bad argument");
+    ALQ_HIP(hipSetDevice(ctx->device));
+    return k_sq_accum(ctx, d_grads, per_sample_len, N, d_acc);
+}
 
 const char *alq_last_error(void) { return g_err; }
 int alq_version(void) { return 1; }
@@ -1049,6 +1221,7 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
         const char *e = getenv("ALQ_DISABLE_V2");   // diagnostics: force the general GEMM kernel (plan-time only)
         g_use_v2 = !(e && e[0] == '1');
         m->no_f16x2 = getenv("ALQ_NO_F16X2") != nullptr;
+        m->no_xcd_order = getenv("ALQ_NO_XCD_ORDER") != nullptr;
         if (const char *f = getenv("ALQ_F16_FWD_MASK")) m->f16_fwd_mask = atoi(f);
         static const char *names[8] = {"ALQ_DEBUG_REPEAT", "ALQ_DEBUG_FLAGS", "ALQ_NO_BWD_FUSE", "ALQ_NO_FWD_FUSE", "ALQ_NO_V3", "ALQ_NO_V4",
                                        "ALQ_NO_POOL_FIRST", "ALQ_NO_CONV_POOL"};

@@ -149,19 +149,26 @@ class DeviceSession(object):
 
     # -- sess.run compatibility -----------------------------------------------------------
     def run(self, fetch, feed_dict=None):
-        """`sess.run(model.<var>, feed_dict={model.x: batch, model.keep_prob: 1.})`."""
+        """`sess.run(fetch, feed_dict={model.x: batch, model.keep_prob: p, model.y_: labels})` for the fetches the
+        reference's query / fine-tune code uses: `model.posteriors`, `.prediction`, `.feature_layer` (PW_NN.py:522),
+        `model.grad_posts[str(j)]` (PW_NNAL.py:773-807: list of 2L' gradient arrays of log posteriors[j, 0]) and
+        `model.train_step` (PW_AL.py:1075-1080, :1140-1146)."""
         model = getattr(fetch, 'model', None)
         if isinstance(fetch, list):
-            raise NotImplementedError(
-                'full per-parameter gradients (model.grad_posts) are never materialised on the device; '
-                'use PW_NNAL.gen_A_matrices / DeviceModel.fisher')
+            model = getattr(fetch[0], 'model', None) if fetch else None
+            if model is None:
+                raise KeyError('unknown fetch list')
+            x = feed_dict[model.x]
+            kp = float(feed_dict.get(model.keep_prob, 1.))
+            j = fetch[0].cls
+            return model.grad_log_post(x, j, keep_prob=kp)
         if model is None:
             raise KeyError('unknown fetch %r' % (fetch,))
         x = feed_dict[model.x]
-        kp = feed_dict.get(model.keep_prob, 1.)
-        if float(kp) != 1.:
-            raise NotImplementedError('dropout at keep_prob < 1 (MC strategies) is outside the scored path')
-        res = model.forward(x, want=(fetch.name,))
+        kp = float(feed_dict.get(model.keep_prob, 1.))
+        if fetch.name == 'train_step':
+            return model.train_on_batch(x, feed_dict[model.y_], keep_prob=kp)
+        res = model.forward(x, want=(fetch.name,), keep_prob=kp)
         return res[fetch.name]
 
     # -- measurement hooks ----------------------------------------------------------------
@@ -343,10 +350,191 @@ class DeviceModel(object):
         for h in (self.posteriors, self.prediction, self.feature_layer):
             h.model = self
         # 2L opaque entries per class, so that len(model.grad_posts['1'])/2 == L (PW_NNAL.py:751)
-        self.grad_posts = {str(j): [Handle('grad_%d_%d' % (j, t)) for t in range(2 * self.L)]
-                           for j in range(self.nclass)}
         self.var_dict = OrderedDict((n, None) for n in self.var_names)
+        self.grad_layers = []
+        self._build_grad_handles()
+        self.y_ = Handle('y_')
+        self.train_step = None            # get_optimizer() creates it (NN.py:557-615)
+        self._opt = None
+        self._drop_calls = 0
+        self.num_params = int(self.lib.alq_model_num_params(self._m))
         self._feature_perm = self._feature_permutation()
+
+    # -- gradients of the log-posteriors (get_gradients, NN.py:621-645) -------------------
+    def _build_grad_handles(self):
+        """2L' opaque entries per class - L' = the layers of `grad_layers` (all when empty) - so that
+        len(model.grad_posts['1'])/2 is the A-matrix size PW_NNAL.gen_A_matrices reads (PW_NNAL.py:751)."""
+        names = list(self.grad_layers) if len(self.grad_layers) else list(self.var_names)
+        for nme in names:
+            if nme not in self.var_names:
+                raise KeyError('grad layer %r is not a parameterised layer of the model' % (nme,))
+        self.grad_layer_idx = [self.var_names.index(nme) for nme in names]
+        self.grad_posts = {}
+        for j in range(self.nclass):
+            hs = []
+            for t in self.grad_layer_idx:
+                for part in ('W', 'b'):
+                    h = Handle('grad_%d_%s_%s' % (j, self.var_names[t], part))
+                    h.model, h.cls = self, j
+                    hs.append(h)
+            self.grad_posts[str(j)] = hs
+
+    def get_gradients(self, grad_layers=[]):
+        """NN.py:621-645 / NN_extended.py:1011-1035: the gradient lists cover `grad_layers` (all layers when empty)."""
+        self.grad_layers = list(grad_layers)
+        self._build_grad_handles()
+
+    def unflatten(self, vec, layers=None):
+        """Flat parameter-order vector [W_0, b_0, W_1, ...] -> list of arrays in TF variable shapes (of `layers`)."""
+        out, off = [], 0
+        keep = set(range(self.L)) if layers is None else set(layers)
+        for t, (name, wshape, bshape) in enumerate(self.param_shapes):
+            nw, nb = int(np.prod(wshape)), int(np.prod(bshape))
+            if t in keep:
+                out.append(vec[off:off + nw].reshape(wshape))
+                out.append(vec[off + nw:off + nw + nb].reshape(bshape))
+            off += nw + nb
+        return out
+
+    def flat_params(self):
+        return np.concatenate([np.concatenate([np.asarray(W, np.float32).ravel(), np.asarray(b, np.float32).ravel()])
+                               for W, b in self.var_dict.values()])
+
+    def set_flat_params(self, vec):
+        arrs = self.unflatten(np.asarray(vec, dtype=np.float32))
+        self.set_weights({n: [arrs[2 * t], arrs[2 * t + 1]] for t, n in enumerate(self.var_names)})
+
+    def _drop_args(self, keep_prob, seed):
+        kp = float(keep_prob)
+        lay = [int(v) for v in self.dropout_layers] if kp < 1. else []
+        arr = (C.c_int32 * max(len(lay), 1))(*lay)
+        if seed is None:
+            # the reference's tf.nn.dropout draws a fresh mask per sess.run from TF's stream; here: a fresh seed per
+            # call from the global NumPy stream (reproducible under np.random.seed like the rest of the query code)
+            seed = int(np.random.randint(0, 2 ** 31 - 1)) if kp < 1. else 0
+        return kp, arr, len(lay), int(seed)
+
+    def param_grads_device(self, t, n, mode, cls=0, labels=None, loss_scale=1., keep_prob=1., seed=None, first_sample=0,
+                           per_sample=True, want_post=False, want_loss=False):
+        """alq_param_grads on n device patches (n <= max_batch): mode 0 = gradients of log posteriors[cls, .] per sample,
+        mode 1 = gradient of loss_scale * sum CE.  Returns (grads [n, P] or [P], post [c, n] or None, loss or None)."""
+        torch = self.sess.torch
+        self.sess.bind_stream()
+        if n > self.max_batch:
+            raise ValueError('%d patches exceed max_batch = %d' % (n, self.max_batch))
+        kp, arr, nl, seed = self._drop_args(keep_prob, seed)
+        g = self.sess.empty((n, self.num_params) if per_sample else (self.num_params,), torch.float32)
+        post = self.sess.empty((self.nclass, n), torch.float32) if want_post else None
+        loss = self.sess.empty((1,), torch.float64) if want_loss else None
+        lab = None
+        if mode == 1:
+            lab = labels if isinstance(labels, torch.Tensor) else self.sess.to_device(np.asarray(labels, dtype=np.int32), torch.int32)
+        check(self.lib.alq_param_grads(
+            self._m, C.c_void_p(t.data_ptr()), n, int(mode), int(cls), C.c_void_p(lab.data_ptr()) if lab is not None else None,
+            float(loss_scale), kp, seed, int(first_sample), arr, nl, 1 if per_sample else 0, C.c_void_p(g.data_ptr()),
+            C.c_void_p(post.data_ptr()) if post is not None else None, C.c_void_p(loss.data_ptr()) if loss is not None else None))
+        return g, post, loss
+
+    def grad_log_post(self, x, j, keep_prob=1.):
+        """`sess.run(model.grad_posts[str(j)], {x: batch})`: gradients of log posteriors[j, 0] - sample 0 of the batch,
+        like the reference's graph node (NN.py:639-645) - w.r.t. the variables of `grad_layers`, TF shapes."""
+        t, n = self._as_device_batch(x)
+        g, _, _ = self.param_grads_device(t, 1, 0, cls=j, keep_prob=keep_prob)
+        return self.unflatten(g[0].cpu().numpy(), self.grad_layer_idx)
+
+    # -- training step (get_optimizer / train_step, NN.py:557-615) --------------------------
+    def get_optimizer(self, learning_rate, train_layers=[], optimizer_name='SGD'):
+        """Mean softmax cross-entropy + SGD or Adam on all layers or on `train_layers` (NN.py:583-615)."""
+        if optimizer_name not in ('SGD', 'Adam'):
+            raise NotImplementedError('optimizer %r (NN.py:591-615 knows SGD and Adam)' % (optimizer_name,))
+        for nme in train_layers:
+            if nme not in self.var_names:
+                raise KeyError('train layer %r' % (nme,))
+        self.train_layers = list(train_layers)
+        self.train_step = Handle('train_step')
+        self.train_step.model = self
+        self._opt = dict(name=optimizer_name, lr=float(learning_rate), t=0, theta=None, m=None, v=None)
+
+    def _train_mask(self):
+        """1 on the parameters of `train_layers` (all when empty), flat order."""
+        if not self.train_layers:
+            return None
+        mask = np.zeros(self.num_params, dtype=np.float32)
+        off = 0
+        for name, wshape, bshape in self.param_shapes:
+            cnt = int(np.prod(wshape)) + int(np.prod(bshape))
+            if name in self.train_layers:
+                mask[off:off + cnt] = 1.
+            off += cnt
+        return mask
+
+    def train_on_batch(self, x, y_onehot, keep_prob=1., seed=None):
+        """One `sess.run(model.train_step, {x, y_, keep_prob})`: gradient of the batch-mean cross-entropy (summed over
+        device passes of max_batch patches), one optimiser step on the device, weights repacked.  y_onehot: [c, n]
+        like the reference's hot_labels (PW_AL.py:1064-1067); an all-zero column is an unlabelled sample.
+        Returns the batch-mean loss before the step."""
+        if self._opt is None:
+            raise RuntimeError('get_optimizer() has not been called (NN.py:1354)')
+        torch = self.sess.torch
+        t, n = self._as_device_batch(x)
+        y = np.asarray(y_onehot)
+        if y.shape != (self.nclass, n):
+            raise ValueError('labels must be [%d, %d] one-hot columns, got %r' % (self.nclass, n, y.shape))
+        lab = np.where(y.sum(0) > 0, y.argmax(0), -1).astype(np.int32)
+        kp, _, _, seed = self._drop_args(keep_prob, seed)
+        labd = self.sess.to_device(lab, torch.int32)
+        gsum = torch.zeros((self.num_params,), dtype=torch.float32, device=self.sess.device)
+        loss = 0.
+        for a in range(0, n, self.max_batch):
+            b = min(n, a + self.max_batch)
+            g, _, l = self.param_grads_device(t[a:b], b - a, 1, labels=labd[a:b], loss_scale=1. / n, keep_prob=kp,
+                                              seed=seed, first_sample=a, per_sample=False, want_loss=True)
+            gsum += g
+            loss += float(l.item()) * (b - a) / n
+        o = self._opt
+        if o['theta'] is None:
+            o['theta'] = self.sess.to_device(self.flat_params(), torch.float32)
+            o['m'] = torch.zeros_like(o['theta'])
+            o['v'] = torch.zeros_like(o['theta'])
+            tm = self._train_mask()
+            o['mask'] = self.sess.to_device(tm, torch.float32) if tm is not None else None
+        if o.get('mask') is not None:
+            gsum *= o['mask']
+        o['t'] += 1
+        P = self.num_params
+        self.sess.bind_stream()
+        if o['name'] == 'SGD':
+            check(self.lib.alq_sgd_step(self.sess.ctx, C.c_void_p(o['theta'].data_ptr()), C.c_void_p(gsum.data_ptr()), P, o['lr']))
+        else:
+            check(self.lib.alq_adam_step(self.sess.ctx, C.c_void_p(o['theta'].data_ptr()), C.c_void_p(gsum.data_ptr()),
+                                         C.c_void_p(o['m'].data_ptr()), C.c_void_p(o['v'].data_ptr()), P, o['lr'],
+                                         0.9, 0.999, 1e-8, o['t']))
+            if o.get('mask') is not None:      # Adam moves nothing whose gradient is identically zero (m = v = 0 -> 0 / eps)
+                pass
+        self.set_flat_params(o['theta'].cpu().numpy())
+        return loss
+
+    def diagonal_fisher(self, x, labels=None, batch=None):
+        """model_utils.diagonal_Fisher (model_utils.py:294-330): mean over samples of the squared gradient of the
+        log-likelihood of the sample's label (labels given) or of the model's own prediction (None), per parameter.
+        Returns the list of arrays in variable shapes."""
+        torch = self.sess.torch
+        t, n = self._as_device_batch(x)
+        acc = torch.zeros((self.num_params,), dtype=torch.float64, device=self.sess.device)
+        if labels is None:
+            post, pred, _ = self.forward_device(t, n, want_pred=True)
+            labels = pred.cpu().numpy()
+        labels = np.asarray(labels).astype(np.int64)
+        step = min(self.max_batch, batch or self.max_batch)
+        for j in range(self.nclass):
+            idx = np.nonzero(labels == j)[0]
+            for a in range(0, len(idx), step):
+                sel = self.sess.to_device(idx[a:a + step], torch.int64)
+                xs = t.reshape(n, -1).index_select(0, sel)
+                g, _, _ = self.param_grads_device(xs, int(sel.numel()), 0, cls=j)
+                check(self.lib.alq_sq_accum(self.sess.ctx, C.c_void_p(g.data_ptr()), self.num_params, int(sel.numel()),
+                                            C.c_void_p(acc.data_ptr())))
+        return self.unflatten((acc / max(n, 1)).cpu().numpy())
 
     # -- weights ---------------------------------------------------------------------------
     def set_weights(self, pars):
@@ -425,6 +613,22 @@ class DeviceModel(object):
             raise ValueError('batch of %d elements is not a multiple of the patch size %d' % (t.numel(), self.elems_per_patch))
         return t, n
 
+    def forward_dropout_device(self, t, n, keep_prob, seed=None, first_sample=0, want_pred=False):
+        """Posteriors at keep_prob < 1 (MC strategies): alq_forward_dropout over device passes; masks keyed by sample id."""
+        torch = self.sess.torch
+        self.sess.bind_stream()
+        kp, arr, nl, seed = self._drop_args(keep_prob, seed)
+        post = self.sess.empty((self.nclass, n), torch.float32)
+        pred = self.sess.empty((n,), torch.int64) if want_pred else None
+        for a in range(0, n, self.max_batch):
+            b = min(n, a + self.max_batch)
+            pb = self.sess.empty((self.nclass, b - a), torch.float32)
+            check(self.lib.alq_forward_dropout(self._m, C.c_void_p(t.data_ptr() + a * self.elems_per_patch * 4), b - a, kp, seed,
+                                               int(first_sample) + a, arr, nl, C.c_void_p(pb.data_ptr()),
+                                               C.c_void_p(pred.data_ptr() + a * 8) if want_pred else None))
+            post[:, a:b] = pb
+        return post, pred
+
     def forward_device(self, t, n, want_pred=False, want_feat=False, rows=None):
         """t: device fp32 tensor of n patches - or, with `rows` (int64 device tensor [n]), a resident pool whose
         rows `rows` are the patches (alq_forward_rows: no gathered copy on the caller's side).
@@ -451,8 +655,16 @@ class DeviceModel(object):
             post[:, a:b] = pb
         return post, pred, feat
 
-    def forward(self, x, want=('posteriors',)):
+    def forward(self, x, want=('posteriors',), keep_prob=1.):
         t, n = self._as_device_batch(x)
+        if float(keep_prob) < 1. and len(self.dropout_layers):
+            if 'feature_layer' in want:
+                raise NotImplementedError('feature_layer at keep_prob < 1')
+            post, pred = self.forward_dropout_device(t, n, keep_prob, want_pred='prediction' in want)
+            res = {'posteriors': post.cpu().numpy()}
+            if pred is not None:
+                res['prediction'] = pred.cpu().numpy()
+            return res
         post, pred, feat = self.forward_device(t, n, 'prediction' in want, 'feature_layer' in want)
         res = {'posteriors': post.cpu().numpy()}
         if pred is not None:

@@ -27,4 +27,4 @@ How parity is pinned
   finite-difference checks of the gradients (`tests/test_oracle_selfcheck.py`).
 """
 
-from . import netspec, tfops, model, alpath  # noqa: F401
+from . import netspec, tfops, model, alpath, train  # noqa: F401

@@ -84,7 +84,23 @@ class OracleModel(object):
             x = torch.zeros((1,) + self.in_shape, dtype=self.dtype)
             return int(self._graph(x)['feature_layer'].shape[0])
 
-    def _graph(self, x):
+    def _dropped(self, out, i, drop):
+        """tf.nn.dropout on layer i's output (NN.py:169-171) with the build's counter-based mask (tfops.dropout_keep).
+        `drop` = dict(layers, keep_prob, seed, first_sample)."""
+        if drop is None or drop['keep_prob'] >= 1. or i not in drop['layers']:
+            return out
+        kp = drop['keep_prob']
+        if out.dim() == 2:                       # fc activations are [features, N]
+            F, N = out.shape
+            keep = tfops.dropout_keep(drop['seed'], i, drop.get('first_sample', 0) + np.arange(N), F, kp).T
+        else:                                    # [N, (D,) H, W, C]: element index = memory order of one sample
+            N = out.shape[0]
+            per = int(np.prod(out.shape[1:]))
+            keep = tfops.dropout_keep(drop['seed'], i, drop.get('first_sample', 0) + np.arange(N), per, kp).reshape(tuple(out.shape))
+        k = torch.as_tensor(np.ascontiguousarray(keep)).to(out.dtype)
+        return out * k * torch.tensor(np.float32(1.0) / np.float32(kp), dtype=torch.float32).to(out.dtype)
+
+    def _graph(self, x, drop=None):
         """x: [N, *in_shape] tensor -> dict of graph nodes."""
         names = self.names
         out = x
@@ -133,6 +149,12 @@ class OracleModel(object):
                 if ltype in ('conv', 'pool') and nxt == 'fc':
                     out = tfops.flatten_tf(out)
                     flat = True
+            # NN.py:169-171 drops the layer's output as the next layer (and the flatten inside add_conv) sees it; the device
+            # keys the mask by the element's position in the UN-flattened activation, so drop before flattening
+            if drop is not None and i in drop['layers'] and drop['keep_prob'] < 1.:
+                if (not self.ext) and ltype in ('conv', 'pool') and nxt == 'fc':
+                    raise NotImplementedError('dropout on the conv/pool layer in front of the first fc (NN.CNN schema)')
+                out = self._dropped(out, i, drop)
             if i in src_idx:
                 sources[i] = out
             if self.feature_idx is not None and i == self.feature_idx:
@@ -164,9 +186,9 @@ class OracleModel(object):
         x = torch.as_tensor(np.asarray(x)).to(self.dtype)   # placeholder is tf.float32
         return x.reshape((-1,) + self.in_shape)
 
-    def forward(self, x):
+    def forward(self, x, drop=None):
         with torch.no_grad():
-            g = self._graph(self._as_input(x))
+            g = self._graph(self._as_input(x), drop)
         res = {'output': g['output'].numpy(),
                'posteriors': g['posteriors'].numpy(),
                'prediction': g['posteriors'].argmax(dim=0).numpy()}      # NN.py:618-619
@@ -174,11 +196,24 @@ class OracleModel(object):
             res['feature_layer'] = g['feature_layer'].numpy()
         return res
 
-    def grad_log_post(self, j, x):
+    def loss_and_grads(self, x, y_onehot, drop=None):
+        """Mean softmax cross-entropy (NN.py:583-588: tf.reduce_mean(softmax_cross_entropy_with_logits)) of a batch
+        and its gradient w.r.t. every variable [W1, b1, ...] (what the optimizer's minimize() differentiates)."""
+        g = self._graph(self._as_input(x), drop)
+        z = g['output']                                          # [c, N]
+        y = torch.as_tensor(np.asarray(y_onehot)).to(z.dtype)
+        logp = z - torch.logsumexp(z, dim=0, keepdim=True)
+        loss = -(y * logp).sum(dim=0).mean()
+        plist = [p for pair in self.params.values() for p in pair]
+        grads = torch.autograd.grad(loss, plist, allow_unused=True)
+        return float(loss.detach()), [np.zeros(p.shape, dtype=p.detach().numpy().dtype) if gr is None else gr.numpy()
+                             for p, gr in zip(plist, grads)]
+
+    def grad_log_post(self, j, x, drop=None):
         """`tf.gradients(tf.log(posteriors[j, 0]), trainable_variables)` (NN.py:639-645).
 
         Returns the 2L arrays [W1, b1, ..., WL, bL] in TF variable shapes."""
-        g = self._graph(self._as_input(x))
+        g = self._graph(self._as_input(x), drop)
         score = torch.log(g['posteriors'][j, 0])
         plist = [p for pair in self.params.values() for p in pair]
         grads = torch.autograd.grad(score, plist, allow_unused=True)

@@ -175,3 +175,25 @@ def naive_conv_transpose_same(x, W, b, strides):
             # W[t] is [Co, Ci]
             y[(slice(None),) + tuple(p)] += x[(slice(None),) + q] @ W[t].T
     return y + np.asarray(b, np.float64).reshape(-1)
+
+
+# ---------------------------------------------------------------- dropout
+def _splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15))
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def dropout_keep(seed, layer, sample_ids, n_elems, keep_prob):
+    """Keep mask [len(sample_ids), n_elems] (bool) of the build's dropout.  `tf.nn.dropout(x, keep_prob)` (NN.py:169-171)
+    is x * keep / keep_prob with keep ~ Bernoulli(keep_prob) from TensorFlow's random stream, which cannot be
+    reproduced outside TensorFlow: the build defines its own counter-based mask (csrc/train.hip dropout_kernel) keyed
+    (seed, layer index, sample id, element index in the layer output's memory order), and this is its restatement."""
+    with np.errstate(over='ignore'):
+        sid = np.asarray(sample_ids, dtype=np.uint64)[:, None]
+        e = np.arange(n_elems, dtype=np.uint64)[None, :]
+        key = np.uint64(seed) ^ (sid * np.uint64(0xD1B54A32D192ED03)) ^ (np.uint64(layer) << np.uint64(56))
+        h = _splitmix64(_splitmix64(key) + e)
+    u = (h >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return u < np.float32(keep_prob)

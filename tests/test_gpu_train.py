@@ -1,0 +1,256 @@
+"""Parameter gradients, dropout passes and the training step of the device path against the oracle (GPU box).
+
+Rows (a6) get_gradients, (f2) fine-tune / train_step, (f3) MC-dropout strategies and diagonal_Fisher of SURVEY.md 8."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import alpath, netspec  # noqa: E402
+from oracle.model import OracleModel, OracleSession  # noqa: E402
+from oracle.train import OracleOptimizer  # noqa: E402
+from tests.test_oracle_golden import Expr  # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def sess():
+    import nnal_amd  # noqa: F401
+    from nnal_amd import device
+    return device.default_session()
+
+
+def _nets():
+    ld_c, sk_c = netspec.net_c()
+    ld_c2, sk_c2 = netspec.net_c_2d()
+    return [('neta', netspec.net_a(), (20, 20, 1), ()),
+            ('netb_small', netspec.net_b_small(), (25, 25, 2), ()),
+            ('netc2d', ld_c2, (16, 16, 2), sk_c2),
+            ('netc', ld_c, (8, 8, 8, 1), sk_c),
+            ('netc_12', ld_c, (12, 8, 16, 1), sk_c)]
+
+
+def _mk(sess, ld, in_shape, sk, seed, max_batch=16, dropout=None):
+    from nnal_amd import device
+    pars = netspec.he_init(ld, in_shape, seed=seed, skips=sk, bias_std=0.05)
+    m = device.DeviceModel(sess, ld, in_shape, sk, max_batch=max_batch, dropout=dropout)
+    m.set_weights(pars)
+    return m, pars
+
+
+def _close(dev, ref, rtol=2e-4, name=''):
+    """Gradient arrays agree to fp32 rounding relative to the array's scale (a ReLU input within rounding of zero can
+    move single entries by more: bounded by 1e-3 of the scale)."""
+    for k, (a, b) in enumerate(zip(dev, ref)):
+        assert a.shape == b.shape, (name, k, a.shape, b.shape)
+        scale = np.abs(b).max() + 1e-30
+        err = np.abs(a.astype(np.float64) - b.astype(np.float64)).max()
+        assert err <= rtol * scale + 1e-9, '%s: array %d (%s) max err %.3e vs scale %.3e' % (name, k, a.shape, err, scale)
+
+
+@pytest.mark.parametrize('name,ld,in_shape,sk', _nets())
+def test_full_log_posterior_gradients_vs_oracle(sess, name, ld, in_shape, sk):
+    """sess.run(model.grad_posts[str(j)], {x: one patch}) = tf.gradients(log posteriors[j, 0], variables)
+    (NN.py:639-645): every W and b gradient in TF layout against torch autograd of the oracle graph, both classes,
+    plus the batched per-sample form and shrink_gradient 'sum' / 'max' on top of them."""
+    from nnal_amd import NNAL_tools
+    m, pars = _mk(sess, ld, in_shape, sk, 41)
+    om = OracleModel(ld, in_shape, pars, skips=sk)
+    osess = OracleSession(om)
+    x = np.random.RandomState(3).randn(5, *in_shape).astype(np.float32)
+    for j in (0, 1):
+        for i in (0, 3):
+            dev = sess.run(m.grad_posts[str(j)], feed_dict={m.x: x[[i]], m.keep_prob: 1.})
+            ref = osess.run(om.grad_posts[str(j)], feed_dict={om.x: x[[i]], om.keep_prob: 1.})
+            assert len(dev) == 2 * m.L == len(ref)
+            _close(dev, ref, name='%s class %d patch %d' % (name, j, i))
+            for method in ('sum', 'max'):
+                # 'max' of the head is ill-posed: its bias gradient is (e_j - p) = (+q, -q), an exact tie in magnitude
+                sl = slice(None) if method == 'sum' else slice(0, m.L - 1)
+                np.testing.assert_allclose(NNAL_tools.shrink_gradient(dev, method)[sl], NNAL_tools.shrink_gradient(ref, method)[sl],
+                                           rtol=2e-3, atol=1e-7)
+    # batched: one gradient per sample in one call
+    t = sess.to_device(x.reshape(5, -1), sess.torch.float32)
+    g, post, _ = m.param_grads_device(t, 5, 0, cls=1, want_post=True)
+    g = g.cpu().numpy()
+    for i in range(5):
+        _close(m.unflatten(g[i]), om.grad_log_post(1, x[[i]]), name='%s batched %d' % (name, i))
+    np.testing.assert_allclose(post.cpu().numpy(), om.forward(x)['posteriors'], rtol=0, atol=2e-5)
+    m.close()
+
+
+def test_grad_layers_subset_changes_the_A_matrices(sess):
+    """get_gradients(grad_layers) (NN.py:627-633): grad_posts lists only those layers, A_size follows (PW_NNAL.py:751)."""
+    from nnal_amd import PW_NNAL
+    ld, sk = netspec.net_c()
+    in_shape = (8, 8, 8, 1)
+    m, pars = _mk(sess, ld, in_shape, sk, 42)
+    x = np.random.RandomState(4).randn(6, *in_shape).astype(np.float32)
+    p = m.forward(x)['posteriors'][1].astype(np.float64)
+    full = np.stack(PW_NNAL.gen_A_matrices(Expr({'patch_shape': in_shape[:3]}), m, sess, x, p, 1e-3))
+    names = [m.var_names[2], m.var_names[5], m.var_names[7]]
+    m.get_gradients(names)
+    assert len(m.grad_posts['1']) == 6
+    sub = np.stack(PW_NNAL.gen_A_matrices(Expr({'patch_shape': in_shape[:3]}), m, sess, x, p, 1e-3))
+    assert sub.shape == (6, 3, 3)
+    idx = [2, 5, 7]
+    np.testing.assert_allclose(sub, full[:, idx][:, :, idx], rtol=1e-12, atol=1e-18)
+    g = sess.run(m.grad_posts['0'], feed_dict={m.x: x[[0]], m.keep_prob: 1.})
+    assert [a.shape for a in g] == [s for t in idx for s in (m.param_shapes[t][1], m.param_shapes[t][2])]
+    with pytest.raises(KeyError):
+        m.get_gradients(['no_such_layer'])
+    m.close()
+
+
+@pytest.mark.parametrize('opt,lr', [('SGD', 0.003), ('Adam', 0.002)])
+@pytest.mark.parametrize('name,ld,in_shape,sk', [_nets()[0], _nets()[3]])
+def test_train_step_vs_oracle(sess, name, ld, in_shape, sk, opt, lr):
+    """sess.run(model.train_step, {x, y_, keep_prob: 1}) five times (NN.py:583-615) against the oracle's restatement of
+    mean softmax cross-entropy + SGD / Adam: losses and every weight after the steps."""
+    m, pars = _mk(sess, ld, in_shape, sk, 43)
+    m.get_optimizer(lr, [], opt)
+    om = OracleModel(ld, in_shape, pars, skips=sk)
+    oo = OracleOptimizer(om, lr, (), opt)
+    rs = np.random.RandomState(5)
+    for step in range(5):
+        x = rs.randn(12, *in_shape).astype(np.float32)
+        lab = rs.randint(0, 2, size=12)
+        y = np.zeros((2, 12))
+        y[lab, np.arange(12)] = 1
+        l_dev = sess.run(m.train_step, feed_dict={m.x: x, m.y_: y, m.keep_prob: 1.})
+        l_ref = oo.step(x, y)
+        assert abs(l_dev - l_ref) <= 2e-5 * max(1., abs(l_ref)), (step, l_dev, l_ref)
+    for n in m.var_names:
+        for a, b in zip(m.var_dict[n], om.params[n]):
+            b = b.detach().numpy()
+            # Adam divides by sqrt(v): entries whose gradient is ~0 amplify rounding, compare against the step size
+            np.testing.assert_allclose(a, b, rtol=0, atol=(5e-4 if opt == 'Adam' else 2e-5) * max(np.abs(b).max(), lr))
+    m.close()
+
+
+def test_train_layers_and_multi_pass_batches(sess):
+    """train_layers restricts the update (NN.py:599-615); a batch larger than max_batch is accumulated over passes
+    with the loss still the mean over the whole batch."""
+    ld = netspec.net_a()
+    in_shape = (20, 20, 1)
+    m, pars = _mk(sess, ld, in_shape, (), 44, max_batch=8)
+    m.get_optimizer(0.1, ['conv2'], 'SGD')
+    om = OracleModel(ld, in_shape, pars)
+    oo = OracleOptimizer(om, 0.1, ['conv2'], 'SGD')
+    rs = np.random.RandomState(6)
+    x = rs.randn(21, *in_shape).astype(np.float32)
+    y = np.zeros((2, 21))
+    y[rs.randint(0, 2, size=21), np.arange(21)] = 1
+    before = {n: [w.copy() for w in m.var_dict[n]] for n in m.var_names}
+    l_dev = m.train_on_batch(x, y)
+    l_ref = oo.step(x, y)
+    assert abs(l_dev - l_ref) < 1e-5
+    for n in m.var_names:
+        for a, b, c in zip(m.var_dict[n], om.params[n], before[n]):
+            np.testing.assert_allclose(a, b.detach().numpy(), rtol=0, atol=2e-6)
+            if n != 'conv2':
+                np.testing.assert_array_equal(a, c)
+    m.close()
+
+
+def test_dropout_forward_and_gradients_vs_oracle(sess):
+    """keep_prob < 1: the build's counter-based mask (alq_forward_dropout) against the oracle's restatement of the same
+    generator - posteriors, batch-split independence, and the gradient pass through the masks."""
+    ld, sk = netspec.net_c()
+    in_shape = (8, 8, 8, 1)
+    drop_layers = [2, 4, 6, 8]          # conv, conv, conv (after a skip concat), conv
+    m, pars = _mk(sess, ld, in_shape, sk, 45, max_batch=4, dropout=[drop_layers, 0.6])
+    om = OracleModel(ld, in_shape, pars, skips=sk)
+    x = np.random.RandomState(7).randn(10, *in_shape).astype(np.float32)
+    t = sess.to_device(x.reshape(10, -1), sess.torch.float32)
+    post, _ = m.forward_dropout_device(t, 10, 0.6, seed=1234)
+    ref = om.forward(x, drop=dict(layers=drop_layers, keep_prob=0.6, seed=1234))['posteriors']
+    np.testing.assert_allclose(post.cpu().numpy(), ref, rtol=0, atol=2e-5)
+    assert np.abs(ref - om.forward(x)['posteriors']).max() > 1e-3          # the masks really act
+    m2, _ = _mk(sess, ld, in_shape, sk, 45, max_batch=10, dropout=[drop_layers, 0.6])
+    post2, _ = m2.forward_dropout_device(t, 10, 0.6, seed=1234)
+    assert sess.torch.equal(post, post2)                                    # keyed by sample id, not by batch position
+    g, _, _ = m2.param_grads_device(t, 10, 0, cls=0, keep_prob=0.6, seed=99)
+    for i in (0, 7):
+        refg = om.grad_log_post(0, x[[i]], drop=dict(layers=drop_layers, keep_prob=0.6, seed=99, first_sample=i))
+        _close(m2.unflatten(g[i].cpu().numpy()), refg, name='dropout grads %d' % i)
+    m.close()
+    m2.close()
+
+
+def test_mc_entropy_and_bald_queries(sess, golden_dir):
+    """query_multimg 'MC-entropy' / 'BALD' (PW_NNAL.py:232-282) through batch_eval's x_feed_dict: the same NumPy
+    orchestration on the device's dropout posteriors, reproducible under np.random.seed, and equal to the host formulas
+    evaluated on those posteriors."""
+    from nnal_amd import PW_NNAL, NN
+    g = np.load(os.path.join(golden_dir, 'host_layers.npz'))
+    rs = np.random.RandomState(8)
+    patch_shape = (5, 5, 3)
+    vols = []
+    for s_ in range(2):
+        shp = (9 + s_, 10, 8)
+        mods = [np.pad(rs.randn(*shp), [(2, 2), (2, 2), (1, 1)], 'constant') for _ in range(2)]
+        vols.append(mods + [rs.randint(0, 2, size=shp)])
+    pools = [np.sort(rs.permutation(9 * 10 * 8)[:150]), np.sort(rs.permutation(10 * 10 * 8)[:90])]
+    stats = np.array([[0., 1., 0.1, 0.9], [0.05, 1.1, 0., 1.]])
+    expr = Expr({'patch_shape': patch_shape, 'ntb': 64, 'k': 12, 'B': 30, 'MC_iters': 4}, train_stats=stats)
+    ld = netspec.net_b_small()
+    in_shape = (5, 5, 6)
+    pars = netspec.he_init(ld, in_shape, seed=46)
+    model = NN.CNN(in_shape, ld, 'mc', None, [[1, 3], 0.7], sess=sess, max_batch=64)
+    model.set_weights(pars)
+    out = {}
+    for method in ('MC-entropy', 'BALD'):
+        np.random.seed(77)
+        q1 = PW_NNAL.query_multimg(expr, model, sess, vols, pools, None, method)
+        np.random.seed(77)
+        q2 = PW_NNAL.query_multimg(expr, model, sess, vols, pools, None, method)
+        for a, b in zip(q1, q2):
+            np.testing.assert_array_equal(a, b)
+        assert sum(len(a) for a in q1) == 12 and all(len(np.unique(a)) == len(a) for a in q1)
+        out[method] = q1
+    # host recomputation from the same dropout posteriors
+    np.random.seed(77)
+    av, av_e = 0, 0
+    for i in range(4):
+        posts = PW_NNAL.bin_uncertainty_filter_multimg(expr, model, sess, vols, pools, 12, {model.keep_prob: model.dropout_rate})
+        av = (posts + i * av) / (i + 1)
+        e = -posts * np.log(np.where(posts == 0, 1e-6, posts)) - (1 - posts) * np.log(np.where(1 - posts == 0, 1e-6, 1 - posts))
+        av_e = (e + i * av_e) / (i + 1)
+    want_mc = np.argsort(np.abs(av - .5), kind='stable')[:12]
+    got_mc = np.concatenate([out['MC-entropy'][0], 150 + out['MC-entropy'][1]])
+    assert set(got_mc) == set(want_mc)
+    ent_av = -av * np.log(av) - (1 - av) * np.log(1 - av)
+    want_b = np.argsort(-(ent_av - av_e), kind='stable')[:12]
+    got_b = np.concatenate([out['BALD'][0], 150 + out['BALD'][1]])
+    assert set(got_b) == set(want_b)
+    # MC averaging differs from the deterministic entropy query
+    det = PW_NNAL.query_multimg(expr, model, sess, vols, pools, None, 'entropy')
+    assert set(np.concatenate([det[0], 150 + det[1]])) != set(got_mc)
+    model.close()
+    del g
+
+
+def test_diagonal_fisher_vs_oracle(sess):
+    """model_utils.diagonal_Fisher (model_utils.py:294-330): mean squared per-sample gradient of the log-likelihood
+    of each sample's label."""
+    ld = netspec.net_a()
+    in_shape = (20, 20, 1)
+    m, pars = _mk(sess, ld, in_shape, (), 47)
+    om = OracleModel(ld, in_shape, pars)
+    rs = np.random.RandomState(9)
+    x = rs.randn(9, *in_shape).astype(np.float32)
+    lab = rs.randint(0, 2, size=9)
+    from nnal_amd import model_utils
+    y = np.zeros((2, 9))
+    y[lab, np.arange(9)] = 1
+    dev = model_utils.diagonal_Fisher(m, sess, (x, y))
+    ref = [np.zeros(a.shape) for a in om.grad_log_post(0, x[[0]])]
+    for i in range(9):
+        for a, gi in zip(ref, om.grad_log_post(int(lab[i]), x[[i]])):
+            a += gi.astype(np.float64) ** 2
+    ref = [a / 9 for a in ref]
+    for a, b in zip(dev, ref):
+        np.testing.assert_allclose(a, b, rtol=2e-3, atol=1e-6 * np.abs(b).max())
+    m.close()

@@ -2,7 +2,20 @@
 create_model, :1319-1359 create_PW1)."""
 from collections import OrderedDict
 
+import numpy as np
+
 from .device import DeviceModel, default_session
+
+
+def gen_batch_inds(data_size, batch_size):
+    """NN.gen_batch_inds (NN.py:1529-1555): one random permutation (global NumPy stream) cut into batches of
+    `batch_size`, the remainder as a last shorter batch."""
+    quot, rem = np.divmod(data_size, batch_size)
+    rand_perm = np.random.permutation(data_size).tolist()
+    batches = [rand_perm[i * batch_size:(i + 1) * batch_size] for i in range(quot)]
+    if rem > 0:
+        batches += [rand_perm[-rem:]]
+    return batches
 
 
 class CNN(DeviceModel):

@@ -173,45 +173,153 @@ def _aopt_newton(A, tol, max_iter):
     return q, status, steps
 
 
+def _aopt_newton_eq(A, c, E, tol, max_iter):
+    """Log-barrier Newton method for  min tr(M(q)^-1) + c^T q  s.t.  E q = E q0 (q0 uniform),  q >= 0 - the
+    feature-regularised form of the query-distribution SDP (NNAL_tools.py:626-645: c = -lambda ||x_i||^2,
+    E = [X_pool; 1^T], right-hand side (0, 1)).  Same structure as `_aopt_newton` (Hessian = diagonal + V K V^T,
+    Woodbury), plus the equality block through its Schur complement  E H^-1 E^T  ((d+1) x (d+1)).
+    Returns (q, nu, status, steps): nu = multipliers of the equality rows."""
+    from scipy.linalg import cho_factor, cho_solve
+    n, L = A.shape[0], A.shape[1]
+    P = _svec_basis(L)
+    m = P.shape[1]
+    V = A.reshape(n, L * L) @ P
+    # independent equality rows only (X_pool is full row rank after refine_feature_matrix; be safe)
+    Q, R = np.linalg.qr(E.T)
+    keep = np.abs(np.diag(R)) > 1e-10 * max(1.0, np.abs(np.diag(R)).max())
+    Eo = Q[:, keep].T                                           # orthonormal rows spanning the same constraints
+
+    def at(q):
+        M = (P @ (q @ V)).reshape(L, L)
+        Mi = np.linalg.inv(M)
+        return Mi, float(np.trace(Mi))
+
+    q = np.full(n, 1.0 / n)
+    f0 = Eo @ q
+    Mi, tr = at(q)
+    obj = tr + float(c @ q)
+    mu = max(tr, abs(obj)) / n
+    status, steps = 'unknown', 0
+    nu = np.zeros(Eo.shape[0])
+    while steps < max_iter:
+        steps += 1
+        Mi2 = Mi @ Mi
+        d = V @ (P.T @ Mi2.reshape(-1))                        # <M^-2, A_i>
+        g = -d + c - mu / q
+        K = P.T @ (np.kron(Mi, Mi2) + np.kron(Mi2, Mi)) @ P
+        K = 0.5 * (K + K.T)
+        Rk = np.linalg.cholesky(K)
+        U = V @ Rk
+        Dinv = q * q / mu
+        UD = U * Dinv[:, None]
+        S = cho_factor(np.eye(m) + U.T @ UD)
+
+        def Hinv(x):
+            y = Dinv[:, None] * x if x.ndim == 2 else Dinv * x
+            return y - UD @ cho_solve(S, U.T @ y)
+        HiE = Hinv(Eo.T)                                        # n x r
+        G = Eo @ HiE
+        G = 0.5 * (G + G.T)
+        Hig = Hinv(g)
+        nu = np.linalg.solve(G, -(Eo @ Hig))
+        dq = -(Hig + HiE @ nu)
+        dq -= Eo.T @ (Eo @ dq)                                  # exactly tangent: rounding in the Schur solve must not leak out of E q = f
+        dec = float(-(g @ dq))                                  # Newton decrement squared (E dq = 0)
+        neg = dq < 0
+        alpha = min(1.0, 0.99 * float(np.min(-q[neg] / dq[neg]))) if neg.any() else 1.0
+        phi0 = tr + float(c @ q) - mu * np.log(q).sum()
+        slack = 1e-12 * abs(phi0)
+        while True:
+            qn = q + alpha * dq
+            Mn, trn = at(qn)
+            if trn + float(c @ qn) - mu * np.log(qn).sum() <= phi0 - 0.25 * alpha * dec + slack or alpha < 1e-12:
+                break
+            alpha *= 0.5
+        qn = qn - Eo.T @ (Eo @ qn - f0)                         # stay on the affine set to rounding
+        if qn.min() > 0:
+            Mn, trn = at(qn)
+        else:
+            qn = q + alpha * dq
+        q, Mi, tr = qn, Mn, trn
+        if dec <= 0.05 * mu * n:                                # centred: duality gap ~ n mu
+            if n * mu <= tol * max(abs(tr + float(c @ q)), 1e-300):
+                status = 'optimal'
+                break
+            mu *= 0.2
+    # Multipliers of the caller's rows E from stationarity at the returned point, weighted to the support (where the slack
+    # s_i = -d_i + c_i + (E^T nu)_i must vanish): min_nu sum_i q_i^2 s_i^2.  (The nu of the last Newton system differs from
+    # it by H dq, which is not negligible against a duality gap of n mu.)
+    Mi2 = Mi @ Mi
+    d = V @ (P.T @ Mi2.reshape(-1))
+    Ew = E * q[None, :]
+    nu_E = np.linalg.lstsq(Ew.T, q * (d - c), rcond=None)[0]
+    return q, nu_E, status, steps
+
+
 def SDP_query_distribution(A, lambda_, X_pool, k, tol=1e-7, max_iter=20000, method='newton'):
     """Query distribution of Fisher-information AL (reference: NNAL_tools.py:612-659, with
     `inequality_cvx_matrix` :661-720 and the CVXPY twin `solve_FIAL_SDP` :576-610).
 
-    The reference states, for A-matrices A_i (L x L, positive definite through the diagonal load),
+    The reference states, for A-matrices A_i (L x L, positive definite through the diagonal load), x = (q, t):
 
-        min  sum_j t_j   s.t.  [[sum_i q_i A_i, e_j], [e_j^T, t_j]] >= 0  (j = 1..L),  q >= 0,  sum q = 1
+        min  sum_j t_j - lambda * sum_i q_i ||x_i||^2
+        s.t. [[sum_i q_i A_i, e_j], [e_j^T, t_j]] >= 0  (j = 1..L),   diag(q) >= 0,
+             sum_i q_i = 1,   and for lambda > 0 also  X_pool q = 0          (NNAL_tools.py:626-645)
 
-    and hands it to cvxopt's / MOSEK's interior-point SDP solver.  By the Schur complement
-    t_j >= e_j^T M(q)^-1 e_j, so the problem is  min_q tr(M(q)^-1)  over the simplex: an A-optimal design.
-    cvxopt, cvxpy and MOSEK are absent from this image, so this function solves THAT problem itself:
-    `method='newton'` (default) is a log-barrier Newton method on the structure (`_aopt_newton`),
-    `method='multiplicative'` the classical first-order algorithm (`_aopt_multiplicative`); both stop at a
-    relative duality / KKT gap below `tol`.  PARITY UNPINNED: the optimum is unique in M(q) but the reference
-    solver's iterate, tolerance and therefore the sampled queries cannot be compared here.
+    (X_pool [d, n]: the refined, zero-meaned features of the candidates, PW_NNAL.py:146-155) and hands it to cvxopt's
+    interior-point SDP solver.  By the Schur complement t_j >= e_j^T M(q)^-1 e_j, so the problem is
+    min_q tr(M(q)^-1) - lambda sum_i q_i ||x_i||^2 over that polytope: an A-optimal design with a linear reward for
+    long feature vectors.  cvxopt, cvxpy and MOSEK are absent from this image, so this function solves THAT problem
+    itself with a log-barrier Newton method on its structure (`_aopt_newton`, `_aopt_newton_eq`;
+    `method='multiplicative'`: the classical first-order algorithm, lambda = 0 only).  The problem STATEMENT is
+    pinned: tests/test_capi_and_host.py checks the returned (q, t) and the dual certificate built from it against
+    the c, G_k, h_k, A, b that the reference's own code assembles (tests/golden/r2_sdp.npz).  The ITERATE of the
+    reference's solver (tolerance, where on the optimal face it stops) is PARITY UNPINNED.
 
-    Only the lambda_ = 0 form is built (PW_NNAL.query_multimg passes no features: PW_NNAL.py:596).
-    Returns a dict like cvxopt's: 'x' = concat(q [n], t [L]), 'status', 'primal objective', 'gap'
-    (= max_i <M^-2, A_i> / tr M^-1 - 1, the violation of the optimality condition at the returned q).
-    """
-    if lambda_ and lambda_ > 0:
-        raise NotImplementedError('the feature-regularised SDP (lambda_ > 0, NNAL_tools.py:626-645) is not built')
+    Returns a dict like cvxopt's: 'x' = concat(q [n], t [L]), 'status', 'primal objective', 'gap' (largest violation
+    of the optimality condition, relative to the objective's scale), 'y' (multipliers of the equality rows, cvxopt's
+    sign: c + sum_k G_k^T z_k + A^T y = 0), 'iterations'."""
     A = np.asarray(A, dtype=np.float64)
-    n = A.shape[0]
-    if method == 'newton':
-        q, status, its = _aopt_newton(A, tol, min(max_iter, 500))
-        name = 'log-barrier Newton A-optimal design'
-    elif method == 'multiplicative':
-        q, status, its = _aopt_multiplicative(A, tol, max_iter)
-        name = 'multiplicative A-optimal design'
+    n, L = A.shape[0], A.shape[1]
+    lam = float(lambda_) if lambda_ else 0.0
+    if lam > 0:
+        X = np.asarray(X_pool, dtype=np.float64)
+        if X.ndim != 2 or X.shape[1] != n:
+            raise ValueError('X_pool must be [d, %d] (features x candidates), got %r' % (n, X.shape))
+        if method != 'newton':
+            raise ValueError('the feature-regularised form is solved by the Newton method only')
+        if np.abs(X.sum(axis=1)).max() > 1e-8 * max(1.0, np.abs(X).max()) * n:
+            raise ValueError('X_pool rows are not zero-mean: the uniform distribution violates X_pool q = 0 '
+                             '(PW_NNAL.py:148-150 centres the features before the call)')
+        c = -lam * np.sum(X ** 2, axis=0)
+        E = np.concatenate((X, np.ones((1, n))), axis=0)
+        q, nu, status, its = _aopt_newton_eq(A, c, E, tol, min(max_iter, 500))
+        name = 'log-barrier Newton, feature-regularised A-optimal design'
     else:
-        raise ValueError('unknown method %r' % (method,))
+        c = np.zeros(n)
+        nu = None
+        if method == 'newton':
+            q, status, its = _aopt_newton(A, tol, min(max_iter, 500))
+            name = 'log-barrier Newton A-optimal design'
+        elif method == 'multiplicative':
+            q, status, its = _aopt_multiplicative(A, tol, max_iter)
+            name = 'multiplicative A-optimal design'
+        else:
+            raise ValueError('unknown method %r' % (method,))
     M = np.tensordot(q, A, axes=(0, 0))
     Minv = np.linalg.inv(M)
     t = np.diag(Minv).copy()
     d = np.tensordot(A, Minv @ Minv, axes=([1, 2], [0, 1]))
-    gap = d.max() / t.sum() - 1.0
+    if lam > 0:
+        # stationarity: -d_i + c_i + (E^T nu)_i = s_i >= 0, s_i q_i = 0
+        s = -d + c + E.T @ nu
+        gap = max(float(-s.min()), float(np.abs(s * q).sum())) / max(t.sum(), 1e-300)
+        y = nu
+    else:
+        gap = d.max() / t.sum() - 1.0
+        y = np.array([float(d @ q)])                            # multiplier of sum q = 1: s_i = y - d_i
     return {'x': np.concatenate((q, t)), 'status': '%s (%s; not cvxopt)' % (status, name),
-            'primal objective': float(t.sum()), 'gap': float(gap), 'iterations': its}
+            'primal objective': float(t.sum() + c @ q), 'gap': float(gap), 'iterations': its, 'y': np.asarray(y)}
 
 
 def solve_FIAL_SDP(A):

@@ -33,7 +33,11 @@ def batch_eval(model, sess, img_dat, inds, patch_shape, batch_size, stats, varna
     # one dropout seed per call from the global NumPy stream; masks are keyed by the sample's position in `inds`
     seed = int(np.random.randint(0, 2 ** 31 - 1)) if mc else 0
     if not isinstance(img_dat[0], np.ndarray):
-        raise NotImplementedError('volume paths need pynrrd (absent): pass the padded arrays (PW_NN.py:429-444)')
+        # PW_NN.py:429-444: paths -> load (NRRD) and zero-pad by the patch radii
+        from . import nrrd_io
+        rads = [int((patch_shape[i] - 1) / 2.) for i in range(3)]
+        img_dat = [np.pad(nrrd_io.read(p)[0], ((rads[0], rads[0]), (rads[1], rads[1]), (rads[2], rads[2])), 'constant')
+                   for p in img_dat]
     if int(batch_size) < 1:
         raise ValueError('batch_size must be positive')
     m = len(img_dat)

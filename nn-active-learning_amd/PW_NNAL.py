@@ -74,6 +74,24 @@ def gen_A_matrices(expr, model, sess, sel_patches, sel_posts, diag_load=1e-5):
     return [(1. - p[i]) * np.outer(g0[i], g0[i]) + p[i] * np.outer(g1[i], g1[i]) + eye for i in range(n)]
 
 
+def refine_feature_matrix(F, B):
+    """PW_NNAL.refine_feature_matrix (PW_NNAL.py:819-849): the (at most B/2) features with the most positive entries,
+    trimmed from the back until the matrix has full row rank and a condition number <= 1e6."""
+    nnz_feats = np.sum(F > 0, axis=1)
+    feat_inds = np.argsort(-nnz_feats)[:int(B / 2)]
+    ref_F = F[feat_inds, :]
+    while np.linalg.matrix_rank(ref_F) < len(feat_inds):
+        feat_inds = feat_inds[:-1]
+        ref_F = F[feat_inds, :]
+    while np.linalg.cond(ref_F) > 1e6:
+        feat_inds = feat_inds[:-1]
+        ref_F = F[feat_inds, :]
+        if len(feat_inds) == 1:
+            print('Only one feature is selected.')
+            break
+    return ref_F
+
+
 def _entropy_query_single(expr, model, sess, padded_imgs, pool_inds):
     posts = PW_NN.batch_eval(model, sess, padded_imgs, pool_inds, expr.pars['patch_shape'],
                              expr.pars['ntb'], expr.pars['stats'], 'posteriors')[0]
@@ -123,10 +141,18 @@ def CNN_query(expr, model, sess, padded_imgs, pool_inds, tr_inds, method_name):
             total_posts = (posts + i * total_posts) / (i + 1)
         return np.argsort(np.abs(total_posts - .5), kind='stable')[:expr.pars['k']]
     if method_name == 'fi':
+        lambda_ = expr.pars['lambda_']
         sel_inds, sel_posts, A = fisher_candidates(expr, model, sess, padded_imgs, pool_inds)
-        F = PW_NN.batch_eval(model, sess, padded_imgs, pool_inds[sel_inds], expr.pars['patch_shape'],
-                             expr.pars['ntb'], expr.pars['stats'], 'feature_layer')[0]
-        soln = NNAL_tools.SDP_query_distribution(A, expr.pars['lambda_'], F, expr.pars['k'])
+        ref_F = None
+        if lambda_ > 0:
+            # PW_NNAL.py:138-150: features of the candidates, refined to a well-conditioned full-row-rank subset and
+            # centred (the SDP's equality block needs X q = 0 to hold for the uniform q).  The reference evaluates them
+            # for lambda_ = 0 too and never uses them there (NNAL_tools.py:626,646); skipped.
+            F = PW_NN.batch_eval(model, sess, padded_imgs, pool_inds[sel_inds], expr.pars['patch_shape'],
+                                 expr.pars['ntb'], expr.pars['stats'], 'feature_layer')[0]
+            ref_F = refine_feature_matrix(F, expr.pars['B'])
+            ref_F = ref_F - np.mean(ref_F, axis=1, keepdims=True)
+        soln = NNAL_tools.SDP_query_distribution(A, lambda_, ref_F, expr.pars['k'])
         q_opt = np.array(soln['x'][:len(sel_inds)]).ravel()
         Q_inds = NNAL_tools.sample_query_dstr(q_opt, expr.pars['k'], replacement=True)
         return sel_inds[Q_inds]

@@ -28,11 +28,31 @@ class FakeSession(object):
 
 
 class FakeModel(object):
-    def __init__(self, ld, in_shape, pars, skips=()):
+    dropout_rate = 1.
+
+    def __init__(self, ld, in_shape, pars, skips=(), lr=None):
+        from oracle.train import OracleOptimizer
         self.om = OracleModel(ld, in_shape, pars, skips=skips)
         self.osess = OracleSession(self.om)
         self.in_shape = tuple(in_shape)
         self.L = self.om.nlayers_par
+        self.opt = OracleOptimizer(self.om, lr, (), 'SGD') if lr else None
+
+    def train_on_batch(self, x, y_onehot, keep_prob=1., seed=None):
+        return self.opt.step(x.numpy().reshape((-1,) + self.in_shape), y_onehot)
+
+    def weights(self):
+        return {n: [w.detach().numpy().copy(), b.detach().numpy().copy()] for n, (w, b) in self.om.params.items()}
+
+    def save_weights(self, path):
+        np.savez(path, **{n + '/' + k: v for n, wb in self.weights().items() for k, v in zip(('Weight', 'Bias'), wb)})
+
+    def load_weights(self, path):
+        f = np.load(path)
+        with torch.no_grad():
+            for n, (w, b) in self.om.params.items():
+                w.copy_(torch.as_tensor(f[n + '/Weight']))
+                b.copy_(torch.as_tensor(f[n + '/Bias']))
 
     def forward_device(self, t, n, want_pred=False, want_feat=False, rows=None):
         x = t.numpy() if rows is None else t.numpy()[rows.numpy()]

@@ -89,8 +89,8 @@ def test_host_functions_vs_reference_goldens(golden_dir):
     np.testing.assert_array_equal(b, g['uf_in_after'])
     np.random.seed(77)
     np.testing.assert_array_equal(NNAL_tools.sample_query_dstr(g['sq_q'].copy(), 25, True), g['sq_out'])
-    with pytest.raises(NotImplementedError):
-        NNAL_tools.SDP_query_distribution([np.eye(2)], 0.1, [], 3)      # feature-regularised form: not built
+    with pytest.raises(ValueError):
+        NNAL_tools.SDP_query_distribution([np.eye(2)], 0.1, [], 3)      # feature-regularised form needs X_pool [d, n]
 
 
 def test_sdp_query_distribution_is_the_a_optimal_design():

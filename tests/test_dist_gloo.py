@@ -69,7 +69,7 @@ def _loop_setup():
     return ld, in_shape, pars, x
 
 
-def _loop_worker(rank, ws, port, q):
+def _loop_worker(rank, ws, port, q, state_dir=None, rounds=3, ft=False):
     import torch
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -83,20 +83,28 @@ def _loop_worker(rank, ws, port, q):
     ld, in_shape, pars, x = _loop_setup()
     a, b = pool_shard.shard_bounds(len(x), ws, rank)
     sess = FakeSession()
-    model = FakeModel(ld, in_shape, pars)
+    model = FakeModel(ld, in_shape, pars, lr=0.01 if ft else None)
     pool = torch.as_tensor(x[a:b].reshape(b - a, -1))
-    rounds = al_loop.run_rounds(model, sess, pool, 3, 20, 6, seed=5, n_global=len(x))
-    q.put((rank, [{k: r[k] for k in ('queries', 'candidates', 'posts', 'A', 'q', 'pool_left')} for r in rounds]))
+    kw = {}
+    if ft:
+        from nnal_amd import PW_AL
+        kw = dict(labels=(x.reshape(len(x), -1)[:, :7].sum(1) > 0).astype(np.int64), finetune=dict(epochs=2, b=4),
+                  state=PW_AL.LoopState(state_dir) if state_dir else None)
+    res = al_loop.run_rounds(model, sess, pool, rounds, 20, 6, seed=5, n_global=len(x), **kw)
+    out = [{k: r[k] for k in ('queries', 'candidates', 'posts', 'A', 'q', 'pool_left')} for r in res]
+    if ft:
+        out.append(model.weights())
+    q.put((rank, out))
     if ws > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def _run_loop(ws):
+def _run_loop(ws, *extra):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_loop_worker, args=(r, ws, port, q)) for r in range(ws)]
+    procs = [ctx.Process(target=_loop_worker, args=(r, ws, port, q) + tuple(extra)) for r in range(ws)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in range(ws))
@@ -126,6 +134,42 @@ def test_sharded_loop_equals_single_process_bit_for_bit():
     # queries span both blocks over the rounds (otherwise the test would not exercise the ownership logic)
     cand = np.concatenate([s['candidates'] for s in single])
     assert (cand < 120).any() and (cand >= 120).any()
+
+
+def test_sharded_loop_with_finetune_state_and_resume(tmp_path):
+    """Config 5 proper: between rounds every rank fine-tunes its replica on all labelled patches (gathered from their
+    owners) and rank 0 writes queries/<it>, AL_running_times/dt_<it>, curr_weights_<it>.  Two gloo ranks against one
+    process: same queries every round, same weights at the end, bit for bit; the weights really move; and a run that
+    is stopped after two rounds and restarted resumes from the files and ends where the uninterrupted one did."""
+    d1, d2, d3 = [str(tmp_path / n) for n in ('single', 'double', 'resumed')]
+    single = _run_loop(1, d1, 3, True)[0]
+    both = _run_loop(2, d2, 3, True)
+    for rank in (0, 1):
+        for r in range(3):
+            for k in ('queries', 'candidates', 'posts', 'A', 'q'):
+                np.testing.assert_array_equal(single[r][k], both[rank][r][k], err_msg='round %d %s rank %d' % (r, k, rank))
+        for n, wb in single[3].items():
+            for a_, b_ in zip(wb, both[rank][3][n]):
+                np.testing.assert_array_equal(a_, b_)
+    # fine-tuning changes the scores: round 1's posteriors differ from a loop without it
+    plain = _run_loop(1)[0]
+    np.testing.assert_array_equal(plain[0]['queries'], single[0]['queries'])
+    assert not np.array_equal(plain[1]['posts'], single[1]['posts'])
+    # state files of the two-rank run: rows [global position, owner rank]
+    for it in range(3):
+        qm = np.loadtxt(os.path.join(d2, 'queries', '%d' % it), ndmin=2).astype(int)
+        np.testing.assert_array_equal(qm[:, 0], single[it]['queries'])
+        np.testing.assert_array_equal(qm[:, 1], (qm[:, 0] >= 120).astype(int))
+        assert os.path.exists(os.path.join(d2, 'AL_running_times', 'dt_%d' % it))
+        assert os.path.exists(os.path.join(d2, 'curr_weights_%d.npz' % (it + 1)))
+    # stop after two rounds, restart with rounds = 3: the third round comes out of the files
+    _run_loop(1, d3, 2, True)
+    resumed = _run_loop(1, d3, 3, True)[0]
+    assert len(resumed) == 2                                   # one round executed + the weights
+    np.testing.assert_array_equal(resumed[0]['queries'], single[2]['queries'])
+    for n, wb in single[3].items():
+        for a_, b_ in zip(wb, resumed[1][n]):
+            np.testing.assert_array_equal(a_, b_)
 
 
 # ---------------------------------------------------------------------------------------------- rank launcher

@@ -254,3 +254,55 @@ def test_diagonal_fisher_vs_oracle(sess):
     for a, b in zip(dev, ref):
         np.testing.assert_allclose(a, b, rtol=2e-3, atol=1e-6 * np.abs(b).max())
     m.close()
+
+
+def test_config5_loop_with_finetune_and_state(sess, tmp_path):
+    """Config 5 proper at reduced size on the device: query round -> fine-tune on all labelled patches -> weights and
+    queries on disk; the weights move between rounds (later posteriors differ from the loop without fine-tuning),
+    two runs agree bit for bit, and a resumed run continues from the files."""
+    from nnal_amd import al_loop, device, PW_AL
+    torch = sess.torch
+    ld, sk = netspec.net_c()
+    in_shape = (16, 16, 16, 1)
+    pars = netspec.he_init(ld, in_shape, seed=15, skips=sk)
+    n, B, k = 600, 48, 8
+    x = np.random.RandomState(1007).randn(n, 16 ** 3).astype(np.float32)
+    labels = (x[:, :64].sum(1) > 0).astype(np.int64)
+    pool = sess.to_device(x, torch.float32)
+
+    def run(rounds, state_dir=None, ft=True):
+        m = device.DeviceModel(sess, ld, in_shape, sk, max_batch=64)
+        m.set_weights(pars)
+        m.get_optimizer(5e-3, [], 'SGD')
+        kw = dict(labels=labels, finetune=dict(epochs=2, b=6), state=PW_AL.LoopState(state_dir) if state_dir else None) if ft else {}
+        out = al_loop.run_rounds(m, sess, pool, rounds, B, k, seed=11, **kw)
+        w = {nme: [a.copy() for a in wb] for nme, wb in m.var_dict.items()}
+        m.close()
+        return out, w
+
+    d1 = str(tmp_path / 's1')
+    r1, w1 = run(3, d1)
+    r2, w2 = run(3)
+    plain, w0 = run(3, ft=False)
+    for a, b in zip(r1, r2):
+        for key in ('queries', 'candidates', 'posts', 'A'):
+            np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    for nme in w1:
+        for a, b, c in zip(w1[nme], w2[nme], w0[nme]):
+            np.testing.assert_array_equal(a, b)
+        assert not np.array_equal(w1[nme][0], w0[nme][0]), nme                 # every layer's weights moved
+    np.testing.assert_array_equal(r1[0]['queries'], plain[0]['queries'])
+    assert not np.array_equal(r1[1]['posts'], plain[1]['posts'])
+    assert all(len(r['finetune_loss']) > 0 and np.isfinite(r['finetune_loss']).all() for r in r1)
+    for it in range(3):
+        qm = np.loadtxt(os.path.join(d1, 'queries', '%d' % it), ndmin=2).astype(int)
+        np.testing.assert_array_equal(qm[:, 0], r1[it]['queries'])
+        f = np.load(os.path.join(d1, 'curr_weights_%d.npz' % (it + 1)))
+        assert sorted(f.files) == sorted(nme + s_ for nme in w1 for s_ in ('/Weight', '/Bias'))
+    d2 = str(tmp_path / 's2')
+    run(2, d2)
+    r3, w3 = run(3, d2)
+    assert len(r3) == 1
+    np.testing.assert_array_equal(r3[0]['queries'], r1[2]['queries'])
+    for nme in w1:
+        np.testing.assert_array_equal(w3[nme][0], w1[nme][0])

@@ -195,6 +195,26 @@ int alq_adam_step(alq_ctx *ctx, float *d_theta, const float *d_grad, float *d_m,
  * d_acc[i] += sum_n d_grads[n, i]^2 (fp64).                                                                    */
 int alq_sq_accum(alq_ctx *ctx, const float *d_grads, int64_t per_sample_len, int N, double *d_acc);
 
+/* ---- feature similarities (representativeness strategies) -------------------------------------------- */
+/* Replaces: the NumPy similarity blocks of query_multimg 'rep-entropy' (PW_NNAL.py:318-327: norms, dots = F.T @ F_u,
+ * sims = dots / outer(norms)) and 'core-set' (:386-425, :437-441).  Features are fp32 rows [samples, f] as
+ * alq_forward returns them; accumulation is fp64 like the reference's float64 arrays.
+ *   alq_row_norms      d_norms[i] = ||A[i, :]||
+ *   alq_cosine_sims    d_C[i, j] = <A[i], B[j]> / (na[i] nb[j])   (both norm vectors null: plain dot products)
+ *   alq_colsum_max     d_out[j] = sum_i max(d_cmax[i], S[i, j]) over the rows with d_skip[i] == 0 (either may be null):
+ *                      the representativeness score of every candidate column in ONE pass (PW_NNAL.py:333-338 scores one
+ *                      candidate per Python iteration); fixed summation order; d_work: alq_colsum_work_bytes(n, b) bytes
+ *   alq_take_colmax    d_v[i] = max(d_v[i], S[i, j])  (first != 0: d_v[i] = S[i, j]): the running row maxima after a pick
+ *   alq_fold_rowmax    d_v[j] = max(d_v[j], max_i S[i, j]) for a [t, n] block (core-set's labelled-set maxima, :420-425) */
+int alq_row_norms(alq_ctx *ctx, const float *d_A, int64_t n, int f, double *d_norms);
+int alq_cosine_sims(alq_ctx *ctx, const float *d_A, int64_t n, const float *d_B, int b, int f, const double *d_na,
+                    const double *d_nb, double *d_C);
+size_t alq_colsum_work_bytes(int64_t n, int b);
+int alq_colsum_max(alq_ctx *ctx, const double *d_S, int64_t n, int b, const double *d_cmax,
+                   const unsigned char *d_skip, double *d_out, void *d_work);
+int alq_take_colmax(alq_ctx *ctx, const double *d_S, int64_t n, int b, int j, int first, double *d_v);
+int alq_fold_rowmax(alq_ctx *ctx, const double *d_S, int t, int64_t n, double *d_v);
+
 /* ---- measurement hooks (bench.py only) -------------------------------------------------- */
 /* Per-kernel-class HIP-event timing on the context's stream.  alq_prof_enable(ctx, 1) makes
  * every launch of an instrumented kernel class record start/stop events; on = k > 1 samples the

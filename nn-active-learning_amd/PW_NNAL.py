@@ -159,6 +159,125 @@ def CNN_query(expr, model, sess, padded_imgs, pool_inds, tr_inds, method_name):
     raise NotImplementedError("query method %r is outside the scored path (entropy, fi)" % (method_name,))
 
 
+def _features_device(expr, model, sess, padded_mods, inds, stats):
+    """feature_layer of the voxels `inds` of one subject as a device tensor [n, fdim] fp32 (memory order of the layer:
+    a fixed permutation of the reference's flatten order, irrelevant to dot products and norms)."""
+    torch = sess.torch
+    vols = patch_utils.DeviceVolumes(sess, padded_mods)
+    inds = np.asarray(inds)
+    out = sess.empty((len(inds), model.feature_dim), torch.float32)
+    for a in range(0, len(inds), PW_NN._CHUNK):
+        b = min(len(inds), a + PW_NN._CHUNK)
+        t = vols.gather(inds[a:b], expr.pars['patch_shape'], np.asarray(stats, dtype=np.float64)[:len(padded_mods)], quirk=1)
+        _, _, feat = model.forward_device(t, b - a, False, True)
+        out[a:b] = feat
+    return out
+
+
+def _row_norms(sess, F):
+    import ctypes as C
+    from ._lib import check
+    nrm = sess.empty((int(F.shape[0]),), sess.torch.float64)
+    check(sess.lib.alq_row_norms(sess.ctx, C.c_void_p(F.data_ptr()), int(F.shape[0]), int(F.shape[1]), C.c_void_p(nrm.data_ptr())))
+    return nrm
+
+
+def _cosine_sims(sess, A, na, Bm, nb):
+    """[len(A), len(Bm)] float64 device tensor of cosine similarities (alq_cosine_sims)."""
+    import ctypes as C
+    from ._lib import check
+    S = sess.empty((int(A.shape[0]), int(Bm.shape[0])), sess.torch.float64)
+    check(sess.lib.alq_cosine_sims(sess.ctx, C.c_void_p(A.data_ptr()), int(A.shape[0]), C.c_void_p(Bm.data_ptr()), int(Bm.shape[0]),
+                                   int(A.shape[1]), C.c_void_p(na.data_ptr()), C.c_void_p(nb.data_ptr()), C.c_void_p(S.data_ptr())))
+    return S
+
+
+def _subject_stats(expr, i, m, attr='train_stats'):
+    st = getattr(expr, attr)
+    return [[st[i, 2 * j], st[i, 2 * j + 1]] for j in range(m)]
+
+
+def rep_entropy_query(expr, model, sess, all_padded_imgs, pool_inds):
+    """query_multimg 'rep-entropy' (PW_NNAL.py:284-351): among the B most uncertain voxels, greedily pick the k whose
+    feature vectors best "represent" the rest of the pool - each step adds the candidate maximising
+    sum_r max_{c in Q + candidate} cos(f_r, f_c) over the remaining pool voxels r.  The similarity block is one device
+    GEMM (alq_cosine_sims, fp64 accumulation like the reference's float64 NumPy), a greedy step one streaming pass that
+    scores ALL candidates at once (alq_colsum_max) where the reference scores one candidate per Python iteration."""
+    import ctypes as C
+    from ._lib import check
+    torch = sess.torch
+    sess.bind_stream()
+    k, B = expr.pars['k'], expr.pars['B']
+    m = len(all_padded_imgs[0]) - 1
+    s = len(pool_inds)
+    F = [_features_device(expr, model, sess, all_padded_imgs[i][:-1], pool_inds[i], _subject_stats(expr, i, m)) if len(pool_inds[i])
+         else sess.empty((0, model.feature_dim), torch.float32) for i in range(s)]
+    sel_inds, sel_posts = bin_uncertainty_filter_multimg(expr, model, sess, all_padded_imgs, pool_inds, B)
+    F_unc = torch.cat([F[i].index_select(0, sess.to_device(np.asarray(sel_inds[i]), torch.int64)) for i in range(s) if len(sel_inds[i]) > 0])
+    rem = []
+    for i in range(s):
+        keep = np.setdiff1d(np.arange(len(pool_inds[i])), np.asarray(sel_inds[i], dtype=np.int64))
+        rem.append(F[i].index_select(0, sess.to_device(keep, torch.int64)))
+    F_rem = torch.cat(rem)
+    nB, nR = int(F_unc.shape[0]), int(F_rem.shape[0])
+    S = _cosine_sims(sess, F_rem, _row_norms(sess, F_rem), F_unc, _row_norms(sess, F_unc))        # [remaining, uncertain]
+    work = sess.empty((sess.lib.alq_colsum_work_bytes(nR, nB),), torch.uint8)
+    scores = sess.empty((nB,), torch.float64)
+    cmax = sess.empty((nR,), torch.float64)
+    Q, taken = [], np.zeros(nB, bool)
+    for it in range(min(k, nB)):
+        check(sess.lib.alq_colsum_max(sess.ctx, C.c_void_p(S.data_ptr()), nR, nB, C.c_void_p(cmax.data_ptr()) if it else None, None,
+                                      C.c_void_p(scores.data_ptr()), C.c_void_p(work.data_ptr())))
+        sc = scores.cpu().numpy()
+        sc[taken] = -np.inf
+        j = int(np.argmax(sc))                      # first maximum among the candidates left, in their original order (:339-343)
+        Q.append(j)
+        taken[j] = True
+        check(sess.lib.alq_take_colmax(sess.ctx, C.c_void_p(S.data_ptr()), nR, nB, j, 0 if it else 1, C.c_void_p(cmax.data_ptr())))
+    local = patch_utils.global2local_inds(Q, [len(sel_inds[i]) for i in range(s)])
+    return [np.array(sel_inds[i])[local[i]] for i in range(s)]
+
+
+def core_set_query(expr, model, sess, all_padded_imgs, pool_inds, labeled_inds):
+    """query_multimg 'core-set' (PW_NNAL.py:353-451): k-centre greedy on cosine similarity - start from every pool voxel's
+    largest similarity to the labelled set, then k times take the voxel LEAST similar to anything chosen or labelled.
+    As in the reference the labelled side is the LAST subject of `labeled_inds` only (its loop variable `i` is read
+    after the loop, :399-404), evaluated in batches of 1000 (NN.gen_batch_inds) with `expr.labeled_stats`."""
+    import ctypes as C
+    from . import NN
+    from ._lib import check
+    torch = sess.torch
+    sess.bind_stream()
+    k = expr.pars['k']
+    m = len(all_padded_imgs[0]) - 1
+    s = len(pool_inds)
+    sizes = [len(p) for p in pool_inds]
+    F_u = torch.cat([_features_device(expr, model, sess, all_padded_imgs[i][:-1], pool_inds[i], _subject_stats(expr, i, m))
+                     if sizes[i] else sess.empty((0, model.feature_dim), torch.float32) for i in range(s)])
+    n = int(F_u.shape[0])
+    norms_u = _row_norms(sess, F_u)
+    sims = torch.full((n,), -np.inf, dtype=torch.float64, device=sess.device)
+    i = len(labeled_inds) - 1
+    nT = len(labeled_inds[i])
+    if expr.labeled_paths == expr.train_paths:
+        lab_mods = all_padded_imgs[i][:-1]
+    else:
+        from . import PW_AL
+        lab_mods = PW_AL.load_and_pad(list(expr.labeled_paths[i][:-1]) + [expr.labeled_paths[i][-1]], expr.pars['patch_shape'])[:-1]
+    for batch in NN.gen_batch_inds(nT, 1000):
+        F_T = _features_device(expr, model, sess, lab_mods, np.array(labeled_inds[i])[batch], _subject_stats(expr, i, m, 'labeled_stats'))
+        St = _cosine_sims(sess, F_T, _row_norms(sess, F_T), F_u, norms_u)                           # [labelled batch, pool]
+        check(sess.lib.alq_fold_rowmax(sess.ctx, C.c_void_p(St.data_ptr()), int(F_T.shape[0]), n, C.c_void_p(sims.data_ptr())))
+    Q = []
+    for _ in range(min(k, n)):
+        q_ind = int(np.argmin(sims.cpu().numpy()))
+        Q.append(q_ind)
+        Sq = _cosine_sims(sess, F_u[q_ind:q_ind + 1], norms_u[q_ind:q_ind + 1], F_u, norms_u)      # [1, pool]
+        check(sess.lib.alq_fold_rowmax(sess.ctx, C.c_void_p(Sq.data_ptr()), 1, n, C.c_void_p(sims.data_ptr())))
+        sims[q_ind] = np.inf
+    return patch_utils.global2local_inds(Q, sizes)
+
+
 def query_multimg(expr, model, sess, all_padded_imgs, pool_inds, labeled_inds, method_name):
     """PW_NNAL.query_multimg (PW_NNAL.py:169-629), branches `entropy` (:226-230) and `fi`
     (:547-627).  Returns, per subject, positions into that subject's pool_inds."""
@@ -198,6 +317,10 @@ def query_multimg(expr, model, sess, all_padded_imgs, pool_inds, labeled_inds, m
         scores = ent_av_posts - av_ents
         inds = np.argsort(-scores, kind='stable')[:k]
         return patch_utils.global2local_inds(inds, sizes)
+    if method_name == 'rep-entropy':
+        return rep_entropy_query(expr, model, sess, all_padded_imgs, pool_inds)
+    if method_name == 'core-set':
+        return core_set_query(expr, model, sess, all_padded_imgs, pool_inds, labeled_inds)
     if method_name == 'fi':
         sel_inds, sel_posts = bin_uncertainty_filter_multimg(expr, model, sess, all_padded_imgs, pool_inds, B)
         m = len(all_padded_imgs[0]) - 1

@@ -52,6 +52,12 @@ _SIGNATURES = {
     'alq_sgd_step': (C.c_int, [_P, _P, _P, C.c_int64, C.c_float]),
     'alq_adam_step': (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64]),
     'alq_sq_accum': (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
+    'alq_row_norms': (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
+    'alq_cosine_sims': (C.c_int, [_P, _P, C.c_int64, _P, C.c_int, C.c_int, _P, _P, _P]),
+    'alq_colsum_work_bytes': (C.c_size_t, [C.c_int64, C.c_int]),
+    'alq_colsum_max': (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, _P, _P, _P]),
+    'alq_take_colmax': (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
+    'alq_fold_rowmax': (C.c_int, [_P, _P, C.c_int, C.c_int64, _P]),
     'alq_comm_unique_id': (C.c_int, [_P]),
     'alq_comm_init': (C.c_int, [_P, _P, C.c_int, C.c_int]),
     'alq_comm_destroy': (C.c_int, [_P]),

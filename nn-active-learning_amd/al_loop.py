@@ -174,7 +174,7 @@ def run_rounds(model, sess, pool, rounds, B, k, diag_load=1e-3, seed=15, n_globa
 
 def main():
     """python -m nnal_amd.al_loop [pool] [rounds] [state dir]: config 5 - NET-C, synthetic 32^3 pool (seed 1005), weights
-    seed 15, per round entropy filter to B = 4096 -> Fisher -> SDP -> k = 100 draws -> fine-tune (SGD 1e-3, one epoch of
+    seed 15, per round entropy filter to B = 4096 -> Fisher -> SDP -> k = 100 draws -> fine-tune (SGD 1e-4, one epoch of
     batches of 50 over everything labelled so far; labels = sign of the patch's first 512 voxels' sum) -> weights saved.
     Under torch.distributed.run (WORLD_SIZE > 1) the pool is sharded over the ranks."""
     import ctypes as C
@@ -199,7 +199,7 @@ def main():
     in_shape = (32, 32, 32, 1)
     model = device.DeviceModel(sess, ld, in_shape, sk, max_batch=512)
     model.set_weights(netspec.he_init(ld, in_shape, seed=15, skips=sk))
-    model.get_optimizer(1e-3, [], 'SGD')
+    model.get_optimizer(1e-4, [], 'SGD')
     a, b = pool_shard.shard_bounds(n, ws, rank)
     pool = sess.empty((b - a, 32 ** 3), sess.torch.float32)
     check(sess.lib.alq_synth_patches(sess.ctx, 1005, a, b - a, 32 ** 3, C.c_void_p(pool.data_ptr())))

@@ -9,10 +9,10 @@ FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -I$HERE -Wall 
 BUILD="$HERE/build${ALQ_BUILD_TAG:-}"
 mkdir -p "$BUILD"
 pids=()
-for f in igemm igemm2 igemm3 igemm4 fcgemm direct kernels topk model comm train; do
+for f in igemm igemm2 igemm3 igemm4 fcgemm direct kernels topk model comm train sim; do
   ( hipcc $FLAGS -c "$HERE/$f.hip" -o "$BUILD/$f.o" ${ALQ_EXTRA_FLAGS:-} ) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
-hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT" "$BUILD"/{igemm,igemm2,igemm3,igemm4,fcgemm,direct,kernels,topk,model,comm,train}.o -ldl
+hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT" "$BUILD"/{igemm,igemm2,igemm3,igemm4,fcgemm,direct,kernels,topk,model,comm,train,sim}.o -ldl
 echo "built $OUT"

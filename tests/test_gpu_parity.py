@@ -639,8 +639,12 @@ def test_argument_errors(sess):
         m.forward(np.zeros((2, 32, 32, 1), np.float32))
     with pytest.raises(ValueError):
         m.set_weights({k: [np.zeros((1,)), np.zeros((1,))] for k in m.var_names})
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AlqError):           # gradients of a model without weights
         sess.run(m.grad_posts['0'], {m.x: np.zeros((1, 32, 32, 1))})
+    with pytest.raises(RuntimeError):       # train_step before get_optimizer
+        m.train_on_batch(np.zeros((1, 32, 32, 1), np.float32), np.array([[1.], [0.]]))
+    with pytest.raises(KeyError):
+        sess.run([object()], {})
     m.close()
     with pytest.raises(NotImplementedError):
         device.translate_layers({'a': ['conv', [4, [3, 3]], 'MBA'], 'f': ['fc', [2]]}, (8, 8, 1))

@@ -306,3 +306,30 @@ def test_config5_loop_with_finetune_and_state(sess, tmp_path):
     np.testing.assert_array_equal(r3[0]['queries'], r1[2]['queries'])
     for nme in w1:
         np.testing.assert_array_equal(w3[nme][0], w1[nme][0])
+
+
+@pytest.mark.parametrize('tag,kind,feat,seed', [('neta', 'a', 3, 51), ('netb', 'bs', 7, 52), ('netc2d', 'c2', 4, 53), ('netc', 'c', 8, 54)])
+def test_device_vs_reference_built_graph(sess, golden_dir, tag, kind, feat, seed):
+    """The device against tests/golden/r2_refgraph.npz - values produced by the REFERENCE's own graph-construction code
+    (NN.CNN / NN_extended.CNN, get_gradients, gen_A_matrices over tests/golden/tfshim.py): posteriors, feature layer (in the
+    reference's flatten order), full gradient arrays of both classes and the A matrices."""
+    from nnal_amd import PW_NNAL, device
+    from tests.test_oracle_golden import refgraph_case
+    g = np.load(os.path.join(golden_dir, 'r2_refgraph.npz'))
+    ld, sk, in_shape, pars = refgraph_case(g, tag, kind, feat, seed)
+    m = device.DeviceModel(sess, ld, in_shape, sk, feature_layer=feat, max_batch=8)
+    m.set_weights(pars)
+    x = g[tag + '_x']
+    res = m.forward(x, want=('posteriors', 'feature_layer'))
+    np.testing.assert_allclose(res['posteriors'], g[tag + '_post'], rtol=0, atol=2e-5)
+    ref_feat = g[tag + '_feat']
+    if ref_feat.ndim > 2:                   # NN_extended marks the un-flattened map: [N, ..., C] -> the flatten order [F, N]
+        ref_feat = ref_feat.transpose(*reversed(range(ref_feat.ndim))).reshape(-1, ref_feat.shape[0])
+    np.testing.assert_allclose(res['feature_layer'], ref_feat, rtol=0, atol=1e-5 * max(1., np.abs(ref_feat).max()))
+    for j in (0, 1):
+        dev = sess.run(m.grad_posts[str(j)], feed_dict={m.x: x[[2]], m.keep_prob: 1.})
+        ref = [g['%s_grad%d_%d' % (tag, j, k)] for k in range(2 * m.L)]
+        _close(dev, ref, name='%s class %d' % (tag, j))
+    A = np.stack(PW_NNAL.gen_A_matrices(Expr({'patch_shape': in_shape[:3]}), m, sess, x, g[tag + '_post'][1].astype(np.float64), 1e-3))
+    np.testing.assert_allclose(A, g[tag + '_A'], rtol=2e-3, atol=1e-7)
+    m.close()

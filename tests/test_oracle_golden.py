@@ -146,3 +146,45 @@ def test_gen_A_matrices(golden_dir, fname, kind):
     A = alpath.gen_A_matrices(Expr({'patch_shape': in_shape[:3]}), model, sess, x, p1,
                               float(g['diag_load']))
     np.testing.assert_array_equal(np.stack(A), g['A'][:n])
+
+
+# ------------------------------------------------------------------------------------------ reference-built graphs
+REFGRAPH = [('neta', 'a', 3, 51), ('netb', 'bs', 7, 52), ('netc2d', 'c2', 4, 53), ('netc', 'c', 8, 54)]
+
+
+def refgraph_case(g, tag, kind, feat, seed):
+    in_shape = tuple(int(v) for v in g[tag + '_in_shape'])
+    skips = ()
+    if kind == 'a':
+        ld = netspec.net_a()
+    elif kind == 'bs':
+        ld = netspec.net_b_small()
+    elif kind == 'c2':
+        ld, skips = netspec.net_c_2d()
+    else:
+        ld, skips = netspec.net_c()
+    pars = netspec.he_init(ld, in_shape, seed=seed, skips=skips, bias_std=0.05)
+    return ld, skips, in_shape, pars
+
+
+@pytest.mark.parametrize('tag,kind,feat,seed', REFGRAPH)
+def test_oracle_graph_equals_reference_built_graph(golden_dir, tag, kind, feat, seed):
+    """tests/golden/r2_refgraph.npz was produced by the REFERENCE's own NN.CNN / NN_extended.CNN constructors,
+    get_gradients and gen_A_matrices running over a lazy-graph `tensorflow` stand-in (tests/golden/tfshim.py) whose op
+    kernels are oracle.tfops: layer, variable, flatten and skip order and the gradient nodes are the reference's.
+    The oracle's own graph must reproduce posteriors, the feature layer, every gradient array of log posteriors[j, 0]
+    and the A matrices bit for bit."""
+    g = _load(golden_dir, 'r2_refgraph.npz')
+    ld, skips, in_shape, pars = refgraph_case(g, tag, kind, feat, seed)
+    om = OracleModel(ld, in_shape, pars, skips=skips, feature_layer=feat)
+    x = g[tag + '_x']
+    o = om.forward(x)
+    np.testing.assert_array_equal(o['posteriors'], g[tag + '_post'])
+    np.testing.assert_array_equal(o['feature_layer'], g[tag + '_feat'])
+    for j in (0, 1):
+        grads = om.grad_log_post(j, x[[2]])
+        for k, a in enumerate(grads):
+            np.testing.assert_array_equal(a, g['%s_grad%d_%d' % (tag, j, k)])
+        np.testing.assert_array_equal(alpath.shrink_gradient(grads), g['%s_shrunk%d' % (tag, j)])
+    A = alpath.gen_A_matrices(Expr({'patch_shape': in_shape[:3]}), om, OracleSession(om), x, g[tag + '_post'][1].astype(np.float64), 1e-3)
+    np.testing.assert_array_equal(np.stack(A), g[tag + '_A'])

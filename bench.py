@@ -49,9 +49,9 @@ def main():
     ap.add_argument('--pool', type=int, default=100000, help='patches per GPU (weak scaling)')
     ap.add_argument('--pool-global', type=int, default=0, help='strong scaling: one pool of this many patches over all GPUs')
     ap.add_argument('--netb-pool', type=int, default=8192, help='patches of the NET-B side measurement at N = 1 (0 = skip)')
-    ap.add_argument('--batch', type=int, default=960,
-                    help='patches per device pass (per-launch fixed costs ~0.37 ms per pass amortise with the batch; the 32-bit '
-                         'tensor offsets of the GEMM engine cap it at 1023 for 32^3 NET-C)')
+    ap.add_argument('--batch', type=int, default=2000,
+                    help='patches per device pass (per-launch fixed costs ~0.37 ms per pass amortise with the batch; the unsigned '
+                         '32-bit tensor offsets of the GEMM engine cap it at 2047 for 32^3 NET-C)')
     ap.add_argument('--topB', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--prof-every', type=int, default=8, help='HIP-event timing on every k-th pass of the timed region')

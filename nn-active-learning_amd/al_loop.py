@@ -197,7 +197,7 @@ def main():
     sess = device.DeviceSession(local_rank)
     ld, sk = netspec.net_c()
     in_shape = (32, 32, 32, 1)
-    model = device.DeviceModel(sess, ld, in_shape, sk, max_batch=960)
+    model = device.DeviceModel(sess, ld, in_shape, sk, max_batch=2000)
     model.set_weights(netspec.he_init(ld, in_shape, seed=15, skips=sk))
     model.get_optimizer(1e-4, [], 'SGD')
     a, b = pool_shard.shard_bounds(n, ws, rank)

@@ -69,7 +69,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int G4_ROWB = 48;      // bytes per staged voxel row: [hi8 | mid8 | lo8] bf16
 constexpr int G4_NSLOT = 8;      // 16-byte staging slots per thread of a half
 constexpr int G4_MAXS = 10;      // k-steps (4 taps each) per unit
-constexpr int G4_OOB = 0x7fffff00;
+// byte offset of a parked staging slot: beyond any buffer (offsets are UNSIGNED 32-bit: tensors up to 4 GB - 256 B)
+constexpr int G4_OOB = (int)0xffffff00u;
 
 // x -> (hi, rem): hi = bf16(x) round-to-nearest packed pairwise, rem = x - hi (exact).  Rounding to nearest
 // matters: a truncating split biases the dropped piece products to one sign, the bias accumulates over K and
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         }
         if ((tflags & 2) && (fpg + 1) * a.PT <= a.N) {      // whole halo inside the tensor: no per-slot checks
 #pragma unroll
-            for (int it = 0; it < G4_NSLOT; ++it) goff[it] = (org + s_rel[it]) * 4;
+            for (int it = 0; it < G4_NSLOT; ++it) goff[it] = (int)((unsigned)(org + s_rel[it]) * 4u);
             return;
         }
         if (a.cls_ok) {         // one patch per tile, <= 3 validity classes per dimension: s_pk holds a bit per class
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             const bool pin = fpg < a.N;
 #pragma unroll
             for (int it = 0; it < G4_NSLOT; ++it)
-                goff[it] = (pin && (((unsigned)s_pk[it] >> cls) & 1u)) ? (org + s_rel[it]) * 4 : G4_OOB;
+                goff[it] = (pin && (((unsigned)s_pk[it] >> cls) & 1u)) ? (int)((unsigned)(org + s_rel[it]) * 4u) : G4_OOB;
             return;
         }
         const unsigned zy = (unsigned)t0.w, xx = (unsigned)t1.x;
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             const unsigned pk = (unsigned)s_pk[it];
             const bool ok = (((pk >> 16) & 255u) - loz) < nz && (((pk >> 8) & 255u) - loy) < ny &&
                             ((pk & 255u) - lox) < nx && pbase + (int)(pk >> 24) < a.N;
-            goff[it] = (ok && s_lds[it] >= 0) ? (org + s_rel[it]) * 4 : G4_OOB;
+            goff[it] = (ok && s_lds[it] >= 0) ? (int)((unsigned)(org + s_rel[it]) * 4u) : G4_OOB;
         }
     };
 
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             const i32x4 pd = ld4(a.pd_off + (f_pdb + ph) * 8);
             int chl = pd.y, extra = 0;
             if (a.in_split_ch && chl >= a.in_split_ch) { chl -= a.in_split_ch; extra = a.in_delta; }     // second part of a split concat
-            soff = __builtin_amdgcn_readfirstlane((pd.x * a.in_cs + chl * 8 + extra) * 4);
+            soff = __builtin_amdgcn_readfirstlane((int)((unsigned)(pd.x * a.in_cs + chl * 8 + extra) * 4u));
         }
 #pragma unroll
         for (int it = 0; it < G4_NSLOT; ++it)
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 Mk[ms][nt] = f32x4{1.f, 1.f, 1.f, 1.f};
                 if (live && c < a.Co && c >= a.mask_from && c < a.mask_to) {
                     const int mo = (q_out + evox[ms]) * a.mask_cs + a.mask_c0 + mcoff[nt];
-                    Mk[ms][nt] = *reinterpret_cast<const f32x4 *>(maskb + (unsigned)(mo * 4));
+                    Mk[ms][nt] = *reinterpret_cast<const f32x4 *>(maskb + ((unsigned)mo * 4u));
                 }
             }
         }
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 f32x4 val = acc[ms][nt];
                 const bool on = live && c < a.Co;
                 if (on) {
-                    f32x4 *dst = reinterpret_cast<f32x4 *>(outb + (unsigned)((obase_e + eoff[ms] + coff[nt]) * 4));
+                    f32x4 *dst = reinterpret_cast<f32x4 *>(outb + ((unsigned)(obase_e + eoff[ms] + coff[nt]) * 4u));
                     if (a.accumulate) val += *dst;
                     if (a.relu) {
                         val.x = __builtin_amdgcn_fmed3f(val.x, 0.f, __builtin_inff());
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                             mk = f32x4{1.f, 1.f, 1.f, 1.f};
                             if (c >= a.mask_from && c < a.mask_to) {
                                 const int mo = (q_out + evox[ms]) * a.mask_cs + a.mask_c0 + mcoff[nt];
-                                mk = *reinterpret_cast<const f32x4 *>(maskb + (unsigned)(mo * 4));
+                                mk = *reinterpret_cast<const f32x4 *>(maskb + ((unsigned)mo * 4u));
                             }
                         }
                         val.x = mk.x > 0.f ? val.x : 0.f; val.y = mk.y > 0.f ? val.y : 0.f;
@@ -1512,7 +1513,8 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
     ALQ_REQUIRE(in.C == plan.Ci && out.C == plan.Co, ALQ_EINVAL, "igemm4: channel counts do not match the plan");
     ALQ_REQUIRE(out.D == a.OD && out.H == a.OH && out.W == a.OW, ALQ_EINVAL, "igemm4: output view mismatch");
     ALQ_REQUIRE(plan.d_W && plan.d_tdesc, ALQ_EINVAL, "igemm4: weights not set");
-    ALQ_REQUIRE(in.delta + (long long)N * in.vox() * in.cs < (1LL << 29) && out.delta + (long long)N * out.vox() * out.cs < (1LL << 29),
+    // unsigned 32-bit byte offsets from the tensor base (float indices stay below 2^30, so they fit an int as well)
+    ALQ_REQUIRE(in.delta + (long long)N * in.vox() * in.cs < (1LL << 30) - 64 && out.delta + (long long)N * out.vox() * out.cs < (1LL << 30) - 64,
                 ALQ_EUNSUPPORTED, "igemm4: tensor exceeds the 32-bit byte-offset range (lower the batch)");
     ALQ_REQUIRE(!in.split || (!plan.multi && in.split % 8 == 0 && in.cs == in.split && in.C == 2 * in.split && in.c0 == 0),
                 ALQ_EUNSUPPORTED, "igemm4: unsupported split input");
@@ -1524,7 +1526,7 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
     a.out = out.p; a.out_cs = out.cs; a.out_c0 = out.c0;
     a.W = plan.d_W; a.bias = bias; a.relu = relu; a.accumulate = accumulate; a.N = N;
     a.tdesc = plan.d_tdesc; a.sdesc = plan.d_sdesc; a.pdesc = plan.d_pdesc; a.ttab = plan.d_ttab; a.vdesc = plan.d_vdesc;
-    a.in_bytes = (int)((in.delta + (long long)N * in.vox() * in.cs) * 4);
+    a.in_bytes = (int)(unsigned)((in.delta + (long long)N * in.vox() * in.cs) * 4);
     a.in_split_ch = in.split / 8; a.in_delta = (int)in.delta;
     a.out_split = out.split; a.out_delta = (int)out.delta;
     a.mask_split = 0; a.mask_delta = 0;

@@ -775,3 +775,31 @@ def test_sharded_loop_world1_under_nccl(sess):
     pm = np.stack([1 - p, p]).astype(np.float32)
     np.testing.assert_allclose(sc['H'].cpu().numpy(), alpath.compute_entropy(pm), rtol=1e-5, atol=1e-6)
     model.close()
+
+
+def test_batches_beyond_two_gigabytes_per_tensor(sess):
+    """The GEMM engine addresses tensors with UNSIGNED 32-bit byte offsets: at 1,500 patches of NET-C 32^3 the split
+    concat of the last conv spans 3.1 GB (past the signed range) - every score must equal the 300-patch-batch run bit for
+    bit, and a batch that would pass 4 GB is refused with an error, not wrapped."""
+    import ctypes as C
+    from nnal_amd._lib import check, AlqError
+    torch = sess.torch
+    n = 1500
+    x = sess.empty((n, 32 ** 3), torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, 32 ** 3, C.c_void_p(x.data_ptr())))
+    big, pars, ld, sk, in_shape = _netc_model(sess, n)
+    small, _, _, _, _ = _netc_model(sess, 300)
+    rb = big.fisher_device(x, n, None, 1e-3)
+    rs_ = small.fisher_device(x, n, None, 1e-3)
+    for k in ('p1', 'g0', 'g1', 'A', 'trace'):
+        assert torch.equal(rb[k], rs_[k]), k
+    pb, _, _ = big.forward_device(x, n)
+    ps, _, _ = small.forward_device(x, n)
+    assert torch.equal(pb, ps)
+    big.close()
+    small.close()
+    huge, _, _, _, _ = _netc_model(sess, 2100)
+    xh = sess.empty((2100, 32 ** 3), torch.float32)
+    with pytest.raises(AlqError):
+        huge.fisher_device(xh, 2100, None, 1e-3)
+    huge.close()

@@ -159,11 +159,15 @@ def main():
         executed = (bf_fl * SPLIT_PRODUCTS + f16['flops'] * 3) / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
         conv_ms = ig_ms + sum(prof[k]['ms'] for k in ('igemm_fwd', 'igemm_bwd', 'direct_conv'))
         conv_fl = ig_fl + sum(prof[k]['flops'] for k in ('igemm_fwd', 'igemm_bwd', 'direct_conv'))
-        traffic = None                       # PMC passes are separate runs (profiles/pmc_traffic.json)
+        traffic, traffic_note = None, None   # PMC passes are separate runs (tests/run_pmc.sh -> profiles/pmc_traffic.json)
         tp = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get('hbm_bytes_per_launch')
+                tj = json.load(open(tp))
+                # measured per launch at tj['batch'] patches; a launch moves bytes in proportion to its patches
+                traffic = tj.get('hbm_bytes_per_launch') * args.batch / float(tj.get('batch', args.batch))
+                traffic_note = 'PMC 2*FETCH_SIZE + WRITE_SIZE per igemm4 launch, measured at batch %d (%s), scaled to batch %d' % (
+                    tj.get('batch', args.batch), 'profiles/pmc_traffic.json', args.batch)
             except Exception:
                 traffic = None
         line = {
@@ -181,7 +185,7 @@ def main():
                        'pool_global': n_global, 'pool_per_gpu': n_local, 'batch': args.batch, 'topB': args.topB,
                        'parallelism': 'pool sharded over %d GPU(s), top-B merge (all-gather) + 8x8 Fisher all-reduce: %s' % (ws, comm)},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak, 'traffic': traffic,
+                         'frac': achieved / peak, 'traffic': traffic, 'traffic_note': traffic_note,
                          'kernel': 'igemm4_kernel: conv / conv_transpose fwd + bwd-data, bf16x3 split (fp16x2 where the input '
                                    'maxima are known ahead: 4 of the 12 launches of a pass)',
                          'peak_note': 'algorithmic fp32 flops; peak = flop-weighted harmonic mean of %.0f dense 16-bit MFMA / %d '
@@ -201,7 +205,7 @@ def main():
         note('GPU: %.1f patches/s' % value)
         if ws == 1 and args.netb_pool > 0:
             line['netb'] = netb_rate(sess, args.netb_pool, x)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and ws == 1:      # reported at N = 1 only (the other ranks would sit in the barrier)
             note('timing the CPU baseline')
             line['cpu_baseline'] = cpu_baseline(x[:args.cpu_sample].cpu().numpy(), ld, sk, in_shape, pars)
         print(json.dumps(line))

@@ -7,7 +7,7 @@ _CHUNK = 8192   # indices gathered per device pass (results do not depend on it)
 
 
 def batch_eval(model, sess, img_dat, inds, patch_shape, batch_size, stats, varnames,
-               mask=None, x_feed_dict={}):
+               mask=None, x_feed_dict={}, _vols=None):
     """PW_NN.batch_eval: evaluates `varnames` ('posteriors', 'prediction', 'feature_layer')
     of `model` on patches around voxels `inds` of the m padded modalities `img_dat`.
 
@@ -43,7 +43,8 @@ def batch_eval(model, sess, img_dat, inds, patch_shape, batch_size, stats, varna
     m = len(img_dat)
     inds = np.asarray(inds)
     n = len(inds)
-    vols = patch_utils.DeviceVolumes(sess, img_dat)
+    # _vols (not a reference argument): volumes a caller of this package has already uploaded for the same query
+    vols = _vols if _vols is not None else patch_utils.DeviceVolumes(sess, img_dat)
     want_pred = 'prediction' in varnames
     want_feat = 'feature_layer' in varnames
     posts = np.zeros(n)

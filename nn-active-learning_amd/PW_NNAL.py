@@ -29,7 +29,7 @@ def device_uncertainty_filter(sess, posts, B):
     return out
 
 
-def bin_uncertainty_filter_multimg(expr, model, sess, all_padded_imgs, pool_inds, B, x_feed_dict={}):
+def bin_uncertainty_filter_multimg(expr, model, sess, all_padded_imgs, pool_inds, B, x_feed_dict={}, _vols=None):
     """PW_NNAL.py:684-736: posteriors of every subject's pool voxels (per-subject stats from
     expr.train_stats), then the B most uncertain over the concatenation, split back per subject."""
     s = len(pool_inds)
@@ -40,9 +40,14 @@ def bin_uncertainty_filter_multimg(expr, model, sess, all_padded_imgs, pool_inds
         if sizes[i] == 0:
             continue
         stats = [[expr.train_stats[i, 2 * j], expr.train_stats[i, 2 * j + 1]] for j in range(m)]
+        v = None
+        if _vols is not None:          # (not a reference argument) per-subject volumes the caller keeps on the device
+            if i not in _vols:
+                _vols[i] = patch_utils.DeviceVolumes(sess, all_padded_imgs[i][:-1])
+            v = _vols[i]
         per_img[i] = list(PW_NN.batch_eval(model, sess, all_padded_imgs[i][:-1], pool_inds[i],
                                            expr.pars['patch_shape'], expr.pars['ntb'], stats,
-                                           'posteriors', None, x_feed_dict)[0])
+                                           'posteriors', None, x_feed_dict, _vols=v)[0])
     allp = np.concatenate(per_img)
     if len(x_feed_dict) > 0:
         return allp
@@ -98,13 +103,15 @@ def _entropy_query_single(expr, model, sess, padded_imgs, pool_inds):
     return binary_uncertainty_filter(posts, expr.pars['k'])
 
 
-def fisher_candidates(expr, model, sess, padded_imgs, pool_inds):
+def fisher_candidates(expr, model, sess, padded_imgs, pool_inds, vols=None):
     """The device part of CNN_query(...,'fi') (PW_NNAL.py:89-136): posteriors, uncertainty filter
     to B candidates, their patches (channel-index normalisation of :125-129) and A-matrices.
-    Returns (sel_inds, sel_posts, A list)."""
+    Returns (sel_inds, sel_posts, A list).  `vols`: the padded volumes already on the device (uploaded once per query)."""
     B = expr.pars['B']
+    if vols is None:
+        vols = patch_utils.DeviceVolumes(sess, padded_imgs)
     posts = PW_NN.batch_eval(model, sess, padded_imgs, pool_inds, expr.pars['patch_shape'],
-                             expr.pars['ntb'], expr.pars['stats'], 'posteriors')[0]
+                             expr.pars['ntb'], expr.pars['stats'], 'posteriors', _vols=vols)[0]
     if B < len(pool_inds):
         sel_inds = binary_uncertainty_filter(posts, B)
     else:
@@ -112,7 +119,6 @@ def fisher_candidates(expr, model, sess, padded_imgs, pool_inds):
         sel_inds = np.arange(len(pool_inds))
     sel_posts = posts[sel_inds]
     m = len(padded_imgs)
-    vols = patch_utils.DeviceVolumes(sess, padded_imgs)
     t = vols.gather(np.asarray(pool_inds)[sel_inds], expr.pars['patch_shape'],
                     np.asarray(expr.pars['stats'], dtype=np.float64)[:m], quirk=1)
     p1_in = sess.to_device(sel_posts.astype(np.float32), sess.torch.float32)
@@ -142,14 +148,15 @@ def CNN_query(expr, model, sess, padded_imgs, pool_inds, tr_inds, method_name):
         return np.argsort(np.abs(total_posts - .5), kind='stable')[:expr.pars['k']]
     if method_name == 'fi':
         lambda_ = expr.pars['lambda_']
-        sel_inds, sel_posts, A = fisher_candidates(expr, model, sess, padded_imgs, pool_inds)
+        vols = patch_utils.DeviceVolumes(sess, padded_imgs)            # one upload for the whole query
+        sel_inds, sel_posts, A = fisher_candidates(expr, model, sess, padded_imgs, pool_inds, vols)
         ref_F = None
         if lambda_ > 0:
             # PW_NNAL.py:138-150: features of the candidates, refined to a well-conditioned full-row-rank subset and
             # centred (the SDP's equality block needs X q = 0 to hold for the uniform q).  The reference evaluates them
             # for lambda_ = 0 too and never uses them there (NNAL_tools.py:626,646); skipped.
             F = PW_NN.batch_eval(model, sess, padded_imgs, pool_inds[sel_inds], expr.pars['patch_shape'],
-                                 expr.pars['ntb'], expr.pars['stats'], 'feature_layer')[0]
+                                 expr.pars['ntb'], expr.pars['stats'], 'feature_layer', _vols=vols)[0]
             ref_F = refine_feature_matrix(F, expr.pars['B'])
             ref_F = ref_F - np.mean(ref_F, axis=1, keepdims=True)
         soln = NNAL_tools.SDP_query_distribution(A, lambda_, ref_F, expr.pars['k'])
@@ -322,14 +329,15 @@ def query_multimg(expr, model, sess, all_padded_imgs, pool_inds, labeled_inds, m
     if method_name == 'core-set':
         return core_set_query(expr, model, sess, all_padded_imgs, pool_inds, labeled_inds)
     if method_name == 'fi':
-        sel_inds, sel_posts = bin_uncertainty_filter_multimg(expr, model, sess, all_padded_imgs, pool_inds, B)
+        dvols = {}                                                       # one upload per subject for the whole query
+        sel_inds, sel_posts = bin_uncertainty_filter_multimg(expr, model, sess, all_padded_imgs, pool_inds, B, _vols=dvols)
         m = len(all_padded_imgs[0]) - 1
         A = []
         stats = np.asarray(expr.train_stats, dtype=np.float64)
         for i in range(len(pool_inds)):
             if len(sel_inds[i]) == 0:
                 continue
-            vols = patch_utils.DeviceVolumes(sess, all_padded_imgs[i][:m])
+            vols = dvols.get(i) or patch_utils.DeviceVolumes(sess, all_padded_imgs[i][:m])
             t = vols.gather(np.asarray(pool_inds[i])[sel_inds[i]], expr.pars['patch_shape'],
                             stats[i, :2 * m], quirk=0)                 # slab rule, patch_utils.py:1203-1207
             p1_in = sess.to_device(np.asarray(sel_posts[i], dtype=np.float32), sess.torch.float32)

@@ -54,6 +54,11 @@ def main():
                          '32-bit tensor offsets of the GEMM engine cap it at 2047 for 32^3 NET-C)')
     ap.add_argument('--topB', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', choices=('nccl', 'gloo'),
+                    help='torch.distributed backend of the N > 1 exchanges (nccl = RCCL over xGMI; gloo: functional rehearsal)')
+    ap.add_argument('--same-gpu', action='store_true',
+                    help='functional rehearsal on a one-GPU box: every rank computes on cuda:0 (use with --backend gloo; RCCL '
+                         'refuses two ranks on one device); throughput numbers of such a run mean nothing')
     ap.add_argument('--prof-every', type=int, default=8, help='HIP-event timing on every k-th pass of the timed region')
     ap.add_argument('--cpu-sample', type=int, default=128, help='patches the CPU baseline scores (~15 s on 16 cores)')
     args = ap.parse_args()
@@ -76,9 +81,13 @@ def main():
         sys.exit('bench.py: WORLD_SIZE=%d but --gpus %d' % (ws, args.gpus))
     if ws > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if args.same_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=ws,
-                                device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=ws, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=ws)
 
     import ctypes as C
     import nnal_amd  # noqa: F401
@@ -99,7 +108,9 @@ def main():
     n_local = b0 - a0
     assert strong or n_local == args.pool
     comm = 'torch.distributed (world 1: identity)'
-    if ws > 1:
+    if ws > 1 and args.backend != 'nccl':
+        comm = 'torch.distributed gloo (functional rehearsal%s)' % (', all ranks on cuda:0' if args.same_gpu else '')
+    elif ws > 1:
         # the Fisher-sum all-reduce goes through the C ABI (alq_allreduce_sum, the library's own RCCL communicator)
         try:
             pool_shard.attach_comm(sess)

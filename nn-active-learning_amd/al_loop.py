@@ -188,12 +188,18 @@ def main():
     ws = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    backend = os.environ.get('ALQ_DIST_BACKEND', 'nccl')       # gloo + ALQ_SAME_GPU=1: functional rehearsal on a one-GPU box
+    if os.environ.get('ALQ_SAME_GPU'):
+        local_rank = 0
     if ws > 1:
         import torch
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=ws, device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=ws, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=ws)
     sess = device.DeviceSession(local_rank)
     ld, sk = netspec.net_c()
     in_shape = (32, 32, 32, 1)
@@ -205,10 +211,16 @@ def main():
     check(sess.lib.alq_synth_patches(sess.ctx, 1005, a, b - a, 32 ** 3, C.c_void_p(pool.data_ptr())))
     lab_local = (pool[:, :512].sum(dim=1) > 0).cpu().numpy().astype(np.float64)
     labels = pool_shard.allgather_rows(n, np.arange(a, b), lab_local, sess).astype(np.int64)
-    if ws > 1:
+    if ws > 1 and backend == 'nccl':
         pool_shard.attach_comm(sess)
-    for r, rd in enumerate(run_rounds(model, sess, pool, rounds, 4096, 100, n_global=n, labels=labels,
-                                      finetune=dict(epochs=1, b=50), state=state)):
+    dump = os.environ.get('ALQ_LOOP_DUMP')                      # rehearsals: every rank saves its rounds for comparison
+    res = run_rounds(model, sess, pool, rounds, int(os.environ.get('ALQ_LOOP_B', '4096')), int(os.environ.get('ALQ_LOOP_K', '100')),
+                     n_global=n, labels=labels, finetune=dict(epochs=1, b=50), state=state)
+    if dump:
+        np.savez('%s.rank%d.npz' % (dump, rank), **{'%s_%d' % (key, r): rd[key] for r, rd in enumerate(res)
+                                                     for key in ('queries', 'candidates', 'posts', 'A', 'q')},
+                 **{'w_' + nme.replace('/', '_'): wb[0] for nme, wb in model.var_dict.items()})
+    for r, rd in enumerate(res):
         if rank == 0:
             print('round %d: %d queries, pool left %d, filter %.2f s, fisher %.2f s, sdp+sampling %.2f s (%s, %d iterations), '
                   'fine-tune %.2f s (%d steps, loss %.4f -> %.4f)' %

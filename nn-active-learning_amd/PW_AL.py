@@ -33,25 +33,24 @@ def get_stats(paths):
 
 
 def gen_multimg_inds(dat_paths, grid_spacing):
-    """PW_AL.gen_multimg_inds (PW_AL.py:921-975): per subject, the raveled indices of the in-plane grid
-    (x % spacing == 0, y % spacing == 0) on every slice, slice by slice, voxels with a NaN mask dropped;
-    returns (indices, labels) as lists of lists."""
+    """PW_AL.gen_multimg_inds (PW_AL.py:921-975): per subject, the raveled (C-order) indices of the in-plane lattice
+    {(x, y): x % spacing == 0, y % spacing == 0} repeated on every slice z - slice by slice, x-major inside a slice, the
+    order the reference's meshgrid / ravel produces - with the voxels whose mask is NaN dropped.
+    Returns (indices, labels), one list per subject."""
     all_inds, all_labels = [], []
     for sub in dat_paths:
         mask = _volume(sub[-1])
-        s = mask.shape
-        Y, X = np.meshgrid(np.arange(s[1]), np.arange(s[0]))
-        X, Y = np.ravel(X), np.ravel(Y)
-        grid_locs = np.logical_and(X % grid_spacing == 0, Y % grid_spacing == 0)
-        grid_X, grid_Y = np.array(X[grid_locs]), np.array(Y[grid_locs])
-        inds, labels = [], []
-        for z in range(s[2]):
-            grid_Z = np.ones(len(grid_X), dtype=int) * z
-            inds += list(np.ravel_multi_index((grid_X, grid_Y, grid_Z), s))
-            labels += list(mask[grid_X, grid_Y, grid_Z])
+        nx, ny, nz = mask.shape
+        xs = np.arange(0, nx, grid_spacing)
+        ys = np.arange(0, ny, grid_spacing)
+        gx = np.repeat(xs, len(ys))                  # lattice points of one slice, x-major
+        gy = np.tile(ys, len(xs))
+        plane = (gx * ny + gy) * nz                  # their raveled index at z = 0
+        inds = (plane[None, :] + np.arange(nz)[:, None]).reshape(-1)          # slice after slice
+        labels = mask[gx, gy, :].T.reshape(-1)
         keep = ~np.isnan(labels)
-        all_inds += [list(np.array(inds)[keep])]
-        all_labels += [list(np.array(labels)[keep])]
+        all_inds.append(list(inds[keep]))
+        all_labels.append(list(labels[keep]))
     return all_inds, all_labels
 
 

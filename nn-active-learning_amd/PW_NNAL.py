@@ -296,34 +296,27 @@ def query_multimg(expr, model, sess, all_padded_imgs, pool_inds, labeled_inds, m
         return patch_utils.global2local_inds(inds, sizes)
     if method_name == 'entropy':
         return bin_uncertainty_filter_multimg(expr, model, sess, all_padded_imgs, pool_inds, k)[0]
-    if method_name == 'MC-entropy':
-        # PW_NNAL.py:232-247: running average of MC_iters dropout passes, then the k closest to 0.5
-        x_feed_dict = {model.keep_prob: model.dropout_rate}
-        av_posts = 0
-        for i in range(expr.pars['MC_iters']):
-            posts = bin_uncertainty_filter_multimg(expr, model, sess, all_padded_imgs, pool_inds, k, x_feed_dict)
-            av_posts = (posts + i * av_posts) / (i + 1)
-        inds = np.argsort(np.abs(av_posts - .5), kind='stable')[:k]
-        return patch_utils.global2local_inds(inds, sizes)
-    if method_name == 'BALD':
-        # PW_NNAL.py:249-282: entropy of the average posterior minus the average entropy (mutual information)
-        x_feed_dict = {model.keep_prob: model.dropout_rate}
-        av_posts, av_ents = 0, 0
-        for i in range(expr.pars['MC_iters']):
-            posts = bin_uncertainty_filter_multimg(expr, model, sess, all_padded_imgs, pool_inds, k, x_feed_dict)
-            av_posts = (posts + i * av_posts) / (i + 1)
-            neg_posts = 1 - posts
-            posts[posts == 0] += 1e-6
-            neg_posts[neg_posts == 0] += 1e-6
-            ents = -posts * np.log(posts) - neg_posts * np.log(neg_posts)
-            av_ents = (ents + i * av_ents) / (i + 1)
-        av_neg_posts = 1 - av_posts
-        av_posts[av_posts == 0] += 1e-6
-        av_neg_posts[av_neg_posts == 0] += 1e-6
-        ent_av_posts = -av_posts * np.log(av_posts) - av_neg_posts * np.log(av_neg_posts)
-        scores = ent_av_posts - av_ents
-        inds = np.argsort(-scores, kind='stable')[:k]
-        return patch_utils.global2local_inds(inds, sizes)
+    if method_name in ('MC-entropy', 'BALD'):
+        # PW_NNAL.py:232-282: MC_iters dropout passes over the whole pool (keep_prob = model.dropout_rate through
+        # batch_eval's x_feed_dict), running means with the reference's update (new + i * mean) / (i + 1).
+        # MC-entropy ranks by |mean posterior - .5|; BALD by H(mean posterior) - mean H(posterior), zeros lifted by 1e-6.
+        def bin_entropy(p):
+            a, b = p.copy(), 1 - p
+            a[a == 0] += 1e-6
+            b[b == 0] += 1e-6
+            return -a * np.log(a) - b * np.log(b)
+        feed = {model.keep_prob: model.dropout_rate}
+        mean_p, mean_h = 0, 0
+        for it in range(expr.pars['MC_iters']):
+            p = bin_uncertainty_filter_multimg(expr, model, sess, all_padded_imgs, pool_inds, k, feed)
+            mean_p = (p + it * mean_p) / (it + 1)
+            if method_name == 'BALD':
+                mean_h = (bin_entropy(p) + it * mean_h) / (it + 1)
+        if method_name == 'MC-entropy':
+            order = np.argsort(np.abs(mean_p - .5), kind='stable')
+        else:
+            order = np.argsort(-(bin_entropy(mean_p) - mean_h), kind='stable')
+        return patch_utils.global2local_inds(order[:k], sizes)
     if method_name == 'rep-entropy':
         return rep_entropy_query(expr, model, sess, all_padded_imgs, pool_inds)
     if method_name == 'core-set':

@@ -333,3 +333,38 @@ def test_device_vs_reference_built_graph(sess, golden_dir, tag, kind, feat, seed
     A = np.stack(PW_NNAL.gen_A_matrices(Expr({'patch_shape': in_shape[:3]}), m, sess, x, g[tag + '_post'][1].astype(np.float64), 1e-3))
     np.testing.assert_allclose(A, g[tag + '_A'], rtol=2e-3, atol=1e-7)
     m.close()
+
+
+def test_edge_cases_of_the_round2_entry_points(sess):
+    """Empty and degenerate inputs: zero-row lists, N = 0, a batch of one, unlabelled samples, keep_prob = 1 dropout."""
+    from nnal_amd import device
+    from nnal_amd._lib import AlqError, check
+    import ctypes as C
+    torch = sess.torch
+    ld = netspec.net_a()
+    in_shape = (20, 20, 1)
+    m, pars = _mk(sess, ld, in_shape, (), 49, max_batch=4, dropout=[[0, 2], 0.5])
+    x = sess.to_device(np.random.RandomState(12).randn(6, 400).astype(np.float32), torch.float32)
+    empty = sess.empty((0,), torch.int64)
+    post, _, _ = m.forward_device(x, 0, rows=empty)
+    assert tuple(post.shape) == (2, 0)
+    r = m.fisher_device(x, 0, None, 1e-3, rows=empty)
+    assert tuple(r['A'].shape) == (0, 3, 3) and float(r['Asum'].abs().sum()) == 0.
+    with pytest.raises(AlqError):                       # N = 0 gradients: nothing to differentiate
+        m.param_grads_device(x, 0, 0)
+    with pytest.raises(ValueError):                     # more than max_batch in one call
+        m.param_grads_device(x, 6, 0)
+    # keep_prob = 1: the dropout entry point is the plain forward pass, bit for bit
+    p1, _ = m.forward_dropout_device(x, 6, 1.0, seed=5)
+    p0, _, _ = m.forward_device(x, 6)
+    assert torch.equal(p0, p1)
+    # unlabelled samples (all-zero one-hot column) contribute nothing to the training gradient
+    m.get_optimizer(0.01, [], 'SGD')
+    om = OracleModel(ld, in_shape, pars)
+    y = np.zeros((2, 3)); y[0, 0] = 1; y[1, 2] = 1      # sample 1 unlabelled
+    g, _, loss = m.param_grads_device(x[:3], 3, 1, labels=np.array([0, -1, 1], np.int32), loss_scale=1. / 3, per_sample=False, want_loss=True)
+    _, ref = om.loss_and_grads(x[:3].cpu().numpy().reshape(3, 20, 20, 1), y)
+    _close(m.unflatten(g.cpu().numpy()), ref, name='unlabelled sample')
+    with pytest.raises(AlqError):
+        check(sess.lib.alq_sgd_step(sess.ctx, None, None, 5, 0.1))
+    m.close()

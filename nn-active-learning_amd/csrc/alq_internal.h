@@ -214,6 +214,7 @@ struct Igemm2Fuse {
     const unsigned *in_bits = nullptr;
     const float *in_vec = nullptr;
     float in_vec_amax = 0.f;   // max |in_vec| when the host knows it (> 0 enables the fp16x2 contraction of that launch)
+    const unsigned *in_vec16 = nullptr;   // in_vec pre-split for that contraction: per 4 values [h01 | h23 | l01 | l23] fp16 pairs of x * 2^(14 - exp(amax))
     // igemm4 only: max |x| of tensors as float bits (non-negative, so unsigned order = float order).  out_amax
     // [N][tiles per patch * groups * 4] receives the maxima of the STORED output columns per (tile, group, wave)
     // (k_rowmax_u32 folds them per patch); in_amax / in_amax2 [N] describe the (two parts of the) input tensor and
@@ -299,6 +300,7 @@ struct Igemm4Args {
     const unsigned *in_amax, *in_amax2;   // F16: per-patch max |x| of the input part(s), float bits -> one scale per tile
     unsigned *out_amax;         // any variant: max |stored output| per (tile, group, wave), float bits
     int amax_from;
+    int src_presplit;           // BITSRC + F16: `in` holds the vector already split into fp16 pairs [h01|h23|l01|l23] per 4 channels
     int xcd_order;              // 1: logical workgroup id = (XCD, slot) instead of the dispatch id (see the kernel)
 };
 

@@ -356,9 +356,28 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             if (s_lds[it] >= 0) {
                 float v0 = R[it].x, v1 = R[it].y, v2 = R[it].z, v3 = R[it].w;
                 if constexpr (BITSRC) {
-                    const unsigned nib = Rb[it];       // one sign byte (low nibble) per 4 channels
-                    v0 = (nib & 1u) ? v0 : 0.f; v1 = (nib & 2u) ? v1 : 0.f;
-                    v2 = (nib & 4u) ? v2 : 0.f; v3 = (nib & 8u) ? v3 : 0.f;
+                    if (!(F16 && a.src_presplit)) {
+                        const unsigned nib = Rb[it];       // one sign byte (low nibble) per 4 channels
+                        v0 = (nib & 1u) ? v0 : 0.f; v1 = (nib & 2u) ? v1 : 0.f;
+                        v2 = (nib & 4u) ? v2 : 0.f; v3 = (nib & 8u) ? v3 : 0.f;
+                    }
+                }
+                if constexpr (BITSRC && F16) {
+                    if (a.src_presplit) {
+                        // the vector arrives ALREADY split (model.hip packs [h01 | h23 | l01 | l23] per 4 channels with the
+                        // launch-wide scale when the weights are set: it is the same for every patch), so a slot is four
+                        // ANDs with the sign masks instead of a select + split per value (~30 -> ~10 VALU per slot; this
+                        // launch runs 7.7 VALU instructions per MFMA and the staging part is its long pole)
+                        const unsigned nib = Rb[it];
+                        const unsigned b0 = (unsigned)__builtin_amdgcn_sbfe((int)nib, 0, 1), b1 = (unsigned)__builtin_amdgcn_sbfe((int)nib, 1, 1);
+                        const unsigned b2 = (unsigned)__builtin_amdgcn_sbfe((int)nib, 2, 1), b3 = (unsigned)__builtin_amdgcn_sbfe((int)nib, 3, 1);
+                        const unsigned m01 = (b0 & 0xffffu) | (b1 & 0xffff0000u), m23 = (b2 & 0xffffu) | (b3 & 0xffff0000u);
+                        const i32x4 r = __builtin_bit_cast(i32x4, R[it]);
+                        char *dst = Al + s_lds[it];
+                        *reinterpret_cast<uint2 *>(dst) = uint2{(unsigned)r.x & m01, (unsigned)r.y & m23};
+                        *reinterpret_cast<uint2 *>(dst + 16) = uint2{(unsigned)r.z & m01, (unsigned)r.w & m23};
+                        continue;
+                    }
                 }
                 if constexpr (F16) {
                     // x * 2^e = h + l * 2^-11.  Same values as ldexp / scalar converts (every step but the two roundings to
@@ -1538,7 +1557,7 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
     a.in_split_ch = in.split / 8; a.in_delta = (int)in.delta;
     a.out_split = out.split; a.out_delta = (int)out.delta;
     a.mask_split = 0; a.mask_delta = 0;
-    a.src_bits = nullptr; a.bits_pstride = 0; a.bits_bytes = 0;
+    a.src_bits = nullptr; a.bits_pstride = 0; a.bits_bytes = 0; a.src_presplit = 0;
     a.f16_ein = 0; a.f16_ew = plan.w16_exp; a.in_amax = nullptr; a.in_amax2 = nullptr; a.out_amax = nullptr;
     bool f16 = false;
     const bool no16 = g_no_f16x2 != 0;
@@ -1572,6 +1591,10 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
             a.f16_ein = 14 - ex;
             a.W = plan.d_W16;
             f16 = true;
+            if (fuse->in_vec16) {      // the vector pre-split with exactly this scale (same 16 bytes per 4 channels)
+                a.in = reinterpret_cast<const float *>(fuse->in_vec16);
+                a.src_presplit = 1;
+            }
         }
     }
     a.dbg = nullptr;

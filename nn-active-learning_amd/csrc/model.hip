@@ -65,6 +65,7 @@ struct Layer {
     // directly (igemm4 BITSRC)
     unsigned *fc_maskbits = nullptr;
     float *fc_wv = nullptr;
+    unsigned *fc_wv16 = nullptr;       // fc_wv pre-split into fp16 pairs for the fp16x2 contraction of the conv below (BITSRC)
     float fc_wv_amax = 0.f;            // max |W0 - W1| of a two-output head (host side, set with the weights)
     const unsigned *dout_amax = nullptr;   // per-patch max |cotangent of this layer's output| of the running backward pass, or null
     unsigned *amax_fwd = nullptr;          // [max_batch] per-patch max |output| of a forward pass that asked for it
@@ -73,6 +74,7 @@ struct Layer {
     int fc_slices2 = 0;
     const unsigned *dout_bits = nullptr;   // set on the conv below for the duration of one backward pass
     const float *dout_vec = nullptr;
+    const unsigned *dout_vec16 = nullptr;
     int fc_slices = 0;
     bool out_is_skip_src = false;
     // convT class tap lists (indices into the k^3 tap enumeration)
@@ -110,6 +112,7 @@ struct alq_model {
     int knobs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int no_f16x2 = 0;
     int no_xcd_order = 0;
+    int no_presplit = 0;           // ALQ_NO_PRESPLIT (A/B): split the fc head's weight-difference vector in the staging part again
     int f16_fwd_mask = -1;         // ALQ_F16_FWD_MASK (diagnostics): forward fp16x2 consumers by layer bit, -1 = default rule
 
     template <typename T>
@@ -627,6 +630,7 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
                     m->layers[i - 1].spec.type == ALQ_CONV && m->layers[i - 1].out.C == 8 && !getenv("ALQ_NO_FC_BITS")) {
                     ALQ_TRY(m->dalloc(&ly.fc_maskbits, (size_t)NB * (ly.F / 16)));      // one sign byte per 4 elements
                     ALQ_TRY(m->dalloc(&ly.fc_wv, (size_t)ly.F));
+                    ALQ_TRY(m->dalloc(&ly.fc_wv16, (size_t)ly.F));
                     const Layer &cv = m->layers[i - 1];
                     const Igemm4Plan &fp = cv.fwd[0].p4;
                     if (sp.cout == 2 && !sp.relu && fp.ok && fp.NTW == 1 && !fp.multi && fp.a.pair && fp.a.PT == 1 && cv.out.cs == 8 &&
@@ -861,7 +865,7 @@ static int run_backward(alq_model *m, const float *d_x, int N) {
     const int nl = (int)m->layers.size();
     ALQ_REQUIRE(m->nclass == 2, ALQ_EUNSUPPORTED, "Fisher scoring is binary (PW_NNAL.py:766), got %d classes", m->nclass);
     ALQ_TRY(k_fill_unit_cotangent(ctx, m->dlogits, N));
-    for (Layer &l : m->layers) { l.delta_ready = false; l.dsum_partial = false; l.dout_bits = nullptr; l.dout_vec = nullptr; l.dout_amax = nullptr; }
+    for (Layer &l : m->layers) { l.delta_ready = false; l.dsum_partial = false; l.dout_bits = nullptr; l.dout_vec = nullptr; l.dout_vec16 = nullptr; l.dout_amax = nullptr; }
     const bool v4_on = !g_dbg_knobs[4] && !g_dbg_knobs[5];
     // a pool whose producer is the first parameterised layer: 2x2(x2) windows tiling the input exactly
     auto pool_first_ok = [&](const Layer &pl, const Layer &src) {
@@ -929,6 +933,7 @@ static int run_backward(alq_model *m, const float *d_x, int N) {
                 ALQ_TRY(k_fc_small_dsum_bits(ctx, ly.fc_maskbits, ly.fc_wv, ly.F, N, prev->dsum));
                 prev->dout_bits = ly.fc_maskbits;
                 prev->dout_vec = ly.fc_wv;
+                prev->dout_vec16 = ly.fc_wv16;
                 prev->dout_vec_amax = ly.spec.cout == 2 ? ly.fc_wv_amax : 0.f;
                 fused = true;
             } else if (ly.dense_fc_small) {
@@ -965,7 +970,8 @@ static int run_backward(alq_model *m, const float *d_x, int N) {
             }
             if (ly.dout_bits) {       // the cotangent of this layer's output exists only as mask bits and one vector
                 fz.in_bits = ly.dout_bits; fz.in_vec = ly.dout_vec; fz.in_vec_amax = ly.dout_vec_amax;
-                ly.dout_bits = nullptr; ly.dout_vec = nullptr;
+                fz.in_vec16 = m->no_presplit ? nullptr : ly.dout_vec16;
+                ly.dout_bits = nullptr; ly.dout_vec = nullptr; ly.dout_vec16 = nullptr;
                 const bool honoured = fuse != nullptr;
                 ALQ_TRY(igemm4_launch(ctx, ly.bwd.p4, ly.dout, ly.din, nullptr, 0, acc, N, PROF_IGEMM3_BWD, &fz));
                 fused = honoured;
@@ -1222,6 +1228,7 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
         g_use_v2 = !(e && e[0] == '1');
         m->no_f16x2 = getenv("ALQ_NO_F16X2") != nullptr;
         m->no_xcd_order = getenv("ALQ_NO_XCD_ORDER") != nullptr;
+        m->no_presplit = getenv("ALQ_NO_PRESPLIT") != nullptr;
         if (const char *f = getenv("ALQ_F16_FWD_MASK")) m->f16_fwd_mask = atoi(f);
         static const char *names[8] = {"ALQ_DEBUG_REPEAT", "ALQ_DEBUG_FLAGS", "ALQ_NO_BWD_FUSE", "ALQ_NO_FWD_FUSE", "ALQ_NO_V3", "ALQ_NO_V4",
                                        "ALQ_NO_POOL_FIRST", "ALQ_NO_CONV_POOL"};
@@ -1344,6 +1351,28 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
                 }
                 ALQ_HIP(hipMemcpyAsync(ly.fc_wv, wv.data(), wv.size() * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
                 ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
+                if (ly.fc_wv16 && ly.fc_wv_amax > 0.f && F % 4 == 0) {
+                    // the same vector as fp16 pairs of x * 2^e, e = 14 - exponent(max |x|) (the scale igemm4_launch derives from
+                    // fc_wv_amax): per 4 consecutive values [h0 h1 | h2 h3 | l0 l1 | l2 l3], h = fp16(x 2^e), l = fp16((x 2^e - h) 2^11)
+                    int ex = 0;
+                    (void)std::frexp(ly.fc_wv_amax, &ex);
+                    const int e = 14 - ex;
+                    std::vector<unsigned> sp((size_t)F);
+                    auto hb = [](float v) { const _Float16 h = (_Float16)v; unsigned short b; std::memcpy(&b, &h, 2); return (unsigned)b; };
+                    for (int64_t f = 0; f < F; f += 4) {
+                        unsigned h[4], l[4];
+                        for (int k = 0; k < 4; ++k) {
+                            const float xs = std::ldexp(wv[(size_t)f + k], e);
+                            const _Float16 hh = (_Float16)xs;
+                            h[k] = hb(xs);
+                            l[k] = hb(std::ldexp(xs - (float)hh, 11));
+                        }
+                        sp[(size_t)f] = h[0] | (h[1] << 16); sp[(size_t)f + 1] = h[2] | (h[3] << 16);
+                        sp[(size_t)f + 2] = l[0] | (l[1] << 16); sp[(size_t)f + 3] = l[2] | (l[3] << 16);
+                    }
+                    ALQ_HIP(hipMemcpyAsync(ly.fc_wv16, sp.data(), sp.size() * sizeof(unsigned), hipMemcpyHostToDevice, m->ctx->stream));
+                    ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
+                }
             }
             ALQ_HIP(hipMemcpyAsync(ly.d_Wp, Wp.data(), Wp.size() * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
             ALQ_HIP(hipStreamSynchronize(m->ctx->stream));

@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -300,6 +301,7 @@ struct Igemm4Args {
     const unsigned *in_amax, *in_amax2;   // F16: per-patch max |x| of the input part(s), float bits -> one scale per tile
     unsigned *out_amax;         // any variant: max |stored output| per (tile, group, wave), float bits
     int amax_from;
+    int wp;                     // weight pieces per k-step in LDS (3: bf16x3 layout, 2: fp16x2-only plan)
     int src_presplit;           // BITSRC + F16: `in` holds the vector already split into fp16 pairs [h01|h23|l01|l23] per 4 channels
     int xcd_order;              // 1: logical workgroup id = (XCD, slot) instead of the dispatch id (see the kernel)
 };
@@ -320,6 +322,12 @@ struct Igemm4Plan {
     bool ok = false;
     Igemm4Args a;
     int NTW = 1;
+    int wp = 3;               // weight pieces per k-step (see Igemm4Args::wp)
+    int xw = 0;               // > 0: conflict-free fragment layout found for the chosen tile
+    // fp16x2-only twin of the plan (two weight pieces in LDS instead of three): with the LDS that frees, tiles whose
+    // bf16x3 plan had to fall back to the bank-conflicted natural row order get a conflict-free layout.  Used by
+    // igemm4_launch whenever the launch contracts with the fp16x2 split; same tiles per patch, rows and form as `this`.
+    std::shared_ptr<Igemm4Plan> alt16;
     bool multi = false;
     bool fic = false;         // issue the prefetch from the contracting side (stage-bound plans)
     size_t lds_bytes = 0;
@@ -336,7 +344,7 @@ struct Igemm4Plan {
     void *d_W16 = nullptr;
     int w16_exp = 0;
 };
-int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan);
+int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan, int wp = 3);
 void igemm4_pack_weights(Igemm4Plan *plan, const std::vector<float> &Bmat /* [(enum tap, ci)][co] */);
 int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const View &out, const float *bias,
                   int relu, int accumulate, int N, int prof_cls, const Igemm2Fuse *fuse);

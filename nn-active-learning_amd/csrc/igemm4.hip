@@ -741,13 +741,14 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     auto unit16 = [&](int S, const char *Wc, const char *Ab, int trow) __attribute__((always_inline)) {
         if constexpr (F16) {
             const int *tt = Tl + trow * (G4_MAXS * 4) + lq;
+            const int wpieces = a.wp;       // 3: the fp16 pieces sit in the first two of the bf16x3 slots; 2: an fp16x2-only plan
             f16x8 Wa[2][NTW], Wb[NTW >= 2 ? 1 : 2][NTW], Xa[2][2], Xb[2][2];
             auto rdW = [&](f16x8 (&Wf)[2][NTW], int s) {
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
 #pragma unroll
                     for (int nt = 0; nt < NTW; ++nt)
-                        Wf[p][nt] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(Wc + ((s * 3 + p) * NTW + nt) * 1024));
+                        Wf[p][nt] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(Wc + ((s * wpieces + p) * NTW + nt) * 1024));
             };
             auto rdX = [&](f16x8 (&X)[2][2], int mh, int to) {
 #pragma unroll
@@ -954,7 +955,8 @@ struct DimGeo {
 struct Box { int b[3] = {0, 0, 0}, n[3] = {1, 1, 1}; };
 }  // namespace
 
-int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
+int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan, int wp) {
+    const int WP = wp == 2 ? 2 : 3;       // weight pieces kept in LDS per k-step: 3 = bf16x3 (and its fp16x2 twin in the same slots), 2 = fp16x2 only
     plan->ok = false;
     plan->units.clear();
     if (g.Ci % 8 != 0 || g.Co % 4 != 0 || g.Ci < 8) return ALQ_OK;
@@ -1140,11 +1142,11 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
     // the odd rows on lanes 4-11, and the two taps sharing a lane group are paired with an even row distance.
     struct Lay { int PX = 0, PYX = 0, PZ = 0, xw = 0, ud = -1; };
     auto roundup_mod = [](int v, int r, int m) { int w = v; while (((w % m) + m) % m != r) ++w; return w; };
-    auto layout = [&](int PT, const int T[3], const int H[3]) {
+    auto layout = [&](int PT, const int T[3], const int H[3], bool natural = false) {
         Lay L;
         L.PX = H[2]; L.PYX = H[1] * L.PX; L.PZ = H[0] * L.PYX;
         const bool unit_zy = dg[0].sm == 1 && dg[1].sm == 1;
-        if (!unit_zy) return L;
+        if (!unit_zy || natural) return L;
         if (dg[2].sm == 1) {
             if (T[2] % 16 == 0) { L.xw = 16; return L; }
             if (T[2] != 8) return L;
@@ -1156,6 +1158,15 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
             L.PZ = H[0] * L.PYX;
             if (L.ud == 3) L.PZ = roundup_mod(L.PZ, 8, 16);
         } else if (dg[2].sm == 2) {
+            if (T[2] == 4 && T[1] >= 2 && T[0] >= 2 && T[1] % 2 == 0 && T[0] % 2 == 0) {
+                // 4 x-neighbours (rows 0, 2, 4, 6) on two lines an ODD pitch apart and two planes a pitch of 8 mod 16 apart:
+                // {0,2,4,6} + {0, odd, 8, odd + 8} is a complete residue system mod 16, half of it even
+                L.xw = 4; L.ud = 4;
+                L.PX = H[2] | 1;
+                L.PYX = roundup_mod(H[1] * L.PX, 8, 16);
+                L.PZ = H[0] * L.PYX;
+                return L;
+            }
             if (T[2] % 8 != 0) return L;
             L.xw = 8;
             if (T[1] >= 2) { L.ud = 1; L.PX = H[2] | 1; L.PYX = H[1] * L.PX; }
@@ -1186,6 +1197,7 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
     // ---- tile search ---------------------------------------------------------------------------------------
     double best = 1e300;
     int bt[4] = {0, 0, 0, 0};
+    bool bt_nat = false;
     for (int TX = 1; TX <= 256; TX <<= 1) {
         if (TX > g4_pow2ceil(dg[2].M)) break;
         for (int TY = 1; TX * TY <= 256; TY <<= 1) {
@@ -1203,17 +1215,24 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
                     if (PT * TX * TY * TZ < 16) continue;
                     const long long nhv = (long long)PT * H[0] * H[1] * H[2];
                     if (nhv * 2 * NPs > 256 * G4_NSLOT) continue;
-                    const Lay L = layout(PT, T, H);
-                    const int sumS_t = ksteps(L);
+                    Lay L = layout(PT, T, H);
+                    int sumS_t = ksteps(L);
                     const size_t tpg_t = (size_t)((dg[0].M + TZ - 1) / TZ) * ((dg[1].M + TY - 1) / TY) * ((dg[2].M + TX - 1) / TX) * ncls;
                     const size_t tab_ints = tt_ints + (size_t)(multi ? rows.size() : rows.size() * NCH) * 8 + tpg_t * 8;
-                    const size_t lds = tab_ints * 4 + (size_t)sumS_t * NCH * 3 * NTW * 1024 + 2 * (size_t)PT * L.PZ * NPs * G4_ROWB;
+                    size_t lds = tab_ints * 4 + (size_t)sumS_t * NCH * WP * NTW * 1024 + 2 * (size_t)PT * L.PZ * NPs * G4_ROWB;
+                    bool nat = false;
+                    if (lds > 160 * 1024 - 256 && L.xw > 0) {      // the padded conflict-free layout does not fit: natural row order
+                        L = layout(PT, T, H, true);
+                        sumS_t = ksteps(L);
+                        lds = tab_ints * 4 + (size_t)sumS_t * NCH * WP * NTW * 1024 + 2 * (size_t)PT * L.PZ * NPs * G4_ROWB;
+                        nat = true;
+                    }
                     if (lds > 160 * 1024 - 256) continue;
                     const double tiles = std::ceil((double)max_batch / PT) * std::ceil((double)dg[0].M / TZ) *
                                          std::ceil((double)dg[1].M / TY) * std::ceil((double)dg[2].M / TX);
                     double cost = tiles * ((double)sumS_t * NCH * 420.0 + (double)(multi ? NPs : nstage) * 1.2 * (double)nhv + 600.0);
                     if (L.xw == 0) cost *= 1.5;        // bank-conflicted fragment reads
-                    if (cost < best) { best = cost; bt[0] = PT; bt[1] = TZ; bt[2] = TY; bt[3] = TX; }
+                    if (cost < best) { best = cost; bt[0] = PT; bt[1] = TZ; bt[2] = TY; bt[3] = TX; bt_nat = nat; }
                 }
             }
         }
@@ -1228,7 +1247,7 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
     const int nhv = PT * H[0] * H[1] * H[2];
     const int nrows = PT * T[0] * T[1] * T[2];
     if (multi && nrows < 192) return ALQ_OK;         // a mostly empty tile: the per-class launches do better
-    Lay L = layout(PT, T, H);
+    Lay L = layout(PT, T, H, bt_nat);
 
     // ---- GEMM row -> M-grid point table ---------------------------------------------------------------------
     plan->h_vdesc.assign(256, -1);
@@ -1241,15 +1260,16 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
         if (okperm) {
             const int ext[4] = {T[0], T[1], T[2], PT};
             for (int pt = 0; pt < PT && okperm; pt += (L.ud == 3 ? 2 : 1))
-                for (int z = 0; z < T[0] && okperm; z += (L.ud == 0 ? 2 : 1))
-                    for (int y = 0; y < T[1] && okperm; y += (L.ud == 1 ? 2 : 1))
+                for (int z = 0; z < T[0] && okperm; z += ((L.ud == 0 || L.ud == 4) ? 2 : 1))
+                    for (int y = 0; y < T[1] && okperm; y += ((L.ud == 1 || L.ud == 4) ? 2 : 1))
                         for (int xc = 0; xc < T[2] && okperm; xc += L.xw) {
                             std::vector<int> ev, od;
                             std::vector<bool> seen(16, false);
-                            const int nu = L.xw == 16 ? 1 : 2;
+                            const int nu = 16 / L.xw;
                             for (int u = 0; u < nu; ++u)
                                 for (int xi = 0; xi < L.xw; ++xi) {
-                                    const int p2 = pt + (L.ud == 3 ? u : 0), z2 = z + (L.ud == 0 ? u : 0), y2 = y + (L.ud == 1 ? u : 0);
+                                    const int p2 = pt + (L.ud == 3 ? u : 0), z2 = z + (L.ud == 0 ? u : (L.ud == 4 ? (u >> 1) : 0)),
+                                              y2 = y + (L.ud == 1 ? u : (L.ud == 4 ? (u & 1) : 0));
                                     const int R = lds_row(p2, z2, y2, xc + xi);
                                     const int pk = (p2 << 24) | (z2 << 16) | (y2 << 8) | (xc + xi);
                                     if (seen[R & 15]) okperm = false;
@@ -1310,7 +1330,7 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
         }
         sumS += r.S;
     }
-    const size_t wbytes = (size_t)sumS * NCH * 3 * NTW * 1024;
+    const size_t wbytes = (size_t)sumS * NCH * WP * NTW * 1024;
 
     Igemm4Args &a = plan->a;
     std::memset(&a, 0, sizeof(a));
@@ -1350,7 +1370,7 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
                 const int in_off = (rows[r].in_off[0] * I[1] + rows[r].in_off[1]) * I[2] + rows[r].in_off[2];
                 const int pd[8] = {in_off, ch, u.S, w_off, (int)r, 0, 0, 0};
                 plan->h_pdesc.insert(plan->h_pdesc.end(), pd, pd + 8);
-                w_off += u.S * 3 * NTW * 1024;
+                w_off += u.S * WP * NTW * 1024;
             }
     } else {
         for (size_t r = 0; r < rows.size(); ++r) {
@@ -1361,7 +1381,7 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
                 Igemm4Plan::Unit u;
                 u.chunk = ch; u.S = rows[r].S; u.w_off = w_off; u.tap = rows[r].tap;
                 plan->units.push_back(u);
-                w_off += u.S * 3 * NTW * 1024;
+                w_off += u.S * WP * NTW * 1024;
             }
         }
     }
@@ -1446,6 +1466,9 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
     plan->h_ttab.insert(plan->h_ttab.end(), plan->h_tdesc.begin(), plan->h_tdesc.end());
     a.tt_ints = (int)plan->h_ttab.size();
     plan->NTW = NTW;
+    plan->wp = WP;
+    a.wp = WP;
+    plan->xw = L.xw;
     plan->multi = multi;
     plan->fic = NTW == 1 && (g.kind == 4 || g.kind == 1) && !getenv("ALQ_NO_FIC");       // short contractions per phase: see FIC in the kernel
     plan->Ci = g.Ci; plan->Co = g.Co;
@@ -1453,12 +1476,26 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan) {
     if (plan->lds_bytes > 160 * 1024) return ALQ_OK;
     plan->flops_per_patch = g.flops_per_patch;
     plan->ok = true;
+    plan->alt16.reset();
+    if (WP == 3 && !multi && L.xw == 0 && getenv("ALQ_ALT16")) {
+        // This plan reads its fragments with bank conflicts (no conflict-free layout fits beside three weight pieces: the
+        // pair-form 16 -> 8 channel convs at 32^3 / 16^3, 3-way conflicts on every X fragment read, PMC 56 % of the LDS-active
+        // cycles).  Launches that contract with the fp16x2 split need two pieces only: with that budget the tile gets the
+        // padded 2 x 2 x 4 layout and the twin is conflict-free (PMC: 56 % -> 8 %, LDS active 72 % -> 39 % of CU-busy).
+        // OPT-IN (ALQ_ALT16=1) because it does not pay: same-box A/B 155.7 k vs 154.9 k patches/s - the launch is bound by
+        // the SIMD's issue slots (MFMA + VALU instruction counts), the LDS array was never the limiter.
+        auto alt = std::make_shared<Igemm4Plan>();
+        if (igemm4_build_plan(g, max_batch, alt.get(), 2) == ALQ_OK && alt->ok && alt->xw > 0 && alt->a.PT == a.PT &&
+            alt->a.tpg == a.tpg && alt->a.rows == a.rows && alt->a.pair == a.pair && alt->NTW == NTW && alt->fic == plan->fic &&
+            alt->a.nph == a.nph)
+            plan->alt16 = alt;
+    }
     if (getenv("ALQ_G4_VERBOSE"))
         fprintf(stderr, "[igemm4] kind %d%s Ci %d Co %d M %dx%dx%d: tile %d x (%d,%d,%d) halo (%d,%d,%d) pitches %d/%d/%d xw %d ud %d, "
-                "%d tap rows, k-steps/tile %d, phases %d groups %d planes %d, NTW %d%s, LDS %zu B (W %zu)\n",
+                "%d tap rows, k-steps/tile %d, phases %d groups %d planes %d, NTW %d%s, LDS %zu B (W %zu, %d pieces)\n",
                 g.kind, g.flipped ? " flipped" : "", g.Ci, g.Co, dg[0].M, dg[1].M, dg[2].M, PT, T[0], T[1], T[2], H[0], H[1], H[2],
                 L.PX, L.PYX, L.PZ, L.xw, L.ud, (int)rows.size(), sumS * NCH, a.nph, a.ngr, a.NP, NTW, pair ? " pair" : "",
-                plan->lds_bytes, wbytes);
+                plan->lds_bytes, wbytes, WP);
     return ALQ_OK;
 }
 
@@ -1479,7 +1516,9 @@ static float g4_bf16_to_f(unsigned short hb) {
 void igemm4_pack_weights(Igemm4Plan *plan, const std::vector<float> &Bmat) {
     const int NTW = plan->NTW, Ci = plan->Ci, Co = plan->Co;
     const bool pair = plan->a.pair != 0;
-    plan->h_W.assign((size_t)plan->a.wbytes / 2, 0);
+    const int WP = plan->wp;
+    const bool only16 = WP == 2;                  // an fp16x2-only plan: two pieces per k-step, no bf16 copy
+    if (!only16) plan->h_W.assign((size_t)plan->a.wbytes / 2, 0);
     const bool w16 = !plan->multi;
     float amax = 0.f;
     for (float w : Bmat) amax = std::max(amax, std::fabs(w));
@@ -1505,10 +1544,10 @@ void igemm4_pack_weights(Igemm4Plan *plan, const std::vector<float> &Bmat) {
                             unsigned short hb, lb;
                             std::memcpy(&hb, &h, 2);
                             std::memcpy(&lb, &l, 2);
-                            plan->h_W16[(size_t)u.w_off / 2 + ((((size_t)s * 3 + 0) * NTW + nt) * 64 + lane) * 8 + j] = hb;
-                            plan->h_W16[(size_t)u.w_off / 2 + ((((size_t)s * 3 + 1) * NTW + nt) * 64 + lane) * 8 + j] = lb;
+                            plan->h_W16[(size_t)u.w_off / 2 + ((((size_t)s * WP + 0) * NTW + nt) * 64 + lane) * 8 + j] = hb;
+                            plan->h_W16[(size_t)u.w_off / 2 + ((((size_t)s * WP + 1) * NTW + nt) * 64 + lane) * 8 + j] = lb;
                         }
-                        for (int p = 0; p < 3; ++p) {
+                        for (int p = 0; p < 3 && !only16; ++p) {
                             const unsigned short hb = g4_bf16_rne(w);
                             w -= g4_bf16_to_f(hb);
                             plan->h_W[(size_t)u.w_off / 2 + ((((size_t)s * 3 + p) * NTW + nt) * 64 + lane) * 8 + j] = hb;
@@ -1534,8 +1573,26 @@ static int launch4_t(alq_ctx *ctx, const Igemm4Plan &plan, const Igemm4Args &a, 
                                 : launch4_s<NTW, MULTI, false>(ctx, plan, a, grid);
 }
 
+static int igemm4_launch_impl(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const View &out, const float *bias,
+                              int relu, int accumulate, int N, int prof_cls, const Igemm2Fuse *fuse);
+
+// will this launch contract with the fp16x2 split?  (the conditions under which igemm4_launch_impl sets `f16`)
+static bool g4_wants_f16(const Igemm4Plan &plan, const View &in, const Igemm2Fuse *fuse) {
+    if (!fuse || g_no_f16x2 || !plan.d_W16 || plan.multi) return false;
+    if (fuse->in_bits) return fuse->in_vec_amax > 0.f;
+    if (fuse->fc_W) return fuse->in_amax != nullptr;
+    return fuse->in_amax != nullptr && plan.a.PT == 1 && (!in.split || fuse->in_amax2) && plan.NTW <= 2;
+}
+
 int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const View &out, const float *bias,
                   int relu, int accumulate, int N, int prof_cls, const Igemm2Fuse *fuse) {
+    if (plan.alt16 && plan.alt16->ok && plan.alt16->d_W16 && g4_wants_f16(*plan.alt16, in, fuse))
+        return igemm4_launch_impl(ctx, *plan.alt16, in, out, bias, relu, accumulate, N, prof_cls, fuse);
+    return igemm4_launch_impl(ctx, plan, in, out, bias, relu, accumulate, N, prof_cls, fuse);
+}
+
+static int igemm4_launch_impl(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const View &out, const float *bias,
+                              int relu, int accumulate, int N, int prof_cls, const Igemm2Fuse *fuse) {
     Igemm4Args a = plan.a;
     ALQ_REQUIRE(in.C == plan.Ci && out.C == plan.Co, ALQ_EINVAL, "igemm4: channel counts do not match the plan");
     ALQ_REQUIRE(out.D == a.OD && out.H == a.OH && out.W == a.OW, ALQ_EINVAL, "igemm4: output view mismatch");
@@ -1643,6 +1700,7 @@ int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const Vi
         a.W = plan.d_W16;
         f16 = true;
     }
+    ALQ_REQUIRE(plan.wp == 3 || f16, ALQ_EINVAL, "igemm4: an fp16x2-only plan was asked for a bf16x3 launch");
     ProfScope ps(ctx, f16 ? (int)PROF_IGEMM_F16 : prof_cls, plan.flops_per_patch * N);
     if (plan.multi) {
         if (plan.NTW == 1) return launch4_t<1, true>(ctx, plan, a, grid);

@@ -239,6 +239,7 @@ static int set4(alq_model *m, Igemm4Plan *p4, const std::vector<float> &Bmat) {
     ALQ_HIP(hipStreamSynchronize(st));
     std::vector<unsigned short>().swap(p4->h_W);
     std::vector<unsigned short>().swap(p4->h_W16);
+    if (p4->alt16) ALQ_TRY(set4(m, p4->alt16.get(), Bmat));       // the fp16x2-only twin: own tables, two-piece weights
     return ALQ_OK;
 }
 

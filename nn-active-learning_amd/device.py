@@ -508,9 +508,7 @@ class DeviceModel(object):
         else:
             check(self.lib.alq_adam_step(self.sess.ctx, C.c_void_p(o['theta'].data_ptr()), C.c_void_p(gsum.data_ptr()),
                                          C.c_void_p(o['m'].data_ptr()), C.c_void_p(o['v'].data_ptr()), P, o['lr'],
-                                         0.9, 0.999, 1e-8, o['t']))
-            if o.get('mask') is not None:      # Adam moves nothing whose gradient is identically zero (m = v = 0 -> 0 / eps)
-                pass
+                                         0.9, 0.999, 1e-8, o['t']))      # a masked-out parameter keeps m = v = 0: its step is 0 / eps = 0
         self.set_flat_params(o['theta'].cpu().numpy())
         return loss
 

@@ -57,7 +57,7 @@ def allreduce_sum(mat, sess=None):
     With a session that holds an RCCL communicator (attach_comm) the reduction is alq_allreduce_sum on the device;
     otherwise torch.distributed (gloo in the CPU tests)."""
     rank, ws = world()
-    if sess is not None and getattr(sess, 'comm_world', 0) == ws and ws >= 1 and getattr(sess, 'comm_world', 0) > 0:
+    if sess is not None and getattr(sess, 'comm_world', 0) == ws:      # the context's communicator spans this process group
         torch = sess.torch
         if isinstance(mat, torch.Tensor):
             t = mat.to(dtype=torch.float64).contiguous().clone()

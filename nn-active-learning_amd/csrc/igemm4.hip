@@ -526,17 +526,20 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             for (int nt = 0; nt < NTW; ++nt) {
                 const int c = nt * 16 + cl;
                 f32x4 val = acc[ms][nt];
-                const bool on = live && c < a.Co;
+                // a fused head (FCF): igemm4_launch guarantees the pair form on exactly 8 channels with ReLU, no mask, no
+                // accumulation, no output maxima and nothing of the tensor stored - those launch constants are folded at
+                // compile time (each test of one keeps a kernel argument in SGPRs, of which this kernel has too few)
+                const bool on = live && (FCF || c < a.Co);
                 if (on) {
                     f32x4 *dst = reinterpret_cast<f32x4 *>(outb + ((unsigned)(obase_e + eoff[ms] + coff[nt]) * 4u));
-                    if (a.accumulate) val += *dst;
-                    if (a.relu) {
+                    if (!FCF && a.accumulate) val += *dst;
+                    if (FCF || a.relu) {
                         val.x = __builtin_amdgcn_fmed3f(val.x, 0.f, __builtin_inff());
                         val.y = __builtin_amdgcn_fmed3f(val.y, 0.f, __builtin_inff());
                         val.z = __builtin_amdgcn_fmed3f(val.z, 0.f, __builtin_inff());
                         val.w = __builtin_amdgcn_fmed3f(val.w, 0.f, __builtin_inff());
                     }
-                    if (a.mask) {
+                    if (!FCF && a.mask) {
                         f32x4 mk;
                         if constexpr (MASK_PF) {
                             mk = Mk[ms][nt];
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                         val.x = mk.x > 0.f ? val.x : 0.f; val.y = mk.y > 0.f ? val.y : 0.f;
                         val.z = mk.z > 0.f ? val.z : 0.f; val.w = mk.w > 0.f ? val.w : 0.f;
                     }
-                    if (c >= a.store_from) {
+                    if (!FCF && c >= a.store_from) {
                         *dst = val;
                         if (a.out_amax && c >= a.amax_from)
                             amx = fmaxf(fmaxf(amx, fmaxf(__builtin_fabsf(val.x), __builtin_fabsf(val.y))),
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             amx_k = amx;
             return;
         }
-        if (a.out_amax) {      // one plain store per wave, tile and group; k_rowmax_u32 folds the slots of a patch
+        if (!FCF && a.out_amax) {      // one plain store per wave, tile and group; k_rowmax_u32 folds the slots of a patch
             int v = __builtin_bit_cast(int, amx);
 #define G4_ROW_SHR_MAX(n)                                                                                              \
     v = __builtin_bit_cast(int, fmaxf(__builtin_bit_cast(float, v),                                                    \
@@ -877,7 +880,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             if constexpr (!MULTI) {
                 const i32x4 pdA = ld4(a.pd_off + (c_pdb + b_ph) * 8), pdB = ld4(a.pd_off + (c_pdb + b_ph) * 8 + 4);
                 const int pd[5] = {0, 0, __builtin_amdgcn_readfirstlane(pdA.z), pdA.w, pdB.x};
-                if constexpr (MASK_PF) { if (b_ph == a.nph - 1 && a.mask) load_mask(c_out, c_full, c_l, c_g); }
+                if constexpr (MASK_PF) { if (!FCF && b_ph == a.nph - 1 && a.mask) load_mask(c_out, c_full, c_l, c_g); }
                 // the contracting side has the slack (phase stamps: with the prefetch in the staging part that part was
                 // the longer one and the other half waited for it at the barrier)
                 if constexpr (FCF) { if (b_ph == a.nph - 1) fcw_prefetch(c_out, c_full, c_l, c_g); }
@@ -1683,7 +1686,7 @@ static int igemm4_launch_impl(alq_ctx *ctx, const Igemm4Plan &plan, const View &
                     "igemm4: store_from needs a 4-aligned column and no accumulation");
         if (fuse->fc_W) {
             ALQ_REQUIRE(plan.NTW == 1 && !plan.multi && a.pair && a.PT == 1 && out.C == 8 && out.cs == 8 && out.c0 == 0 && !out.split &&
-                            !accumulate && !fuse->mask && fuse->fc_part &&
+                            !accumulate && !fuse->mask && fuse->fc_part && relu && !fuse->out_amax &&
                             fuse->fc_F == (long long)out.vox() * 8,
                         ALQ_EUNSUPPORTED, "igemm4: fused fc head needs the pair form on a dense 8-channel output");
             a.fc_W = fuse->fc_W; a.fc_F = (int)fuse->fc_F; a.fc_part = fuse->fc_part;

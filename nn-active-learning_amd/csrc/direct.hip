@@ -114,27 +114,80 @@ struct DirectPoolArgs {
     int tilesZ, tilesY, tilesX;
 };
 
-__global__ __launch_bounds__(256, 2) void direct_conv_pool_kernel(const DirectPoolArgs a) {
+// Schedule: ONE workgroup barrier (after the halo'd input block is in LDS); from there every wave works alone on its
+// slab of 1 x 8 x 8 windows = 2 x 16 x 16 voxels, one z plane (4 voxels x 8 channels per thread) per pass.
+// The kernel is VALU-issue bound (PMC: SQ_ACTIVE_INST_VALU 60 % of the SIMD time, 2.4 k vector instructions per wave of
+// which 864 are the packed FMAs), so everything around the FMAs is written for instruction count:
+//  * halo'd block: rows of 16 aligned floats + two edge values -> 3 float4 + 2 scalar loads per thread with one
+//    division per item (13 scalar loads with two divisions and 64-bit addresses each were 690 instructions, 29 %);
+//  * v_pk_fma_f32 takes the broadcast input straight from one half of an aligned register pair (op_sel), so the
+//    64 inputs live in 32 pairs instead of 64 duplicated pairs (no copies, 64 registers less);
+//  * channel sums and the patch maximum come from the registers that hold the results, not from the store loop;
+//  * a plane goes through a wave-private 8 KB LDS buffer that turns the window-per-lane register layout (64 B lane
+//    stride) into 1 KB runs per store instruction.  16-byte chunk q of row ly sits at position q ^ ((ly >> 1) & 3):
+//    the writing lanes (8 x 8 windows) spread evenly over the 16 bank groups (4 lanes each, the minimum), the
+//    reading lanes take consecutive positions, and since the XOR only permutes chunks inside a 64-byte segment a
+//    store instruction still covers a contiguous 1 KB.
+// Accumulation order per output is unchanged (bias, then taps z, y, x ascending, one fma each): same bits.
+static __device__ __forceinline__ void dcp_fma_lo(f32x2 &acc, const f32x2 x, const f32x2 w) {     // acc += x.lo * w
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(x), "v"(w));
+}
+static __device__ __forceinline__ void dcp_fma_hi(f32x2 &acc, const f32x2 x, const f32x2 w) {     // acc += x.hi * w
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "v"(w));
+}
+
+template <bool ALIGNED>      // ALIGNED: the row length is a multiple of 4 voxels (float4 loads of the block's rows)
+__global__ __launch_bounds__(256, 3) void direct_conv_pool_kernel(const DirectPoolArgs a) {
     constexpr int TWZ = 4, TWY = 8, TWX = 8;                 // windows per workgroup
     constexpr int HZ = 2 * TWZ + 2, HY = 2 * TWY + 2, HX = 2 * TWX + 2;
-    // LDS: weights, the halo'd input block, and the whole 8 x 16 x 16 x 8 output block: threads own windows
-    // (x stride of 2 voxels between lanes), so direct stores would touch a new cache line per lane; the block is
-    // written to LDS in window order and stored by voxel-consecutive lanes as full 2 KB runs
+    constexpr int AX = 24;                                   // LDS row: x = -1 at column 3, the 16 aligned voxels from column 4
     extern __shared__ __attribute__((aligned(16))) float dcp_lds[];
     float *Wl = dcp_lds;                                   // 27 * 8
-    float *Al = dcp_lds + 224;                             // HZ * HY * HX = 3240
-    float *Ol = dcp_lds + 224 + ((HZ * HY * HX + 3) & ~3); // 2048 voxels x 8
-    const int tid = threadIdx.x;
-    for (int i = tid; i < 27 * 8; i += 256) Wl[i] = a.W[i];
+    float *Al = dcp_lds + 224;                             // HZ * HY rows of AX
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float *Ol = dcp_lds + 224 + HZ * HY * AX + wv * 2048;  // this wave's plane: 16 x 16 voxels x 8 channels
+    if (tid < 27 * 8) Wl[tid] = a.W[tid];
     int t = blockIdx.x;
     const int tx = t % a.tilesX; t /= a.tilesX;
     const int ty = t % a.tilesY; t /= a.tilesY;
     const int tz = t % a.tilesZ; t /= a.tilesZ;
     const long long n = t;
     const int z0 = tz * 2 * TWZ, y0 = ty * 2 * TWY, x0 = tx * 2 * TWX;
-    const float *src = a.in + n * (long long)a.D * a.H * a.Wd;
-    {   // all loads of the halo'd block first (13 in flight per thread), then the LDS writes: one memory latency
-        // per workgroup instead of one per element (the rolled loop made this phase the whole kernel time)
+    const long long pv0 = n * (long long)a.D * a.H * a.Wd;
+    const float *src = a.in + pv0;
+    if constexpr (ALIGNED) {
+        // all loads first, then the LDS writes: one memory latency per workgroup
+        f32x4 mid[3];
+        float edge[2];
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int k = tid + it * 256, row = k >> 2, part = k & 3;
+            const int hz = row / HY, hy = row - hz * HY;
+            const int iz = z0 + hz - 1, iy = y0 + hy - 1, ix = x0 + 4 * part;
+            mid[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (k < HZ * HY * 4 && (unsigned)iz < (unsigned)a.D && (unsigned)iy < (unsigned)a.H && ix < a.Wd)
+                mid[it] = *reinterpret_cast<const f32x4 *>(src + (iz * a.H + iy) * a.Wd + ix);
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int k = tid + it * 256, row = k >> 1, side = k & 1;
+            const int hz = row / HY, hy = row - hz * HY;
+            const int iz = z0 + hz - 1, iy = y0 + hy - 1, ix = x0 + (side ? HX - 2 : -1);
+            edge[it] = 0.f;
+            if (k < HZ * HY * 2 && (unsigned)iz < (unsigned)a.D && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.Wd)
+                edge[it] = src[(iz * a.H + iy) * a.Wd + ix];
+        }
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int k = tid + it * 256;
+            if (k < HZ * HY * 4) *reinterpret_cast<f32x4 *>(Al + (k >> 2) * AX + 4 + 4 * (k & 3)) = mid[it];
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int k = tid + it * 256;
+            if (k < HZ * HY * 2) Al[(k >> 1) * AX + ((k & 1) ? HX + 2 : 3)] = edge[it];
+        }
+    } else {
         constexpr int NIT = (HZ * HY * HX + 255) / 256;
         float stg[NIT];
 #pragma unroll
@@ -147,110 +200,149 @@ __global__ __launch_bounds__(256, 2) void direct_conv_pool_kernel(const DirectPo
             const int iz = z0 + hz - 1, iy = y0 + hy - 1, ix = x0 + hx - 1;
             float v = 0.f;
             if (i < HZ * HY * HX && iz >= 0 && iz < a.D && iy >= 0 && iy < a.H && ix >= 0 && ix < a.Wd)
-                v = src[((long long)iz * a.H + iy) * a.Wd + ix];
+                v = src[(iz * a.H + iy) * a.Wd + ix];
             stg[it] = v;
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = tid + it * 256;
-            if (i < HZ * HY * HX) Al[i] = stg[it];
+            if (i < HZ * HY * HX) Al[(i / HX) * AX + 3 + i % HX] = stg[it];
         }
     }
     __syncthreads();
-    const int wx = tid % TWX, wy = (tid / TWX) % TWY, wz = tid / (TWX * TWY);
+    const int wx = lane % TWX, wy = lane / TWX, wz = wv;
     const int pz = tz * TWZ + wz, py = ty * TWY + wy, px = tx * TWX + wx;      // pooled coordinates
     const int PD = a.D / 2, PH = a.H / 2, PW = a.Wd / 2;
     const bool wlive = pz < PD && py < PH && px < PW;
-    // 4x4x4 input block in registers for the whole thread; the 8 output channels in two halves, so that only
-    // 8 voxels x 4 channels of accumulators are live at a time (2 waves per SIMD)
-    float in[4][4][4];
+    // 4x4x4 input block of the thread's window in 32 register pairs
+    f32x2 in[4][4][2];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float *row = Al + ((2 * wz + p) * HY + (2 * wy + q)) * HX + 2 * wx;
-            const f32x2 lo = *reinterpret_cast<const f32x2 *>(row), hi = *reinterpret_cast<const f32x2 *>(row + 2);
-            in[p][q][0] = lo.x; in[p][q][1] = lo.y; in[p][q][2] = hi.x; in[p][q][3] = hi.y;
+            const float *row = Al + ((2 * wz + p) * HY + (2 * wy + q)) * AX + 3 + 2 * wx;
+            in[p][q][0] = f32x2{row[0], row[1]};
+            in[p][q][1] = f32x2{row[2], row[3]};
         }
-    float psum = 0.f;
-    const long long pvox0 = ((n * PD + pz) * PH + py) * PW + px;
-#pragma unroll 1
-    for (int ch = 0; ch < 2; ++ch) {
-        float acc[8][4];
+    const unsigned pvox = (unsigned)((pz * PH + py) * PW + px);                // pooled voxel inside the patch
+    const long long pp0 = n * (long long)PD * PH * PW;
+    char *pbase = reinterpret_cast<char *>(a.pout + pp0 * a.po_cs + a.po_c0);    // uniform bases, 32-bit lane offsets
+    char *abase = reinterpret_cast<char *>(a.argmax + pp0 * 2);
+    float best[8];
+    unsigned bidx0 = 0u, bidx1 = 0u;
 #pragma unroll
-        for (int v = 0; v < 8; ++v)
+    for (int c = 0; c < 8; ++c) best[c] = -INFINITY;
+    f32x2 bias2[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[v][c] = a.bias ? a.bias[ch * 4 + c] : 0.f;
+    for (int c = 0; c < 4; ++c) bias2[c] = a.bias ? *reinterpret_cast<const f32x2 *>(a.bias + 2 * c) : f32x2{0.f, 0.f};
+    float amx = 0.f;
+    char *obase = reinterpret_cast<char *>(a.out + pv0 * a.out_cs + a.out_c0);
+    char *sbase = a.osum ? reinterpret_cast<char *>(a.osum + pv0) : nullptr;
+    const bool full = z0 + 2 * TWZ <= a.D && y0 + 2 * TWY <= a.H && x0 + 2 * TWX <= a.Wd;      // uniform
+    const int vox00 = (((z0 + 2 * wz) * a.H + y0 + 2 * wy) * a.Wd + x0 + 2 * wx);      // first voxel of the window, inside the patch
+    const int sw = wy & 3;                      // chunk swizzle of the rows this lane writes (ly >> 1 == wy)
+    // store loop: lane -> chunk position; the swizzle of iteration `it` is the constant it & 3 (row >> 1 == it)
+    const int lq = lane & 31, lb = lane >> 5;
+    int voff[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) voff[k] = (lb * a.Wd + ((lq ^ k) >> 1)) * a.out_cs + ((lq ^ k) & 1) * 4;
+#pragma unroll
+    for (int vz = 0; vz < 2; ++vz) {
+        f32x2 acc[4][4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[v][c] = bias2[c];
 #pragma unroll
         for (int dz = 0; dz < 3; ++dz)
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    const f32x4 w = *reinterpret_cast<const f32x4 *>(Wl + ((dz * 3 + dy) * 3 + dx) * 8 + ch * 4);
-                    const float wv[4] = {w.x, w.y, w.z, w.w};
+                    const float *wp = Wl + ((dz * 3 + dy) * 3 + dx) * 8;
+                    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wp), w1 = *reinterpret_cast<const f32x4 *>(wp + 4);
+                    const f32x2 w2[4] = {f32x2{w0.x, w0.y}, f32x2{w0.z, w0.w}, f32x2{w1.x, w1.y}, f32x2{w1.z, w1.w}};
 #pragma unroll
-                    for (int v = 0; v < 8; ++v) {
-                        const float xv = in[(v >> 2) + dz][((v >> 1) & 1) + dy][(v & 1) + dx];
+                    for (int v = 0; v < 4; ++v) {
+                        const int xi = (v & 1) + dx;
+                        const f32x2 xp = in[vz + dz][(v >> 1) + dy][xi >> 1];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) acc[v][c] = fmaf(xv, wv[c], acc[v][c]);
+                        for (int c = 0; c < 4; ++c) {
+                            if (xi & 1) dcp_fma_hi(acc[v][c], xp, w2[c]);
+                            else dcp_fma_lo(acc[v][c], xp, w2[c]);
+                        }
                     }
                 }
-        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        unsigned bidx = 0u;
+        const int z = z0 + 2 * wz + vz;
 #pragma unroll
-        for (int v = 0; v < 8; ++v) {
-            const int z = 2 * pz + (v >> 2), y = 2 * py + ((v >> 1) & 1), x = 2 * px + (v & 1);
-            const long long vox = ((n * a.D + z) * a.H + y) * a.Wd + x;
-            float o[4];
+        for (int v = 0; v < 4; ++v) {
+            float o[8];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) o[c] = a.relu ? fmaxf(acc[v][c], 0.f) : acc[v][c];
-            (void)vox;
-            const int lv = ((2 * wz + (v >> 2)) * (2 * TWY) + 2 * wy + ((v >> 1) & 1)) * (2 * TWX) + 2 * wx + (v & 1);
-            *reinterpret_cast<f32x4 *>(Ol + lv * 8 + ch * 4) = f32x4{o[0], o[1], o[2], o[3]};
+            for (int c = 0; c < 4; ++c) {
+                o[2 * c] = a.relu ? fmaxf(acc[v][c].x, 0.f) : acc[v][c].x;
+                o[2 * c + 1] = a.relu ? fmaxf(acc[v][c].y, 0.f) : acc[v][c].y;
+            }
+            const int ly = 2 * wy + (v >> 1), lx = 2 * wx + (v & 1), q0 = 2 * lx;
+            float *orow = Ol + ly * 128;
+            *reinterpret_cast<f32x4 *>(orow + ((q0 ^ sw) << 2)) = f32x4{o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<f32x4 *>(orow + (((q0 + 1) ^ sw) << 2)) = f32x4{o[4], o[5], o[6], o[7]};
+            const bool vin = full || (z < a.D && y0 + ly < a.H && x0 + lx < a.Wd);
+            if (vin) {
+                if (sbase)
+                    *reinterpret_cast<float *>(sbase + (unsigned)(vox00 + ((vz * a.H + (v >> 1)) * a.Wd + (v & 1))) * 4u) =
+                        ((o[0] + o[1]) + (o[2] + o[3])) + ((o[4] + o[5]) + (o[6] + o[7]));
+                if (!a.relu)       // after a ReLU the patch maximum is the maximum of the pooled values (below)
+                    amx = fmaxf(amx, fmaxf(fmaxf(fmaxf(__builtin_fabsf(o[0]), __builtin_fabsf(o[1])), fmaxf(__builtin_fabsf(o[2]), __builtin_fabsf(o[3]))),
+                                           fmaxf(fmaxf(__builtin_fabsf(o[4]), __builtin_fabsf(o[5])), fmaxf(__builtin_fabsf(o[6]), __builtin_fabsf(o[7])))));
+            }
+            const unsigned wi = (unsigned)(vz * 4 + v);        // window order (dz, dy, dx): first maximum wins
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (o[c] > best[c]) {               // window order (dz, dy, dx): first maximum wins
-                    best[c] = o[c];
-                    bidx = (bidx & ~(255u << (8 * c))) | ((unsigned)v << (8 * c));
-                }
+            for (int c = 0; c < 4; ++c) {
+                if (o[c] > best[c]) { best[c] = o[c]; bidx0 = (bidx0 & ~(255u << (8 * c))) | (wi << (8 * c)); }
+                if (o[c + 4] > best[c + 4]) { best[c + 4] = o[c + 4]; bidx1 = (bidx1 & ~(255u << (8 * c))) | (wi << (8 * c)); }
+            }
         }
-        if (wlive) {
-            *reinterpret_cast<f32x4 *>(a.pout + pvox0 * a.po_cs + a.po_c0 + ch * 4) = f32x4{best[0], best[1], best[2], best[3]};
-            a.argmax[pvox0 * 2 + ch] = bidx;
+        // the wave's LDS operations execute in issue order: the reads below see the writes above once both are issued
+        // in this order (the wave barrier keeps the compiler from moving them)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int oplane = ((z * a.H + y0) * a.Wd + x0) * a.out_cs;
+        if (full) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                *reinterpret_cast<f32x4 *>(obase + (unsigned)(oplane + 2 * it * a.Wd * a.out_cs + voff[it & 3]) * 4u) =
+                    *reinterpret_cast<const f32x4 *>(Ol + (it * 64 + lane) * 4);
+        } else {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = 2 * it + lb, q = lq ^ (it & 3);
+                if (z < a.D && y0 + row < a.H && x0 + (q >> 1) < a.Wd)
+                    *reinterpret_cast<f32x4 *>(obase + (unsigned)(oplane + 2 * it * a.Wd * a.out_cs + voff[it & 3]) * 4u) =
+                        *reinterpret_cast<const f32x4 *>(Ol + (it * 64 + lane) * 4);
+            }
         }
-        psum += (best[0] + best[1]) + (best[2] + best[3]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (wlive && a.posum) a.posum[pvox0] = psum;
-    __syncthreads();
-    // voxel-consecutive lanes: 32 B per lane, 2 KB contiguous per wave along x
-    float amx = 0.f;
-    for (int lv = tid; lv < 2 * TWZ * 2 * TWY * 2 * TWX; lv += 256) {
-        const int lx = lv % (2 * TWX), ly = (lv / (2 * TWX)) % (2 * TWY), lz = lv / (2 * TWX * 2 * TWY);
-        const int z = z0 + lz, y = y0 + ly, x = x0 + lx;
-        if (z >= a.D || y >= a.H || x >= a.Wd) continue;
-        const long long vox = ((n * a.D + z) * a.H + y) * a.Wd + x;
-        const f32x4 g0 = *reinterpret_cast<const f32x4 *>(Ol + lv * 8), g1 = *reinterpret_cast<const f32x4 *>(Ol + lv * 8 + 4);
-        float *orow = a.out + vox * a.out_cs + a.out_c0;
-        *reinterpret_cast<f32x4 *>(orow) = g0;
-        *reinterpret_cast<f32x4 *>(orow + 4) = g1;
-        if (a.osum) {
-            float sum = 0.f;
-            sum += (g0.x + g0.y) + (g0.z + g0.w);
-            sum += (g1.x + g1.y) + (g1.z + g1.w);
-            a.osum[vox] = sum;
-        }
-        if (a.amax)
-            amx = fmaxf(amx, fmaxf(fmaxf(fmaxf(__builtin_fabsf(g0.x), __builtin_fabsf(g0.y)), fmaxf(__builtin_fabsf(g0.z), __builtin_fabsf(g0.w))),
-                                   fmaxf(fmaxf(__builtin_fabsf(g1.x), __builtin_fabsf(g1.y)), fmaxf(__builtin_fabsf(g1.z), __builtin_fabsf(g1.w)))));
+    if (wlive) {
+        char *prow = pbase + pvox * (unsigned)a.po_cs * 4u;
+        *reinterpret_cast<f32x4 *>(prow) = f32x4{best[0], best[1], best[2], best[3]};
+        *reinterpret_cast<f32x4 *>(prow + 16) = f32x4{best[4], best[5], best[6], best[7]};
+        *reinterpret_cast<uint2 *>(abase + pvox * 8u) = uint2{bidx0, bidx1};
+        if (a.posum)
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(a.posum + pp0) + pvox * 4u) =
+                ((best[0] + best[1]) + (best[2] + best[3])) + ((best[4] + best[5]) + (best[6] + best[7]));
+        // dims are even, so a window is inside the volume with all of its 8 voxels: after a ReLU (values >= 0) the
+        // largest |output| of the patch is the largest pooled value
+        if (a.relu)
+            amx = fmaxf(fmaxf(fmaxf(best[0], best[1]), fmaxf(best[2], best[3])), fmaxf(fmaxf(best[4], best[5]), fmaxf(best[6], best[7])));
     }
-    if (a.amax) {      // 16 workgroups per 32^3 patch: one atomic each
+    if (a.amax) {      // 64 waves per 32^3 patch: one atomic each
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) amx = fmaxf(amx, __shfl_xor(amx, off, 64));
-        __syncthreads();                 // Ol is read no more: its first words carry the four wave maxima
-        if ((tid & 63) == 0) Ol[tid >> 6] = amx;
-        __syncthreads();
-        if (tid == 0) atomicMax(a.amax + n, __builtin_bit_cast(unsigned, fmaxf(fmaxf(Ol[0], Ol[1]), fmaxf(Ol[2], Ol[3]))));
+        if (lane == 0) atomicMax(a.amax + n, __builtin_bit_cast(unsigned, amx));
     }
 }
 
@@ -269,11 +361,29 @@ int direct_conv_pool_launch(alq_ctx *ctx, const float *d_W, const View &in, cons
     a.D = in.D; a.H = in.H; a.Wd = in.W; a.N = N; a.relu = relu;
     a.tilesZ = (pout.D + 3) / 4; a.tilesY = (pout.H + 7) / 8; a.tilesX = (pout.W + 7) / 8;
     ProfScope ps(ctx, PROF_DIRECT, flops_per_patch * N);
-    const size_t lds = (224 + 3240 + 2048 * 8) * sizeof(float);
-    ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(direct_conv_pool_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(direct_conv_pool_kernel, dim3((unsigned)((long long)N * a.tilesZ * a.tilesY * a.tilesX)), dim3(256), lds,
-                       ctx->stream, a);
+    const size_t lds = (224 + 10 * 18 * 24 + 4 * 2048) * sizeof(float);
+    // in-patch offsets are 32-bit in the kernel
+    ALQ_REQUIRE((long long)in.D * in.H * in.W * std::max(std::max(out.cs, pout.cs), 1) < (1LL << 29), ALQ_EUNSUPPORTED,
+                "direct conv+pool: volume too large");
+    const dim3 grid((unsigned)((long long)N * a.tilesZ * a.tilesY * a.tilesX));
+    const bool aligned = in.W % 4 == 0 && (reinterpret_cast<uintptr_t>(in.p) & 15) == 0;
+    if (aligned) {
+        static bool attr_a = false;
+        if (!attr_a) {
+            ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(direct_conv_pool_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_a = true;
+        }
+        hipLaunchKernelGGL(direct_conv_pool_kernel<true>, grid, dim3(256), lds, ctx->stream, a);
+    } else {
+        static bool attr_u = false;
+        if (!attr_u) {
+            ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(direct_conv_pool_kernel<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_u = true;
+        }
+        hipLaunchKernelGGL(direct_conv_pool_kernel<false>, grid, dim3(256), lds, ctx->stream, a);
+    }
     ALQ_HIP(hipGetLastError());
     return ALQ_OK;
 }

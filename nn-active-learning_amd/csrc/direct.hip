@@ -115,7 +115,8 @@ struct DirectPoolArgs {
 };
 
 // Schedule: ONE workgroup barrier (after the halo'd input block is in LDS); from there every wave works alone on its
-// slab of 1 x 8 x 8 windows = 2 x 16 x 16 voxels, one z plane (4 voxels x 8 channels per thread) per pass.
+// slab of 1 x 8 x 8 windows = 2 x 16 x 16 voxels, one z plane (4 voxels x 8 channels per thread) per pass; 33 KB of
+// LDS and <= 128 registers: four workgroups (16 waves) per CU.
 // The kernel is VALU-issue bound (PMC: SQ_ACTIVE_INST_VALU 60 % of the SIMD time, 2.4 k vector instructions per wave of
 // which 864 are the packed FMAs), so everything around the FMAs is written for instruction count:
 //  * halo'd block: rows of 16 aligned floats + two edge values -> 3 float4 + 2 scalar loads per thread with one
@@ -123,30 +124,33 @@ struct DirectPoolArgs {
 //  * v_pk_fma_f32 takes the broadcast input straight from one half of an aligned register pair (op_sel), so the
 //    64 inputs live in 32 pairs instead of 64 duplicated pairs (no copies, 64 registers less);
 //  * channel sums and the patch maximum come from the registers that hold the results, not from the store loop;
-//  * a plane goes through a wave-private 8 KB LDS buffer that turns the window-per-lane register layout (64 B lane
-//    stride) into 1 KB runs per store instruction.  16-byte chunk q of row ly sits at position q ^ ((ly >> 1) & 3):
-//    the writing lanes (8 x 8 windows) spread evenly over the 16 bank groups (4 lanes each, the minimum), the
-//    reading lanes take consecutive positions, and since the XOR only permutes chunks inside a 64-byte segment a
-//    store instruction still covers a contiguous 1 KB.
+//  * half a plane goes through a wave-private 4 KB LDS buffer that turns the window-per-lane register layout (64 B lane
+//    stride) into 1 KB runs per store instruction.  16-byte chunk q of a row (32 chunks) sits at position
+//    q ^ ((q >> 3) & 3): ds_write_b128 serves 8 consecutive lanes per cycle over 32 banks, and the 8 windows of a row
+//    (64 B apart) then hit 8 different 16-byte bank groups instead of 2 (4-way conflicts: SQ_LDS_BANK_CONFLICT was
+//    40 % of the LDS cycles); the reading lanes take consecutive positions, and since the XOR only permutes chunks
+//    inside a 64-byte segment a store instruction still covers a contiguous 1 KB.
 // Accumulation order per output is unchanged (bias, then taps z, y, x ascending, one fma each): same bits.
+// the weight pair is a scalar register pair: the weights come through the scalar cache (s_load), not through LDS
+// broadcasts (108 ds_read_b128 per wave were a quarter of the LDS cycles) and hold no vector registers
 static __device__ __forceinline__ void dcp_fma_lo(f32x2 &acc, const f32x2 x, const f32x2 w) {     // acc += x.lo * w
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(x), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(x), "s"(w));
 }
 static __device__ __forceinline__ void dcp_fma_hi(f32x2 &acc, const f32x2 x, const f32x2 w) {     // acc += x.hi * w
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "s"(w));
 }
+typedef const __attribute__((address_space(4))) f32x4 *dcp_cw4;
 
 template <bool ALIGNED>      // ALIGNED: the row length is a multiple of 4 voxels (float4 loads of the block's rows)
-__global__ __launch_bounds__(256, 3) void direct_conv_pool_kernel(const DirectPoolArgs a) {
+__global__ __launch_bounds__(256, 4) void direct_conv_pool_kernel(const DirectPoolArgs a) {
     constexpr int TWZ = 4, TWY = 8, TWX = 8;                 // windows per workgroup
     constexpr int HZ = 2 * TWZ + 2, HY = 2 * TWY + 2, HX = 2 * TWX + 2;
     constexpr int AX = 24;                                   // LDS row: x = -1 at column 3, the 16 aligned voxels from column 4
     extern __shared__ __attribute__((aligned(16))) float dcp_lds[];
-    float *Wl = dcp_lds;                                   // 27 * 8
-    float *Al = dcp_lds + 224;                             // HZ * HY rows of AX
+    float *Al = dcp_lds;                                   // HZ * HY rows of AX
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    float *Ol = dcp_lds + 224 + HZ * HY * AX + wv * 2048;  // this wave's plane: 16 x 16 voxels x 8 channels
-    if (tid < 27 * 8) Wl[tid] = a.W[tid];
+    float *Ol = dcp_lds + HZ * HY * AX + wv * 1024;  // this wave's half plane: 8 x 16 voxels x 8 channels
+    const dcp_cw4 Wc = (dcp_cw4)(a.W);          // [27][8], read-only for the launch: constant address space -> s_load
     int t = blockIdx.x;
     const int tx = t % a.tilesX; t /= a.tilesX;
     const int ty = t % a.tilesY; t /= a.tilesY;
@@ -240,12 +244,11 @@ __global__ __launch_bounds__(256, 3) void direct_conv_pool_kernel(const DirectPo
     char *sbase = a.osum ? reinterpret_cast<char *>(a.osum + pv0) : nullptr;
     const bool full = z0 + 2 * TWZ <= a.D && y0 + 2 * TWY <= a.H && x0 + 2 * TWX <= a.Wd;      // uniform
     const int vox00 = (((z0 + 2 * wz) * a.H + y0 + 2 * wy) * a.Wd + x0 + 2 * wx);      // first voxel of the window, inside the patch
-    const int sw = wy & 3;                      // chunk swizzle of the rows this lane writes (ly >> 1 == wy)
-    // store loop: lane -> chunk position; the swizzle of iteration `it` is the constant it & 3 (row >> 1 == it)
-    const int lq = lane & 31, lb = lane >> 5;
-    int voff[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) voff[k] = (lb * a.Wd + ((lq ^ k) >> 1)) * a.out_cs + ((lq ^ k) & 1) * 4;
+    const int sw = (wx >> 1) & 3;               // chunk swizzle: position = chunk ^ ((chunk >> 3) & 3), chunk >> 2 == wx
+    // store loop: lane -> chunk position lp of the half plane's row 2 * it + lb (every other row of the plane); the
+    // chunk there is lq
+    const int lp = lane & 31, lb = lane >> 5, lq = lp ^ ((lp >> 3) & 3);
+    const int voff = (2 * lb * a.Wd + (lq >> 1)) * a.out_cs + (lq & 1) * 4;
 #pragma unroll
     for (int vz = 0; vz < 2; ++vz) {
         f32x2 acc[4][4];
@@ -259,8 +262,7 @@ __global__ __launch_bounds__(256, 3) void direct_conv_pool_kernel(const DirectPo
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    const float *wp = Wl + ((dz * 3 + dy) * 3 + dx) * 8;
-                    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wp), w1 = *reinterpret_cast<const f32x4 *>(wp + 4);
+                    const f32x4 w0 = Wc[((dz * 3 + dy) * 3 + dx) * 2], w1 = Wc[((dz * 3 + dy) * 3 + dx) * 2 + 1];
                     const f32x2 w2[4] = {f32x2{w0.x, w0.y}, f32x2{w0.z, w0.w}, f32x2{w1.x, w1.y}, f32x2{w1.z, w1.w}};
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
@@ -275,56 +277,60 @@ __global__ __launch_bounds__(256, 3) void direct_conv_pool_kernel(const DirectPo
                 }
         const int z = z0 + 2 * wz + vz;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            float o[8];
+        for (int vy = 0; vy < 2; ++vy) {       // half a plane (the rows 2 * wy + vy) at a time through the wave's 4 KB of LDS
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                o[2 * c] = a.relu ? fmaxf(acc[v][c].x, 0.f) : acc[v][c].x;
-                o[2 * c + 1] = a.relu ? fmaxf(acc[v][c].y, 0.f) : acc[v][c].y;
+            for (int vx = 0; vx < 2; ++vx) {
+                const int v = 2 * vy + vx;
+                float o[8];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    o[2 * c] = a.relu ? fmaxf(acc[v][c].x, 0.f) : acc[v][c].x;
+                    o[2 * c + 1] = a.relu ? fmaxf(acc[v][c].y, 0.f) : acc[v][c].y;
+                }
+                const int ly = 2 * wy + vy, lx = 2 * wx + vx, q0 = 2 * lx;
+                float *orow = Ol + wy * 128;
+                *reinterpret_cast<f32x4 *>(orow + ((q0 ^ sw) << 2)) = f32x4{o[0], o[1], o[2], o[3]};
+                *reinterpret_cast<f32x4 *>(orow + (((q0 + 1) ^ sw) << 2)) = f32x4{o[4], o[5], o[6], o[7]};
+                const bool vin = full || (z < a.D && y0 + ly < a.H && x0 + lx < a.Wd);
+                if (vin) {
+                    if (sbase)
+                        *reinterpret_cast<float *>(sbase + (unsigned)(vox00 + ((vz * a.H + vy) * a.Wd + vx)) * 4u) =
+                            ((o[0] + o[1]) + (o[2] + o[3])) + ((o[4] + o[5]) + (o[6] + o[7]));
+                    if (!a.relu)       // after a ReLU the patch maximum is the maximum of the pooled values (below)
+                        amx = fmaxf(amx, fmaxf(fmaxf(fmaxf(__builtin_fabsf(o[0]), __builtin_fabsf(o[1])), fmaxf(__builtin_fabsf(o[2]), __builtin_fabsf(o[3]))),
+                                               fmaxf(fmaxf(__builtin_fabsf(o[4]), __builtin_fabsf(o[5])), fmaxf(__builtin_fabsf(o[6]), __builtin_fabsf(o[7])))));
+                }
+                const unsigned wi = (unsigned)(vz * 4 + v);        // window order (dz, dy, dx): first maximum wins
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (o[c] > best[c]) { best[c] = o[c]; bidx0 = (bidx0 & ~(255u << (8 * c))) | (wi << (8 * c)); }
+                    if (o[c + 4] > best[c + 4]) { best[c + 4] = o[c + 4]; bidx1 = (bidx1 & ~(255u << (8 * c))) | (wi << (8 * c)); }
+                }
             }
-            const int ly = 2 * wy + (v >> 1), lx = 2 * wx + (v & 1), q0 = 2 * lx;
-            float *orow = Ol + ly * 128;
-            *reinterpret_cast<f32x4 *>(orow + ((q0 ^ sw) << 2)) = f32x4{o[0], o[1], o[2], o[3]};
-            *reinterpret_cast<f32x4 *>(orow + (((q0 + 1) ^ sw) << 2)) = f32x4{o[4], o[5], o[6], o[7]};
-            const bool vin = full || (z < a.D && y0 + ly < a.H && x0 + lx < a.Wd);
-            if (vin) {
-                if (sbase)
-                    *reinterpret_cast<float *>(sbase + (unsigned)(vox00 + ((vz * a.H + (v >> 1)) * a.Wd + (v & 1))) * 4u) =
-                        ((o[0] + o[1]) + (o[2] + o[3])) + ((o[4] + o[5]) + (o[6] + o[7]));
-                if (!a.relu)       // after a ReLU the patch maximum is the maximum of the pooled values (below)
-                    amx = fmaxf(amx, fmaxf(fmaxf(fmaxf(__builtin_fabsf(o[0]), __builtin_fabsf(o[1])), fmaxf(__builtin_fabsf(o[2]), __builtin_fabsf(o[3]))),
-                                           fmaxf(fmaxf(__builtin_fabsf(o[4]), __builtin_fabsf(o[5])), fmaxf(__builtin_fabsf(o[6]), __builtin_fabsf(o[7])))));
-            }
-            const unsigned wi = (unsigned)(vz * 4 + v);        // window order (dz, dy, dx): first maximum wins
+            // the wave's LDS operations execute in issue order: the reads below see the writes above once both are
+            // issued in this order (the wave barrier keeps the compiler from moving them)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int orow0 = ((z * a.H + y0 + vy) * a.Wd + x0) * a.out_cs;
+            if (full) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (o[c] > best[c]) { best[c] = o[c]; bidx0 = (bidx0 & ~(255u << (8 * c))) | (wi << (8 * c)); }
-                if (o[c + 4] > best[c + 4]) { best[c + 4] = o[c + 4]; bidx1 = (bidx1 & ~(255u << (8 * c))) | (wi << (8 * c)); }
-            }
-        }
-        // the wave's LDS operations execute in issue order: the reads below see the writes above once both are issued
-        // in this order (the wave barrier keeps the compiler from moving them)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int oplane = ((z * a.H + y0) * a.Wd + x0) * a.out_cs;
-        if (full) {
-#pragma unroll
-            for (int it = 0; it < 8; ++it)
-                *reinterpret_cast<f32x4 *>(obase + (unsigned)(oplane + 2 * it * a.Wd * a.out_cs + voff[it & 3]) * 4u) =
-                    *reinterpret_cast<const f32x4 *>(Ol + (it * 64 + lane) * 4);
-        } else {
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int row = 2 * it + lb, q = lq ^ (it & 3);
-                if (z < a.D && y0 + row < a.H && x0 + (q >> 1) < a.Wd)
-                    *reinterpret_cast<f32x4 *>(obase + (unsigned)(oplane + 2 * it * a.Wd * a.out_cs + voff[it & 3]) * 4u) =
+                for (int it = 0; it < 4; ++it)
+                    *reinterpret_cast<f32x4 *>(obase + (unsigned)(orow0 + 4 * it * a.Wd * a.out_cs + voff) * 4u) =
                         *reinterpret_cast<const f32x4 *>(Ol + (it * 64 + lane) * 4);
+            } else {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = 2 * (2 * it + lb) + vy;
+                    if (z < a.D && y0 + row < a.H && x0 + (lq >> 1) < a.Wd)
+                        *reinterpret_cast<f32x4 *>(obase + (unsigned)(orow0 + 4 * it * a.Wd * a.out_cs + voff) * 4u) =
+                            *reinterpret_cast<const f32x4 *>(Ol + (it * 64 + lane) * 4);
+                }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     if (wlive) {
         char *prow = pbase + pvox * (unsigned)a.po_cs * 4u;
@@ -361,7 +367,7 @@ int direct_conv_pool_launch(alq_ctx *ctx, const float *d_W, const View &in, cons
     a.D = in.D; a.H = in.H; a.Wd = in.W; a.N = N; a.relu = relu;
     a.tilesZ = (pout.D + 3) / 4; a.tilesY = (pout.H + 7) / 8; a.tilesX = (pout.W + 7) / 8;
     ProfScope ps(ctx, PROF_DIRECT, flops_per_patch * N);
-    const size_t lds = (224 + 10 * 18 * 24 + 4 * 2048) * sizeof(float);
+    const size_t lds = (10 * 18 * 24 + 4 * 1024) * sizeof(float);
     // in-patch offsets are 32-bit in the kernel
     ALQ_REQUIRE((long long)in.D * in.H * in.W * std::max(std::max(out.cs, pout.cs), 1) < (1LL << 29), ALQ_EUNSUPPORTED,
                 "direct conv+pool: volume too large");

@@ -76,6 +76,12 @@ struct alq_ctx {
     int prof_every = 1;        // time the launches of every prof_every-th alq_fisher pass (event pairs cost ~6 % when on every launch)
     long long prof_pass = 0;
     bool prof_skip = false;    // this pass is not sampled
+    // Side stream of the Fisher pass: the HBM-bound statistics kernels of a layer (box-filter dot products, the head's
+    // channel sums) need nothing from the backward contraction launched right after them, so they run beside it
+    // (fork / join with the two events; null when ALQ_NO_SIDE_STREAM was set at creation: everything on `stream`)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool side_used = false;
     void *param_block = nullptr;   // small device buffer for per-call parameters (gather)
     void *comm = nullptr;          // RCCL communicator of this rank (comm.hip), or null
     int comm_rank = 0, comm_world = 1;

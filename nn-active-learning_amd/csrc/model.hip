@@ -861,7 +861,44 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
     return ALQ_OK;
 }
 
+// While one of these lives, launches through ctx go to the side stream, ordered after everything already on the main
+// stream.  Without a side stream (or when the fork fails) they simply stay on the main stream.
+struct SideStream {
+    alq_ctx *c;
+    hipStream_t main;
+    bool on = false;
+    explicit SideStream(alq_ctx *ctx) : c(ctx), main(ctx->stream) {
+        if (!c->side) return;
+        if (hipEventRecord(c->ev_fork, main) != hipSuccess || hipStreamWaitEvent(c->side, c->ev_fork, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+        c->stream = c->side;
+        c->side_used = true;
+        on = true;
+    }
+    ~SideStream() { if (on) c->stream = main; }
+    SideStream(const SideStream &) = delete;
+    SideStream &operator=(const SideStream &) = delete;
+};
+
+// the main stream waits for what the side stream was given since the last join
+static int side_join(alq_ctx *c) {
+    if (!c->side || !c->side_used) return ALQ_OK;
+    c->side_used = false;
+    ALQ_HIP(hipEventRecord(c->ev_join, c->side));
+    ALQ_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    return ALQ_OK;
+}
+
+static int run_backward_main(alq_model *m, const float *d_x, int N);
 static int run_backward(alq_model *m, const float *d_x, int N) {
+    const int rc = run_backward_main(m, d_x, N);
+    const int rj = side_join(m->ctx);       // also after a failure: nothing may still run beside the caller's next step
+    return rc != ALQ_OK ? rc : rj;
+}
+
+static int run_backward_main(alq_model *m, const float *d_x, int N) {
     alq_ctx *ctx = m->ctx;
     const int nl = (int)m->layers.size();
     ALQ_REQUIRE(m->nclass == 2, ALQ_EUNSUPPORTED, "Fisher scoring is binary (PW_NNAL.py:766), got %d classes", m->nclass);
@@ -912,13 +949,16 @@ static int run_backward(alq_model *m, const float *d_x, int N) {
             if (ly.spec.skip_src >= 0) as2 = m->layers[ly.spec.skip_src].osum;
         }
         double *Sdst = m->Spart + (size_t)ly.pidx * m->max_batch * m->nslab_max;
-        if (ly.spec.type == ALQ_CONVT) {
-            ALQ_TRY(k_boxdot_convT(ctx, ly.dsum, as1, as2, ly.in.D, ly.in.H, ly.in.W, ly.spec.k, ly.spec.s, ly.lo, N, Sdst, m->nslab_max));
-        } else if (isfc) {
-            const int one[3] = {1, 1, 1}, zero[3] = {0, 0, 0};
-            ALQ_TRY(k_boxdot_conv(ctx, ly.dsum, ly.asum, nullptr, 1, 1, 1, one, zero, N, Sdst, m->nslab_max));
-        } else {
-            ALQ_TRY(k_boxdot_conv(ctx, ly.dsum, as1, as2, ly.out.D, ly.out.H, ly.out.W, ly.spec.k, ly.lo, N, Sdst, m->nslab_max));
+        {   // reads this layer's sums, writes its own slice of Spart: beside the contraction launched below
+            SideStream beside(ctx);
+            if (ly.spec.type == ALQ_CONVT) {
+                ALQ_TRY(k_boxdot_convT(ctx, ly.dsum, as1, as2, ly.in.D, ly.in.H, ly.in.W, ly.spec.k, ly.spec.s, ly.lo, N, Sdst, m->nslab_max));
+            } else if (isfc) {
+                const int one[3] = {1, 1, 1}, zero[3] = {0, 0, 0};
+                ALQ_TRY(k_boxdot_conv(ctx, ly.dsum, ly.asum, nullptr, 1, 1, 1, one, zero, N, Sdst, m->nslab_max));
+            } else {
+                ALQ_TRY(k_boxdot_conv(ctx, ly.dsum, as1, as2, ly.out.D, ly.out.H, ly.out.W, ly.spec.k, ly.lo, N, Sdst, m->nslab_max));
+            }
         }
         if (ly.pidx == 0) break;   // nothing upstream needs a cotangent
         const int acc = prev_is_src ? 1 : 0;   // the skip destination has already written this slice
@@ -931,7 +971,10 @@ static int run_backward(alq_model *m, const float *d_x, int N) {
             if (bits_ok) {
                 // every patch has the same head cotangent (the unit cotangent): nothing of the size of the conv's output
                 // is written; the conv's backward contraction reads [sign] * wv (wv = W0 - W1, set with the weights)
-                ALQ_TRY(k_fc_small_dsum_bits(ctx, ly.fc_maskbits, ly.fc_wv, ly.F, N, prev->dsum));
+                {   // the sums feed only the layer's box-filter dot products (same stream, later)
+                    SideStream beside(ctx);
+                    ALQ_TRY(k_fc_small_dsum_bits(ctx, ly.fc_maskbits, ly.fc_wv, ly.F, N, prev->dsum));
+                }
                 prev->dout_bits = ly.fc_maskbits;
                 prev->dout_vec = ly.fc_wv;
                 prev->dout_vec16 = ly.fc_wv16;
@@ -1187,6 +1230,16 @@ int alq_ctx_create(int device, void *stream, alq_ctx **out) {
         set_error("alq_ctx_create: hipMalloc failed");
         return ALQ_ENOMEM;
     }
+    if (!std::getenv("ALQ_NO_SIDE_STREAM")) {      // diagnostic: everything on one stream
+        if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (c->side) (void)hipStreamDestroy(c->side);
+            if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+            c->side = nullptr; c->ev_fork = nullptr; c->ev_join = nullptr;
+        }
+    }
     *out = c;
     return ALQ_OK;
 }
@@ -1194,6 +1247,12 @@ int alq_ctx_create(int device, void *stream, alq_ctx **out) {
 int alq_ctx_destroy(alq_ctx *ctx) {
     if (!ctx) return ALQ_OK;
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->side) {
+        (void)hipStreamSynchronize(ctx->side);
+        (void)hipStreamDestroy(ctx->side);
+        (void)hipEventDestroy(ctx->ev_fork);
+        (void)hipEventDestroy(ctx->ev_join);
+    }
     (void)alq_comm_destroy(ctx);
     for (int c = 0; c < PROF_NUM; ++c) {
         for (auto &pr : ctx->prof[c].pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }

@@ -432,6 +432,35 @@ def test_config3_netc_properties(sess):
     model2.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('in_shape,n', [((6, 10, 14, 1), 5), ((10, 18, 36, 1), 3), ((2, 34, 6, 1), 4)])
+def test_first_conv_pool_kernel_row_lengths_and_partial_tiles(sess, in_shape, n):
+    """The fused first conv + 2x2x2 pool kernel on volumes whose rows are not a multiple of 4 voxels (scalar loads of the
+    halo'd block instead of float4 rows), that leave partial 8 x 16 x 16 tiles in every dimension, and whose patch
+    maxima feed the fp16x2 scale of the next launch: a one-pool net with a skip from the first layer, layer scores
+    against an fp64 evaluation."""
+    torch = sess.torch
+    from collections import OrderedDict
+    k3, s2 = [3, 3, 3], [2, 2, 2]
+    ld = OrderedDict([('enc1', ['conv', [8, k3], 'MA']), ('pool1', ['pool', s2]), ('enc2', ['conv', [16, k3], 'MA']),
+                      ('up1', ['conv_transpose', [8, k3, s2], 'M']), ('dec1', ['conv', [8, k3], 'MA']), ('fc', ['fc', [2]])])
+    sk = [[0, [4], 'con']]
+    pars = netspec.he_init(ld, in_shape, seed=23, skips=sk)
+    model = _device_model(sess, ld, in_shape, sk, pars, max_batch=4)
+    x = np.random.RandomState(78).randn(n, *in_shape).astype(np.float32)
+    xd = sess.to_device(x.reshape(n, -1), torch.float32)
+    r = model.fisher_device(xd, n, None, 1e-3)
+    pars64 = {k: [v[0].astype(np.float64), v[1].astype(np.float64)] for k, v in pars.items()}
+    om64 = OracleModel(ld, in_shape, pars64, skips=sk, dtype=torch.float64)
+    p64, S64, sizes = factored_ref.factored_unit_scores(om64, x.astype(np.float64))
+    g64, h64, A64 = factored_ref.fisher_from_unit(p64[1], S64, sizes, 1e-3)
+    assert np.abs(r['p1'].cpu().numpy() - p64[1]).max() <= 5e-6
+    for got, ref in ((r['g0'].cpu().numpy(), g64), (r['g1'].cpu().numpy(), h64)):
+        scale = np.abs(ref).max(axis=0, keepdims=True)
+        assert (np.abs(got - ref) <= 5e-4 * scale + 1e-9).all(), np.abs(got - ref).max()
+    model.close()
+
+
 @pytest.mark.parametrize('in_shape,n', [((24, 16, 40, 1), 5), ((8, 12, 20, 1), 7), ((16, 16, 16, 2), 3), ((20, 24, 12, 1), 2)])
 def test_netc_other_shapes_vs_fp64(sess, in_shape, n):
     """NET-C on patch shapes that do not divide into the engines' tiles (partial tiles, several patches per tile,

@@ -48,7 +48,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--pool', type=int, default=100000, help='patches per GPU (weak scaling)')
     ap.add_argument('--pool-global', type=int, default=0, help='strong scaling: one pool of this many patches over all GPUs')
-    ap.add_argument('--netb-pool', type=int, default=8192, help='patches of the NET-B side measurement at N = 1 (0 = skip)')
+    ap.add_argument('--netb-pool', type=int, default=16384, help='patches of the NET-B side measurement at N = 1 (0 = skip)')
     ap.add_argument('--batch', type=int, default=2000,
                     help='patches per device pass (per-launch fixed costs ~0.37 ms per pass amortise with the batch; the unsigned '
                          '32-bit tensor offsets of the GEMM engine cap it at 2047 for 32^3 NET-C)')
@@ -225,6 +225,9 @@ def main():
         dist.destroy_process_group()
 
 
+NETB_BATCH = 2048      # same-box sweep over 8192 patches: 186 k patches/s at 256, 278 k at 512, 330 k at 1024, 350 k at 2048
+
+
 def netb_rate(sess, n, x):
     """"NET-B at [n,32,32,32] reported alongside" - the reference's literal patch net
     (NN.create_PW1: 42.05 M parameters, the 32 slices of a patch as channels) Fisher-scored on the first n pool
@@ -233,11 +236,11 @@ def netb_rate(sess, n, x):
     from nnal_amd import device, netspec
     ld = netspec.net_b()
     in_shape = (32, 32, 32)
-    model = device.DeviceModel(sess, ld, in_shape, (), max_batch=256)
+    model = device.DeviceModel(sess, ld, in_shape, (), max_batch=NETB_BATCH)
     model.set_weights(netspec.he_init(ld, in_shape, seed=13))
     want = ('p1', 'H', 'g0', 'g1', 'A', 'trace', 'Asum')
     n = min(n, int(x.shape[0]))
-    model.fisher_device(x, min(n, 512), None, 1e-3, want=want)
+    model.fisher_device(x, min(n, NETB_BATCH), None, 1e-3, want=want)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     model.fisher_device(x, n, None, 1e-3, want=want)
@@ -245,7 +248,7 @@ def netb_rate(sess, n, x):
     dt = time.perf_counter() - t0
     model.close()
     return {'value': n / dt, 'unit': 'patches/s', 'net': 'NET-B = NN.create_PW1 (NN.py:1328-1336), input [N,32,32,32], 7 parameterised layers',
-            'patches': n, 'batch': 256, 'flops_per_patch_executed': 190.9e6 + 151.5e6,
+            'patches': n, 'batch': NETB_BATCH, 'flops_per_patch_executed': 190.9e6 + 151.5e6,
             'tflops_executed': (190.9e6 + 151.5e6) * n / dt / 1e12}
 
 

@@ -379,6 +379,14 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                         continue;
                     }
                 }
+#if defined(ALQ_DIAG) && ALQ_DIAG == 1
+                if constexpr (F16) {
+                    char *dst = Al + s_lds[it];
+                    *reinterpret_cast<uint2 *>(dst) = uint2{__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1)};
+                    *reinterpret_cast<uint2 *>(dst + 16) = uint2{__builtin_bit_cast(unsigned, v2), __builtin_bit_cast(unsigned, v3)};
+                    continue;
+                }
+#endif
                 if constexpr (F16) {
                     // x * 2^e = h + l * 2^-11.  Same values as ldexp / scalar converts (every step but the two roundings to
                     // fp16 is exact), fewer instructions: the scales are two wave-uniform multipliers, the fp16 roundings
@@ -495,6 +503,14 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     int flush_grp = 0;                // a.out_amax: output group of the running flush (MULTI)
     auto flush = [&](int q_out, int q_full, int q_l, int q_g, auto MS0, auto MS1) __attribute__((always_inline)) {
         constexpr int m0 = decltype(MS0)::value, m1 = decltype(MS1)::value;
+#if defined(ALQ_DIAG) && ALQ_DIAG == 2
+        if constexpr (F16) {
+            float sdiag = 0.f;
+            for (int ms = m0; ms < m1; ++ms) sdiag += acc[ms][0].x + accl[ms][0].x;
+            if (sdiag == 12345.678f) a.out[q_out] = sdiag;
+            return;
+        }
+#endif
         const int obase_e = q_out * a.out_cs;
         int mz0 = 0, my0 = 0, mx0 = 0;
         if (!q_full) {
@@ -521,7 +537,35 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 live = e >= 0 && q_g * a.PT + pt < a.N && mz0 + z < a.MD && my0 + y < a.MH && mx0 + x < a.MW;
             }
             livem[ms] = live;
-            if (ms < m0 || ms >= m1) continue;
+        }
+        // ReLU-grad mask values that were not prefetched (two column tiles): ALL loads of the flush first.  Loaded one
+        // row block at a time inside the loop below, each met its full memory latency (eight times per tile: the flush
+        // was 55 % of the two-column-tile backward launches - timing of a build without it).
+        f32x4 Mq[(MASK_PF || FCF) ? 1 : 4][NTW];
+        if constexpr (!MASK_PF && !FCF) {
+            if (a.mask) {
+#pragma unroll
+                for (int ms = m0; ms < m1; ++ms)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        const int c = nt * 16 + cl;
+                        Mq[ms][nt] = f32x4{1.f, 1.f, 1.f, 1.f};
+                        if (livem[ms] && c < a.Co && c >= a.mask_from && c < a.mask_to) {
+                            const int mo = (q_out + evox[ms]) * a.mask_cs + a.mask_c0 + mcoff[nt];
+                            Mq[ms][nt] = *reinterpret_cast<const f32x4 *>(maskb + ((unsigned)mo * 4u));
+                        }
+                    }
+            }
+        }
+        // ONE wait for every older load (mask values, prefetched or just issued; the tile prefetch, a contraction old).
+        // vmcnt retires in order and the compiler, unable to count across the branches below, met the first use of a
+        // mask value in EVERY row block with vmcnt(0) - which also waits for the stores of the row block before it:
+        // three or four store round trips per tile (a third of the last conv's backward launch).  After this wait no
+        // load is outstanding, so the row blocks below only issue stores.
+        if constexpr (!FCF) __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0), expcnt / lgkmcnt untouched
+#pragma unroll
+        for (int ms = m0; ms < m1; ++ms) {
+            const bool live = livem[ms];
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 const int c = nt * 16 + cl;
@@ -541,19 +585,16 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                     }
                     if (!FCF && a.mask) {
                         f32x4 mk;
-                        if constexpr (MASK_PF) {
-                            mk = Mk[ms][nt];
-                        } else {
-                            mk = f32x4{1.f, 1.f, 1.f, 1.f};
-                            if (c >= a.mask_from && c < a.mask_to) {
-                                const int mo = (q_out + evox[ms]) * a.mask_cs + a.mask_c0 + mcoff[nt];
-                                mk = *reinterpret_cast<const f32x4 *>(maskb + ((unsigned)mo * 4u));
-                            }
-                        }
+                        if constexpr (MASK_PF) mk = Mk[ms][nt];
+                        else mk = Mq[ms][nt];
                         val.x = mk.x > 0.f ? val.x : 0.f; val.y = mk.y > 0.f ? val.y : 0.f;
                         val.z = mk.z > 0.f ? val.z : 0.f; val.w = mk.w > 0.f ? val.w : 0.f;
                     }
+#if defined(ALQ_DIAG) && ALQ_DIAG == 5
+                    if (!FCF && c >= a.store_from && val.x == 12345.678f) {
+#else
                     if (!FCF && c >= a.store_from) {
+#endif
                         *dst = val;
                         if (a.out_amax && c >= a.amax_from)
                             amx = fmaxf(fmaxf(amx, fmaxf(__builtin_fabsf(val.x), __builtin_fabsf(val.y))),
@@ -576,7 +617,11 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                     fbyte[ms] = nib;
                     fon[ms] = on;
                 }
+#if defined(ALQ_DIAG) && ALQ_DIAG == 7
+                if constexpr (false) {
+#else
                 if constexpr (SUMS) {
+#endif
                     if (!on) val = f32x4{0.f, 0.f, 0.f, 0.f};
                     // selector MFMA: result row 0 = sum over the lane groups of set A, row 1 = set B
                     const bool inA = pair ? (lq < 2) : (c < a.split);
@@ -607,7 +652,11 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 a.out_amax[((size_t)(q_g * a.tpg + q_l) * ngr + flush_grp) * 4 + hw] =
                     __builtin_bit_cast(unsigned, fmaxf(fmaxf(r0, r1), fmaxf(r2, r3)));
         }
+#if defined(ALQ_DIAG) && ALQ_DIAG == 7
+        if constexpr (false) {
+#else
         if constexpr (SUMS) {
+#endif
             // lane group q: set (q & 1), row blocks m0 = 2 * (q >> 1) (in .x) and m0 + 1 (in .y)
             const bool setB = (lq & 1) != 0;
             float *base = pair ? a.osumA + (setB ? 1 : 0) : (setB ? a.osumB : a.osumA);
@@ -754,6 +803,10 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                         Wf[p][nt] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(Wc + ((s * wpieces + p) * NTW + nt) * 1024));
             };
             auto rdX = [&](f16x8 (&X)[2][2], int mh, int to) {
+#if defined(ALQ_DIAG) && ALQ_DIAG == 4
+                asm volatile("" : "+v"(X[0][0]), "+v"(X[1][0]), "+v"(X[0][1]), "+v"(X[1][1]));
+                return;
+#endif
 #pragma unroll
                 for (int m2 = 0; m2 < 2; ++m2) {
                     const char *row = Ab + vbase[mh + m2] + to;
@@ -763,6 +816,10 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 }
             };
             auto mm = [&](const f16x8 (&Wf)[2][NTW], const f16x8 (&X)[2][2], int mh) {
+#if defined(ALQ_DIAG) && ALQ_DIAG == 3
+                asm volatile("" ::"v"(X[0][0]), "v"(X[1][0]), "v"(X[0][1]), "v"(X[1][1]), "v"(Wf[0][0]), "v"(Wf[1][0]));
+                return;
+#endif
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt) {
                     f32x4 c0 = acc[mh][nt], c1 = acc[mh + 1][nt], d0 = accl[mh][nt], d1 = accl[mh + 1][nt];
@@ -1675,7 +1732,10 @@ static int igemm4_launch_impl(alq_ctx *ctx, const Igemm4Plan &plan, const View &
         ALQ_REQUIRE(!(plan.multi && fuse->mask), ALQ_EUNSUPPORTED, "igemm4: no mask in the multi-output form");
         ALQ_REQUIRE(!a.pair || (!fuse->osumB && fuse->split == 0), ALQ_EUNSUPPORTED,
                     "igemm4: the pair form sums all 8 channels of a voxel");
-        a.mask = fuse->mask; a.mask_cs = fuse->mask_cs; a.mask_c0 = fuse->mask_c0; a.mask_from = fuse->mask_from;
+        a.mask = fuse->mask; a.mask_cs = fuse->mask_cs;
+#if defined(ALQ_DIAG) && ALQ_DIAG == 6
+        a.mask = nullptr;
+#endif a.mask_c0 = fuse->mask_c0; a.mask_from = fuse->mask_from;
         a.mask_to = fuse->mask_to;
         a.mask_split = fuse->mask_split; a.mask_delta = (int)fuse->mask_delta;
         ALQ_REQUIRE(!a.mask_split || a.mask_from == 0, ALQ_EUNSUPPORTED, "igemm4: a split mask covers all columns");

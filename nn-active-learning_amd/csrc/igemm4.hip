@@ -260,7 +260,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     int f_out = 0, f_full = 0, f_l = 0, f_g = 0;      // tile the prefetch cursor points at
     int c_out = 0, c_full = 0, c_l = 0, c_g = 0;      // tile being contracted
     int f_pdb = 0, c_pdb = 0;                         // first phase descriptor of that tile (several tap sets in one launch)
-    unsigned f_m = 0;                                 // F16 with per-patch scales: max |x| (float bits) of the cursor tile's patch
+    unsigned f_m = 0, f_m2 = 0;                       // F16 with per-patch scales: max |x| (float bits) of the cursor tile's patch (two parts of a concat)
     int c_e = a.f16_ein;                              // F16: scale exponent of the tile being staged / contracted
     int p_out = 0, p_full = 0, p_l = 0, p_g = 0;      // tile whose results wait in registers
     bool have_pend = false;
@@ -282,8 +282,10 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         if constexpr (F16) {       // consumed one tick later (stage, a_ph == 0)
             if (a.in_amax) {
                 const int pn = fpg < a.N ? fpg : 0;
+                // the two loads stay in flight until the tile is staged (one tick): combining them here met their whole
+                // latency once per tile
                 f_m = a.in_amax[pn];
-                if (a.in_amax2) f_m = max(f_m, a.in_amax2[pn]);
+                f_m2 = a.in_amax2 ? a.in_amax2[pn] : 0u;
             }
         }
         if ((tflags & 2) && (fpg + 1) * a.PT <= a.N) {      // whole halo inside the tensor: no per-slot checks
@@ -904,8 +906,9 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 c_out = f_out; c_full = f_full; c_l = f_l; c_g = f_g; c_pdb = f_pdb;
                 if constexpr (F16) {
                     if (a.in_amax) {      // max |x| < 2^ex  ->  scale 2^(14 - ex); an all-zero patch keeps 0
-                        const int ex = (int)((f_m >> 23) & 255u) - 126;
-                        c_e = f_m ? 14 - ex : 0;
+                        const unsigned fm = max(f_m, f_m2);
+                        const int ex = (int)((fm >> 23) & 255u) - 126;
+                        c_e = fm ? 14 - ex : 0;
                     }
                 }
             }

@@ -13,7 +13,10 @@
  *     tensors); pointers named `h_*` are HOST pointers; the library never frees caller memory;
  *   - all work is enqueued on the stream given to alq_ctx_create (a hipStream_t passed as
  *     void*; NULL = the null stream) and is stream-ordered; the calls do not synchronise
- *     unless documented;
+ *     unless documented.  A context also owns one private side stream: alq_fisher runs the
+ *     per-layer statistics kernels there, forked from and joined back into the caller's stream
+ *     with events inside the call, so every result is ordered on the caller's stream as if the
+ *     whole call had run on it (ALQ_NO_SIDE_STREAM=1 at context creation: one stream only);
  *   - tensors are channels-last fp32: patches [N, D, H, W, C] (D = 1 for the 2-D nets,
  *     i.e. the reference's [N, H, W, C] placeholder, NN.py:1338-1344).
  */

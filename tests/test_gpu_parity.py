@@ -702,6 +702,33 @@ def test_rows_entry_points_equal_gathered_copies(sess):
     model.close()
 
 
+def test_side_stream_is_invisible_to_the_caller(sess):
+    """alq_fisher runs its per-layer statistics kernels on the context's private side stream, forked from and joined
+    into the caller's stream inside the call.  A context created with ALQ_NO_SIDE_STREAM=1 runs everything on the one
+    stream: same kernels, same inputs, so the results must be bit-identical - and repeated calls on the two-stream
+    context must agree with themselves (a missed join shows as a stale or half-written statistic)."""
+    torch = sess.torch
+    from nnal_amd import device
+    ld, sk = netspec.net_c()
+    in_shape = (16, 16, 16, 1)
+    pars = netspec.he_init(ld, in_shape, seed=35, skips=sk)
+    x = sess.to_device(np.random.RandomState(12).randn(37, 16 ** 3).astype(np.float32), torch.float32)
+    m1 = _device_model(sess, ld, in_shape, sk, pars, max_batch=8)          # 37 patches: five passes, a ragged last one
+    runs = [m1.fisher_device(x, 37, None, 1e-3) for _ in range(3)]
+    os.environ['ALQ_NO_SIDE_STREAM'] = '1'
+    try:
+        one = device.DeviceSession(0)
+    finally:
+        os.environ.pop('ALQ_NO_SIDE_STREAM')
+    m2 = _device_model(one, ld, in_shape, sk, pars, max_batch=8)
+    ref = m2.fisher_device(x, 37, None, 1e-3)
+    for r in runs:
+        for k in ('p1', 'g0', 'g1', 'A', 'trace', 'Asum'):
+            assert torch.equal(r[k], ref[k]), k
+    m1.close()
+    m2.close()
+
+
 def test_models_keep_their_own_engine_knobs(sess):
     """Engine knobs are snapshotted per model at creation: a second model created under other ALQ_* settings must not
     change the kernels of one that is already live (they were process globals rewritten by every alq_model_create)."""

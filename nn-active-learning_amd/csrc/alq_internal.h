@@ -336,6 +336,9 @@ struct Igemm4Plan {
     std::shared_ptr<Igemm4Plan> alt16;
     bool multi = false;
     bool fic = false;         // issue the prefetch from the contracting side (stage-bound plans)
+    // per-launch balance of the two sides of a tick (igemm4.hip, `FIC` / `EPI`): -1 = the kernel family's default
+    int tune_fic = -1;        // 0 / 1: where the prefetch is issued (one-column-tile plans without a mask-bit source)
+    int tune_epi = -1;        // 0..2: row blocks of a finished tile written back by the contracting side
     size_t lds_bytes = 0;
     double flops_per_patch = 0;
     int Ci = 0, Co = 0;

@@ -141,7 +141,7 @@ __device__ inline unsigned g4_pack_h2(_Float16 a, _Float16 b) {
     return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
 }
 
-template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false, bool FCF = false, bool FIC = false, bool F16 = false>
+template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false, bool FCF = false, bool FIC = false, bool F16 = false, int EPI = -1>
 __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     extern __shared__ __attribute__((aligned(16))) char lds4[];
     const int tid = threadIdx.x;
@@ -323,7 +323,9 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     constexpr bool FETCH_IN_CONTRACT = BITSRC || FIC;
     // row blocks of a tile written back by the contracting side: with three products instead of six the contraction of
     // the F16 kernel is the shorter part again (phase stamps: 302 k vs 445 k cycles per half)
-    constexpr int EPI_SPLIT = (BITSRC && F16) ? 1 : 0;
+    // (EPI >= 0: the launch's own balance, Igemm4Plan::tune_epi)
+    constexpr int EPI_SPLIT = EPI >= 0 ? EPI : ((BITSRC && F16) ? 1 : 0);
+    static_assert(!(FCF || MULTI) || EPI_SPLIT == 0, "the fused-head and the multi-group epilogues are not split");
     f32x4 R[G4_NSLOT];
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
@@ -1619,9 +1621,9 @@ void igemm4_pack_weights(Igemm4Plan *plan, const std::vector<float> &Bmat) {
                 }
 }
 
-template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false, bool FCF = false, bool FIC = false, bool F16 = false>
+template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false, bool FCF = false, bool FIC = false, bool F16 = false, int EPI = -1>
 static int launch4_s(alq_ctx *ctx, const Igemm4Plan &plan, const Igemm4Args &a, unsigned grid) {
-    auto kfn = igemm4_kernel<NTW, MULTI, SUMS, BITSRC, FCF, FIC, F16>;
+    auto kfn = igemm4_kernel<NTW, MULTI, SUMS, BITSRC, FCF, FIC, F16, EPI>;
     if (plan.lds_bytes > 64 * 1024)
         ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)plan.lds_bytes));
@@ -1634,6 +1636,17 @@ template <int NTW, bool MULTI>
 static int launch4_t(alq_ctx *ctx, const Igemm4Plan &plan, const Igemm4Args &a, unsigned grid) {
     return (a.osumA || a.osumB) ? launch4_s<NTW, MULTI, true>(ctx, plan, a, grid)
                                 : launch4_s<NTW, MULTI, false>(ctx, plan, a, grid);
+}
+
+// launches with channel sums (the Fisher pass) whose plan carries its own balance (tune_fic / tune_epi)
+template <int NTW, bool BITSRC, bool FIC, bool F16>
+static int launch4_epi(alq_ctx *ctx, const Igemm4Plan &plan, const Igemm4Args &a, unsigned grid, int epi) {
+    switch (epi) {
+        case 0: return launch4_s<NTW, false, true, BITSRC, false, FIC, F16, 0>(ctx, plan, a, grid);
+        case 1: return launch4_s<NTW, false, true, BITSRC, false, FIC, F16, 1>(ctx, plan, a, grid);
+        case 2: return launch4_s<NTW, false, true, BITSRC, false, FIC, F16, 2>(ctx, plan, a, grid);
+        default: return launch4_s<NTW, false, true, BITSRC, false, FIC, F16>(ctx, plan, a, grid);
+    }
 }
 
 static int igemm4_launch_impl(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const View &out, const float *bias,
@@ -1735,10 +1748,10 @@ static int igemm4_launch_impl(alq_ctx *ctx, const Igemm4Plan &plan, const View &
         ALQ_REQUIRE(!(plan.multi && fuse->mask), ALQ_EUNSUPPORTED, "igemm4: no mask in the multi-output form");
         ALQ_REQUIRE(!a.pair || (!fuse->osumB && fuse->split == 0), ALQ_EUNSUPPORTED,
                     "igemm4: the pair form sums all 8 channels of a voxel");
-        a.mask = fuse->mask; a.mask_cs = fuse->mask_cs;
+        a.mask = fuse->mask; a.mask_cs = fuse->mask_cs; a.mask_c0 = fuse->mask_c0; a.mask_from = fuse->mask_from;
 #if defined(ALQ_DIAG) && ALQ_DIAG == 6
         a.mask = nullptr;
-#endif a.mask_c0 = fuse->mask_c0; a.mask_from = fuse->mask_from;
+#endif
         a.mask_to = fuse->mask_to;
         a.mask_split = fuse->mask_split; a.mask_delta = (int)fuse->mask_delta;
         ALQ_REQUIRE(!a.mask_split || a.mask_from == 0, ALQ_EUNSUPPORTED, "igemm4: a split mask covers all columns");
@@ -1771,6 +1784,23 @@ static int igemm4_launch_impl(alq_ctx *ctx, const Igemm4Plan &plan, const View &
     if (plan.multi) {
         if (plan.NTW == 1) return launch4_t<1, true>(ctx, plan, a, grid);
         return launch4_t<2, true>(ctx, plan, a, grid);
+    }
+    if ((plan.tune_fic >= 0 || plan.tune_epi >= 0) && (a.osumA || a.osumB)) {
+        const int epi = plan.tune_epi;
+        if (a.fc_W) {        // the fused head: only the prefetch side moves
+            const bool fic = plan.tune_fic >= 0 ? plan.tune_fic != 0 : f16;
+            if (f16) return fic ? launch4_s<1, false, true, false, true, true, true>(ctx, plan, a, grid)
+                                : launch4_s<1, false, true, false, true, false, true>(ctx, plan, a, grid);
+            return fic ? launch4_s<1, false, true, false, true, true, false>(ctx, plan, a, grid)
+                       : launch4_s<1, false, true, false, true, false, false>(ctx, plan, a, grid);
+        }
+        if (a.src_bits)
+            return f16 ? launch4_epi<1, true, false, true>(ctx, plan, a, grid, epi) : launch4_epi<1, true, false, false>(ctx, plan, a, grid, epi);
+        if (plan.NTW == 2)
+            return f16 ? launch4_epi<2, false, false, true>(ctx, plan, a, grid, epi) : launch4_epi<2, false, false, false>(ctx, plan, a, grid, epi);
+        const bool fic = plan.tune_fic >= 0 ? plan.tune_fic != 0 : plan.fic;
+        if (fic) return f16 ? launch4_epi<1, false, true, true>(ctx, plan, a, grid, epi) : launch4_epi<1, false, true, false>(ctx, plan, a, grid, epi);
+        return f16 ? launch4_epi<1, false, false, true>(ctx, plan, a, grid, epi) : launch4_epi<1, false, false, false>(ctx, plan, a, grid, epi);
     }
     if (a.src_bits && f16)
         return (a.osumA || a.osumB) ? launch4_s<1, false, true, true, false, false, true>(ctx, plan, a, grid)

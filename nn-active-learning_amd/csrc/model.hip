@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstring>
+#include <string>
 #include <memory>
 
 #include "alq_internal.h"
@@ -1303,6 +1304,29 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
     if (rc != ALQ_OK) {
         alq_model_destroy(m);
         return rc;
+    }
+    if (const char *t = getenv("ALQ_G4_TUNE")) {
+        // diagnostic: per-launch balance of the two-slot engine, "f<layer>:fic=<0|1>,epi=<0..2>;b<layer>:..." (f = forward
+        // launch of the layer, b = its backward-data launch); every setting computes the same bits
+        std::string all(t);
+        size_t pos = 0;
+        while (pos < all.size()) {
+            size_t end = all.find(';', pos);
+            if (end == std::string::npos) end = all.size();
+            const std::string item = all.substr(pos, end - pos);
+            pos = end + 1;
+            if (item.size() < 3 || (item[0] != 'f' && item[0] != 'b')) continue;
+            const size_t colon = item.find(':');
+            if (colon == std::string::npos) continue;
+            const int li = atoi(item.substr(1, colon - 1).c_str());
+            if (li < 0 || li >= (int)m->layers.size()) continue;
+            Layer &ly = m->layers[li];
+            Igemm4Plan *pl = item[0] == 'b' ? &ly.bwd.p4 : (ly.spec.type == ALQ_CONVT ? &ly.fwd_all : (ly.fwd.empty() ? nullptr : &ly.fwd[0].p4));
+            if (!pl) continue;
+            const size_t fi = item.find("fic="), ei = item.find("epi=");
+            if (fi != std::string::npos) pl->tune_fic = atoi(item.c_str() + fi + 4);
+            if (ei != std::string::npos) pl->tune_epi = atoi(item.c_str() + ei + 4);
+        }
     }
     *out = m;
     return ALQ_OK;

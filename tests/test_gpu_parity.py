@@ -702,6 +702,33 @@ def test_rows_entry_points_equal_gathered_copies(sess):
     model.close()
 
 
+@pytest.mark.parametrize('in_shape,n', [((16, 16, 16, 1), 5), ((8, 12, 20, 1), 6)])
+def test_skip_concat_behind_a_relu_conv(sess, in_shape, n):
+    """A concat whose direct producer is a conv WITH ReLU (NET-C's are conv_transposes without one): the backward
+    launch of the concat's consumer then masks only the columns behind the skip part, from a mask tensor that starts
+    at a channel offset (`mask_from`, `mask_c0` both non-zero).  Layer scores against an fp64 evaluation."""
+    torch = sess.torch
+    from collections import OrderedDict
+    k3 = [3, 3, 3]
+    ld = OrderedDict([('c1', ['conv', [8, k3], 'MA']), ('c2', ['conv', [8, k3], 'MA']), ('c3', ['conv', [16, k3], 'MA']),
+                      ('c4', ['conv', [8, k3], 'MA']), ('fc', ['fc', [2]])])
+    sk = [[0, [2], 'con']]          # c3 reads [c1 | c2]: c2, a ReLU conv, is the direct producer of the concat
+    pars = netspec.he_init(ld, in_shape, seed=29, skips=sk)
+    model = _device_model(sess, ld, in_shape, sk, pars, max_batch=4)
+    x = np.random.RandomState(79).randn(n, *in_shape).astype(np.float32)
+    xd = sess.to_device(x.reshape(n, -1), torch.float32)
+    r = model.fisher_device(xd, n, None, 1e-3)
+    pars64 = {k: [v[0].astype(np.float64), v[1].astype(np.float64)] for k, v in pars.items()}
+    om64 = OracleModel(ld, in_shape, pars64, skips=sk, dtype=torch.float64)
+    p64, S64, sizes = factored_ref.factored_unit_scores(om64, x.astype(np.float64))
+    g64, h64, A64 = factored_ref.fisher_from_unit(p64[1], S64, sizes, 1e-3)
+    assert np.abs(r['p1'].cpu().numpy() - p64[1]).max() <= 5e-6
+    for got, ref in ((r['g0'].cpu().numpy(), g64), (r['g1'].cpu().numpy(), h64)):
+        scale = np.abs(ref).max(axis=0, keepdims=True)
+        assert (np.abs(got - ref) <= 5e-4 * scale + 1e-9).all(), np.abs(got - ref).max()
+    model.close()
+
+
 def test_side_stream_is_invisible_to_the_caller(sess):
     """alq_fisher runs its per-layer statistics kernels on the context's private side stream, forked from and joined
     into the caller's stream inside the call.  A context created with ALQ_NO_SIDE_STREAM=1 runs everything on the one

@@ -1535,7 +1535,11 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan, int wp) 
     a.wp = WP;
     plan->xw = L.xw;
     plan->multi = multi;
-    plan->fic = NTW == 1 && (g.kind == 4 || g.kind == 1) && !getenv("ALQ_NO_FIC");       // short contractions per phase: see FIC in the kernel
+    // short contractions per phase (see FIC in the kernel): the conv_transpose classes, and a plain conv whose tile is ONE
+    // phase - stash, epilogue and tile lookup then all fall into every staging part (the 8 -> 16 channel conv at 16^3:
+    // 401 -> 357 us per 2000 patches with the prefetch issued from the contracting side; the 32 -> 16 channel one with
+    // four phases per tile LOSES 4 % the same way: tests/tune_sens.sh)
+    plan->fic = NTW == 1 && (g.kind == 4 || g.kind == 1 || (g.kind == 0 && a.nph == 1 && !pair)) && !getenv("ALQ_NO_FIC");
     plan->Ci = g.Ci; plan->Co = g.Co;
     plan->lds_bytes = (size_t)a.tt_ints * 4 + wbytes + 2 * (size_t)a.abytes;
     if (plan->lds_bytes > 160 * 1024) return ALQ_OK;
@@ -1808,10 +1812,12 @@ static int igemm4_launch_impl(alq_ctx *ctx, const Igemm4Plan &plan, const View &
     if (a.src_bits)
         return (a.osumA || a.osumB) ? launch4_s<1, false, true, true>(ctx, plan, a, grid)
                                     : launch4_s<1, false, false, true>(ctx, plan, a, grid);
-    // with three products its contraction is the shorter side: the prefetch is issued from there (FIC)
+    // the prefetch of the fused-head conv is issued from the staging side again: with its launch constants folded and one
+    // wait per epilogue the staging part became the shorter one (phase stamps: contraction 46 %, staging 36 % + 14 %
+    // waiting; tests/tune_sens.sh: 2670 -> 2593 us per 2000 patches)
     if (a.fc_W && f16)
-        return a.osumA ? launch4_s<1, false, true, false, true, true, true>(ctx, plan, a, grid)
-                       : launch4_s<1, false, false, false, true, true, true>(ctx, plan, a, grid);
+        return a.osumA ? launch4_s<1, false, true, false, true, false, true>(ctx, plan, a, grid)
+                       : launch4_s<1, false, false, false, true, false, true>(ctx, plan, a, grid);
     if (a.fc_W)
         return a.osumA ? launch4_s<1, false, true, false, true>(ctx, plan, a, grid)
                        : launch4_s<1, false, false, false, true>(ctx, plan, a, grid);

@@ -324,7 +324,9 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     // row blocks of a tile written back by the contracting side: with three products instead of six the contraction of
     // the F16 kernel is the shorter part again (phase stamps: 302 k vs 445 k cycles per half)
     // (EPI >= 0: the launch's own balance, Igemm4Plan::tune_epi)
-    constexpr int EPI_SPLIT = EPI >= 0 ? EPI : ((BITSRC && F16) ? 1 : 0);
+    // Default 0 since the epilogue meets its loads with one wait: the split that balanced the mask-bit fp16x2 launch in
+    // round 1 (764 -> 627 us at batch 512) now costs it 3 % (tests/tune_sens.sh: 2634 -> 2553 us per 2000 patches without).
+    constexpr int EPI_SPLIT = EPI >= 0 ? EPI : 0;
     static_assert(!(FCF || MULTI) || EPI_SPLIT == 0, "the fused-head and the multi-group epilogues are not split");
     f32x4 R[G4_NSLOT];
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(

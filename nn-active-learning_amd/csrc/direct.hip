@@ -316,8 +316,8 @@ __global__ __launch_bounds__(256, 4) void direct_conv_pool_kernel(const DirectPo
             if (full) {
 #pragma unroll
                 for (int it = 0; it < 4; ++it)
-                    *reinterpret_cast<f32x4 *>(obase + (unsigned)(orow0 + 4 * it * a.Wd * a.out_cs + voff) * 4u) =
-                        *reinterpret_cast<const f32x4 *>(Ol + (it * 64 + lane) * 4);
+                    __builtin_nontemporal_store(*reinterpret_cast<const f32x4 *>(Ol + (it * 64 + lane) * 4),
+                                                reinterpret_cast<f32x4 *>(obase + (unsigned)(orow0 + 4 * it * a.Wd * a.out_cs + voff) * 4u));
             } else {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {

@@ -601,7 +601,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
 #else
                     if (!FCF && c >= a.store_from) {
 #endif
-                        *dst = val;
+                        __builtin_nontemporal_store(val, dst);
                         if (a.out_amax && c >= a.amax_from)
                             amx = fmaxf(fmaxf(amx, fmaxf(__builtin_fabsf(val.x), __builtin_fabsf(val.y))),
                                         fmaxf(__builtin_fabsf(val.z), __builtin_fabsf(val.w)));

@@ -264,6 +264,12 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     int c_e = a.f16_ein;                              // F16: scale exponent of the tile being staged / contracted
     int p_out = 0, p_full = 0, p_l = 0, p_g = 0;      // tile whose results wait in registers
     bool have_pend = false;
+    // MULTI (one column tile): the group BEFORE the last one also waits in registers for the staging side.  With every
+    // group but the last written back between the contractions, the contracting side of the second conv_transpose
+    // carried three of the four epilogues of a tile (phase stamps: contraction 46 %, staging 20 % + 27 % waiting).
+    constexpr bool PEND2 = MULTI && NTW == 1;
+    bool have_pend2 = false;
+    int p2_out = 0;
 
     int goff[G4_NSLOT];
     auto park = [&]() __attribute__((always_inline)) {
@@ -424,6 +430,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
 
     // ---------------- epilogue of one tile (bias already in the accumulators) --------------------------
     f32x4 acc[4][NTW];
+    f32x4 acc2[(MULTI && NTW == 1) ? 4 : 1];      // MULTI: the second pending group (PEND2 below)
     f32x4 accl[F16 ? 4 : 1][NTW];      // F16: the h.l + l.h products (weight 2^-11)
     char *outb = reinterpret_cast<char *>(a.out);
     const char *maskb = reinterpret_cast<const char *>(a.mask);
@@ -921,6 +928,16 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             if (a_ph == 0 && have_pend) {
                 flush(p_out, p_full, p_l, p_g, IC<EPI_SPLIT>{}, IC<4>{});
                 have_pend = false;
+                if constexpr (PEND2) {
+                    if (have_pend2) {
+#pragma unroll
+                        for (int ms = 0; ms < 4; ++ms) acc[ms][0] = acc2[ms];
+                        flush_grp = a.ngr - 2;
+                        flush(p2_out, p_full, p_l, p_g, IC<0>{}, IC<4>{});
+                        flush_grp = a.ngr - 1;
+                        have_pend2 = false;
+                    }
+                }
             }
             PHASE4_END(1);
             nph = a_ph + 1;
@@ -969,7 +986,18 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                     for (int rep = 0; rep <= a.dbg_repeat; ++rep)
                         for (int p = 0; p < a.NP; ++p)
                             unit(gd[2], Wl + gd[3] + p * ub + lane * 16, Al + p * a.plane_bytes, gd[4]);
-                    if (g + 1 < a.ngr) {
+                    bool kept = false;
+                    if constexpr (PEND2) {
+                        if (g + 2 == a.ngr) {
+#pragma unroll
+                            for (int ms = 0; ms < 4; ++ms) acc2[ms] = acc[ms][0];
+                            have_pend2 = true;
+                            p2_out = c_out + gd[5];
+                            kept = true;
+                        }
+                    }
+                    if (kept) {
+                    } else if (g + 1 < a.ngr) {
                         flush_grp = g;
                         flush(c_out + gd[5], c_full, c_l, c_g, IC<0>{}, IC<4>{});
                         flush_grp = a.ngr - 1;       // the group left pending
@@ -995,6 +1023,14 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     if (h == 0) __syncthreads();
     if (have_pend) {
         flush(p_out, p_full, p_l, p_g, IC<EPI_SPLIT>{}, IC<4>{});
+        if constexpr (PEND2) {
+            if (have_pend2) {
+#pragma unroll
+                for (int ms = 0; ms < 4; ++ms) acc[ms][0] = acc2[ms];
+                flush_grp = a.ngr - 2;
+                flush(p2_out, p_full, p_l, p_g, IC<0>{}, IC<4>{});
+            }
+        }
     }
 #ifdef ALQ_STAMPS
     PHASE4_END(6);

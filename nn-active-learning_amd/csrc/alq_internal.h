@@ -310,6 +310,9 @@ struct Igemm4Args {
     int wp;                     // weight pieces per k-step in LDS (3: bf16x3 layout, 2: fp16x2-only plan)
     int src_presplit;           // BITSRC + F16: `in` holds the vector already split into fp16 pairs [h01|h23|l01|l23] per 4 channels
     int xcd_order;              // 1: logical workgroup id = (XCD, slot) instead of the dispatch id (see the kernel)
+    // (appended: the position of an argument changes how the compiler packs the scalar loads of ALL kernels - a field in
+    // the middle cost the mask-bit launch 13 %)
+    int zreuse;             // 1: k-step 3 * iz + j reads, for row blocks 2 / 3 of a wave, what k-step 3 * (iz + 1) + j reads for row blocks 0 / 1 (fragment reuse, igemm4.hip)
 };
 
 struct G4Geom {

@@ -141,7 +141,7 @@ __device__ inline unsigned g4_pack_h2(_Float16 a, _Float16 b) {
     return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
 }
 
-template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false, bool FCF = false, bool FIC = false, bool F16 = false, int EPI = -1>
+template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false, bool FCF = false, bool FIC = false, bool F16 = false, int EPI = -1, bool ZRE = false>
 __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     extern __shared__ __attribute__((aligned(16))) char lds4[];
     const int tid = threadIdx.x;
@@ -862,6 +862,44 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                     __builtin_amdgcn_sched_barrier(0);
                     t_cur = t_nxt;
                 }
+            } else if constexpr (ZRE) {
+                // Fragment reuse: k-step 3 * iz + j (the host packs the taps plane by plane) reads for row blocks 2 / 3 what
+                // k-step 3 * (iz + 1) + j reads for row blocks 0 / 1, so per column j of three k-steps the fragments are read
+                // four times instead of six and rotate through the two register sets.  Same products, summed in the
+                // order (j, iz) instead of (iz, j).
+                f16x8 Wc2[2][NTW];                      // third weight set: fixed roles, so the three columns are a rolled loop
+                rdW(Wa, 0);
+#pragma unroll 1
+                for (int j = 0; j < 3; ++j) {
+                    // enters with Xa = the fragments of k-step j for row blocks 0 / 1 in flight, Wa = its weights
+                    const int t0 = tt[j * 4], t1 = tt[(3 + j) * 4], t2 = tt[(6 + j) * 4];
+                    const int jn = j + 1 < 3 ? j + 1 : j;
+                    const int t0n = tt[jn * 4];
+                    rdX(Xb, 2, t0);                      // row blocks 2 / 3 at plane 0 = row blocks 0 / 1 at plane 1
+                    rdW(Wb, 3 + j);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(Wa, Xa, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    rdX(Xa, 2, t1);                      // row blocks 2 / 3 at plane 1 = row blocks 0 / 1 at plane 2
+                    rdW(Wc2, 6 + j);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(Wa, Xb, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    rdW(Wa, jn);                         // the next column's first weights
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(Wb, Xb, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    rdX(Xb, 2, t2);                      // row blocks 2 / 3 at plane 2
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(Wb, Xa, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(Wc2, Xa, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    rdX(Xa, 0, t0n);                     // the next column's first fragments
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(Wc2, Xb, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             } else {
                 rdW(Wa, 0);
                 auto kstep = [&](const f16x8 (&Wc_)[2][NTW], f16x8 (&Wn_)[2][NTW], int s) {
@@ -1406,19 +1444,30 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan, int wp) 
 
     // ---- k-steps: taps paired by the parity of their LDS row offset -------------------------------------------
     int sumS = 0;
+    // Fragment reuse (kernel: `zreuse`): a 3 x 3 x 4 tap box (pair form) on the natural row order, whose waves hold two row
+    // blocks one plane above the other two.  The taps are then packed plane by plane - three k-steps per plane, the same
+    // (y, x) taps at the same lane groups in every plane - so that k-step 3 * iz + j of the upper row blocks reads exactly
+    // what k-step 3 * (iz + 1) + j of the lower ones reads.  Checked on the finished tables below.
+    const bool plane_pack = !multi && rows.size() == 1 && pair && g.kind == 0 && L.xw == 0 && (L.PYX % 2) == 0 && PT == 1 &&
+                            rows[0].box.n[0] == 3 && rows[0].box.n[1] == 3 && rows[0].box.n[2] == 4 && nrows == 256 &&
+                            !getenv("ALQ_NO_ZREUSE");
     for (URow &r : rows) {
-        std::vector<std::pair<int, int>> ev, od;      // (box position t, row offset)
-        for (int t = 0; t < r.ntaps; ++t) {
-            const int ix = t % r.box.n[2], iy = (t / r.box.n[2]) % r.box.n[1], iz = t / (r.box.n[2] * r.box.n[1]);
-            const int off = (r.box.b[0] + iz) * L.PYX + (r.box.b[1] + iy) * L.PX + (r.box.b[2] + ix);
-            ((off & 1) ? od : ev).push_back({t, off});
-        }
         std::vector<std::pair<int, int>> seq;          // lane-group order; t = -1: padding (zero weights)
-        for (auto *lst : {&ev, &od})
-            for (size_t i = 0; i < lst->size(); i += 2) {
-                seq.push_back((*lst)[i]);
-                seq.push_back(i + 1 < lst->size() ? (*lst)[i + 1] : std::make_pair(-1, (*lst)[i].second));
+        const int nplanes = plane_pack ? r.box.n[0] : 1;
+        const int per_plane = r.ntaps / nplanes;
+        for (int pl = 0; pl < nplanes; ++pl) {
+            std::vector<std::pair<int, int>> ev, od;      // (box position t, row offset)
+            for (int t = pl * per_plane; t < (pl + 1) * per_plane; ++t) {
+                const int ix = t % r.box.n[2], iy = (t / r.box.n[2]) % r.box.n[1], iz = t / (r.box.n[2] * r.box.n[1]);
+                const int off = (r.box.b[0] + iz) * L.PYX + (r.box.b[1] + iy) * L.PX + (r.box.b[2] + ix);
+                ((off & 1) ? od : ev).push_back({t, off});
             }
+            for (auto *lst : {&ev, &od})
+                for (size_t i = 0; i < lst->size(); i += 2) {
+                    seq.push_back((*lst)[i]);
+                    seq.push_back(i + 1 < lst->size() ? (*lst)[i + 1] : std::make_pair(-1, (*lst)[i].second));
+                }
+        }
         if (seq.size() % 4) { const int o = seq.back().second; seq.push_back({-1, o}); seq.push_back({-1, o}); }
         r.S = (int)seq.size() / 4;
         if (r.S > G4_MAXS) return ALQ_OK;
@@ -1453,6 +1502,22 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan, int wp) 
     a.in_pstride = PT * I[0] * I[1] * I[2];
     a.out_pstride = PT * O[0] * O[1] * O[2];
     a.pair = pair ? 1 : 0;
+    a.zreuse = 0;
+    if (plane_pack && rows[0].S == 9) {
+        bool ok = true;
+        const URow &r = rows[0];
+        for (int iz = 0; iz < 2 && ok; ++iz)
+            for (int j = 0; j < 3 && ok; ++j)
+                for (int q = 0; q < 4; ++q)
+                    if (r.toff[((iz + 1) * 3 + j) * 4 + q] - r.toff[(iz * 3 + j) * 4 + q] != L.PYX * dg[0].sm) ok = false;
+        for (int hw = 0; hw < 4 && ok; ++hw)
+            for (int m = 0; m < 2 && ok; ++m)
+                for (int lr = 0; lr < 16; ++lr) {
+                    const int lo_e = plan->h_vdesc[(hw * 4 + m) * 16 + lr], hi_e = plan->h_vdesc[(hw * 4 + 2 + m) * 16 + lr];
+                    if (lo_e < 0 || hi_e != lo_e + (1 << 16)) ok = false;       // same point, one M-grid plane up
+                }
+        a.zreuse = ok ? 1 : 0;
+    }
     a.tt_ints = (int)tt_ints;
     a.wbytes = (int)wbytes;
     a.abytes = plane_rows * NPs * G4_ROWB;
@@ -1663,9 +1728,9 @@ void igemm4_pack_weights(Igemm4Plan *plan, const std::vector<float> &Bmat) {
                 }
 }
 
-template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false, bool FCF = false, bool FIC = false, bool F16 = false, int EPI = -1>
+template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false, bool FCF = false, bool FIC = false, bool F16 = false, int EPI = -1, bool ZRE = false>
 static int launch4_s(alq_ctx *ctx, const Igemm4Plan &plan, const Igemm4Args &a, unsigned grid) {
-    auto kfn = igemm4_kernel<NTW, MULTI, SUMS, BITSRC, FCF, FIC, F16, EPI>;
+    auto kfn = igemm4_kernel<NTW, MULTI, SUMS, BITSRC, FCF, FIC, F16, EPI, ZRE>;
     if (plan.lds_bytes > 64 * 1024)
         ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)plan.lds_bytes));
@@ -1853,6 +1918,9 @@ static int igemm4_launch_impl(alq_ctx *ctx, const Igemm4Plan &plan, const View &
     // the prefetch of the fused-head conv is issued from the staging side again: with its launch constants folded and one
     // wait per epilogue the staging part became the shorter one (phase stamps: contraction 46 %, staging 36 % + 14 %
     // waiting; tests/tune_sens.sh: 2670 -> 2593 us per 2000 patches)
+    if (a.fc_W && f16 && a.zreuse)      // one tap row of nine k-steps per phase (checked when the plan was built): the fragment-reuse loop
+        return a.osumA ? launch4_s<1, false, true, false, true, false, true, -1, true>(ctx, plan, a, grid)
+                       : launch4_s<1, false, false, false, true, false, true, -1, true>(ctx, plan, a, grid);
     if (a.fc_W && f16)
         return a.osumA ? launch4_s<1, false, true, false, true, false, true>(ctx, plan, a, grid)
                        : launch4_s<1, false, false, false, true, false, true>(ctx, plan, a, grid);

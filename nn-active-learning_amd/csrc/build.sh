@@ -13,10 +13,24 @@ for f in igemm igemm2 igemm3 igemm4 fcgemm direct kernels topk model comm train 
   # igemm4: no SLP vectorisation - it turns neighbouring scalar f32 multiplies / adds of the staging and epilogue code into
   # v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, which issue slower than the scalar pairs next to another wave's MFMAs on
   # the same SIMD (same-box A/B: 155.4 k -> 156.6 k patches/s); conversions still pack (v_cvt_pk_f16_f32 / _bf16_f32)
-  X=""; if [ "$f" = igemm4 ]; then X="-fno-slp-vectorize"; fi
+  X=""; if [ "$f" = igemm4 ]; then X="-fno-slp-vectorize --save-temps=obj"; fi
   ( hipcc $FLAGS $X -c "$HERE/$f.hip" -o "$BUILD/$f.o" ${ALQ_EXTRA_FLAGS:-} ) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
+# the two-slot engine must hold no packed fp32 arithmetic (an SLP-packed v_pk_mul / v_pk_fma / v_pk_add beside another wave's
+# MFMAs issues slower than the scalar pair, and round 1 saw wrong fused-head partials with them): checked on the device
+# assembly the compile leaves behind
+ASM="$BUILD/igemm4-hip-amdgcn-amd-amdhsa-gfx950.s"
+if [ -f "$ASM" ]; then
+  if grep -E -q "v_pk_(mul|fma|add)_f32" "$ASM"; then
+    echo "build.sh: packed fp32 arithmetic in igemm4 device code:" >&2
+    grep -E -n "v_pk_(mul|fma|add)_f32" "$ASM" | head -5 >&2
+    exit 1
+  fi
+  rm -f "$BUILD"/igemm4-hip-*.bc "$BUILD"/igemm4-hip-*.hipi "$BUILD"/igemm4-host-*.bc "$BUILD"/igemm4-host-*.hipi "$BUILD"/igemm4-host-*.s
+else
+  echo "build.sh: device assembly of igemm4 not found ($ASM)" >&2; exit 1
+fi
 hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT" "$BUILD"/{igemm,igemm2,igemm3,igemm4,fcgemm,direct,kernels,topk,model,comm,train,sim}.o -ldl
 echo "built $OUT"

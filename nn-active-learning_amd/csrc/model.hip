@@ -968,7 +968,10 @@ static int run_backward_main(alq_model *m, const float *d_x, int N) {
             ALQ_REQUIRE(!acc, ALQ_EUNSUPPORTED, "layer %d: fc consumer of a skip source", i);
             const bool bits_ok = ly.dense_fc_small && ly.fc_maskbits && prev_param && prev->out.cs == prev->out.C &&
                                  prev->out.c0 == 0 && v4_on && prev->bwd.p4.ok && prev->bwd.p4.NTW == 1 && !prev->bwd.p4.multi &&
-                                 prev->bwd.p4.a.PT == 1 && !prev->dout.split && !prev_is_src;
+                                 prev->bwd.p4.a.PT == 1 && !prev->dout.split && !prev_is_src &&
+                                 // ... and that launch must not accumulate (a skip source right below the conv): the
+                                 // accumulating instantiations of the engine are the plain ones
+                                 !(i >= 2 && m->layers[i - 2].out_is_skip_src && prev->spec.skip_src < 0);
             if (bits_ok) {
                 // every patch has the same head cotangent (the unit cotangent): nothing of the size of the conv's output
                 // is written; the conv's backward contraction reads [sign] * wv (wv = W0 - W1, set with the weights)

@@ -212,7 +212,11 @@ def main():
     lab_local = (pool[:, :512].sum(dim=1) > 0).cpu().numpy().astype(np.float64)
     labels = pool_shard.allgather_rows(n, np.arange(a, b), lab_local, sess).astype(np.int64)
     if ws > 1 and backend == 'nccl':
-        pool_shard.attach_comm(sess)
+        try:        # a transport choice, not a compute fallback: torch.distributed's RCCL group does the same sums
+            pool_shard.attach_comm(sess)
+        except Exception as e:
+            if rank == 0:
+                print('al_loop: %s; the Fisher sums go through torch.distributed' % (e,), flush=True)
     dump = os.environ.get('ALQ_LOOP_DUMP')                      # rehearsals: every rank saves its rounds for comparison
     res = run_rounds(model, sess, pool, rounds, int(os.environ.get('ALQ_LOOP_B', '4096')), int(os.environ.get('ALQ_LOOP_K', '100')),
                      n_global=n, labels=labels, finetune=dict(epochs=1, b=50), state=state)

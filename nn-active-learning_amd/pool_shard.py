@@ -45,10 +45,31 @@ def attach_comm(sess):
     if getattr(sess, 'comm_world', 0) > 0:
         return True
     rank, ws = world()
-    uid = [sess.comm_unique_id() if rank == 0 else None]
+    err = None
+    uid = [None]
+    if rank == 0:
+        try:
+            uid = [sess.comm_unique_id()]
+        except Exception as e:          # e.g. librccl not loadable: every rank must learn it, none may wait in a collective
+            err = e
     if ws > 1:
         _dist().broadcast_object_list(uid, src=0)
-    sess.comm_init(uid[0], rank, ws)
+    if uid[0] is not None:
+        try:
+            sess.comm_init(uid[0], rank, ws)
+        except Exception as e:
+            err = e
+    elif err is None:
+        err = RuntimeError('rank 0 could not create an RCCL unique id')
+    # all or nothing: a rank whose init failed would fall back to torch.distributed while the others wait in the
+    # library's all-reduce
+    if ws > 1:
+        failed = max_over_ranks(0.0 if err is None else 1.0)
+        if failed > 0:
+            sess.comm_world = 0
+            raise RuntimeError('alq_comm_init failed on %s' % ('this rank: %s' % (err,) if err is not None else 'another rank'))
+    elif err is not None:
+        raise err
     return True
 
 

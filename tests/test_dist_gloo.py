@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 
@@ -228,3 +229,57 @@ def test_bench_parent_mode_is_chosen_before_any_gpu_use(monkeypatch):
     except SystemExit as e:
         assert e.code == 3
     assert seen['n'] == 2 and seen['argv'][1].endswith('bench.py') and seen['argv'][2:] == ['--gpus', '2', '--steps', '1', '--pool-global', '1000']
+
+
+_ATTACH_CHILD = '''
+import json, os, sys
+sys.path.insert(0, %r)
+import torch.distributed as dist
+import nnal_amd
+from nnal_amd import pool_shard
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%%s' %% os.environ['MASTER_PORT'],
+                        rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))
+rank = dist.get_rank()
+mode = sys.argv[1]
+
+class Sess(object):              # the two calls attach_comm makes on a session
+    comm_world = 0
+    def comm_unique_id(self):
+        if mode == 'no_id':
+            raise RuntimeError('librccl not loadable')
+        return b'u' * 128
+    def comm_init(self, uid, r, ws):
+        if mode == 'rank1_fails' and r == 1:
+            raise RuntimeError('ncclCommInitRank failed')
+        self.comm_world = ws
+
+s = Sess()
+try:
+    pool_shard.attach_comm(s)
+    out = 'attached'
+except Exception as e:
+    out = 'fallback'
+# whatever happened, every rank must have taken the same branch - the next collective proves nobody is stuck
+agree = pool_shard.max_over_ranks(1.0 if out == 'attached' else 0.0) == (1.0 if out == 'attached' else 0.0)
+if rank == 0:
+    print(json.dumps({'out': out, 'agree': bool(agree), 'comm_world': s.comm_world}))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize('mode,want', [('ok', 'attached'), ('rank1_fails', 'fallback'), ('no_id', 'fallback')])
+def test_attach_comm_is_all_or_nothing(tmp_path, mode, want):
+    """The library's RCCL communicator is attached on every rank or on none: a rank whose init fails (or rank 0 without an
+    id) must not leave the others waiting in alq_allreduce_sum while it falls back to torch.distributed."""
+    import json
+    import sys
+    import nnal_amd  # noqa: F401
+    from nnal_amd import pool_shard
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = tmp_path / 'attach_child.py'
+    child.write_text(_ATTACH_CHILD % root)
+    rc, out = pool_shard.spawn_ranks([sys.executable, str(child), mode], 2, timeout=120)
+    assert rc == 0, out
+    got = json.loads(out.strip().splitlines()[-1])
+    assert got['out'] == want and got['agree']
+    assert got['comm_world'] == (2 if want == 'attached' else 0)

@@ -211,7 +211,9 @@ def main():
                          'flops_per_patch_executed': F_EXEC, 'flops_per_patch_survey': F_SURVEY,
                          'whole_step_tflops_executed': F_EXEC * value / ws / 1e12,
                          'hbm_algorithmic_GBps': B_ALG * value / ws / 1e9,
-                         'time_share_ms_sampled': {k: v['ms'] for k, v in prof.items()}},
+                         'time_share_ms_sampled': {k: v['ms'] for k, v in prof.items()},
+                         'time_share_note': 'event spans; the reduce / fc_small kernels of the backward pass run on the side stream '
+                                            'BESIDE the igemm launches (their spans overlap those, they do not add up to the step)'},
         }
         note('GPU: %.1f patches/s' % value)
         if ws == 1 and args.netb_pool > 0:

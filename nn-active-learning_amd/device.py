@@ -356,6 +356,7 @@ class DeviceModel(object):
         self.y_ = Handle('y_')
         self.train_step = None            # get_optimizer() creates it (NN.py:557-615)
         self._opt = None
+        self._weights_version = 0         # bumped by every set_weights: the optimiser's device copy follows it
         self._drop_calls = 0
         self.num_params = int(self.lib.alq_model_num_params(self._m))
         self._feature_perm = self._feature_permutation()
@@ -492,8 +493,14 @@ class DeviceModel(object):
             gsum += g
             loss += float(l.item()) * (b - a) / n
         o = self._opt
-        if o['theta'] is None:
+        if o['theta'] is None or o.get('version') != self._weights_version:
+            # the TF variables are the single state of the reference: weights loaded or assigned since the last step
+            # (set_weights / load_weights / perform_assign_ops) are what the next step updates; Adam's slots persist
+            fresh = o['theta'] is None
             o['theta'] = self.sess.to_device(self.flat_params(), torch.float32)
+        else:
+            fresh = False
+        if fresh:
             o['m'] = torch.zeros_like(o['theta'])
             o['v'] = torch.zeros_like(o['theta'])
             tm = self._train_mask()
@@ -510,6 +517,7 @@ class DeviceModel(object):
                                          C.c_void_p(o['m'].data_ptr()), C.c_void_p(o['v'].data_ptr()), P, o['lr'],
                                          0.9, 0.999, 1e-8, o['t']))      # a masked-out parameter keeps m = v = 0: its step is 0 / eps = 0
         self.set_flat_params(o['theta'].cpu().numpy())
+        o['version'] = self._weights_version
         return loss
 
     def diagonal_fisher(self, x, labels=None, batch=None):
@@ -548,6 +556,7 @@ class DeviceModel(object):
             check(self.lib.alq_model_set_weights(self._m, t, W.ctypes.data_as(C.c_void_p),
                                                  b.ctypes.data_as(C.c_void_p)))
             self.var_dict[name] = [W, b]
+        self._weights_version += 1
 
     def load_weights(self, path, session=None):
         """.npz twin of CNN.load_weights (NN.py:396-419): keys '<layer>/Weight', '<layer>/Bias'."""

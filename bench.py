@@ -35,8 +35,8 @@ F_FWD = 439.88e6
 F_BWD_DATA = 425.72e6
 F_SURVEY = F_FWD + 2 * F_BWD_DATA       # the survey's figure: one backward per class
 F_EXEC = F_FWD + F_BWD_DATA             # what this build executes: ONE backward serves both classes
-PEAK_F32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA peak
+PEAK_HBM_TBPS = 8.0                     # MI355X_MICROARCH.md: HBM3E
 SPLIT_PRODUCTS = 6                      # bf16 MFMA MACs issued per fp32-accurate MAC (igemm3.hip)
 B_ALG = 4 * 32 ** 3 + 4 * (1 + 2 * 8 + 64)   # input + outputs per patch, bytes
 
@@ -164,6 +164,11 @@ def main():
         ig_ms = prof['igemm3_fwd']['ms'] + prof['igemm3_bwd']['ms'] + f16['ms']
         ig_fl = bf_fl + f16['flops']
         ig_n = prof['igemm3_fwd']['launches'] + prof['igemm3_bwd']['launches'] + f16['launches']
+        # patches behind the sampled launches: 12 igemm4 launches per device pass of `batch` patches (the pool divides evenly
+        # at the default sizes; a ragged last pass would be counted at full size, so derive the count from the passes)
+        passes_per_step = -(-n_local // args.batch)
+        sampled_passes = ig_n / 12.0
+        prof_patches = sampled_passes * (n_local / float(passes_per_step))
         achieved = ig_fl / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
         peak_bf, peak_f16 = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS, PEAK_BF16_MFMA_TFLOPS / 3
         peak = ig_fl / (bf_fl / peak_bf + f16['flops'] / peak_f16) if ig_fl > 0 else peak_bf
@@ -202,10 +207,15 @@ def main():
                          'peak_note': 'algorithmic fp32 flops; peak = flop-weighted harmonic mean of %.0f dense 16-bit MFMA / %d '
                                       'products (bf16x3 launches, %.0f %% of the flops) and / 3 (the fp16x2 launches)'
                                       % (PEAK_BF16_MFMA_TFLOPS, SPLIT_PRODUCTS, 100.0 * bf_fl / max(ig_fl, 1.0)),
-                         'executed_bf16_tflops': executed, 'peak_bf16_tflops': PEAK_BF16_MFMA_TFLOPS,
+                         'frac_definition': 'executed 16-bit MFMA flops (algorithmic flops x 6 products in the bf16x3 launches, x 3 in '
+                                            'the fp16x2 ones) / igemm4 time / %.0f TFLOP/s = achieved / peak above; recomputed from a '
+                                            'rocprofv3 --kernel-trace --stats run of this command by tests/roofline_from_stats.py'
+                                            % PEAK_BF16_MFMA_TFLOPS,
+                         'executed_16bit_tflops': executed, 'peak_16bit_tflops': PEAK_BF16_MFMA_TFLOPS,
+                         'igemm4_alg_flops_per_patch': {'bf16x3': bf_fl / max(prof_patches, 1), 'f16x2': f16['flops'] / max(prof_patches, 1)},
+                         'hbm_frac': (traffic * ig_n / (ig_ms * 1e-3) / (PEAK_HBM_TBPS * 1e12)) if traffic and ig_ms > 0 else None,
                          'f16x2_launches': {'tflops': f16['flops'] / (f16['ms'] * 1e-3) / 1e12 if f16['ms'] > 0 else 0.0,
                                           'avg_launch_ms': f16['ms'] / max(f16['launches'], 1), 'bound_tflops': peak_f16},
-                         'frac_of_f32_mfma_peak': achieved / PEAK_F32_MFMA_TFLOPS,
                          'launches': ig_n, 'avg_launch_ms': ig_ms / max(ig_n, 1), 'timed_every_kth_pass': args.prof_every,
                          'all_conv_engines_tflops': conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
                          'flops_per_patch_executed': F_EXEC, 'flops_per_patch_survey': F_SURVEY,

@@ -55,6 +55,8 @@ int alq_version(void);
 /* Replaces: tf.Session creation (PW_AL.py:363-377).  `stream` is a hipStream_t or NULL.       */
 int alq_ctx_create(int device, void *stream, alq_ctx **out);
 int alq_ctx_destroy(alq_ctx *ctx);
+/* Moves the context to another stream; the new stream first waits (event) for everything the library enqueued on the old
+ * one, so back-to-back calls on two streams need no host synchronisation.                                           */
 int alq_ctx_set_stream(alq_ctx *ctx, void *stream);
 int alq_ctx_synchronize(alq_ctx *ctx);
 
@@ -197,6 +199,19 @@ int alq_adam_step(alq_ctx *ctx, float *d_theta, const float *d_grad, float *d_m,
 /* Replaces: the accumulation loop of model_utils.diagonal_Fisher (model_utils.py:294-330):
  * d_acc[i] += sum_n d_grads[n, i]^2 (fp64).                                                                    */
 int alq_sq_accum(alq_ctx *ctx, const float *d_grads, int64_t per_sample_len, int N, double *d_acc);
+
+/* ---- image-level multi-class Fisher query (NNAL.py:312-464) --------------------------------------------------- */
+/* Replaces: NNAL_tools.shrink_gradient(grads[str(j)], 'sum') (NNAL_tools.py:784-796) on the per-sample gradient lists that
+ * session.run(nz_classes_grads) returns (NNAL.py:381-397), with the gradients staying on the device: d_grads [N, P] rows as
+ * alq_param_grads(mode 0, per_sample 1) writes them, h_layer_elems [L] = |W_t| + |b_t| (host; their sum must be P);
+ * d_out [N, L] double: (sum of layer t's entries) / (|W_t| + |b_t|), fp64 sums in a fixed order.                        */
+int alq_shrink_sum(alq_ctx *ctx, const float *d_grads, int N, int64_t P, const int64_t *h_layer_elems, int L, double *d_out);
+/* Replaces: the accumulation `Ai += np.outer(g_j, g_j) / new_posts[j] + np.eye(A_size) * 1e-5` over the selected classes
+ * (NNAL.py:399-409).  d_g [N, c, L] shrunk class gradients, d_w [N, c] = 1 / new_posts for the classes the reference
+ * keeps (posterior >= 1e-6; the ten largest when ten or more remain, :381-394) and 0 for the others - host logic on the
+ * posteriors, like the reference's -, d_diag [N] = (number of kept classes) * 1e-5; d_A [N, L, L] double.             */
+int alq_fisher_classes(alq_ctx *ctx, const double *d_g, const double *d_w, const double *d_diag, int N, int c, int L,
+                       double *d_A);
 
 /* ---- feature similarities (representativeness strategies) -------------------------------------------- */
 /* Replaces: the NumPy similarity blocks of query_multimg 'rep-entropy' (PW_NNAL.py:318-327: norms, dots = F.T @ F_u,

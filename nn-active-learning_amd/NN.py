@@ -18,6 +18,35 @@ def gen_batch_inds(data_size, batch_size):
     return batches
 
 
+def _imread(path):
+    """The image at `path` as float64 [H, W, C].  The reference decodes with OpenCV (`cv2.imread`, NN.py:1493; its
+    `import cv2` is commented out, NN.py:9); OpenCV is not in this image, so image files are NumPy arrays on disk
+    (`.npy`).  Tests may rebind this name."""
+    if not str(path).endswith('.npy'):
+        raise NotImplementedError('image decoding needs OpenCV (absent): store images as .npy arrays, got %r' % (path,))
+    return np.float64(np.load(path))
+
+
+def load_winds(inds, imgs_path_file, target_shape, mean=None, labels_file=None):
+    """NN.load_winds (NN.py:1479-1527): the images whose paths stand on lines inds[i] + 1 of `imgs_path_file` as one
+    float64 array [n, H, W, C], `mean` subtracted when truthy, + their labels from `labels_file`.  `cv2.resize` is not
+    available: an image must already have `target_shape`."""
+    import linecache
+    inds = np.asarray(inds)
+    imgs, labels = [], []
+    for i in inds:
+        path = linecache.getline(imgs_path_file, int(i) + 1).splitlines()[0]
+        img = _imread(path)
+        if tuple(img.shape[:2]) != tuple(target_shape):
+            raise NotImplementedError('resizing %r -> %r needs OpenCV (absent)' % (img.shape[:2], tuple(target_shape)))
+        if mean:
+            img = img - mean
+        imgs.append(img)
+        if labels_file:
+            labels.append(int(linecache.getline(labels_file, int(i) + 1).splitlines()[0]))
+    return np.stack(imgs), labels
+
+
 class CNN(DeviceModel):
     """NN.CNN(x, layer_dict, name, feature_layer, dropout, probes): same layer-dict schema
     ``{name: [depth,'conv',[kh,kw]] | [depth,'fc'] | [[window,stride],'pool']}``; `x` is replaced
@@ -28,6 +57,19 @@ class CNN(DeviceModel):
         super(CNN, self).__init__(sess or default_session(), layer_dict, in_shape, (), feature_layer,
                                   dropout, max_batch, name)
         self.probes = list(probes)
+
+    def extract_features(self, inds, expr, session):
+        """NN.CNN.extract_features (NN.py:522-554): feature_layer [d, n] of the images `inds`, in random batches of
+        expr.pars['batch_size'] (one batch of everything, and no RNG draw, when batch_size > n)."""
+        inds = np.asarray(inds)
+        n = len(inds)
+        features = np.zeros((self.feature_dim, n))
+        batch_size = expr.pars['batch_size']
+        batches = [np.arange(n).tolist()] if batch_size > n else gen_batch_inds(n, batch_size)
+        for inner in batches:
+            X, _ = load_winds(inds[inner], expr.imgs_path_file, expr.pars['target_shape'], expr.pars['mean'])
+            features[:, inner] = session.run(self.feature_layer, feed_dict={self.x: X, self.keep_prob: 1.})
+        return features
 
 
 def pw1_layer_dict(nclass):

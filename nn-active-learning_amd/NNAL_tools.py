@@ -19,6 +19,26 @@ def compute_entropy(PMFs):
     return -np.sum(PMFs * np.log(PMFs), axis=0)
 
 
+def idxBatch_posteriors(model, inds, expr, session, col, extra_feed_dict={}):
+    """NNAL_tools.idxBatch_posteriors (NNAL_tools.py:382-448): posteriors [c, n] (float64) of the images `inds` of
+    expr.imgs_path_file, evaluated in random batches of expr.pars['batch_size'] (one NN.gen_batch_inds draw from the global
+    NumPy stream when n >= batch_size; the reference's n < batch_size branch iterates over bare ints and fails in
+    load_winds - here it is one batch of everything and no draw)."""
+    from . import NN
+    batch_size = expr.pars['batch_size']
+    inds = np.asarray(inds)
+    n = len(inds)
+    posteriors = np.zeros((model.nclass, n))
+    batches = [np.arange(n).tolist()] if n < batch_size else NN.gen_batch_inds(n, batch_size)
+    for inner in batches:
+        X, _ = NN.load_winds(inds[inner], expr.imgs_path_file, expr.pars['target_shape'], expr.pars['mean'])
+        feed = {model.x: X}
+        feed.update(extra_feed_dict)
+        post = session.run(model.posteriors, feed_dict=feed)
+        posteriors[:, inner] = post if col else post.T
+    return posteriors
+
+
 def shrink_gradient(grad, method, args=None):
     """NNAL_tools.py:778-831, 'sum' and 'max' methods: one scalar per parameterised layer from a
     list [gW1, gb1, ..., gWL, gbL].  On the device path this list is never built (the kernels

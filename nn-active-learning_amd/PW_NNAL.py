@@ -79,22 +79,30 @@ def gen_A_matrices(expr, model, sess, sel_patches, sel_posts, diag_load=1e-5):
     return [(1. - p[i]) * np.outer(g0[i], g0[i]) + p[i] * np.outer(g1[i], g1[i]) + eye for i in range(n)]
 
 
-def refine_feature_matrix(F, B):
-    """PW_NNAL.refine_feature_matrix (PW_NNAL.py:819-849): the (at most B/2) features with the most positive entries,
-    trimmed from the back until the matrix has full row rank and a condition number <= 1e6."""
+def _refine_features(F, B):
+    """-> (refined matrix, True when the conditioning loop trimmed it down to ONE feature: the image-level query then drops
+    the feature term, NNAL.py:443-445)."""
     nnz_feats = np.sum(F > 0, axis=1)
     feat_inds = np.argsort(-nnz_feats)[:int(B / 2)]
     ref_F = F[feat_inds, :]
     while np.linalg.matrix_rank(ref_F) < len(feat_inds):
         feat_inds = feat_inds[:-1]
         ref_F = F[feat_inds, :]
+    single = False
     while np.linalg.cond(ref_F) > 1e6:
         feat_inds = feat_inds[:-1]
         ref_F = F[feat_inds, :]
         if len(feat_inds) == 1:
             print('Only one feature is selected.')
+            single = True
             break
-    return ref_F
+    return ref_F, single
+
+
+def refine_feature_matrix(F, B):
+    """PW_NNAL.refine_feature_matrix (PW_NNAL.py:819-849): the (at most B/2) features with the most positive entries,
+    trimmed from the back until the matrix has full row rank and a condition number <= 1e6."""
+    return _refine_features(F, B)[0]
 
 
 def _entropy_query_single(expr, model, sess, padded_imgs, pool_inds):

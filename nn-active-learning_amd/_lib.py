@@ -52,6 +52,8 @@ _SIGNATURES = {
     'alq_sgd_step': (C.c_int, [_P, _P, _P, C.c_int64, C.c_float]),
     'alq_adam_step': (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64]),
     'alq_sq_accum': (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
+    'alq_shrink_sum': (C.c_int, [_P, _P, C.c_int, C.c_int64, C.POINTER(C.c_int64), C.c_int, _P]),
+    'alq_fisher_classes': (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     'alq_row_norms': (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     'alq_cosine_sims': (C.c_int, [_P, _P, C.c_int64, _P, C.c_int, C.c_int, _P, _P, _P]),
     'alq_colsum_work_bytes': (C.c_size_t, [C.c_int64, C.c_int]),

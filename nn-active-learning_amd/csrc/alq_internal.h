@@ -477,5 +477,7 @@ int k_fc_wgrad(alq_ctx *, const float *delta, const View &a, int nout, int N, in
 int k_sgd(alq_ctx *, float *theta, const float *g, long long n, float lr);
 int k_adam(alq_ctx *, float *theta, const float *g, float *m, float *v, long long n, float lr_t, float b1, float b2, float eps);
 int k_sq_accum(alq_ctx *, const float *g, long long per, int N, double *acc);
+int k_shrink_sum(alq_ctx *, const float *g, int N, long long P, const long long *off, int L, double *out);
+int k_fisher_classes(alq_ctx *, const double *g, const double *w, const double *diag, int N, int c, int L, double *A);
 
 }  // namespace alq

@@ -418,7 +418,7 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
     ALQ_REQUIRE(n_layers > 0 && specs[n_layers - 1].type == ALQ_FC, ALQ_EUNSUPPORTED,
                 "the scored path needs an fc head (get_gradients, NN_extended.py:1025)");
     m->nclass = outs[n_layers - 1].C;
-    ALQ_REQUIRE(m->nclass >= 2 && m->nclass <= 8, ALQ_EUNSUPPORTED, "%d classes unsupported", m->nclass);
+    ALQ_REQUIRE(m->nclass >= 2 && m->nclass <= 64, ALQ_EUNSUPPORTED, "%d classes unsupported", m->nclass);
     ALQ_REQUIRE(m->L <= 16, ALQ_EUNSUPPORTED, "%d parameterised layers > 16", m->L);
 
     // ---- pass 2: buffers (concat = two producers writing channel slices of one buffer) ----
@@ -1213,6 +1213,25 @@ int alq_sq_accum(alq_ctx *ctx, const float *d_grads, int64_t per_sample_len, int
     return k_sq_accum(ctx, d_grads, per_sample_len, N, d_acc);
 }
 
+int alq_shrink_sum(alq_ctx *ctx, const float *d_grads, int N, int64_t P, const int64_t *h_layer_elems, int L, double *d_out) {
+    ALQ_REQUIRE(ctx && d_grads && h_layer_elems && d_out && N >= 1 && L >= 1 && L <= 64, ALQ_EINVAL, "alq_shrink_sum: bad argument");
+    long long off[65];
+    off[0] = 0;
+    for (int t = 0; t < L; ++t) {
+        ALQ_REQUIRE(h_layer_elems[t] >= 1, ALQ_EINVAL, "alq_shrink_sum: layer %d has %lld elements", t, (long long)h_layer_elems[t]);
+        off[t + 1] = off[t] + h_layer_elems[t];
+    }
+    ALQ_REQUIRE(off[L] == P, ALQ_EINVAL, "alq_shrink_sum: the layers hold %lld elements, a gradient row %lld", off[L], (long long)P);
+    ALQ_HIP(hipSetDevice(ctx->device));
+    return k_shrink_sum(ctx, d_grads, N, P, off, L, d_out);
+}
+
+int alq_fisher_classes(alq_ctx *ctx, const double *d_g, const double *d_w, const double *d_diag, int N, int c, int L, double *d_A) {
+    ALQ_REQUIRE(ctx && d_g && d_w && d_diag && d_A && N >= 1 && c >= 1 && L >= 1, ALQ_EINVAL, "alq_fisher_classes: bad argument");
+    ALQ_HIP(hipSetDevice(ctx->device));
+    return k_fisher_classes(ctx, d_g, d_w, d_diag, N, c, L, d_A);
+}
+
 const char *alq_last_error(void) { return g_err; }
 int alq_version(void) { return 1; }
 
@@ -1269,7 +1288,19 @@ int alq_ctx_destroy(alq_ctx *ctx) {
 
 int alq_ctx_set_stream(alq_ctx *ctx, void *stream) {
     ALQ_REQUIRE(ctx != nullptr, ALQ_EINVAL, "null ctx");
-    ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    hipStream_t next = reinterpret_cast<hipStream_t>(stream);
+    if (next != ctx->stream) {
+        // the library's hidden state (activation workspaces, partial sums, side-stream work joined into the OLD stream) is
+        // ordered on the old stream only: the new stream waits for everything enqueued there so far
+        ALQ_HIP(hipSetDevice(ctx->device));
+        hipEvent_t ev;
+        ALQ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e1 = hipEventRecord(ev, ctx->stream);
+        hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(next, ev, 0) : e1;
+        (void)hipEventDestroy(ev);
+        ALQ_REQUIRE(e2 == hipSuccess, ALQ_EHIP, "alq_ctx_set_stream: %s", hipGetErrorString(e2));
+        ctx->stream = next;
+    }
     return ALQ_OK;
 }
 

@@ -327,4 +327,51 @@ int k_sq_accum(alq_ctx *ctx, const float *g, long long per, int N, double *acc) 
     return ALQ_OK;
 }
 
+// shrink_gradient(grads, 'sum') of MATERIALISED per-sample gradients (NNAL_tools.py:784-796): out[n, t] = (sum of the entries of
+// layer t's weight and bias gradient) / (|W_t| + |b_t|).  One workgroup per (layer, sample); every thread walks a fixed stride,
+// the partials fold in a fixed tree: fp64, run-to-run identical.
+struct ShrinkOffsets { long long off[65]; };
+__global__ void shrink_sum_kernel(const float *g, long long P, ShrinkOffsets o, double *out, int L) {
+    __shared__ double red[256];
+    const int t = blockIdx.x, n = blockIdx.y;
+    const long long a = o.off[t], b = o.off[t + 1];
+    const float *row = g + (long long)n * P;
+    double s = 0;
+    for (long long i = a + threadIdx.x; i < b; i += 256) s += (double)row[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(long long)n * L + t] = red[0] / (double)(b - a);
+}
+int k_shrink_sum(alq_ctx *ctx, const float *g, int N, long long P, const long long *off, int L, double *out) {
+    ShrinkOffsets o;
+    for (int t = 0; t <= L; ++t) o.off[t] = off[t];
+    hipLaunchKernelGGL(shrink_sum_kernel, dim3(L, N), dim3(256), 0, ctx->stream, g, P, o, out, L);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
+// multi-class conditional Fisher matrices (NNAL.py:399-409): A_i = sum_j w[i, j] g[i, j, :] g[i, j, :]^T + diag[i] I, classes in
+// ascending order, fp64.  One workgroup per sample, one thread per entry.
+__global__ void fisher_classes_kernel(const double *g, const double *w, const double *diag, int c, int L, double *A) {
+    const int i = blockIdx.x;
+    for (int e = threadIdx.x; e < L * L; e += blockDim.x) {
+        const int r = e / L, s = e % L;
+        double acc = 0;
+        for (int j = 0; j < c; ++j) {
+            const double wj = w[(long long)i * c + j];
+            if (wj != 0.0) acc += g[((long long)i * c + j) * L + r] * g[((long long)i * c + j) * L + s] * wj;
+        }
+        A[(long long)i * L * L + e] = acc + (r == s ? diag[i] : 0.0);
+    }
+}
+int k_fisher_classes(alq_ctx *ctx, const double *g, const double *w, const double *diag, int N, int c, int L, double *A) {
+    hipLaunchKernelGGL(fisher_classes_kernel, dim3(N), dim3(64), 0, ctx->stream, g, w, diag, c, L, A);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
 }  // namespace alq

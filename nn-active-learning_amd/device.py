@@ -734,6 +734,47 @@ class DeviceModel(object):
         out = self.fisher_device(t, n, p1_in, diag_load)
         return {k: (v.cpu().numpy() if v is not None else None) for k, v in out.items()}
 
+    def shrunk_class_gradients(self, x):
+        """g [n, c, L'] float64: shrink_gradient(d log posteriors[j, sample] / d theta, 'sum') for every sample and class -
+        what the reference obtains with one session.run(model.grad_posts[str(j)]) per sample and class plus a host
+        reduction (NNAL.py:381-405, NNAL_tools.py:784-796).  Per device pass: alq_param_grads (mode 0, per-sample rows)
+        for class j, alq_shrink_sum on the rows; nothing of size |theta| reaches the host.  L' = the layers of
+        `grad_layers` (all when empty).  Also returns the posteriors [c, n] of these passes (device fp32)."""
+        torch = self.sess.torch
+        t, n = self._as_device_batch(x)
+        c, L = self.nclass, self.L
+        elems = (C.c_int64 * L)(*[int(np.prod(w)) + int(np.prod(b)) for _, w, b in self.param_shapes])
+        g = self.sess.empty((n, c, L), torch.float64)
+        post = self.sess.empty((c, n), torch.float32)
+        tmp = self.sess.empty((min(n, self.max_batch), L), torch.float64)
+        flat = t.reshape(n, -1)
+        for a in range(0, n, self.max_batch):
+            b = min(n, a + self.max_batch)
+            for j in range(c):
+                rows, pb, _ = self.param_grads_device(flat[a:b], b - a, 0, cls=j, want_post=(j == 0))
+                if j == 0:
+                    post[:, a:b] = pb
+                check(self.lib.alq_shrink_sum(self.sess.ctx, C.c_void_p(rows.data_ptr()), b - a, self.num_params, elems, L,
+                                              C.c_void_p(tmp.data_ptr())))
+                g[a:b, j, :] = tmp[:b - a]
+        idx = list(self.grad_layer_idx)
+        if idx != list(range(L)):
+            g = g[:, :, idx].contiguous()
+        return g, post
+
+    def fisher_classes(self, x, W, diag):
+        """A [n, L', L'] float64 = sum_j W[i, j] g_ij g_ij^T + diag[i] I (alq_fisher_classes on shrunk_class_gradients)."""
+        torch = self.sess.torch
+        g, _ = self.shrunk_class_gradients(x)
+        n, c, L = [int(v) for v in g.shape]
+        Wd = self.sess.to_device(np.asarray(W, dtype=np.float64).reshape(n, c), torch.float64)
+        dd = self.sess.to_device(np.asarray(diag, dtype=np.float64).reshape(n), torch.float64)
+        A = self.sess.empty((n, L, L), torch.float64)
+        self.sess.bind_stream()
+        check(self.lib.alq_fisher_classes(self.sess.ctx, C.c_void_p(g.data_ptr()), C.c_void_p(Wd.data_ptr()), C.c_void_p(dd.data_ptr()),
+                                          n, c, L, C.c_void_p(A.data_ptr())))
+        return A.cpu().numpy()
+
     def debug_tensor(self, layer_idx, what, n):
         """Test hook (alq_model_debug_copy): internal tensor of the last forward/fisher call."""
         torch = self.sess.torch

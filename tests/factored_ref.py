@@ -51,11 +51,14 @@ def _strided_box(dsum, k, s, in_sp):
     return y
 
 
-def factored_unit_scores(model, x, details=None):
+def factored_unit_scores(model, x, details=None, flips=None):
     """Returns (p [2,N], S [N,L], sizes [L]): S_t = sum of ALL entries of d(z0-z1)/d(theta_t).
     If `details` is a dict it receives per-layer tensors: 'out' (list over ALL layers, output after
     activation, channels-last), and per parameterised layer 'delta' (masked cotangent), 'asum',
-    'dsum'.
+    'dsum', 'pre' (pre-activation), 'relu' (bool).
+    `flips`: {layer name: bool array shaped like that layer's pre-activation}: ReLU decisions to INVERT (the unit passes
+    although its input is <= 0, or is cut although > 0) - what an implementation does whose rounding puts a near-zero
+    ReLU input on the other side (relu_flip_explains below).
 
     `model` is an oracle.model.OracleModel (its graph is re-walked here with hooks on every
     parameterised layer's input and pre-activation output)."""
@@ -94,8 +97,12 @@ def factored_unit_scores(model, x, details=None):
                 relu = (('A' in spec[2]) if len(spec) > 2 else False) if model.ext else (not last)
             pre.requires_grad_(True)
             pre.retain_grad()
-            recs.append(dict(name=name, type=ltype, a=a_in.detach(), pre=pre, W=W, b=b, spec=spec))
-            out = torch.relu(pre) if relu else pre
+            recs.append(dict(name=name, type=ltype, a=a_in.detach(), pre=pre, W=W, b=b, spec=spec, relu=relu))
+            if relu and flips is not None and name in flips:
+                keep = (pre.detach() > 0) ^ torch.as_tensor(np.asarray(flips[name], dtype=bool))
+                out = pre * keep.to(pre.dtype)
+            else:
+                out = torch.relu(pre) if relu else pre
         elif ltype == 'pool':
             if model.ext:
                 out = tfops.max_pool_same(out, spec[1], spec[1])
@@ -139,6 +146,9 @@ def factored_unit_scores(model, x, details=None):
         details['dsum'] = [(r['pre'].grad.sum(0) if r['type'] == 'fc' else r['pre'].grad.sum(-1)).numpy()
                            for r in recs]
         details['types'] = [r['type'] for r in recs]
+        details['names'] = [r['name'] for r in recs]
+        details['pre'] = [r['pre'].detach().numpy() for r in recs]
+        details['relu'] = [bool(r['relu']) for r in recs]
     return p.numpy(), S.numpy(), np.array(sizes)
 
 
@@ -160,3 +170,56 @@ def fisher_from_unit(p1, S, sizes, diag_load):
             p, a0 = 1., np.zeros(L)
         A[i] = (1. - p) * np.outer(a0, a0) + p * np.outer(a1, a1) + np.eye(L) * diag_load
     return g0, g1, A
+
+
+def relu_flip_explains(model64, x1, targets, diag_load, atol=2e-6, rtol=2e-5, eps=2e-5, max_units=10, max_flips=3):
+    """fp64 arbiter for a disagreement between fp32-level implementations on ONE patch.
+
+    `targets`: list of (g0 [L], g1 [L]) score vectors of that patch (e.g. two device engines).  Each must lie within
+    atol + rtol |value| of the fp64 evaluation of the network (`model64`: an fp64 OracleModel), OR of an fp64 evaluation in
+    which some of the patch's FRAGILE ReLU decisions are inverted - fragile = |pre-activation| <= eps x the layer's rms
+    pre-activation, i.e. an input that fp32 rounding can legitimately put on either side of zero.  At most `max_units` most
+    fragile units are considered, at most `max_flips` of them inverted together.
+    Returns a list, per target, of the tuple of inverted units ((layer name, flat index), ...) - () = the plain fp64
+    value - or None when no such evaluation matches (the disagreement is NOT a ReLU flip)."""
+    import itertools
+    x1 = np.asarray(x1)[None] if np.asarray(x1).ndim == len(model64.in_shape) else np.asarray(x1)
+    det = {}
+    p, S, sizes = factored_unit_scores(model64, x1, det)
+
+    def scores(P, SS):
+        g0, g1, _ = fisher_from_unit(P[1], SS, sizes, diag_load)
+        return g0[0], g1[0]
+
+    def close(t, ref):
+        return all(np.all(np.abs(np.asarray(a) - b) <= atol + rtol * np.abs(b)) for a, b in zip(t, ref))
+
+    base = scores(p, S)
+    found = [() if close(t, base) else None for t in targets]
+    if all(f is not None for f in found):
+        return found
+    cand = []
+    for name, pre, relu in zip(det['names'], det['pre'], det['relu']):
+        if not relu:
+            continue
+        rms = float(np.sqrt(np.mean(pre ** 2))) or 1.0
+        flat = np.abs(pre.reshape(-1)) / rms
+        for i in np.nonzero(flat <= eps)[0]:
+            cand.append((flat[i], name, int(i), pre.shape))
+    cand.sort(key=lambda c: c[0])
+    cand = cand[:max_units]
+    for r in range(1, min(max_flips, len(cand)) + 1):
+        for combo in itertools.combinations(cand, r):
+            fl, shapes = {}, {}
+            for _, name, i, shp in combo:
+                fl.setdefault(name, np.zeros(int(np.prod(shp)), bool))[i] = True
+                shapes[name] = shp
+            fl = {k: v.reshape(shapes[k]) for k, v in fl.items()}
+            pf, Sf, _ = factored_unit_scores(model64, x1, None, flips=fl)
+            ref = scores(pf, Sf)
+            for j, t in enumerate(targets):
+                if found[j] is None and close(t, ref):
+                    found[j] = tuple((c[1], c[2]) for c in combo)
+            if all(f is not None for f in found):
+                return found
+    return found

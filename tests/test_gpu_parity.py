@@ -636,22 +636,27 @@ def test_layout_and_engine_switches_agree(sess):
     c = scores({'ALQ_DISABLE_V4': '1', 'ALQ_DISABLE_V3': '1'})
     d = scores({'ALQ_NO_FC_BITS': '1'})
     e = scores({'ALQ_NO_FC_FUSE': '1'})
-    # fp16x2 (three products; with the fragment-reuse loop also another summation order) against bf16x3 (six): both at
-    # fp32-level accuracy, another rounding pattern.  A ReLU input of the last conv within rounding of zero may land on
-    # the other side (this seed: one unit of patch 4, |dg| = 9e-5), which moves that patch's scores by the unit's whole
-    # contribution: at most one patch may do so, and by no more than 3 % of the layer's scale.
-    np.testing.assert_allclose(a16['p1'], a['p1'], rtol=0, atol=1e-6)
-    for k in ('g0', 'g1'):
-        tight = np.abs(a16[k] - a[k]) <= 2e-5 * np.abs(a[k]) + 1e-9 + 2e-6 * np.abs(a[k]).max()
-        flipped = ~tight.all(axis=1)
-        assert flipped.sum() <= 1, (k, flipped)
-        scale = np.abs(a[k]).max(axis=0, keepdims=True)
-        assert (np.abs(a16[k] - a[k]) <= 3e-2 * scale + 1e-9).all(), k
+    # fp16x2 (three products; with the fragment-reuse loop also another summation order) against bf16x3 (six) against the
+    # plain k-step loop: all at fp32-level accuracy with different rounding patterns.  The arbiter is an fp64 evaluation
+    # of the same network: every engine's scores of every patch lie within 2e-6 (+ 2e-5 relative) of the fp64 values -
+    # or, for a patch with a ReLU input within rounding of zero (this seed: unit 2722 of the last conv in patch 4,
+    # |pre-activation| < 2e-5 of the layer's rms), of the fp64 values with THAT decision inverted
+    # (factored_ref.relu_flip_explains re-evaluates the network in fp64 with the fragile decisions flipped).  A
+    # disagreement that no fragile unit explains fails the test.
     z = scores({'ALQ_NO_ZREUSE': '1'})         # the same fp16x2 launch with the plain k-step loop
+    np.testing.assert_allclose(a16['p1'], a['p1'], rtol=0, atol=1e-6)
     np.testing.assert_allclose(z['p1'], a16['p1'], rtol=0, atol=1e-6)
-    for k in ('g0', 'g1'):
-        tight = np.abs(a16[k] - z[k]) <= 2e-5 * np.abs(z[k]) + 1e-9 + 2e-6 * np.abs(z[k]).max()
-        assert (~tight.all(axis=1)).sum() <= 1, k
+    pars64 = {k: [v[0].astype(np.float64), v[1].astype(np.float64)] for k, v in pars.items()}
+    om64 = OracleModel(ld, in_shape, pars64, skips=sk, dtype=torch.float64)
+    engines = (('fp16x2', a16), ('bf16x3', a), ('fp16x2 plain loop', z), ('fp32 MFMA', c))
+    flipped_patches = set()
+    for i in range(9):
+        found = factored_ref.relu_flip_explains(om64, x[i].astype(np.float64), [(r['g0'][i], r['g1'][i]) for _, r in engines], 1e-3)
+        for (name, _), f in zip(engines, found):
+            assert f is not None, 'patch %d, engine %s: scores differ from fp64 and no near-zero ReLU input explains it' % (i, name)
+            if f:
+                flipped_patches.add(i)
+    assert len(flipped_patches) <= 2, flipped_patches     # ~0.2 fragile units per 16^3 patch are expected, not many
     for k in a:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
     # (e) contracts [sign] * (W0 - W1) in the last conv's backward with the fp16x2 split (three products), (d) the stored
@@ -815,6 +820,23 @@ def test_calls_follow_torchs_current_stream(sess):
     torch.cuda.current_stream(sess.device).wait_stream(s)
     r2 = model.fisher_device(x, 200, None, 1e-5)                  # back on the default stream
     assert torch.equal(r2['A'], r0['A'])
+    # back-to-back calls on two streams WITHOUT a host sync in between and on different inputs: the model's hidden
+    # workspaces are ordered by alq_ctx_set_stream (event on the old stream, wait on the new one), so pass k + 1 on the
+    # other stream cannot overwrite activations pass k is still reading
+    x2 = sess.to_device(np.random.RandomState(12).randn(200, 32 * 32).astype(np.float32), torch.float32)
+    want2 = model.fisher_device(x2, 200, None, 1e-5)['A'].clone()
+    torch.cuda.synchronize()
+    s2 = torch.cuda.Stream(device=sess.device)
+    s.wait_stream(torch.cuda.current_stream(sess.device))
+    s2.wait_stream(torch.cuda.current_stream(sess.device))
+    outs = []
+    for it in range(6):
+        st, xin = (s, x) if it % 2 == 0 else (s2, x2)
+        with torch.cuda.stream(st):
+            outs.append(model.fisher_device(xin, 200, None, 1e-5)['A'])
+    torch.cuda.synchronize()
+    for it, o in enumerate(outs):
+        assert torch.equal(o, r0['A'] if it % 2 == 0 else want2), it
     model.close()
 
 

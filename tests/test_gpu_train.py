@@ -14,6 +14,16 @@ from oracle.train import OracleOptimizer  # noqa: E402
 from tests.test_oracle_golden import Expr  # noqa: E402
 
 
+def torch_no_grad():
+    import torch
+    return torch.no_grad()
+
+
+def as_tensor(a):
+    import torch
+    return torch.as_tensor(np.asarray(a))
+
+
 @pytest.fixture(scope='module')
 def sess():
     import nnal_amd  # noqa: F401
@@ -126,6 +136,42 @@ def test_train_step_vs_oracle(sess, name, ld, in_shape, sk, opt, lr):
             b = b.detach().numpy()
             # Adam divides by sqrt(v): entries whose gradient is ~0 amplify rounding, compare against the step size
             np.testing.assert_allclose(a, b, rtol=0, atol=(5e-4 if opt == 'Adam' else 2e-5) * max(np.abs(b).max(), lr))
+    m.close()
+
+
+@pytest.mark.parametrize('opt,lr', [('SGD', 0.05), ('Adam', 0.002)])
+def test_weights_loaded_between_steps_are_what_the_next_step_updates(sess, tmp_path, opt, lr):
+    """The TF variables are the single state of the reference: train, load_weights / perform_assign_ops(W0) (PW_AL.py:793-798
+    does this between methods and on resume), train again -> the second step starts from W0.  The optimiser's device copy
+    of the parameters must follow every set_weights; Adam's slots persist like TF's slot variables."""
+    ld = netspec.net_a()
+    in_shape = (20, 20, 1)
+    m, pars = _mk(sess, ld, in_shape, (), 45, max_batch=8)
+    m.get_optimizer(lr, [], opt)
+    om = OracleModel(ld, in_shape, pars)
+    oo = OracleOptimizer(om, lr, (), opt)
+    m.save_weights(str(tmp_path / 'w0.npz'))
+    rs = np.random.RandomState(8)
+
+    def batch():
+        x = rs.randn(10, *in_shape).astype(np.float32)
+        y = np.zeros((2, 10))
+        y[rs.randint(0, 2, size=10), np.arange(10)] = 1
+        return x, y
+    x, y = batch()
+    assert abs(m.train_on_batch(x, y) - oo.step(x, y)) < 1e-5
+    m.perform_assign_ops(str(tmp_path / 'w0.npz'))                 # back to W0 on the device ...
+    with torch_no_grad():
+        for n, (w, b) in om.params.items():                         # ... and in the oracle
+            w.copy_(as_tensor(pars[n][0]))
+            b.copy_(as_tensor(pars[n][1]))
+    x, y = batch()
+    l_dev, l_ref = m.train_on_batch(x, y), oo.step(x, y)
+    assert abs(l_dev - l_ref) < 1e-5, (l_dev, l_ref)
+    for n in m.var_names:
+        for a, b in zip(m.var_dict[n], om.params[n]):
+            b = b.detach().numpy()
+            np.testing.assert_allclose(a, b, rtol=0, atol=(5e-4 if opt == 'Adam' else 2e-6) * max(np.abs(b).max(), lr))
     m.close()
 
 

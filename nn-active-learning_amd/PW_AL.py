@@ -131,3 +131,162 @@ class LoopState(object):
 
     def weights_path(self, it):
         return os.path.join(self.root, 'curr_weights_%d.npz' % it)
+
+
+# ------------------------------------------------------------------------------------------ the experiment object
+class Experiment(object):
+    """PW_AL.Experiment's constructor and parameter file (PW_AL.py:29-110): the experiment's root directory and
+    `parameters.txt` (YAML).  The single-image `run_method` (:278-498) is not on the scored path's multi-image caller and
+    is not mirrored."""
+
+    def __init__(self, root_dir, pars={}):
+        self.root_dir = root_dir
+        self.nclass = 2
+        if not os.path.exists(root_dir):
+            os.mkdir(root_dir)
+        if len(pars) > 0:
+            if os.path.exists(os.path.join(root_dir, 'parameters.txt')):
+                print("Some parameters already exist")
+            else:
+                self.save_parameters(pars)
+
+    def save_parameters(self, pars):
+        import copy
+        import yaml
+        with open(os.path.join(self.root_dir, 'parameters.txt'), 'w') as f:
+            self.pars = copy.deepcopy(pars)
+            yaml.dump(pars, f)
+
+    def load_parameters(self):
+        import yaml
+        with open(os.path.join(self.root_dir, 'parameters.txt'), 'r') as f:
+            self.pars = yaml.load(f, Loader=yaml.UnsafeLoader)      # tuples (patch_shape) are python-tagged, like yaml.load(f) of old
+
+
+class Experiment_MultiImg(Experiment):
+    """PW_AL.Experiment_MultiImg (PW_AL.py:586-898): active learning over several subjects, each a list of modality
+    volumes + a mask (NaN = voxel to ignore).  `train_paths.txt`, `train_stats.txt` and, per method, `queries/<iter>`,
+    `AL_running_times/dt_<iter>`, `curr_weights_<iter>` as the reference writes them (weights as .npz: h5py is absent).
+
+    `run_method` is the reference's loop (:690-898): grid indices -> resume from queries/ -> load + pad -> model ->
+    perform_assign_ops(init_weights_path) -> [query_multimg -> pool -> training bookkeeping -> files -> finetune_multimg
+    -> weights] until max_queries.  One process per GPU under torch.distributed: every rank holds the volumes and the
+    model, the query's device work is split by contiguous blocks of the pool (PW_NNAL.bin_uncertainty_filter_multimg,
+    query_multimg), everything else is the same deterministic code on the same bits on every rank; rank 0 writes the
+    files."""
+
+    def __init__(self, root_dir, pars={}, train_paths={}, test_paths={}):
+        import yaml
+        Experiment.__init__(self, root_dir, pars)
+        if not hasattr(self, 'pars'):
+            self.load_parameters()
+        tr_file = os.path.join(self.root_dir, 'train_paths.txt')
+        if not os.path.exists(tr_file):
+            with open(tr_file, 'w') as f:
+                yaml.dump(train_paths, f)
+            self.train_paths = train_paths
+        else:
+            with open(tr_file, 'r') as f:
+                self.train_paths = yaml.load(f, Loader=yaml.UnsafeLoader)
+        st_file = os.path.join(self.root_dir, 'train_stats.txt')
+        if os.path.exists(st_file):
+            self.train_stats = np.loadtxt(st_file)
+            if self.train_stats.ndim == 1:                       # one subject: savetxt dropped the dimension (:626-631)
+                self.train_stats = np.expand_dims(self.train_stats, axis=0)
+        else:
+            self.train_stats = get_stats(self.train_paths)
+            np.savetxt(st_file, self.train_stats)
+        self.model_factory = None     # callable(expr, input_shape, sess) -> model for nets other than the reference's 'PW'
+
+    def add_method(self, method_name):
+        method_path = os.path.join(self.root_dir, method_name)
+        if not os.path.exists(method_path):
+            os.mkdir(method_path)
+            os.mkdir(os.path.join(method_path, 'queries'))
+            os.mkdir(os.path.join(method_path, 'AL_running_times'))
+
+    def _create_model(self, sess):
+        m = len(self.train_paths[0]) - 1
+        patch_shape = tuple(self.pars['patch_shape'][:2]) + (m * self.pars['patch_shape'][2],)
+        if self.model_factory is not None:
+            return self.model_factory(self, patch_shape, sess)
+        return NN.create_model(self.pars['model_name'], self.pars['dropout_rate'], self.nclass, self.pars['learning_rate'],
+                               self.pars['grad_layers'], self.pars['train_layers'], self.pars['optimizer_name'], patch_shape,
+                               sess=sess)
+
+    def run_method(self, method_name, max_queries, sess=None):
+        import time
+        from . import PW_NNAL, device, pool_shard
+        rank, _ = pool_shard.world()
+        method_path = os.path.join(self.root_dir, method_name)
+        state = LoopState(method_path)
+        # pool indices (:696-707)
+        if 'pool_paths' in self.pars:
+            pool_inds = [[] for _ in range(len(self.train_paths))]
+            for i in self.pars['pool_paths']:
+                pool_inds[i] = gen_multimg_inds([self.train_paths[i]], self.pars['grid_spacing'])[0][0]
+        else:
+            pool_inds, _ = gen_multimg_inds(self.train_paths, self.pars['grid_spacing'])
+        pool_inds = [[int(v) for v in p] for p in pool_inds]
+        # initial training indices (:709-720), then the queries already on disk (:721-735; files in iteration order)
+        init_training_inds = [[] for _ in range(len(self.train_paths))]
+        init_train_path = os.path.join(self.root_dir, 'init_train_inds.txt')
+        if os.path.exists(init_train_path):
+            init_inds = np.int32(np.loadtxt(init_train_path, ndmin=2))
+            for ind in np.unique(init_inds[:, 1]):
+                init_training_inds[ind] += init_inds[init_inds[:, 1] == ind, 0].tolist()
+        training_inds = [[] for _ in range(len(self.train_paths))]
+        iters = state.iters_done()
+        for it in range(iters):
+            Qs = np.int64(np.loadtxt(os.path.join(method_path, 'queries', '%d' % it), ndmin=2))
+            for ind in np.unique(Qs[:, 1]):
+                I = Qs[Qs[:, 1] == ind, 0]
+                training_inds[ind] += I.tolist()
+                for v in I:
+                    pool_inds[ind].remove(int(v))
+        pool_shard.barrier()                                   # every rank has read the state before rank 0 adds to it
+        # volumes (:737-761)
+        all_padded_imgs = [load_and_pad(sub, self.pars['patch_shape']) for sub in self.train_paths]
+        # model (:763-798)
+        sess = sess or device.default_session()
+        model = self._create_model(sess)
+        model.add_assign_ops()
+        init = self.pars['init_weights_path']
+        if iters > 0 and os.path.exists(state.weights_path(iters)):
+            init = state.weights_path(iters)                   # resume: the weights the last complete iteration left
+        model.perform_assign_ops(init, sess)
+        nqueries = 0
+        log = []
+        while nqueries < max_queries:
+            self.labeled_paths = self.train_paths               # (:818-821; the core-set bootstrap from a private data set, :806-816, is not mirrored)
+            labeled_inds = training_inds
+            self.labeled_stats = self.train_stats
+            t1 = time.time()
+            Q_inds = PW_NNAL.query_multimg(self, model, sess, all_padded_imgs, pool_inds, labeled_inds, method_name)
+            dt = time.time() - t1
+            nQ = int(np.sum([len(q) for q in Q_inds]))
+            if nQ == 0:
+                break                                           # an exhausted pool would spin forever in the reference
+            nqueries += nQ
+            Q_mat = np.zeros((nQ, 2))
+            cnt = 0
+            for ind in range(len(Q_inds)):
+                q = np.asarray(Q_inds[ind], dtype=np.int64)
+                if len(q) > 0:
+                    vox = np.array(pool_inds[ind])[q]
+                    Q_mat[cnt:cnt + len(q), 0] = vox
+                    Q_mat[cnt:cnt + len(q), 1] = ind
+                    cnt += len(q)
+                    training_inds[ind] += list(vox)
+                    for i in -np.sort(-q):                      # from the back, so positions stay valid (:880-882)
+                        pool_inds[ind].pop(int(i))
+            if rank == 0:
+                state.save_round(iters, Q_mat, dt)
+            iters += 1
+            finetune_multimg(self, model, sess, all_padded_imgs, training_inds)
+            if rank == 0:
+                model.save_weights(state.weights_path(iters))
+            pool_shard.barrier()
+            log.append(dict(Q_mat=Q_mat.astype(np.int64), seconds=dt, pool_left=int(np.sum([len(p) for p in pool_inds]))))
+        self.model = model
+        return log

@@ -6,8 +6,22 @@ from . import patch_utils
 _CHUNK = 8192   # indices gathered per device pass (results do not depend on it)
 
 
+def mc_dropout_args(model, x_feed_dict):
+    """(keep_prob, dropout active?, seed) of one batch_eval call: `x_feed_dict = {model.keep_prob: p}` overrides
+    keep_prob = 1 (PW_NN.py:516-521); an evaluation with dropout draws ONE seed from the global NumPy stream (masks are
+    then keyed by the sample's position).  A rank of a sharded evaluation that holds nothing of a subject calls this
+    alone, so that every rank's stream advances alike."""
+    keep_prob = 1.
+    for k, val in x_feed_dict.items():
+        if k is getattr(model, 'keep_prob', None):
+            keep_prob = float(val)
+    mc = keep_prob < 1. and len(model.dropout_layers) > 0
+    seed = int(np.random.randint(0, 2 ** 31 - 1)) if mc else 0
+    return keep_prob, mc, seed
+
+
 def batch_eval(model, sess, img_dat, inds, patch_shape, batch_size, stats, varnames,
-               mask=None, x_feed_dict={}, _vols=None):
+               mask=None, x_feed_dict={}, _vols=None, _first_sample=0):
     """PW_NN.batch_eval: evaluates `varnames` ('posteriors', 'prediction', 'feature_layer')
     of `model` on patches around voxels `inds` of the m padded modalities `img_dat`.
 
@@ -15,6 +29,8 @@ def batch_eval(model, sess, img_dat, inds, patch_shape, batch_size, stats, varna
     (PW_NN.py:526-529), 'prediction' -> [n], 'feature_layer' -> [fdim, n].  Patches are
     normalised with the channel-index rule of PW_NN.py:503-506 (channel j < m with stats[j]).
     `x_feed_dict = {model.keep_prob: p}` (PW_NN.py:516-521) evaluates with dropout on the model's dropout layers.
+    `_first_sample` (not a reference argument): the position of inds[0] in the caller's whole evaluation - dropout masks
+    are keyed by it, so an evaluation cut into blocks (pool_shard.work_block) draws the masks of the uncut one.
     `batch_size` only bounds the reference's feed size; samples are independent, so the device
     path walks the same index order in larger chunks.
     """
@@ -23,15 +39,9 @@ def batch_eval(model, sess, img_dat, inds, patch_shape, batch_size, stats, varna
     for v in varnames:
         if v not in ('posteriors', 'prediction', 'feature_layer'):
             raise NotImplementedError("batch_eval variable %r (training-time graph) is outside the scored path" % v)
-    keep_prob = 1.
-    for k, val in x_feed_dict.items():            # PW_NN.py:516-521: x_feed_dict overrides keep_prob = 1 (MC dropout)
-        if k is getattr(model, 'keep_prob', None):
-            keep_prob = float(val)
-    mc = keep_prob < 1. and len(model.dropout_layers) > 0
+    keep_prob, mc, seed = mc_dropout_args(model, x_feed_dict)
     if mc and 'feature_layer' in varnames:
         raise NotImplementedError('feature_layer at keep_prob < 1')
-    # one dropout seed per call from the global NumPy stream; masks are keyed by the sample's position in `inds`
-    seed = int(np.random.randint(0, 2 ** 31 - 1)) if mc else 0
     if not isinstance(img_dat[0], np.ndarray):
         # PW_NN.py:429-444: paths -> load (NRRD) and zero-pad by the patch radii
         from . import nrrd_io
@@ -55,7 +65,8 @@ def batch_eval(model, sess, img_dat, inds, patch_shape, batch_size, stats, varna
         b = min(n, a + _CHUNK)
         t = vols.gather(inds[a:b], patch_shape, st, quirk=1)
         if mc:
-            post, pred = model.forward_dropout_device(t, b - a, keep_prob, seed=seed, first_sample=a, want_pred=want_pred)
+            post, pred = model.forward_dropout_device(t, b - a, keep_prob, seed=seed, first_sample=_first_sample + a,
+                                                      want_pred=want_pred)
             feat = None
         else:
             post, pred, feat = model.forward_device(t, b - a, want_pred, want_feat)

@@ -31,29 +31,43 @@ def device_uncertainty_filter(sess, posts, B):
 
 def bin_uncertainty_filter_multimg(expr, model, sess, all_padded_imgs, pool_inds, B, x_feed_dict={}, _vols=None):
     """PW_NNAL.py:684-736: posteriors of every subject's pool voxels (per-subject stats from
-    expr.train_stats), then the B most uncertain over the concatenation, split back per subject."""
+    expr.train_stats), then the B most uncertain over the concatenation, split back per subject.
+
+    Under torch.distributed (one process per GPU, volumes replicated) every rank evaluates one contiguous block of the
+    concatenated pool (pool_shard.work_block) and the posterior vector is assembled on every rank by one all-reduce of
+    owner-filled entries (pool_shard.allgather_rows: x + 0.0 is exact), after which this function continues exactly as
+    in one process - per-patch results do not depend on how the pool is cut into device passes."""
+    from . import pool_shard
     s = len(pool_inds)
     sizes = [len(p) for p in pool_inds]
     m = len(all_padded_imgs[0]) - 1
-    per_img = [[] for _ in range(s)]
+    n = int(np.sum(sizes))
+    a, b = pool_shard.work_block(n)
+    allp = np.zeros(n)
+    off = 0
     for i in range(s):
-        if sizes[i] == 0:
-            continue
-        stats = [[expr.train_stats[i, 2 * j], expr.train_stats[i, 2 * j + 1]] for j in range(m)]
-        v = None
-        if _vols is not None:          # (not a reference argument) per-subject volumes the caller keeps on the device
-            if i not in _vols:
-                _vols[i] = patch_utils.DeviceVolumes(sess, all_padded_imgs[i][:-1])
-            v = _vols[i]
-        per_img[i] = list(PW_NN.batch_eval(model, sess, all_padded_imgs[i][:-1], pool_inds[i],
-                                           expr.pars['patch_shape'], expr.pars['ntb'], stats,
-                                           'posteriors', None, x_feed_dict, _vols=v)[0])
-    allp = np.concatenate(per_img)
+        lo, hi = max(a, off) - off, min(b, off + sizes[i]) - off      # this rank's part of subject i, local positions
+        if hi > lo:
+            stats = [[expr.train_stats[i, 2 * j], expr.train_stats[i, 2 * j + 1]] for j in range(m)]
+            v = None
+            if _vols is not None:          # (not a reference argument) per-subject volumes the caller keeps on the device
+                if i not in _vols:
+                    _vols[i] = patch_utils.DeviceVolumes(sess, all_padded_imgs[i][:-1])
+                v = _vols[i]
+            allp[off + lo:off + hi] = PW_NN.batch_eval(model, sess, all_padded_imgs[i][:-1], np.asarray(pool_inds[i])[lo:hi],
+                                                       expr.pars['patch_shape'], expr.pars['ntb'], stats,
+                                                       'posteriors', None, x_feed_dict, _vols=v, _first_sample=off + lo)[0]
+        elif sizes[i] > 0:
+            PW_NN.mc_dropout_args(model, x_feed_dict)       # another rank's subject: keep the RNG streams in step
+        off += sizes[i]
+    if (a, b) != (0, n):
+        allp = pool_shard.allgather_rows(n, np.arange(a, b), allp[a:b], sess)
     if len(x_feed_dict) > 0:
         return allp
     order = binary_uncertainty_filter(allp, B)
     sel_inds = patch_utils.global2local_inds(order, sizes)
-    sel_posts = [np.array(per_img[i])[sel_inds[i]] for i in range(s)]
+    ends = np.cumsum(sizes)
+    sel_posts = [allp[ends[i] - sizes[i]:ends[i]][sel_inds[i]] for i in range(s)]
     return sel_inds, sel_posts
 
 
@@ -330,21 +344,30 @@ def query_multimg(expr, model, sess, all_padded_imgs, pool_inds, labeled_inds, m
     if method_name == 'core-set':
         return core_set_query(expr, model, sess, all_padded_imgs, pool_inds, labeled_inds)
     if method_name == 'fi':
+        from . import pool_shard
         dvols = {}                                                       # one upload per subject for the whole query
         sel_inds, sel_posts = bin_uncertainty_filter_multimg(expr, model, sess, all_padded_imgs, pool_inds, B, _vols=dvols)
         m = len(all_padded_imgs[0]) - 1
-        A = []
         stats = np.asarray(expr.train_stats, dtype=np.float64)
+        nsel = [len(s_) for s_ in sel_inds]
+        ncand = int(np.sum(nsel))
+        a, b = pool_shard.work_block(ncand)            # this rank's block of the candidate list (volumes are replicated)
+        rows = []
+        off = 0
         for i in range(len(pool_inds)):
-            if len(sel_inds[i]) == 0:
-                continue
-            vols = dvols.get(i) or patch_utils.DeviceVolumes(sess, all_padded_imgs[i][:m])
-            t = vols.gather(np.asarray(pool_inds[i])[sel_inds[i]], expr.pars['patch_shape'],
-                            stats[i, :2 * m], quirk=0)                 # slab rule, patch_utils.py:1203-1207
-            p1_in = sess.to_device(np.asarray(sel_posts[i], dtype=np.float32), sess.torch.float32)
-            out = model.fisher_device(t, len(sel_inds[i]), p1_in, 1e-3, want=('A',))   # diag_load 1e-3, :578
-            Ai = out['A'].cpu().numpy()
-            A += [Ai[j] for j in range(Ai.shape[0])]
+            lo, hi = max(a, off) - off, min(b, off + nsel[i]) - off
+            if hi > lo:
+                vols = dvols.get(i) or patch_utils.DeviceVolumes(sess, all_padded_imgs[i][:m])
+                t = vols.gather(np.asarray(pool_inds[i])[np.asarray(sel_inds[i])[lo:hi]], expr.pars['patch_shape'],
+                                stats[i, :2 * m], quirk=0)                 # slab rule, patch_utils.py:1203-1207
+                p1_in = sess.to_device(np.asarray(sel_posts[i][lo:hi], dtype=np.float32), sess.torch.float32)
+                out = model.fisher_device(t, hi - lo, p1_in, 1e-3, want=('A',))   # diag_load 1e-3, :578
+                rows.append(out['A'].cpu().numpy())
+            off += nsel[i]
+        A_rows = np.concatenate(rows) if rows else np.zeros((0, model.L, model.L))
+        if (a, b) != (0, ncand):
+            A_rows = pool_shard.allgather_rows(ncand, np.arange(a, b), A_rows, sess)
+        A = [A_rows[j] for j in range(ncand)]
         # PW_NNAL.py:600-614: 'CVXOPT' -> SDP_query_distribution, 'MOSEK' -> solve_FIAL_SDP; both end in
         # the same A-optimal-design problem, solved here by NNAL_tools' own routine (parity unpinned)
         if expr.pars.get('SDP_solver', 'CVXOPT') == 'MOSEK':

@@ -28,6 +28,13 @@ def shard_bounds(n, world_size, rank):
     return a, min(int(n), a + per)
 
 
+def work_block(n):
+    """[a, b): this rank's contiguous share of n independent work items whose inputs every rank holds (the voxels of
+    replicated volumes): the same block rule as shard_bounds.  World 1: everything."""
+    rank, ws = world()
+    return shard_bounds(n, ws, rank)
+
+
 def _comm_device():
     import torch
     dist = _dist()

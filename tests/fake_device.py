@@ -26,9 +26,48 @@ class FakeSession(object):
     def bind_stream(self):
         pass
 
+    def run(self, fetch, feed_dict=None):
+        assert fetch.name == 'train_step'
+        m = self.model
+        return m.train_on_batch(torch.as_tensor(np.asarray(feed_dict[m.x], dtype=np.float32)), feed_dict[m.y_])
+
+
+class FakeVolumes(object):
+    """patch_utils.DeviceVolumes on the CPU (oracle gather + the two normalisation rules)."""
+
+    def __init__(self, sess, padded_imgs):
+        self.vols = [np.asarray(v) for v in padded_imgs]
+        self.m = len(self.vols)
+
+    def gather(self, inds, patch_shape, stats=None, quirk=2, out_f64=False):
+        p = alpath.get_patches(self.vols, np.asarray(inds, dtype=np.int64), tuple(patch_shape), True) if len(inds) else \
+            np.zeros((0, patch_shape[0], patch_shape[1], self.m * patch_shape[2]))
+        if quirk != 2 and len(inds):
+            st = np.asarray(stats, dtype=np.float64).reshape(-1)[:2 * self.m].reshape(self.m, 2)
+            d3 = patch_shape[2]
+            for j in range(self.m):
+                sl = slice(j, j + 1) if quirk == 1 else slice(j * d3, (j + 1) * d3)
+                p[:, :, :, sl] = (p[:, :, :, sl] - st[j, 0]) / st[j, 1]
+        return torch.as_tensor(p if out_f64 else p.astype(np.float32))
+
+
+class _H(object):
+    def __init__(self, name):
+        self.name = name
+
 
 class FakeModel(object):
     dropout_rate = 1.
+    dropout_layers = ()
+    grad_layers = ()
+    x, keep_prob, y_, train_step = _H('x'), _H('keep_prob'), _H('y_'), _H('train_step')
+
+    def add_assign_ops(self):
+        pass
+
+    def perform_assign_ops(self, path, sess=None):
+        if path != 'init':
+            self.load_weights(path)
 
     def __init__(self, ld, in_shape, pars, skips=(), lr=None):
         from oracle.train import OracleOptimizer

@@ -283,3 +283,134 @@ def test_attach_comm_is_all_or_nothing(tmp_path, mode, want):
     got = json.loads(out.strip().splitlines()[-1])
     assert got['out'] == want and got['agree']
     assert got['comm_world'] == (2 if want == 'attached' else 0)
+
+
+# ---------------------------------------------------------------------------------------------- volume-level experiment
+def _write_subjects(root, seed=4100):
+    """Two synthetic subjects (two modalities + a mask with NaN voxels) as NRRD files."""
+    import nnal_amd  # noqa: F401
+    from nnal_amd import nrrd_io
+    rs = np.random.RandomState(seed)
+    paths = []
+    for s_, shp in enumerate([(14, 12, 6), (12, 15, 5)]):
+        sub = []
+        for j in range(2):
+            p = os.path.join(root, 'sub%d_mod%d.nrrd' % (s_, j))
+            nrrd_io.write(p, rs.randn(*shp) * (1. + j) + 0.2 * s_)
+            sub.append(p)
+        mask = rs.randint(0, 2, size=shp).astype(np.float64)
+        mask[rs.rand(*shp) < 0.1] = np.nan
+        p = os.path.join(root, 'sub%d_mask.nrrd' % s_)
+        nrrd_io.write(p, mask)
+        sub.append(p)
+        paths.append(sub)
+    return paths
+
+
+VOL_PARS = dict(grid_spacing=2, patch_shape=(5, 5, 3), model_name='NET-A', dropout_rate=1., learning_rate=0.02, grad_layers=[],
+                train_layers=[], optimizer_name='SGD', init_weights_path='init', k=5, B=30, lambda_=0., ntb=40, b=4, epochs=2)
+
+
+def _experiment_worker(rank, ws, port, q, root, data, rounds):      # rounds = max_queries of run_method
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    if ws > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=ws)
+    import nnal_amd  # noqa: F401
+    from nnal_amd import PW_AL, patch_utils
+    from oracle import alpath, netspec
+    from tests.fake_device import FakeModel, FakeSession, FakeVolumes
+    patch_utils.DeviceVolumes = FakeVolumes                       # the gather on the CPU (no GPU in this test)
+    patch_utils.get_patches_multimg = alpath.get_patches_multimg
+    if rank == 0:
+        os.makedirs(root, exist_ok=True)
+    if ws > 1:
+        dist.barrier()
+    if rank == 0:
+        PW_AL.Experiment_MultiImg(root, VOL_PARS, _subject_paths(data))       # writes parameters / paths / stats once
+    if ws > 1:
+        dist.barrier()
+    expr = PW_AL.Experiment_MultiImg(root)                                    # every rank reads them back
+    sess = FakeSession()
+
+    def factory(e, in_shape, s):
+        ld = netspec.net_a()
+        m = FakeModel(ld, in_shape, netspec.he_init(ld, in_shape, seed=61, bias_std=0.05), lr=e.pars['learning_rate'])
+        s.model = m
+        return m
+    expr.model_factory = factory
+    if rank == 0:
+        expr.add_method('fi')
+    if ws > 1:
+        dist.barrier()
+    np.random.seed(17)
+    log = expr.run_method('fi', rounds, sess=sess)
+    q.put((rank, [l['Q_mat'] for l in log], expr.model.weights()))
+    if ws > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _subject_paths(data):
+    return [[os.path.join(data, 'sub%d_%s.nrrd' % (s_, t)) for t in ('mod0', 'mod1', 'mask')] for s_ in range(2)]
+
+
+def _run_experiment(ws, root, data, rounds):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_experiment_worker, args=(r, ws, port, q, root, data, rounds)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    res = {r: (Q, w) for r, Q, w in (q.get(timeout=600) for _ in range(ws))}
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_volume_level_experiment_world2_equals_single_process(tmp_path):
+    """PW_AL.Experiment_MultiImg.run_method (the reference's config-5 control flow, PW_AL.py:690-898) over synthetic NRRD
+    subjects: gen_multimg_inds -> query_multimg('fi') -> queries/<iter> -> finetune_multimg -> curr_weights_<iter> until
+    six voxels are queried (the draws of a round collapse onto the support of the SDP's optimum, np.unique in
+    sample_query_dstr, so a round yields 1 .. k queries).  Two gloo ranks (the query's device work split by contiguous
+    blocks of the pool and of the candidate list) against one process: the query files, every round's Q_mat and the
+    final weights agree bit for bit; a run stopped after three queries and resumed continues with the rounds of the
+    uninterrupted run."""
+    data = str(tmp_path / 'data')
+    os.makedirs(data)
+    _write_subjects(data)
+    one = _run_experiment(1, str(tmp_path / 'e1'), data, 6)
+    two = _run_experiment(2, str(tmp_path / 'e2'), data, 6)
+    Q1, w1 = one[0]
+    assert len(Q1) >= 2 and all(len(Q) > 0 for Q in Q1) and sum(len(Q) for Q in Q1) >= 6
+    for r in (0, 1):
+        Qr, wr = two[r]
+        for a, b in zip(Q1, Qr):
+            np.testing.assert_array_equal(a, b)
+        for n in w1:
+            for a, b in zip(w1[n], wr[n]):
+                np.testing.assert_array_equal(a, b)
+    for it in range(len(Q1)):
+        f1 = np.loadtxt(os.path.join(str(tmp_path / 'e1'), 'fi', 'queries', '%d' % it), ndmin=2)
+        f2 = np.loadtxt(os.path.join(str(tmp_path / 'e2'), 'fi', 'queries', '%d' % it), ndmin=2)
+        np.testing.assert_array_equal(f1, f2)
+        np.testing.assert_array_equal(f1.astype(np.int64), Q1[it])
+        assert os.path.exists(os.path.join(str(tmp_path / 'e2'), 'fi', 'curr_weights_%d.npz' % (it + 1)))
+    # no queried voxel is queried twice, and every query is a grid voxel with a non-NaN mask
+    allq = np.concatenate(Q1)
+    assert len(np.unique(allq, axis=0)) == len(allq)
+    # resume: stop after the rounds that reach three queries, run again up to six in total
+    part = _run_experiment(1, str(tmp_path / 'e3'), data, 3)[0][0]
+    n_part = len(part)
+    for a, b in zip(Q1, part):
+        np.testing.assert_array_equal(a, b)
+    rest, w3 = _run_experiment(1, str(tmp_path / 'e3'), data, 2)[0]
+    # the resumed run continues the numbering, starts from the saved weights' pool state and never re-queries a voxel
+    # (its RNG stream restarts, as in the reference, so its draws are its own)
+    assert sorted(os.listdir(os.path.join(str(tmp_path / 'e3'), 'fi', 'queries')), key=int) == [str(i) for i in range(n_part + len(rest))]
+    both = np.concatenate(part + rest)
+    assert len(np.unique(both, axis=0)) == len(both)

@@ -414,3 +414,62 @@ def test_edge_cases_of_the_round2_entry_points(sess):
     with pytest.raises(AlqError):
         check(sess.lib.alq_sgd_step(sess.ctx, None, None, 5, 0.1))
     m.close()
+
+
+def test_volume_level_experiment_on_the_device(sess, tmp_path):
+    """PW_AL.Experiment_MultiImg.run_method (PW_AL.py:690-898) on synthetic NRRD subjects, everything on the device:
+    grid indices -> query_multimg('fi') -> queries/<iter> -> finetune_multimg -> curr_weights_<iter>.  Two runs agree bit
+    for bit; the files are what the loop reported; the reference's own 'PW' net (NN.create_model) runs the same loop."""
+    from nnal_amd import NN, PW_AL
+    from tests.test_dist_gloo import VOL_PARS, _subject_paths, _write_subjects
+    data = str(tmp_path / 'data')
+    os.makedirs(data)
+    _write_subjects(data)
+
+    def factory(e, in_shape, s):
+        ld = netspec.net_a()
+        m = NN.CNN(in_shape, ld, 'vol', len(ld) - 2, None, sess=s, max_batch=32)
+        m.set_weights(netspec.he_init(ld, in_shape, seed=61, bias_std=0.05))
+        m.get_optimizer(e.pars['learning_rate'], [], 'SGD')
+        return m
+
+    def run(root, method, max_q, fac=factory):
+        expr = PW_AL.Experiment_MultiImg(str(tmp_path / root), VOL_PARS, _subject_paths(data))
+        expr.model_factory = fac
+        expr.add_method(method)
+        np.random.seed(17)
+        log = expr.run_method(method, max_q, sess=sess)
+        w = {n: [a.copy() for a in wb] for n, wb in expr.model.var_dict.items()}
+        expr.model.close()
+        return log, w
+    l1, w1 = run('e1', 'fi', 6)
+    l2, w2 = run('e2', 'fi', 6)
+    assert len(l1) >= 2 and sum(len(l['Q_mat']) for l in l1) >= 6
+    for a, b in zip(l1, l2):
+        np.testing.assert_array_equal(a['Q_mat'], b['Q_mat'])
+    for n in w1:
+        for a, b in zip(w1[n], w2[n]):
+            np.testing.assert_array_equal(a, b)
+    w0 = netspec.he_init(netspec.net_a(), (5, 5, 6), seed=61, bias_std=0.05)
+    assert all(not np.array_equal(w1[n][0], w0[n][0]) for n in w1)           # the fine-tune moved every layer
+    for it, l in enumerate(l1):
+        f = np.loadtxt(os.path.join(str(tmp_path / 'e1'), 'fi', 'queries', '%d' % it), ndmin=2).astype(np.int64)
+        np.testing.assert_array_equal(f, l['Q_mat'])
+        assert os.path.exists(os.path.join(str(tmp_path / 'e1'), 'fi', 'AL_running_times', 'dt_%d' % it))
+        assert os.path.exists(os.path.join(str(tmp_path / 'e1'), 'fi', 'curr_weights_%d.npz' % (it + 1)))
+    # queried voxels are grid voxels of their subject with a mask label, none twice
+    inds, _ = PW_AL.gen_multimg_inds(_subject_paths(data), VOL_PARS['grid_spacing'])
+    allq = np.concatenate([l['Q_mat'] for l in l1])
+    assert len(np.unique(allq, axis=0)) == len(allq)
+    for v, s_ in allq:
+        assert v in inds[s_]
+    le, _ = run('e3', 'entropy', VOL_PARS['k'])
+    assert len(le) == 1 and len(le[0]['Q_mat']) == VOL_PARS['k']
+    # the reference's literal model: NN.create_model('PW', ...) = create_PW1 on the [5, 5, 6] patches of two modalities
+    pars = dict(VOL_PARS, model_name='PW', learning_rate=1e-3)
+    expr = PW_AL.Experiment_MultiImg(str(tmp_path / 'e4'), pars, _subject_paths(data))
+    expr.add_method('fi')
+    np.random.seed(18)
+    lp = expr.run_method('fi', 1, sess=sess)
+    assert len(lp) == 1 and len(lp[0]['Q_mat']) >= 1 and expr.model.L == 7
+    expr.model.close()

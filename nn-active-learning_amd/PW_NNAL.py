@@ -11,9 +11,10 @@ def binary_uncertainty_filter(posts, B):
     return np.argsort(np.abs(np.array(posts) - 0.5), kind='stable')[:B]
 
 
-def device_uncertainty_filter(sess, posts, B):
+def device_uncertainty_filter(sess, posts, B, with_keys=False):
     """Same selection on the device (alq_score_entropy + alq_topk_uncertain) for posteriors that
-    are already resident: `posts` float32 device tensor [n] -> int64 device tensor [B]."""
+    are already resident: `posts` float32 device tensor [n] -> int64 device tensor [B]
+    (with_keys: also their keys |p - .5| as a float64 device tensor [B], ascending)."""
     import ctypes as C
     from ._lib import check
     torch = sess.torch
@@ -26,6 +27,8 @@ def device_uncertainty_filter(sess, posts, B):
     out = sess.empty((B,), torch.int64)
     check(sess.lib.alq_topk_uncertain(sess.ctx, C.c_void_p(keys.data_ptr()), n, B, C.c_void_p(out.data_ptr()),
                                       C.c_void_p(work.data_ptr())))
+    if with_keys:
+        return out, keys.index_select(0, out)
     return out
 
 

@@ -73,7 +73,7 @@ def run_rounds(model, sess, pool, rounds, B, k, diag_load=1e-3, seed=15, n_globa
     if end - off != n_local:
         raise ValueError('rank %d holds %d patches, its block of a %d-patch pool over %d ranks has %d' %
                          (rank, n_local, n_global, ws, end - off))
-    flat = pool.reshape(n_local, -1)
+    flat = pool.reshape(n_local, int(np.prod(pool.shape[1:])))      # (an empty shard has no -1 to infer)
     remaining = np.arange(n_local, dtype=np.int64)          # LOCAL positions of this rank's patches still in the pool
     left_global = int(n_global)
     out = []

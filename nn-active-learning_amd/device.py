@@ -100,11 +100,23 @@ class DeviceSession(object):
             check(self.lib.alq_ctx_set_stream(self._ctx, C.c_void_p(s)))
             self._stream = s
 
-    def uncertainty_filter(self, posts, B):
+    def uncertainty_filter(self, posts, B, with_keys=False):
         """The B positions of `posts` (device fp32 [n]) closest to 0.5, ascending |p - .5|, ties -> lower position
-        (alq_score_entropy + alq_topk_uncertain); int64 device tensor [min(B, n)]."""
+        (alq_score_entropy + alq_topk_uncertain); int64 device tensor [min(B, n)] (+ their fp64 keys on request)."""
         from .PW_NNAL import device_uncertainty_filter
-        return device_uncertainty_filter(self, posts, B)
+        return device_uncertainty_filter(self, posts, B, with_keys)
+
+    def topk_smallest(self, keys, B):
+        """Positions of the B smallest entries of a float64 device vector, ascending, ties -> lower position (bit-pattern
+        order: +inf and NaN come last)."""
+        torch = self.torch
+        self.bind_stream()
+        n = int(keys.numel())
+        work = self.empty((self.lib.alq_topk_work_bytes(n),), torch.uint8)
+        out = self.empty((int(B),), torch.int64)
+        check(self.lib.alq_topk_uncertain(self._ctx, C.c_void_p(keys.data_ptr()), n, int(B), C.c_void_p(out.data_ptr()),
+                                          C.c_void_p(work.data_ptr())))
+        return out
 
     # -- RCCL communicator of the sharded pool (pool_shard.attach_comm) --------------------
     def comm_unique_id(self):
@@ -116,6 +128,10 @@ class DeviceSession(object):
         self.bind_stream()
         check(self.lib.alq_comm_init(self._ctx, C.c_char_p(uid), int(rank), int(world)))
         self.comm_world = int(world)
+
+    def comm_destroy(self):
+        check(self.lib.alq_comm_destroy(self._ctx))
+        self.comm_world = 0
 
     def allreduce_sum_(self, t):
         """In-place all-reduce(sum) of a float64 device tensor over the context's RCCL communicator."""

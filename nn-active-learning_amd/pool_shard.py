@@ -52,30 +52,33 @@ def attach_comm(sess):
     if getattr(sess, 'comm_world', 0) > 0:
         return True
     rank, ws = world()
-    err = None
-    uid = [None]
-    if rank == 0:
-        try:
-            uid = [sess.comm_unique_id()]
-        except Exception as e:          # e.g. librccl not loadable: every rank must learn it, none may wait in a collective
-            err = e
+    # vote 1 - BEFORE the collective init: can every rank reach RCCL at all (alq_comm_unique_id is the cheapest call that
+    # needs the library)?  ncclCommInitRank blocks until every rank has joined, so a rank that cannot join must be
+    # known before any rank enters it.
+    err, my_uid = None, None
+    try:
+        my_uid = sess.comm_unique_id()
+    except Exception as e:
+        err = e
+    if ws > 1 and max_over_ranks(0.0 if err is None else 1.0) > 0:
+        raise RuntimeError('RCCL is not usable on %s' % ('this rank: %s' % (err,) if err is not None else 'another rank'))
+    if err is not None:
+        raise err
+    uid = [my_uid if rank == 0 else None]
     if ws > 1:
         _dist().broadcast_object_list(uid, src=0)
-    if uid[0] is not None:
-        try:
-            sess.comm_init(uid[0], rank, ws)
-        except Exception as e:
-            err = e
-    elif err is None:
-        err = RuntimeError('rank 0 could not create an RCCL unique id')
-    # all or nothing: a rank whose init failed would fall back to torch.distributed while the others wait in the
-    # library's all-reduce
-    if ws > 1:
-        failed = max_over_ranks(0.0 if err is None else 1.0)
-        if failed > 0:
-            sess.comm_world = 0
-            raise RuntimeError('alq_comm_init failed on %s' % ('this rank: %s' % (err,) if err is not None else 'another rank'))
-    elif err is not None:
+    try:
+        sess.comm_init(uid[0], rank, ws)
+    except Exception as e:
+        err = e
+    # vote 2 - all or nothing: a rank whose init failed would fall back to torch.distributed while the others wait in the
+    # library's all-reduce; the ranks that did get a communicator give it back, so a later attempt starts clean
+    if ws > 1 and max_over_ranks(0.0 if err is None else 1.0) > 0:
+        if err is None:
+            sess.comm_destroy()
+        sess.comm_world = 0
+        raise RuntimeError('alq_comm_init failed on %s' % ('this rank: %s' % (err,) if err is not None else 'another rank'))
+    if err is not None:
         raise err
     return True
 
@@ -161,6 +164,59 @@ def merge_topB(local_keys, local_global_idx, B):
     return _topk_merge(k, g, B)
 
 
+def merge_topB_device(sess, keys, gidx, B):
+    """merge_topB on device tensors, nothing staged through the host: every rank passes its (at most B) best candidates as a
+    float64 key tensor in ascending order (ties -> lower index) and their GLOBAL indices; fixed-size all-gather of the padded
+    (key, index) vectors over the process group (RCCL under "nccl"), then the device top-B of the concatenation
+    (alq_topk_uncertain: ascending key, ties -> lower POSITION, and position order IS global-index order among equal keys
+    because ranks own ascending index blocks and each rank's list is already tie-ordered).  Returns the global indices as
+    an int64 device tensor [min(B, candidates in total)], identical on every rank."""
+    torch = sess.torch
+    rank, ws = world()
+    nl = int(keys.numel())
+    if nl > B:
+        keys, gidx, nl = keys[:B], gidx[:B], B
+    if ws > 1:
+        dist = _dist()
+        kk = torch.full((B,), float('inf'), dtype=torch.float64, device=keys.device)
+        gg = torch.full((B,), -1, dtype=torch.int64, device=keys.device)
+        kk[:nl] = keys
+        gg[:nl] = gidx
+        if dist.get_backend() != 'nccl':                     # gloo rehearsal: the exchange runs on host tensors
+            kk, gg = kk.cpu(), gg.cpu()
+        K = torch.empty((ws * B,), dtype=torch.float64, device=kk.device)
+        G = torch.empty((ws * B,), dtype=torch.int64, device=gg.device)
+        dist.all_gather_into_tensor(K, kk)
+        dist.all_gather_into_tensor(G, gg)
+        K, G = K.to(keys.device), G.to(keys.device)
+        valid = int((G >= 0).sum().item()) if B > 0 else 0   # n_global < B only: padding must not be selected
+    else:
+        K, G, valid = keys.contiguous(), gidx.contiguous(), nl
+    take = min(int(B), valid)
+    if take == 0:
+        return torch.empty((0,), dtype=torch.int64, device=keys.device)
+    return G.index_select(0, sess.topk_smallest(K, take))
+
+
+def allreduce_sum_device(t, sess):
+    """In-place sum of a float64 device tensor over the ranks, result left on the device (no host copy): the context's RCCL
+    communicator when it has one (alq_allreduce_sum), else torch.distributed on the tensor itself (nccl) or through the
+    host (gloo rehearsal).  Identity at world 1."""
+    rank, ws = world()
+    if ws == 1:
+        return t
+    if getattr(sess, 'comm_world', 0) == ws:
+        return sess.allreduce_sum_(t)
+    dist = _dist()
+    if dist.get_backend() == 'nccl':
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+    h = t.cpu()
+    dist.all_reduce(h, op=dist.ReduceOp.SUM)
+    t.copy_(h)
+    return t
+
+
 def max_over_ranks(value):
     rank, ws = world()
     if ws == 1:
@@ -183,8 +239,8 @@ def score_pool(model, sess, local_patches, n_global, B, diag_load=1e-5,
     |p1-.5| (through the top-B keys), H, g0, g1, A_i, tr A_i, and the pool sum of A_i).
 
     local_patches: device fp32 tensor [n_local, ...] = patches shard_bounds(n_global, R, rank).
-    Returns dict: 'sel' global top-B most-uncertain positions (same on all ranks), 'Asum' the
-    all-reduced sum of A_i over the pool and the local per-patch outputs as device tensors."""
+    Returns dict of DEVICE tensors: 'sel' global top-B most-uncertain positions (int64, same on all ranks), 'Asum' the
+    all-reduced sum of A_i over the pool, and the local per-patch outputs."""
     torch = sess.torch
     rank, ws = world()
     a, b = shard_bounds(n_global, ws, rank)
@@ -193,13 +249,14 @@ def score_pool(model, sess, local_patches, n_global, B, diag_load=1e-5,
     out = model.fisher_device(local_patches, n_local, None, diag_load, want=want)
     Bl = min(B, n_local)
     if Bl > 0:
-        loc = sess.uncertainty_filter(out['p1'], Bl)
-        keys = (out['p1'][loc].double() - 0.5).abs().cpu().numpy()
-        gidx = loc.cpu().numpy() + a
+        loc, keys = sess.uncertainty_filter(out['p1'], Bl, with_keys=True)
+        gidx = loc + a
     else:
-        keys, gidx = np.zeros(0), np.zeros(0, dtype=np.int64)
-    sel = merge_topB(keys, gidx, min(B, n_global))
-    Asum = allreduce_sum(out['Asum'], sess)
+        keys = sess.empty((0,), torch.float64)
+        gidx = sess.empty((0,), torch.int64)
+    # both exchanges stay on the device: nothing in this function copies to the host or synchronises
+    sel = merge_topB_device(sess, keys, gidx, min(B, n_global))
+    Asum = allreduce_sum_device(out['Asum'], sess) if out.get('Asum') is not None else None
     out.update(sel=sel, Asum=Asum, offset=a)
     return out
 

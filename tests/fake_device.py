@@ -26,6 +26,10 @@ class FakeSession(object):
     def bind_stream(self):
         pass
 
+    def topk_smallest(self, keys, B):
+        k = keys.numpy().view(np.uint64)                      # bit-pattern order like alq_topk_uncertain
+        return torch.as_tensor(np.lexsort((np.arange(len(k)), k))[:int(B)].astype(np.int64))
+
     def run(self, fetch, feed_dict=None):
         assert fetch.name == 'train_step'
         m = self.model

@@ -60,6 +60,65 @@ def test_world2_merge_and_allreduce():
         assert mx == 2.0
 
 
+def _worker8(rank, ws, port, n, B, q):
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=ws)
+    import nnal_amd  # noqa: F401
+    from nnal_amd import pool_shard
+    from tests.fake_device import FakeSession
+    sess = FakeSession()
+    rs = np.random.RandomState(321)
+    key = np.abs(rs.randint(0, 40, size=n) / 40. - .5)            # heavy ties, also across ranks
+    A = rs.randn(n, 2, 2)
+    a, b = pool_shard.shard_bounds(n, ws, rank)
+    lk, lg = key[a:b], np.arange(a, b)
+    o = np.lexsort((lg, lk))[:B]                                  # what the device filter hands over: ascending, tie-ordered
+    sel_dev = pool_shard.merge_topB_device(sess, torch.as_tensor(lk[o]), torch.as_tensor(lg[o]), min(B, n)).numpy()
+    sel_host = pool_shard.merge_topB(lk, lg, min(B, n))
+    Asum = pool_shard.allreduce_sum_device(torch.as_tensor(A[a:b].sum(0)), sess).numpy()
+    rows = pool_shard.allgather_rows(n, np.arange(a, b), A[a:b])
+    blocks = pool_shard.work_block(n)
+    pool_shard.barrier()
+    q.put((rank, sel_dev, sel_host, Asum, rows, blocks, (a, b)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n,B', [(43, 16), (5, 16), (41, 41)])
+def test_world8_ragged_and_empty_shards(n, B):
+    """Eight ranks, a pool that does not divide by eight (43 -> blocks of 6, the last holds 1; 41 -> the last rank is
+    EMPTY; 5 -> three ranks are empty and B exceeds the pool): the device-tensor merge (merge_topB_device), the host merge,
+    the Fisher all-reduce and the row all-gather agree with the single-process answer on every rank."""
+    ws = 8
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, ws, port, n, B, q)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(ws)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    rs = np.random.RandomState(321)
+    key = np.abs(rs.randint(0, 40, size=n) / 40. - .5)
+    A = rs.randn(n, 2, 2)
+    want = np.lexsort((np.arange(n), key))[:min(B, n)]
+    covered = np.zeros(n, int)
+    for rank, sel_dev, sel_host, Asum, rows, blocks, (a, b) in res:
+        np.testing.assert_array_equal(sel_dev, want)
+        np.testing.assert_array_equal(sel_host, want)
+        np.testing.assert_allclose(Asum, A.sum(0), rtol=1e-12, atol=1e-14)
+        np.testing.assert_array_equal(rows, A)
+        assert blocks == (a, b)
+        covered[a:b] += 1
+    assert (covered == 1).all()                                   # the blocks tile the pool exactly once
+    assert any(a == b for *_, (a, b) in res) or n % ws == 0 or n == 43
+
+
 # ---------------------------------------------------------------------------------------------- sharded AL loop
 def _loop_setup():
     from oracle import netspec
@@ -70,7 +129,7 @@ def _loop_setup():
     return ld, in_shape, pars, x
 
 
-def _loop_worker(rank, ws, port, q, state_dir=None, rounds=3, ft=False):
+def _loop_worker(rank, ws, port, q, state_dir=None, rounds=3, ft=False, n_pool=None):
     import torch
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -82,10 +141,12 @@ def _loop_worker(rank, ws, port, q, state_dir=None, rounds=3, ft=False):
     from nnal_amd import al_loop, pool_shard
     from tests.fake_device import FakeModel, FakeSession
     ld, in_shape, pars, x = _loop_setup()
+    if n_pool:
+        x = x[:n_pool]
     a, b = pool_shard.shard_bounds(len(x), ws, rank)
     sess = FakeSession()
     model = FakeModel(ld, in_shape, pars, lr=0.01 if ft else None)
-    pool = torch.as_tensor(x[a:b].reshape(b - a, -1))
+    pool = torch.as_tensor(x[a:b].reshape(b - a, int(np.prod(x.shape[1:]))))
     kw = {}
     if ft:
         from nnal_amd import PW_AL
@@ -135,6 +196,20 @@ def test_sharded_loop_equals_single_process_bit_for_bit():
     # queries span both blocks over the rounds (otherwise the test would not exercise the ownership logic)
     cand = np.concatenate([s['candidates'] for s in single])
     assert (cand < 120).any() and (cand >= 120).any()
+
+
+def test_sharded_loop_world8_with_an_empty_shard():
+    """The same loop over EIGHT ranks on a 41-patch pool (blocks of 6: rank 6 holds 5, rank 7 nothing) with fine-tuning:
+    every rank reports the single-process rounds and ends with the single-process weights, bit for bit."""
+    single = _run_loop(1, None, 2, True, 41)[0]
+    eight = _run_loop(8, None, 2, True, 41)
+    for rank in range(8):
+        for r in range(2):
+            for k in ('queries', 'candidates', 'posts', 'A', 'q'):
+                np.testing.assert_array_equal(single[r][k], eight[rank][r][k], err_msg='round %d %s rank %d' % (r, k, rank))
+        for n, wb in single[2].items():
+            for a_, b_ in zip(wb, eight[rank][2][n]):
+                np.testing.assert_array_equal(a_, b_)
 
 
 def test_sharded_loop_with_finetune_state_and_resume(tmp_path):
@@ -242,16 +317,22 @@ dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%%s' %% os.environ[
 rank = dist.get_rank()
 mode = sys.argv[1]
 
-class Sess(object):              # the two calls attach_comm makes on a session
+class Sess(object):              # the calls attach_comm makes on a session
     comm_world = 0
+    inits = 0
+    destroyed = 0
     def comm_unique_id(self):
-        if mode == 'no_id':
+        if mode == 'no_id' or (mode == 'rank1_no_rccl' and rank == 1):
             raise RuntimeError('librccl not loadable')
         return b'u' * 128
     def comm_init(self, uid, r, ws):
+        self.inits += 1
         if mode == 'rank1_fails' and r == 1:
             raise RuntimeError('ncclCommInitRank failed')
         self.comm_world = ws
+    def comm_destroy(self):
+        self.destroyed += 1
+        self.comm_world = 0
 
 s = Sess()
 try:
@@ -261,16 +342,19 @@ except Exception as e:
     out = 'fallback'
 # whatever happened, every rank must have taken the same branch - the next collective proves nobody is stuck
 agree = pool_shard.max_over_ranks(1.0 if out == 'attached' else 0.0) == (1.0 if out == 'attached' else 0.0)
+inits = pool_shard.max_over_ranks(float(s.inits))
 if rank == 0:
-    print(json.dumps({'out': out, 'agree': bool(agree), 'comm_world': s.comm_world}))
+    print(json.dumps({'out': out, 'agree': bool(agree), 'comm_world': s.comm_world, 'max_inits': inits, 'destroyed': s.destroyed}))
 dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize('mode,want', [('ok', 'attached'), ('rank1_fails', 'fallback'), ('no_id', 'fallback')])
+@pytest.mark.parametrize('mode,want', [('ok', 'attached'), ('rank1_fails', 'fallback'), ('no_id', 'fallback'), ('rank1_no_rccl', 'fallback')])
 def test_attach_comm_is_all_or_nothing(tmp_path, mode, want):
-    """The library's RCCL communicator is attached on every rank or on none: a rank whose init fails (or rank 0 without an
-    id) must not leave the others waiting in alq_allreduce_sum while it falls back to torch.distributed."""
+    """The library's RCCL communicator is attached on every rank or on none: a rank whose init fails must not leave the
+    others waiting in alq_allreduce_sum while it falls back to torch.distributed, and the ranks that did get a
+    communicator give it back (alq_comm_destroy).  A rank that cannot reach RCCL at all is found by a vote BEFORE the
+    collective init, so no rank enters ncclCommInitRank to wait for it."""
     import json
     import sys
     import nnal_amd  # noqa: F401
@@ -283,6 +367,10 @@ def test_attach_comm_is_all_or_nothing(tmp_path, mode, want):
     got = json.loads(out.strip().splitlines()[-1])
     assert got['out'] == want and got['agree']
     assert got['comm_world'] == (2 if want == 'attached' else 0)
+    if mode in ('no_id', 'rank1_no_rccl'):
+        assert got['max_inits'] == 0                      # nobody entered the collective init
+    if mode == 'rank1_fails':
+        assert got['destroyed'] == 1                      # rank 0 had a communicator and gave it back
 
 
 # ---------------------------------------------------------------------------------------------- volume-level experiment

@@ -886,8 +886,9 @@ def test_sharded_loop_world1_under_nccl(sess):
     # score_pool stores what "Fisher-scored" names: p1, H, g0, g1, A, trace per patch + the pool sum
     for key in ('p1', 'H', 'g0', 'g1', 'A', 'trace'):
         assert sc[key] is not None and int(sc[key].shape[0]) == n, key
-    np.testing.assert_array_equal(sc['sel'], plain[0]['candidates'])
-    np.testing.assert_allclose(sc['Asum'], sc['A'].cpu().numpy().sum(0), rtol=1e-10)
+    assert sc['sel'].is_cuda and sc['Asum'].is_cuda                 # both exchanges leave their results on the device
+    np.testing.assert_array_equal(sc['sel'].cpu().numpy(), plain[0]['candidates'])
+    np.testing.assert_allclose(sc['Asum'].cpu().numpy(), sc['A'].cpu().numpy().sum(0), rtol=1e-10)
     p = sc['p1'].cpu().numpy().astype(np.float64)
     pm = np.stack([1 - p, p]).astype(np.float32)
     np.testing.assert_allclose(sc['H'].cpu().numpy(), alpath.compute_entropy(pm), rtol=1e-5, atol=1e-6)

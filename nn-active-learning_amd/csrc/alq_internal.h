@@ -241,6 +241,7 @@ struct Igemm2Fuse {
 extern unsigned long long *g_igemm2_dbg;
 extern int g_dbg_knobs[8];
 extern int g_no_f16x2;        // ALQ_NO_F16X2, read when a model is created: bf16x3 split in every launch
+extern int g_no_fixed;        // ALQ_NO_FIXED (A/B runs, bit-identity test): igemm4 launches use the runtime-constant instantiation only
 extern int g_no_xcd_order;    // ALQ_NO_XCD_ORDER (A/B runs): igemm4 tiles in dispatch order
 int igemm2_build_plan(const IgemmPlan &p1, Igemm2Plan *p2);
 void igemm2_pack_weights(Igemm2Plan *p2, const std::vector<float> &Bmat);

@@ -570,6 +570,7 @@ void igemm2_pack_weights(Igemm2Plan *p2, const std::vector<float> &Bmat) {
 unsigned long long *g_igemm2_dbg = nullptr;
 int g_no_f16x2 = 0;
 int g_no_xcd_order = 0;
+int g_no_fixed = 0;
 int g_dbg_knobs[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 0 repeat, 1 flags, 2 no-bwd-fuse, 3 no-fwd-fuse   // set by alq_debug_set_stamp_buffer (diagnostic build)
 
 template <int NTW, bool WRES, int GEO, bool SUMS>

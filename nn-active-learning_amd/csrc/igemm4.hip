@@ -39,7 +39,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <string>
 #include <type_traits>
+#include <vector>
 
 namespace alq {
 
@@ -135,6 +137,34 @@ __device__ inline float g4_dot4(const f32x4 &a, const f32x4 &b) {
 // two LDS pieces per operand instead of six and three, at the accuracy of a plain fp32 GEMM for operands within 2^28 of
 // the scale (tests/study_split_precision.py).  Needs max |x| of the input ahead of the launch: available for free
 // where the input is [sign] * one host-known vector (BITSRC).
+// launch constants a specialised instantiation may fold (everything that depends only on the layer geometry and the fusion
+// choices, not on the batch, the buffers or the weights), and the pointers whose presence it may assume
+#define G4_FIXED_INTS(X) X(in_cs) X(in_c0) X(out_cs) X(out_c0) X(Co) X(mask_cs) X(mask_c0) X(mask_from) X(mask_to) X(split) X(PT) X(tpg) \
+    X(rows) X(PX) X(PYX) X(PZ) X(smz) X(smy) X(smx) X(soz) X(soy) X(sox) X(OD) X(OH) X(OW) X(MD) X(MH) X(MW) X(nph) X(ngr) X(NP) X(nslots) \
+    X(plane_bytes) X(in_pstride) X(out_pstride) X(relu) X(accumulate) X(pair) X(store_from) X(cls_ok) X(in_split_ch) X(out_split) \
+    X(mask_split) X(tt_ints) X(pd_off) X(td_off) X(wbytes) X(abytes) X(dbg_repeat) X(bits_pstride) X(fc_F) X(amax_from) X(wp) \
+    X(src_presplit) X(xcd_order) X(zreuse)
+#define G4_FIXED_PTRS(X) X(bias) X(mask) X(osumA) X(osumB) X(out_amax) X(in_amax) X(in_amax2) X(fc_bits) X(dbg)
+
+// Launch-constant traits of a kernel instantiation.  G4Runtime (the default): every constant is read from the argument
+// block.  A generated G4F_<n> (igemm4_fixed.inc, tests/gen_igemm4_fixed.py) states the constants of ONE launch of a known
+// network - geometry, table offsets, fusion switches, which optional pointers are present - so that the compiler folds them:
+// the generic kernel keeps ~80 arguments live in 102 SGPRs and moves the overflow through v_readlane / v_writelane inside
+// the tick loop (the issue slots of an issue-bound kernel); with the constants folded the spills and the address
+// multiplications disappear.  Same code path, same arithmetic, same bits.  igemm4_launch_impl picks a G4F_<n> only when
+// EVERY listed constant of the launch equals the trait's (g4_matches), otherwise the runtime instantiation runs.
+struct G4Runtime {
+    static constexpr bool fixed = false;
+#define X(f) static constexpr int f = 0;
+    G4_FIXED_INTS(X)
+#undef X
+#define X(f) static constexpr bool has_##f = false;
+    G4_FIXED_PTRS(X)
+#undef X
+};
+#define AF(f) (G::fixed ? (int)G::f : a.f)
+#define AHAS(p) (G::fixed ? (bool)G::has_##p : (a.p != nullptr))
+
 template <int V> using IC = std::integral_constant<int, V>;
 __device__ inline float g4_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ inline unsigned g4_pack_h2(_Float16 a, _Float16 b) {
@@ -142,7 +172,7 @@ __device__ inline unsigned g4_pack_h2(_Float16 a, _Float16 b) {
 }
 
 template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false, bool FCF = false, bool FIC = false, bool F16 = false, int EPI = -1, bool ZRE = false,
-          bool ACC = false>
+          bool ACC = false, class G = G4Runtime>
 __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     extern __shared__ __attribute__((aligned(16))) char lds4[];
     const int tid = threadIdx.x;
@@ -155,26 +185,26 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     const int lq = lane >> 4;
 
     int *Tl = reinterpret_cast<int *>(lds4);
-    char *Wl = lds4 + a.tt_ints * 4;
-    char *Al = Wl + a.wbytes + h * a.abytes;
+    char *Wl = lds4 + AF(tt_ints) * 4;
+    char *Al = Wl + AF(wbytes) + h * AF(abytes);
     {
         const char *Wg = reinterpret_cast<const char *>(a.W);
         // eight 16-byte loads in flight per thread (the rolled copy paid one L2 latency per 8 KB of weights: ~15 us
         // at the head of a launch with 86 KB resident)
-        for (int i0 = tid * 16; i0 < a.wbytes; i0 += 8 * 512 * 16) {
+        for (int i0 = tid * 16; i0 < AF(wbytes); i0 += 8 * 512 * 16) {
             i32x4 w8[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = i0 + u * 512 * 16;
-                w8[u] = (i < a.wbytes) ? *reinterpret_cast<const i32x4 *>(Wg + i) : i32x4{0, 0, 0, 0};
+                w8[u] = (i < AF(wbytes)) ? *reinterpret_cast<const i32x4 *>(Wg + i) : i32x4{0, 0, 0, 0};
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = i0 + u * 512 * 16;
-                if (i < a.wbytes) *reinterpret_cast<i32x4 *>(Wl + i) = w8[u];
+                if (i < AF(wbytes)) *reinterpret_cast<i32x4 *>(Wl + i) = w8[u];
             }
         }
-        for (int i = tid; i < a.tt_ints; i += 512) Tl[i] = a.ttab[i];
+        for (int i = tid; i < AF(tt_ints); i += 512) Tl[i] = a.ttab[i];
     }
 
     // tile / phase descriptors live in LDS next to the tap table: a broadcast ds_read costs ~100 cycles where a
@@ -186,10 +216,10 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
 #pragma unroll
     for (int it = 0; it < G4_NSLOT; ++it) {
         const int slot = ht + it * 256;
-        int rel = 0x20000000, pk = a.cls_ok ? 0 : 0x00ff0000, ld = -1; // unused slot: past the buffer on the fast path; no class bit / hz = 255 on the checked ones
-        if (slot < a.nslots) {
+        int rel = 0x20000000, pk = AF(cls_ok) ? 0 : 0x00ff0000, ld = -1; // unused slot: past the buffer on the fast path; no class bit / hz = 255 on the checked ones
+        if (slot < AF(nslots)) {
             const int4 sd = *reinterpret_cast<const int4 *>(a.sdesc + slot * 4);
-            rel = sd.x * a.in_cs + a.in_c0 + sd.w;
+            rel = sd.x * AF(in_cs) + AF(in_c0) + sd.w;
             pk = sd.y;
             ld = sd.z;
         }
@@ -197,7 +227,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     }
 
     // ---- per-lane row geometry ------------------------------------------------------------------------
-    const bool pair = a.pair != 0;
+    const bool pair = AF(pair) != 0;
     const int cl = pair ? (lq & 1) * 4 : lq * 4;       // first of this lane's 4 output channels (tile 0)
     // GEMM row -> M-grid point through a host-built table: the host orders the 16 points of every MFMA
     // column block so that the 16 lanes of each ds_read_b128 lane group hit 16 different LDS rows mod 16
@@ -208,9 +238,9 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         const int e = a.vdesc[(hw * 4 + ms) * 16 + lrow];
         const int ee = e < 0 ? 0 : e;
         const int pt = ee >> 24, z = (ee >> 16) & 255, y = (ee >> 8) & 255, x = ee & 255;
-        vbase[ms] = (pt * a.PZ + z * a.smz * a.PYX + y * a.smy * a.PX + x * a.smx) * G4_ROWB;
-        evox[ms] = ((pt * a.OD + z * a.soz) * a.OH + y * a.soy) * a.OW + x * a.sox + (pair ? (lq >> 1) : 0);
-        eoff[ms] = evox[ms] * a.out_cs + a.out_c0;
+        vbase[ms] = (pt * AF(PZ) + z * AF(smz) * AF(PYX) + y * AF(smy) * AF(PX) + x * AF(smx)) * G4_ROWB;
+        evox[ms] = ((pt * AF(OD) + z * AF(soz)) * AF(OH) + y * AF(soy)) * AF(OW) + x * AF(sox) + (pair ? (lq >> 1) : 0);
+        eoff[ms] = evox[ms] * AF(out_cs) + AF(out_c0);
         vpk[ms] = e;
         erow_ok = erow_ok && e >= 0;
     }
@@ -219,21 +249,21 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int c = nt * 16 + cl;
-        coff[nt] = (a.out_split && c >= a.out_split) ? a.out_delta + c - a.out_split : c;
-        const int mc = c - a.mask_from;
-        mcoff[nt] = (a.mask_split && c >= a.mask_split) ? a.mask_delta + c - a.mask_split : mc;
+        coff[nt] = (AF(out_split) && c >= AF(out_split)) ? a.out_delta + c - AF(out_split) : c;
+        const int mc = c - AF(mask_from);
+        mcoff[nt] = (AF(mask_split) && c >= AF(mask_split)) ? a.mask_delta + c - AF(mask_split) : mc;
     }
     f32x4 bias4[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         bias4[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int c = nt * 16 + cl;
-        if (a.bias && c < a.Co) bias4[nt] = *reinterpret_cast<const f32x4 *>(a.bias + c);
+        if (AHAS(bias) && c < AF(Co)) bias4[nt] = *reinterpret_cast<const f32x4 *>(a.bias + c);
     }
 
     // ---- this half's share of the tile list ------------------------------------------------------------
-    const int pgroups = (a.N + a.PT - 1) / a.PT;
-    const int total = pgroups * a.tpg;
+    const int pgroups = (a.N + AF(PT) - 1) / AF(PT);
+    const int total = pgroups * AF(tpg);
     const int nwork = gridDim.x * 2;
     // XCD-aware work order: consecutive workgroup ids land on different XCDs (8 of them, each with its own L2), so with
     // me = 2 * blockIdx.x + h the tiles of one patch - which share halo planes - were spread over all eight L2s.
@@ -241,7 +271,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     // (dec2 at 32^3: exactly one patch's 64 tiles), so a halo re-read hits the L2 that already holds it.
     // Placement-independent for correctness (a bijection of the block ids); the id -> XCD map is only assumed for speed.
     int bx = blockIdx.x;
-    if (a.xcd_order) {
+    if (AF(xcd_order)) {
         const int per = gridDim.x >> 3;
         bx = (bx & 7) * per + (bx >> 3);
     }
@@ -249,12 +279,12 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     const int n_mine = me < total ? (total - me + nwork - 1) / nwork : 0;
     const int oth = me ^ 1;
     const int n_oth = oth < total ? (total - oth + nwork - 1) / nwork : 0;
-    const int gp = nwork / a.tpg, gl = nwork % a.tpg;
-    int fpg = me / a.tpg, fl = me % a.tpg;
+    const int gp = nwork / AF(tpg), gl = nwork % AF(tpg);
+    int fpg = me / AF(tpg), fl = me % AF(tpg);
     auto advance_cursor = [&]() __attribute__((always_inline)) {
         fl += gl;
-        const int c = fl >= a.tpg;
-        fl -= c ? a.tpg : 0;
+        const int c = fl >= AF(tpg);
+        fl -= c ? AF(tpg) : 0;
         fpg += gp + c;
     };
 
@@ -278,29 +308,29 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         for (int it = 0; it < G4_NSLOT; ++it) goff[it] = G4_OOB;
     };
     auto locate = [&]() __attribute__((always_inline)) {
-        const i32x4 t0 = ld4(a.td_off + fl * 8);
-        const i32x4 t1 = ld4(a.td_off + fl * 8 + 4);
-        const int org = (t0.x + fpg * a.in_pstride) * a.in_cs;
+        const i32x4 t0 = ld4(AF(td_off) + fl * 8);
+        const i32x4 t1 = ld4(AF(td_off) + fl * 8 + 4);
+        const int org = (t0.x + fpg * AF(in_pstride)) * AF(in_cs);
         const int tflags = __builtin_amdgcn_readfirstlane(t0.z);
-        f_out = t0.y + fpg * a.out_pstride;
+        f_out = t0.y + fpg * AF(out_pstride);
         f_pdb = __builtin_amdgcn_readfirstlane(t1.z);
-        f_full = (tflags & 1) && (fpg + 1) * a.PT <= a.N;
+        f_full = (tflags & 1) && (fpg + 1) * AF(PT) <= a.N;
         f_l = fl; f_g = fpg;
         if constexpr (F16) {       // consumed one tick later (stage, a_ph == 0)
-            if (a.in_amax) {
+            if (AHAS(in_amax)) {
                 const int pn = fpg < a.N ? fpg : 0;
                 // the two loads stay in flight until the tile is staged (one tick): combining them here met their whole
                 // latency once per tile
                 f_m = a.in_amax[pn];
-                f_m2 = a.in_amax2 ? a.in_amax2[pn] : 0u;
+                f_m2 = AHAS(in_amax2) ? a.in_amax2[pn] : 0u;
             }
         }
-        if ((tflags & 2) && (fpg + 1) * a.PT <= a.N) {      // whole halo inside the tensor: no per-slot checks
+        if ((tflags & 2) && (fpg + 1) * AF(PT) <= a.N) {      // whole halo inside the tensor: no per-slot checks
 #pragma unroll
             for (int it = 0; it < G4_NSLOT; ++it) goff[it] = (int)((unsigned)(org + s_rel[it]) * 4u);
             return;
         }
-        if (a.cls_ok) {         // one patch per tile, <= 3 validity classes per dimension: s_pk holds a bit per class
+        if (AF(cls_ok)) {         // one patch per tile, <= 3 validity classes per dimension: s_pk holds a bit per class
             const int cls = __builtin_amdgcn_readfirstlane(t1.w);
             const bool pin = fpg < a.N;
 #pragma unroll
@@ -312,7 +342,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         const unsigned loz = zy & 255u, nz = ((zy >> 8) & 255u) - loz;
         const unsigned loy = (zy >> 16) & 255u, ny = (zy >> 24) - loy;
         const unsigned lox = xx & 255u, nx = ((xx >> 8) & 255u) - lox;
-        const int pbase = fpg * a.PT;
+        const int pbase = fpg * AF(PT);
 #pragma unroll
         for (int it = 0; it < G4_NSLOT; ++it) {
             const unsigned pk = (unsigned)s_pk[it];
@@ -345,16 +375,16 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     auto fetch = [&](int ph) __attribute__((always_inline)) {
         int soff = 0;
         if constexpr (!MULTI) {
-            const i32x4 pd = ld4(a.pd_off + (f_pdb + ph) * 8);
+            const i32x4 pd = ld4(AF(pd_off) + (f_pdb + ph) * 8);
             int chl = pd.y, extra = 0;
-            if (a.in_split_ch && chl >= a.in_split_ch) { chl -= a.in_split_ch; extra = a.in_delta; }     // second part of a split concat
-            soff = __builtin_amdgcn_readfirstlane((int)((unsigned)(pd.x * a.in_cs + chl * 8 + extra) * 4u));
+            if (AF(in_split_ch) && chl >= AF(in_split_ch)) { chl -= AF(in_split_ch); extra = a.in_delta; }     // second part of a split concat
+            soff = __builtin_amdgcn_readfirstlane((int)((unsigned)(pd.x * AF(in_cs) + chl * 8 + extra) * 4u));
         }
 #pragma unroll
         for (int it = 0; it < G4_NSLOT; ++it)
             R[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, goff[it], soff, 0));
         if constexpr (BITSRC) {
-            const unsigned pbase = (unsigned)f_g * (unsigned)a.bits_pstride;
+            const unsigned pbase = (unsigned)f_g * (unsigned)AF(bits_pstride);
 #pragma unroll
             for (int it = 0; it < G4_NSLOT; ++it) {
                 const unsigned e = (unsigned)(goff[it] + soff) >> 2;          // float index inside the patch (huge when parked)
@@ -369,14 +399,14 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             if (s_lds[it] >= 0) {
                 float v0 = R[it].x, v1 = R[it].y, v2 = R[it].z, v3 = R[it].w;
                 if constexpr (BITSRC) {
-                    if (!(F16 && a.src_presplit)) {
+                    if (!(F16 && AF(src_presplit))) {
                         const unsigned nib = Rb[it];       // one sign byte (low nibble) per 4 channels
                         v0 = (nib & 1u) ? v0 : 0.f; v1 = (nib & 2u) ? v1 : 0.f;
                         v2 = (nib & 4u) ? v2 : 0.f; v3 = (nib & 8u) ? v3 : 0.f;
                     }
                 }
                 if constexpr (BITSRC && F16) {
-                    if (a.src_presplit) {
+                    if (AF(src_presplit)) {
                         // the vector arrives ALREADY split (model.hip packs [h01 | h23 | l01 | l23] per 4 channels with the
                         // launch-wide scale when the weights are set: it is the same for every patch), so a slot is four
                         // ANDs with the sign masks instead of a select + split per value (~30 -> ~10 VALU per slot; this
@@ -443,7 +473,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         if constexpr (MASK_PF) {
         int mz0 = 0, my0 = 0, mx0 = 0;
         if (!q_full) {
-            const i32x4 t1 = ld4(a.td_off + q_l * 8 + 4);
+            const i32x4 t1 = ld4(AF(td_off) + q_l * 8 + 4);
             mz0 = t1.y & 255; my0 = (t1.y >> 8) & 255; mx0 = (t1.y >> 16) & 255;
         }
 #pragma unroll
@@ -452,14 +482,14 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             if (!q_full) {
                 const int e = vpk[ms];
                 const int pt = e >> 24, z = (e >> 16) & 255, y = (e >> 8) & 255, x = e & 255;
-                live = e >= 0 && q_g * a.PT + pt < a.N && mz0 + z < a.MD && my0 + y < a.MH && mx0 + x < a.MW;
+                live = e >= 0 && q_g * AF(PT) + pt < a.N && mz0 + z < AF(MD) && my0 + y < AF(MH) && mx0 + x < AF(MW);
             }
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 const int c = nt * 16 + cl;
                 Mk[ms][nt] = f32x4{1.f, 1.f, 1.f, 1.f};
-                if (live && c < a.Co && c >= a.mask_from && c < a.mask_to) {
-                    const int mo = (q_out + evox[ms]) * a.mask_cs + a.mask_c0 + mcoff[nt];
+                if (live && c < AF(Co) && c >= AF(mask_from) && c < AF(mask_to)) {
+                    const int mo = (q_out + evox[ms]) * AF(mask_cs) + AF(mask_c0) + mcoff[nt];
                     Mk[ms][nt] = *reinterpret_cast<const f32x4 *>(maskb + ((unsigned)mo * 4u));
                 }
             }
@@ -474,17 +504,17 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         if constexpr (FCF) {
             int mz0 = 0, my0 = 0, mx0 = 0;
             if (!q_full) {
-                const i32x4 t1 = ld4(a.td_off + q_l * 8 + 4);
+                const i32x4 t1 = ld4(AF(td_off) + q_l * 8 + 4);
                 mz0 = t1.y & 255; my0 = (t1.y >> 8) & 255; mx0 = (t1.y >> 16) & 255;
             }
-            const int jb = (q_out - q_g * a.out_pstride) * a.out_cs;
+            const int jb = (q_out - q_g * AF(out_pstride)) * AF(out_cs);
 #pragma unroll
             for (int ms = 0; ms < 4; ++ms) {
                 bool live = erow_ok;
                 if (!q_full) {
                     const int e = vpk[ms];
                     const int z = (e >> 16) & 255, y = (e >> 8) & 255, x = e & 255;
-                    live = e >= 0 && q_g < a.N && mz0 + z < a.MD && my0 + y < a.MH && mx0 + x < a.MW;
+                    live = e >= 0 && q_g < a.N && mz0 + z < AF(MD) && my0 + y < AF(MH) && mx0 + x < AF(MW);
                 }
                 fwv[ms] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (live) fwv[ms] = *reinterpret_cast<const f32x4 *>(a.fc_W + (jb + eoff[ms] + coff[0]));
@@ -525,10 +555,10 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             return;
         }
 #endif
-        const int obase_e = q_out * a.out_cs;
+        const int obase_e = q_out * AF(out_cs);
         int mz0 = 0, my0 = 0, mx0 = 0;
         if (!q_full) {
-            const i32x4 t1 = ld4(a.td_off + q_l * 8 + 4);
+            const i32x4 t1 = ld4(AF(td_off) + q_l * 8 + 4);
             mz0 = t1.y & 255; my0 = (t1.y >> 8) & 255; mx0 = (t1.y >> 16) & 255;
         }
         // channel sums: ONE accumulator for the four row blocks.  The selector puts set A / set B of row block ms
@@ -541,14 +571,14 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         float fs0 = 0.f;
         unsigned fbyte[FCF ? 4 : 1];
         bool fon[FCF ? 4 : 1];
-        const int jbase = (q_out - q_g * a.out_pstride) * a.out_cs;      // FCF: float offset of the tile inside its patch
+        const int jbase = (q_out - q_g * AF(out_pstride)) * AF(out_cs);      // FCF: float offset of the tile inside its patch
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms) {
             bool live = erow_ok;
             if (!q_full) {
                 const int e = vpk[ms];
                 const int pt = e >> 24, z = (e >> 16) & 255, y = (e >> 8) & 255, x = e & 255;
-                live = e >= 0 && q_g * a.PT + pt < a.N && mz0 + z < a.MD && my0 + y < a.MH && mx0 + x < a.MW;
+                live = e >= 0 && q_g * AF(PT) + pt < a.N && mz0 + z < AF(MD) && my0 + y < AF(MH) && mx0 + x < AF(MW);
             }
             livem[ms] = live;
         }
@@ -557,15 +587,15 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         // was 55 % of the two-column-tile backward launches - timing of a build without it).
         f32x4 Mq[(MASK_PF || FCF) ? 1 : 4][NTW];
         if constexpr (!MASK_PF && !FCF) {
-            if (a.mask) {
+            if (AHAS(mask)) {
 #pragma unroll
                 for (int ms = m0; ms < m1; ++ms)
 #pragma unroll
                     for (int nt = 0; nt < NTW; ++nt) {
                         const int c = nt * 16 + cl;
                         Mq[ms][nt] = f32x4{1.f, 1.f, 1.f, 1.f};
-                        if (livem[ms] && c < a.Co && c >= a.mask_from && c < a.mask_to) {
-                            const int mo = (q_out + evox[ms]) * a.mask_cs + a.mask_c0 + mcoff[nt];
+                        if (livem[ms] && c < AF(Co) && c >= AF(mask_from) && c < AF(mask_to)) {
+                            const int mo = (q_out + evox[ms]) * AF(mask_cs) + AF(mask_c0) + mcoff[nt];
                             Mq[ms][nt] = *reinterpret_cast<const f32x4 *>(maskb + ((unsigned)mo * 4u));
                         }
                     }
@@ -587,19 +617,19 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 // a fused head (FCF): igemm4_launch guarantees the pair form on exactly 8 channels with ReLU, no mask, no
                 // accumulation, no output maxima and nothing of the tensor stored - those launch constants are folded at
                 // compile time (each test of one keeps a kernel argument in SGPRs, of which this kernel has too few)
-                const bool on = live && (FCF || c < a.Co);
+                const bool on = live && (FCF || c < AF(Co));
                 if (on) {
                     f32x4 *dst = reinterpret_cast<f32x4 *>(outb + ((unsigned)(obase_e + eoff[ms] + coff[nt]) * 4u));
                     // accumulating launches (a skip source whose direct consumer is a conv) have their own instantiations: the
                     // read-modify-write path in every kernel cost 1 % of a pass it never ran in (same-box A/B of a build without it)
-                    if constexpr (ACC) { if (a.accumulate) val += *dst; }      // (the one packed fp32 op of the kernel: v_pk_add_f32)
-                    if (FCF || a.relu) {
+                    if constexpr (ACC) { if (AF(accumulate)) val += *dst; }      // (the one packed fp32 op of the kernel: v_pk_add_f32)
+                    if (FCF || AF(relu)) {
                         val.x = __builtin_amdgcn_fmed3f(val.x, 0.f, __builtin_inff());
                         val.y = __builtin_amdgcn_fmed3f(val.y, 0.f, __builtin_inff());
                         val.z = __builtin_amdgcn_fmed3f(val.z, 0.f, __builtin_inff());
                         val.w = __builtin_amdgcn_fmed3f(val.w, 0.f, __builtin_inff());
                     }
-                    if (!FCF && a.mask) {
+                    if (!FCF && AHAS(mask)) {
                         f32x4 mk;
                         if constexpr (MASK_PF) mk = Mk[ms][nt];
                         else mk = Mq[ms][nt];
@@ -607,12 +637,12 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                         val.z = mk.z > 0.f ? val.z : 0.f; val.w = mk.w > 0.f ? val.w : 0.f;
                     }
 #if defined(ALQ_DIAG) && ALQ_DIAG == 5
-                    if (!FCF && c >= a.store_from && val.x == 12345.678f) {
+                    if (!FCF && c >= AF(store_from) && val.x == 12345.678f) {
 #else
-                    if (!FCF && c >= a.store_from) {
+                    if (!FCF && c >= AF(store_from)) {
 #endif
                         __builtin_nontemporal_store(val, dst);
-                        if (a.out_amax && c >= a.amax_from)
+                        if (AHAS(out_amax) && c >= AF(amax_from))
                             amx = fmaxf(fmaxf(amx, fmaxf(__builtin_fabsf(val.x), __builtin_fabsf(val.y))),
                                         fmaxf(__builtin_fabsf(val.z), __builtin_fabsf(val.w)));
                     }
@@ -640,7 +670,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
 #endif
                     if (!on) val = f32x4{0.f, 0.f, 0.f, 0.f};
                     // selector MFMA: result row 0 = sum over the lane groups of set A, row 1 = set B
-                    const bool inA = pair ? (lq < 2) : (c < a.split);
+                    const bool inA = pair ? (lq < 2) : (c < AF(split));
                     constexpr int rowA[4] = {0, 1, 8, 9};
                     const float sel = (lrow == rowA[ms]) ? (inA ? 1.f : 0.f) : ((lrow == rowA[ms] + 4) ? (inA ? 0.f : 1.f) : 0.f);
                     sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, (val.x + val.y) + (val.z + val.w), sacc, 0, 0, 0);
@@ -652,7 +682,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             amx_k = amx;
             return;
         }
-        if (!FCF && a.out_amax) {      // one plain store per wave, tile and group; k_rowmax_u32 folds the slots of a patch
+        if (!FCF && AHAS(out_amax)) {      // one plain store per wave, tile and group; k_rowmax_u32 folds the slots of a patch
             int v = __builtin_bit_cast(int, amx);
 #define G4_ROW_SHR_MAX(n)                                                                                              \
     v = __builtin_bit_cast(int, fmaxf(__builtin_bit_cast(float, v),                                                    \
@@ -663,9 +693,9 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 31));
             const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 47));
             const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 63));
-            const int ngr = MULTI ? a.ngr : 1;
+            const int ngr = MULTI ? AF(ngr) : 1;
             if (lane == 0)
-                a.out_amax[((size_t)(q_g * a.tpg + q_l) * ngr + flush_grp) * 4 + hw] =
+                a.out_amax[((size_t)(q_g * AF(tpg) + q_l) * ngr + flush_grp) * 4 + hw] =
                     __builtin_bit_cast(unsigned, fmaxf(fmaxf(r0, r1), fmaxf(r2, r3)));
         }
 #if defined(ALQ_DIAG) && ALQ_DIAG == 7
@@ -682,7 +712,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             // pair form: evox of this lane carries + (q >> 1) for the lanes' own voxel; the sums belong to the pair's
             // first voxel (+ 1 through `base` for the second)
             const int fix = pair ? (lq >> 1) : 0;
-            if (base) {
+            if (pair ? AHAS(osumA) : (setB ? AHAS(osumB) : AHAS(osumA))) {
                 if (l0) base[q_out + ev0 - fix] = sacc.x;
                 if (l1) base[q_out + ev1 - fix] = sacc.y;
             }
@@ -691,8 +721,8 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ms = 0; ms < 4; ++ms)
-                if (fon[ms] && a.fc_bits)
-                    a.fc_bits[(size_t)q_g * (a.fc_F >> 2) + ((jbase + eoff[ms] + coff[0]) >> 2)] = (unsigned char)fbyte[ms];
+                if (fon[ms] && AHAS(fc_bits))
+                    a.fc_bits[(size_t)q_g * (AF(fc_F) >> 2) + ((jbase + eoff[ms] + coff[0]) >> 2)] = (unsigned char)fbyte[ms];
             // wave sum without the LDS crossbar (six dependent ds_bpermute round trips were ~1 k cycles per tile): prefix
             // sums inside each row of 16 lanes with DPP shifts, then the four row totals through scalar registers
             int v = __builtin_bit_cast(int, fs0);
@@ -705,7 +735,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 31));
             const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 47));
             const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 63));
-            if (lane == 0) a.fc_part[(size_t)(q_g * a.tpg + q_l) * 4 + hw] = (r0 + r1) + (r2 + r3);
+            if (lane == 0) a.fc_part[(size_t)(q_g * AF(tpg) + q_l) * 4 + hw] = (r0 + r1) + (r2 + r3);
         }
     };
 
@@ -809,7 +839,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     auto unit16 = [&](int S, const char *Wc, const char *Ab, int trow) __attribute__((always_inline)) {
         if constexpr (F16) {
             const int *tt = Tl + trow * (G4_MAXS * 4) + lq;
-            const int wpieces = a.wp;       // 3: the fp16 pieces sit in the first two of the bf16x3 slots; 2: an fp16x2-only plan
+            const int wpieces = AF(wp);       // 3: the fp16 pieces sit in the first two of the bf16x3 slots; 2: an fp16x2-only plan
             f16x8 Wa[2][NTW], Wb[NTW >= 2 ? 1 : 2][NTW], Xa[2][2], Xb[2][2];
             auto rdW = [&](f16x8 (&Wf)[2][NTW], int s) {
 #pragma unroll
@@ -938,8 +968,8 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     // only meet operations that are at least one tick old.  Per half the order is
     //   stage(i):    split (prefetch of tick i-1, mask loads of contract(i-1)) -> epilogue stores -> prefetch
     //   contract(i): mask loads of the tile (last phase only) -> MFMAs
-    const int n_ph = n_mine * a.nph;     // staging phases of this half
-    const int n_iter = (n_mine > n_oth ? n_mine : n_oth) * a.nph;
+    const int n_ph = n_mine * AF(nph);     // staging phases of this half
+    const int n_iter = (n_mine > n_oth ? n_mine : n_oth) * AF(nph);
     int a_i = 0, a_ph = 0;               // next phase to stage (counter, index within the tile)
     int b_i = 0, b_ph = 0;               // next phase to contract
     __syncthreads();                     // the descriptor / tap tables (and weights) copied above are read from here on
@@ -957,7 +987,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             if (a_ph == 0) {
                 c_out = f_out; c_full = f_full; c_l = f_l; c_g = f_g; c_pdb = f_pdb;
                 if constexpr (F16) {
-                    if (a.in_amax) {      // max |x| < 2^ex  ->  scale 2^(14 - ex); an all-zero patch keeps 0
+                    if (AHAS(in_amax)) {      // max |x| < 2^ex  ->  scale 2^(14 - ex); an all-zero patch keeps 0
                         const unsigned fm = max(f_m, f_m2);
                         const int ex = (int)((fm >> 23) & 255u) - 126;
                         c_e = fm ? 14 - ex : 0;
@@ -973,16 +1003,16 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                     if (have_pend2) {
 #pragma unroll
                         for (int ms = 0; ms < 4; ++ms) acc[ms][0] = acc2[ms];
-                        flush_grp = a.ngr - 2;
+                        flush_grp = AF(ngr) - 2;
                         flush(p2_out, p_full, p_l, p_g, IC<0>{}, IC<4>{});
-                        flush_grp = a.ngr - 1;
+                        flush_grp = AF(ngr) - 1;
                         have_pend2 = false;
                     }
                 }
             }
             PHASE4_END(1);
             nph = a_ph + 1;
-            if (nph == a.nph) {
+            if (nph == AF(nph)) {
                 nph = 0;
                 advance_cursor();
                 if (a_i + 1 < n_ph) locate(); else park();
@@ -1000,36 +1030,36 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         if constexpr (FETCH_IN_CONTRACT) fetch(a_i < n_ph ? a_ph : 0);
         if (b_i < a_i) {
             if constexpr (!MULTI) {
-                const i32x4 pdA = ld4(a.pd_off + (c_pdb + b_ph) * 8), pdB = ld4(a.pd_off + (c_pdb + b_ph) * 8 + 4);
+                const i32x4 pdA = ld4(AF(pd_off) + (c_pdb + b_ph) * 8), pdB = ld4(AF(pd_off) + (c_pdb + b_ph) * 8 + 4);
                 const int pd[5] = {0, 0, __builtin_amdgcn_readfirstlane(pdA.z), pdA.w, pdB.x};
-                if constexpr (MASK_PF) { if (!FCF && b_ph == a.nph - 1 && a.mask) load_mask(c_out, c_full, c_l, c_g); }
+                if constexpr (MASK_PF) { if (!FCF && b_ph == AF(nph) - 1 && AHAS(mask)) load_mask(c_out, c_full, c_l, c_g); }
                 // the contracting side has the slack (phase stamps: with the prefetch in the staging part that part was
                 // the longer one and the other half waited for it at the barrier)
-                if constexpr (FCF) { if (b_ph == a.nph - 1) fcw_prefetch(c_out, c_full, c_l, c_g); }
+                if constexpr (FCF) { if (b_ph == AF(nph) - 1) fcw_prefetch(c_out, c_full, c_l, c_g); }
                 if (b_ph == 0) init_acc();
-                for (int rep = 0; rep <= a.dbg_repeat; ++rep) {
+                for (int rep = 0; rep <= AF(dbg_repeat); ++rep) {
                     if constexpr (F16) unit16(pd[2], Wl + pd[3] + lane * 16, Al, pd[4]);
                     else unit(pd[2], Wl + pd[3] + lane * 16, Al, pd[4]);
                 }
-                if (b_ph == a.nph - 1) {
+                if (b_ph == AF(nph) - 1) {
                     f16_combine();
                     if constexpr (EPI_SPLIT > 0) flush(c_out, c_full, c_l, c_g, IC<0>{}, IC<EPI_SPLIT>{});
                     have_pend = true;
                     p_out = c_out; p_full = c_full; p_l = c_l; p_g = c_g;
                 }
-                b_ph = b_ph + 1 == a.nph ? 0 : b_ph + 1;
+                b_ph = b_ph + 1 == AF(nph) ? 0 : b_ph + 1;
             } else {
-                for (int g = 0; g < a.ngr; ++g) {
-                    const i32x4 gdA = ld4(a.pd_off + g * 8), gdB = ld4(a.pd_off + g * 8 + 4);
+                for (int g = 0; g < AF(ngr); ++g) {
+                    const i32x4 gdA = ld4(AF(pd_off) + g * 8), gdB = ld4(AF(pd_off) + g * 8 + 4);
                     const int gd[6] = {0, 0, __builtin_amdgcn_readfirstlane(gdA.z), gdA.w, gdB.x, gdB.y};
                     init_acc();
                     const int ub = gd[2] * (3 * NTW * 1024);
-                    for (int rep = 0; rep <= a.dbg_repeat; ++rep)
-                        for (int p = 0; p < a.NP; ++p)
-                            unit(gd[2], Wl + gd[3] + p * ub + lane * 16, Al + p * a.plane_bytes, gd[4]);
+                    for (int rep = 0; rep <= AF(dbg_repeat); ++rep)
+                        for (int p = 0; p < AF(NP); ++p)
+                            unit(gd[2], Wl + gd[3] + p * ub + lane * 16, Al + p * AF(plane_bytes), gd[4]);
                     bool kept = false;
                     if constexpr (PEND2) {
-                        if (g + 2 == a.ngr) {
+                        if (g + 2 == AF(ngr)) {
 #pragma unroll
                             for (int ms = 0; ms < 4; ++ms) acc2[ms] = acc[ms][0];
                             have_pend2 = true;
@@ -1038,10 +1068,10 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                         }
                     }
                     if (kept) {
-                    } else if (g + 1 < a.ngr) {
+                    } else if (g + 1 < AF(ngr)) {
                         flush_grp = g;
                         flush(c_out + gd[5], c_full, c_l, c_g, IC<0>{}, IC<4>{});
-                        flush_grp = a.ngr - 1;       // the group left pending
+                        flush_grp = AF(ngr) - 1;       // the group left pending
                     } else {
                         have_pend = true;
                         p_out = c_out + gd[5]; p_full = c_full; p_l = c_l; p_g = c_g;
@@ -1068,7 +1098,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             if (have_pend2) {
 #pragma unroll
                 for (int ms = 0; ms < 4; ++ms) acc[ms][0] = acc2[ms];
-                flush_grp = a.ngr - 2;
+                flush_grp = AF(ngr) - 2;
                 flush(p2_out, p_full, p_l, p_g, IC<0>{}, IC<4>{});
             }
         }
@@ -1731,16 +1761,63 @@ void igemm4_pack_weights(Igemm4Plan *plan, const std::vector<float> &Bmat) {
                 }
 }
 
-template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false, bool FCF = false, bool FIC = false, bool F16 = false, int EPI = -1, bool ZRE = false,
-          bool ACC = false>
-static int launch4_s(alq_ctx *ctx, const Igemm4Plan &plan, const Igemm4Args &a, unsigned grid) {
-    auto kfn = igemm4_kernel<NTW, MULTI, SUMS, BITSRC, FCF, FIC, F16, EPI, ZRE, ACC>;
+
+static void g4_dump_args(const char *fmt, const Igemm4Args &a, int f0, int f1, int f2, int f3, int f4, int f5, int f6, int f7, int f8, int f9) {
+    static std::vector<std::string> seen;
+    std::string line;
+    char buf[256];
+    snprintf(buf, sizeof buf, fmt, f0, f1, f2, f3, f4, f5, f6, f7, f8, f9);
+    line = std::string("G4ARGS flags ") + buf + " |";
+#define X(f) snprintf(buf, sizeof buf, " " #f "=%d", a.f); line += buf;
+    G4_FIXED_INTS(X)
+#undef X
+#define X(f) snprintf(buf, sizeof buf, " has_" #f "=%d", a.f ? 1 : 0); line += buf;
+    G4_FIXED_PTRS(X)
+#undef X
+    for (const std::string &s : seen) if (s == line) return;
+    seen.push_back(line);
+    fprintf(stderr, "%s\n", line.c_str());
+}
+
+template <int NTW, bool MULTI, bool SUMS, bool BITSRC, bool FCF, bool FIC, bool F16, int EPI, bool ZRE, bool ACC, class G>
+static int launch4_k(alq_ctx *ctx, const Igemm4Plan &plan, const Igemm4Args &a, unsigned grid) {
+    auto kfn = igemm4_kernel<NTW, MULTI, SUMS, BITSRC, FCF, FIC, F16, EPI, ZRE, ACC, G>;
     if (plan.lds_bytes > 64 * 1024)
         ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)plan.lds_bytes));
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), plan.lds_bytes, ctx->stream, a);
     ALQ_HIP(hipGetLastError());
     return ALQ_OK;
+}
+
+// every constant a trait states equals the launch's (and the optional pointers are present / absent as stated)
+template <class G>
+static bool g4_matches(const Igemm4Args &a) {
+    bool ok = true;
+#define X(f) ok = ok && a.f == G::f;
+    G4_FIXED_INTS(X)
+#undef X
+#define X(f) ok = ok && ((a.f != nullptr) == G::has_##f);
+    G4_FIXED_PTRS(X)
+#undef X
+    return ok;
+}
+
+#include "igemm4_fixed.inc"
+
+template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false, bool FCF = false, bool FIC = false, bool F16 = false, int EPI = -1, bool ZRE = false,
+          bool ACC = false>
+static int launch4_s(alq_ctx *ctx, const Igemm4Plan &plan, const Igemm4Args &a, unsigned grid) {
+    {   // ALQ_DUMP_ARGS=1: the launch constants of every distinct launch, as input for tests/gen_igemm4_fixed.py
+        static const bool dump = getenv("ALQ_DUMP_ARGS") != nullptr;
+        if (dump) g4_dump_args("%d %d %d %d %d %d %d %d %d %d", a, NTW, (int)MULTI, (int)SUMS, (int)BITSRC, (int)FCF, (int)FIC, (int)F16, EPI, (int)ZRE, (int)ACC);
+    }
+    if (!g_no_fixed) {
+        bool done = false;
+        const int rc = launch4_fixed<NTW, MULTI, SUMS, BITSRC, FCF, FIC, F16, EPI, ZRE, ACC>(ctx, plan, a, grid, &done);
+        if (done) return rc;
+    }
+    return launch4_k<NTW, MULTI, SUMS, BITSRC, FCF, FIC, F16, EPI, ZRE, ACC, G4Runtime>(ctx, plan, a, grid);
 }
 
 template <int NTW, bool MULTI>

@@ -113,6 +113,7 @@ struct alq_model {
     int knobs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int no_f16x2 = 0;
     int no_xcd_order = 0;
+    int no_fixed = 0;             // ALQ_NO_FIXED at creation: runtime-constant igemm4 instantiations only
     int no_presplit = 0;           // ALQ_NO_PRESPLIT (A/B): split the fc head's weight-difference vector in the staging part again
     int f16_fwd_mask = -1;         // ALQ_F16_FWD_MASK (diagnostics): forward fp16x2 consumers by layer bit, -1 = default rule
 
@@ -193,6 +194,7 @@ static void apply_knobs(const alq_model *m) {
     for (int k = 0; k < 8; ++k) g_dbg_knobs[k] = g_knob_override[k] >= 0 ? g_knob_override[k] : m->knobs[k];
     g_no_f16x2 = m->no_f16x2;
     g_no_xcd_order = m->no_xcd_order;
+    g_no_fixed = m->no_fixed;
 }
 
 static int gemm_build(const ConvDesc &d, int max_batch, Gemm *g, const G4Geom *g4 = nullptr) {
@@ -1323,6 +1325,7 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
         g_use_v2 = !(e && e[0] == '1');
         m->no_f16x2 = getenv("ALQ_NO_F16X2") != nullptr;
         m->no_xcd_order = getenv("ALQ_NO_XCD_ORDER") != nullptr;
+        m->no_fixed = getenv("ALQ_NO_FIXED") != nullptr;
         m->no_presplit = getenv("ALQ_NO_PRESPLIT") != nullptr;
         if (const char *f = getenv("ALQ_F16_FWD_MASK")) m->f16_fwd_mask = atoi(f);
         static const char *names[8] = {"ALQ_DEBUG_REPEAT", "ALQ_DEBUG_FLAGS", "ALQ_NO_BWD_FUSE", "ALQ_NO_FWD_FUSE", "ALQ_NO_V3", "ALQ_NO_V4",

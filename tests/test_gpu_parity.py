@@ -921,3 +921,32 @@ def test_batches_beyond_two_gigabytes_per_tensor(sess):
     with pytest.raises(AlqError):
         huge.fisher_device(xh, 2100, None, 1e-3)
     huge.close()
+
+
+def test_constant_folded_instantiations_are_bit_identical(sess):
+    """The igemm4 launches of NET-C at 32^3 run instantiations whose launch constants are folded at compile time
+    (csrc/igemm4_fixed.inc, chosen only when every constant matches); ALQ_NO_FIXED=1 at model creation keeps the
+    runtime-constant kernels.  Same code path and arithmetic: every output must agree bit for bit - Fisher pass and
+    forward-only pass, a full and a ragged batch."""
+    torch = sess.torch
+    ld, sk = netspec.net_c()
+    in_shape = (32, 32, 32, 1)
+    pars = netspec.he_init(ld, in_shape, seed=14, skips=sk, bias_std=0.05)
+    x = sess.to_device(np.random.RandomState(77).randn(21, 32 ** 3).astype(np.float32), torch.float32)
+
+    def run(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            m = _device_model(sess, ld, in_shape, sk, pars, max_batch=8)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        r = m.fisher_device(x, 21, None, 1e-3)
+        out = {k: r[k].cpu().numpy() for k in ('p1', 'g0', 'g1', 'A', 'trace', 'Asum')}
+        out['post'] = m.forward_device(x, 21)[0].cpu().numpy()
+        m.close()
+        return out
+    a, b = run({}), run({'ALQ_NO_FIXED': '1'})
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)

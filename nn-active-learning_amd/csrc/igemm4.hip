@@ -879,7 +879,11 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 }
             };
             int t_cur = tt[0];
+#if !defined(ALQ_ZRE_DEEP) || ALQ_ZRE_DEEP
+            if constexpr (!(ZRE && NTW == 1)) rdX(Xa, 0, t_cur);
+#else
             rdX(Xa, 0, t_cur);
+#endif
             if constexpr (NTW >= 2) {       // one weight fragment set, as in `unit`
                 for (int s = 0; s < S; ++s) {
                     const int s1 = s + 1 < S ? s + 1 : s;
@@ -898,8 +902,56 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             } else if constexpr (ZRE) {
                 // Fragment reuse: k-step 3 * iz + j (the host packs the taps plane by plane) reads for row blocks 2 / 3 what
                 // k-step 3 * (iz + 1) + j reads for row blocks 0 / 1, so per column j of three k-steps the fragments are read
-                // four times instead of six and rotate through the two register sets.  Same products, summed in the
-                // order (j, iz) instead of (iz, j).
+                // four times instead of six.  Same products, summed in the order (j, iz) instead of (iz, j).
+#if !defined(ALQ_ZRE_DEEP) || ALQ_ZRE_DEEP
+                // The three columns unrolled over THREE fragment register sets: fragment n = 4 j + i (i = 0: rows 0 / 1 at
+                // plane 0, 1: rows 2 / 3 at plane 0 = rows 0 / 1 at plane 1, 2: ... plane 1 / 2, 3: rows 2 / 3 at plane 2) lives
+                // in set n mod 3, whose previous tenant n - 3 has just had its last use when n is issued.  Every fragment
+                // read is then issued at least TWO six-MFMA groups (>= 192 cycles) ahead of its first use, every weight read
+                // four; with two sets the distance was one group (96 cycles), less than the LDS round trip while the other
+                // half stages (PMC: a third of the wave cycles of this launch waiting, LDS conflicts or not).
+                f16x8 Xs[3][2][2], Wc2[2][NTW];
+                auto tj = [&](int j, int iz) __attribute__((always_inline)) { return tt[(3 * iz + j) * 4]; };
+                auto issue = [&](auto N) __attribute__((always_inline)) {          // fragment n = 4 j + i into set n mod 3
+                    constexpr int n = decltype(N)::value, j = n >> 2, i = n & 3;
+                    if constexpr (j < 3) rdX(Xs[n % 3], i == 0 ? 0 : 2, tj(j, i == 0 ? 0 : i - 1));
+                };
+                rdW(Wa, 0);
+                issue(IC<0>{});
+                issue(IC<1>{});
+                rdW(Wb, 3);
+                auto column = [&](auto J) __attribute__((always_inline)) {
+                    constexpr int j = decltype(J)::value, n0 = 4 * j;
+                    issue(IC<n0 + 2>{});
+                    rdW(Wc2, 6 + j);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(Wa, Xs[n0 % 3], 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue(IC<n0 + 3>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(Wa, Xs[(n0 + 1) % 3], 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (j < 2) rdW(Wa, j + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(Wb, Xs[(n0 + 1) % 3], 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue(IC<n0 + 4>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(Wb, Xs[(n0 + 2) % 3], 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (j < 2) rdW(Wb, 3 + j + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(Wc2, Xs[(n0 + 2) % 3], 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue(IC<n0 + 5>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(Wc2, Xs[(n0 + 3) % 3], 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                column(IC<0>{});
+                column(IC<1>{});
+                column(IC<2>{});
+#else
                 f16x8 Wc2[2][NTW];                      // third weight set: fixed roles, so the three columns are a rolled loop
                 rdW(Wa, 0);
 #pragma unroll 1
@@ -933,6 +985,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                     mm(Wc2, Xb, 2);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#endif
             } else {
                 rdW(Wa, 0);
                 auto kstep = [&](const f16x8 (&Wc_)[2][NTW], f16x8 (&Wn_)[2][NTW], int s) {

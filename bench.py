@@ -292,9 +292,15 @@ def cpu_baseline(xs, ld, sk, in_shape, pars):
     p = om.forward(xs)['posteriors'][1].astype(np.float64)
     alpath.gen_A_matrices(E(), om, osess, xs, p, 1e-3)
     dt = time.perf_counter() - t0
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = None
     return {'value': len(xs) / dt, 'unit': 'patches/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d of the pool\'s patches (NET-C 32^3), forward + per-sample gen_A_matrices, %.1f s'
-                      % (len(xs), dt)}
+            'host_cores': os.cpu_count(), 'affinity_cores': affinity,
+            'sample': '%d of the pool\'s patches (NET-C 32^3), forward + per-sample gen_A_matrices, %.1f s; %d threads '
+                      '(the box reports %s cores, %s in this process\'s affinity mask; capped at 16)'
+                      % (len(xs), dt, torch.get_num_threads(), os.cpu_count(), affinity)}
 
 
 if __name__ == '__main__':

@@ -99,37 +99,13 @@ __device__ inline unsigned g4_pack2(float a, float b) {
 // posteriors of two classes depend on the logit difference only), reduces them to one partial per (tile, wave) -
 // summed in fixed order by fc_small_finish_diff - and writes the signs of its 4 channels as one byte for the
 // backward pass (each lane its own byte: 4 channels, no cross-lane step); nothing else of the tensor is stored.
-// The dot product of the FCF epilogue is plain C++ (the compiler forms v_pk_mul_f32 / v_pk_add_f32 from it).  Round 1
-// shipped single-width inline asm here after seeing logit partials "wrong by ~1e-2 and different from run to run" with
-// packed multiplies in a tile written back inside the tick loop.  That does not reproduce: compiler-formed and
-// hand-written packed builds of this kernel AND of the kernel of the commit that introduced the workaround give
-// bit-identical partials inside and after the loop, pass after pass (tests/gpu_fcf_diag.py, profiles/r02_fcf_diag.txt);
-// the observation belonged to an uncommitted intermediate state, not to packed math under concurrent MFMAs.  Plain
-// C++ also keeps every read of an MFMA result (f16_combine) under the compiler's hazard recognizer, which inline asm
-// operands are not.  tests/test_gpu_parity.py::test_writeback_inside_and_after_the_tick_loop_agree stays as the guard.
+// The dot product of the FCF epilogue is plain C++: scalar multiplies and adds (this file is compiled with
+// -fno-slp-vectorize, build.sh: packed fp32 math issues slower beside another wave's MFMAs; the build checks the device
+// assembly for v_pk_mul / v_pk_fma).  Round 1's "wrong partials with packed multiplies" was refuted in round 2 (packed and
+// scalar builds are bit-identical, profiles/r02_fcf_diag.txt); plain C++ keeps every read of an MFMA result (f16_combine)
+// under the compiler's hazard recognizer.  test_writeback_inside_and_after_the_tick_loop_agree stays as the guard.
 __device__ inline float g4_dot4(const f32x4 &a, const f32x4 &b) {
-#if defined(ALQ_PK_DOT) && (ALQ_PK_DOT == 3 || ALQ_PK_DOT == 4)                     // diagnostics: hand-written packed math
-    f32x2 p0, p1, q;
-    const f32x2 a0 = {a.x, a.y}, a1 = {a.z, a.w}, b0 = {b.x, b.y}, b1 = {b.z, b.w};
-#if ALQ_PK_DOT == 4
-#define G4_PAD "\n\ts_nop 7\n\ts_nop 7"
-#else
-#define G4_PAD ""
-#endif
-    asm volatile("v_pk_mul_f32 %0, %1, %2" G4_PAD : "=v"(p0) : "v"(a0), "v"(b0));
-    asm volatile("v_pk_mul_f32 %0, %1, %2" G4_PAD : "=v"(p1) : "v"(a1), "v"(b1));
-    asm volatile("v_pk_add_f32 %0, %1, %2" G4_PAD : "=v"(q) : "v"(p0), "v"(p1));
-    return q.x + q.y;
-#elif defined(ALQ_PK_DOT) && ALQ_PK_DOT == 6                                         // diagnostics: round 1's single-width asm
-    float t0, t1;
-    asm("v_mul_f32 %0, %1, %2" : "=v"(t0) : "v"(a.x), "v"(b.x));
-    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(a.y), "v"(b.y), "v"(t0));
-    asm("v_mul_f32 %0, %1, %2" : "=v"(t1) : "v"(a.z), "v"(b.z));
-    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t1) : "v"(a.w), "v"(b.w), "v"(t1));
-    return t0 + t1;
-#else
     return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
-#endif
 }
 
 // F16 (one column tile): fp16x2 split instead of bf16x3 - x * 2^e = h + l * 2^-11 with fp16 h, l (weights alike, packed
@@ -137,6 +113,7 @@ __device__ inline float g4_dot4(const f32x4 &a, const f32x4 &b) {
 // two LDS pieces per operand instead of six and three, at the accuracy of a plain fp32 GEMM for operands within 2^28 of
 // the scale (tests/study_split_precision.py).  Needs max |x| of the input ahead of the launch: available for free
 // where the input is [sign] * one host-known vector (BITSRC).
+
 // launch constants a specialised instantiation may fold (everything that depends only on the layer geometry and the fusion
 // choices, not on the batch, the buffers or the weights), and the pointers whose presence it may assume
 #define G4_FIXED_INTS(X) X(in_cs) X(in_c0) X(out_cs) X(out_c0) X(Co) X(mask_cs) X(mask_c0) X(mask_from) X(mask_to) X(split) X(PT) X(tpg) \
@@ -422,14 +399,6 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                         continue;
                     }
                 }
-#if defined(ALQ_DIAG) && ALQ_DIAG == 1
-                if constexpr (F16) {
-                    char *dst = Al + s_lds[it];
-                    *reinterpret_cast<uint2 *>(dst) = uint2{__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1)};
-                    *reinterpret_cast<uint2 *>(dst + 16) = uint2{__builtin_bit_cast(unsigned, v2), __builtin_bit_cast(unsigned, v3)};
-                    continue;
-                }
-#endif
                 if constexpr (F16) {
                     // x * 2^e = h + l * 2^-11.  Same values as ldexp / scalar converts (every step but the two roundings to
                     // fp16 is exact), fewer instructions: the scales are two wave-uniform multipliers, the fp16 roundings
@@ -547,14 +516,6 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     int flush_grp = 0;                // a.out_amax: output group of the running flush (MULTI)
     auto flush = [&](int q_out, int q_full, int q_l, int q_g, auto MS0, auto MS1) __attribute__((always_inline)) {
         constexpr int m0 = decltype(MS0)::value, m1 = decltype(MS1)::value;
-#if defined(ALQ_DIAG) && ALQ_DIAG == 2
-        if constexpr (F16) {
-            float sdiag = 0.f;
-            for (int ms = m0; ms < m1; ++ms) sdiag += acc[ms][0].x + accl[ms][0].x;
-            if (sdiag == 12345.678f) a.out[q_out] = sdiag;
-            return;
-        }
-#endif
         const int obase_e = q_out * AF(out_cs);
         int mz0 = 0, my0 = 0, mx0 = 0;
         if (!q_full) {
@@ -636,11 +597,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                         val.x = mk.x > 0.f ? val.x : 0.f; val.y = mk.y > 0.f ? val.y : 0.f;
                         val.z = mk.z > 0.f ? val.z : 0.f; val.w = mk.w > 0.f ? val.w : 0.f;
                     }
-#if defined(ALQ_DIAG) && ALQ_DIAG == 5
-                    if (!FCF && c >= AF(store_from) && val.x == 12345.678f) {
-#else
                     if (!FCF && c >= AF(store_from)) {
-#endif
                         __builtin_nontemporal_store(val, dst);
                         if (AHAS(out_amax) && c >= AF(amax_from))
                             amx = fmaxf(fmaxf(amx, fmaxf(__builtin_fabsf(val.x), __builtin_fabsf(val.y))),
@@ -650,12 +607,6 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 if constexpr (FCF) {
                     // the sign bytes go out after the loop: no store between the weight loads above and their use
                     unsigned nib = 0;
-#if defined(ALQ_PK_DOT) && ALQ_PK_DOT == 2
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");
-#endif
-#if defined(ALQ_PK_DOT) && ALQ_PK_DOT == 5
-                    __builtin_amdgcn_s_setprio(3);
-#endif
                     if (on) {
                         fs0 += g4_dot4(val, fwv[ms]);
                         nib = (val.x > 0.f ? 1u : 0u) | (val.y > 0.f ? 2u : 0u) | (val.z > 0.f ? 4u : 0u) | (val.w > 0.f ? 8u : 0u);
@@ -663,11 +614,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                     fbyte[ms] = nib;
                     fon[ms] = on;
                 }
-#if defined(ALQ_DIAG) && ALQ_DIAG == 7
-                if constexpr (false) {
-#else
                 if constexpr (SUMS) {
-#endif
                     if (!on) val = f32x4{0.f, 0.f, 0.f, 0.f};
                     // selector MFMA: result row 0 = sum over the lane groups of set A, row 1 = set B
                     const bool inA = pair ? (lq < 2) : (c < AF(split));
@@ -698,11 +645,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 a.out_amax[((size_t)(q_g * AF(tpg) + q_l) * ngr + flush_grp) * 4 + hw] =
                     __builtin_bit_cast(unsigned, fmaxf(fmaxf(r0, r1), fmaxf(r2, r3)));
         }
-#if defined(ALQ_DIAG) && ALQ_DIAG == 7
-        if constexpr (false) {
-#else
         if constexpr (SUMS) {
-#endif
             // lane group q: set (q & 1), row blocks m0 = 2 * (q >> 1) (in .x) and m0 + 1 (in .y)
             const bool setB = (lq & 1) != 0;
             float *base = pair ? a.osumA + (setB ? 1 : 0) : (setB ? a.osumB : a.osumA);
@@ -849,10 +792,6 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                         Wf[p][nt] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(Wc + ((s * wpieces + p) * NTW + nt) * 1024));
             };
             auto rdX = [&](f16x8 (&X)[2][2], int mh, int to) {
-#if defined(ALQ_DIAG) && ALQ_DIAG == 4
-                asm volatile("" : "+v"(X[0][0]), "+v"(X[1][0]), "+v"(X[0][1]), "+v"(X[1][1]));
-                return;
-#endif
 #pragma unroll
                 for (int m2 = 0; m2 < 2; ++m2) {
                     const char *row = Ab + vbase[mh + m2] + to;
@@ -862,10 +801,6 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 }
             };
             auto mm = [&](const f16x8 (&Wf)[2][NTW], const f16x8 (&X)[2][2], int mh) {
-#if defined(ALQ_DIAG) && ALQ_DIAG == 3
-                asm volatile("" ::"v"(X[0][0]), "v"(X[1][0]), "v"(X[0][1]), "v"(X[1][1]), "v"(Wf[0][0]), "v"(Wf[1][0]));
-                return;
-#endif
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt) {
                     f32x4 c0 = acc[mh][nt], c1 = acc[mh + 1][nt], d0 = accl[mh][nt], d1 = accl[mh + 1][nt];
@@ -879,7 +814,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 }
             };
             int t_cur = tt[0];
-#if !defined(ALQ_ZRE_DEEP) || ALQ_ZRE_DEEP
+#if defined(ALQ_ZRE_DEEP) && ALQ_ZRE_DEEP
             if constexpr (!(ZRE && NTW == 1)) rdX(Xa, 0, t_cur);
 #else
             rdX(Xa, 0, t_cur);
@@ -903,7 +838,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 // Fragment reuse: k-step 3 * iz + j (the host packs the taps plane by plane) reads for row blocks 2 / 3 what
                 // k-step 3 * (iz + 1) + j reads for row blocks 0 / 1, so per column j of three k-steps the fragments are read
                 // four times instead of six.  Same products, summed in the order (j, iz) instead of (iz, j).
-#if !defined(ALQ_ZRE_DEEP) || ALQ_ZRE_DEEP
+#if defined(ALQ_ZRE_DEEP) && ALQ_ZRE_DEEP       // opt-in: same-box kernel A/B 2476 -> 2505 us (no gain: the launch is bound by its staging side)
                 // The three columns unrolled over THREE fragment register sets: fragment n = 4 j + i (i = 0: rows 0 / 1 at
                 // plane 0, 1: rows 2 / 3 at plane 0 = rows 0 / 1 at plane 1, 2: ... plane 1 / 2, 3: rows 2 / 3 at plane 2) lives
                 // in set n mod 3, whose previous tenant n - 3 has just had its last use when n is issued.  Every fragment
@@ -1991,9 +1926,6 @@ static int igemm4_launch_impl(alq_ctx *ctx, const Igemm4Plan &plan, const View &
         ALQ_REQUIRE(!a.pair || (!fuse->osumB && fuse->split == 0), ALQ_EUNSUPPORTED,
                     "igemm4: the pair form sums all 8 channels of a voxel");
         a.mask = fuse->mask; a.mask_cs = fuse->mask_cs; a.mask_c0 = fuse->mask_c0; a.mask_from = fuse->mask_from;
-#if defined(ALQ_DIAG) && ALQ_DIAG == 6
-        a.mask = nullptr;
-#endif
         a.mask_to = fuse->mask_to;
         a.mask_split = fuse->mask_split; a.mask_delta = (int)fuse->mask_delta;
         ALQ_REQUIRE(!a.mask_split || a.mask_from == 0, ALQ_EUNSUPPORTED, "igemm4: a split mask covers all columns");

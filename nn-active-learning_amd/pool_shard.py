@@ -176,8 +176,10 @@ def merge_topB_device(sess, keys, gidx, B):
     nl = int(keys.numel())
     if nl > B:
         keys, gidx, nl = keys[:B], gidx[:B], B
-    if ws > 1:
-        dist = _dist()
+    dist = _dist()
+    # a one-rank "nccl" group still takes the collective path: that is how the one-GPU box exercises the RCCL all-gather of
+    # device tensors this function issues on a real node
+    if ws > 1 or (dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl'):
         kk = torch.full((B,), float('inf'), dtype=torch.float64, device=keys.device)
         gg = torch.full((B,), -1, dtype=torch.int64, device=keys.device)
         kk[:nl] = keys
@@ -203,10 +205,10 @@ def allreduce_sum_device(t, sess):
     communicator when it has one (alq_allreduce_sum), else torch.distributed on the tensor itself (nccl) or through the
     host (gloo rehearsal).  Identity at world 1."""
     rank, ws = world()
+    if getattr(sess, 'comm_world', 0) == ws:          # (also a one-rank communicator: the GPU test's RCCL path)
+        return sess.allreduce_sum_(t)
     if ws == 1:
         return t
-    if getattr(sess, 'comm_world', 0) == ws:
-        return sess.allreduce_sum_(t)
     dist = _dist()
     if dist.get_backend() == 'nccl':
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

@@ -838,7 +838,8 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 // Fragment reuse: k-step 3 * iz + j (the host packs the taps plane by plane) reads for row blocks 2 / 3 what
                 // k-step 3 * (iz + 1) + j reads for row blocks 0 / 1, so per column j of three k-steps the fragments are read
                 // four times instead of six.  Same products, summed in the order (j, iz) instead of (iz, j).
-#if defined(ALQ_ZRE_DEEP) && ALQ_ZRE_DEEP       // opt-in: same-box kernel A/B 2476 -> 2505 us (no gain: the launch is bound by its staging side)
+#if defined(ALQ_ZRE_DEEP) && ALQ_ZRE_DEEP       // opt-in (-DALQ_ZRE_DEEP=1): same-box kernel A/B 2405 -> 2476 us, i.e. NO gain - the fragment reads'
+                // latency is not what holds this contraction back (the two waves of a SIMD add their issue cycles)
                 // The three columns unrolled over THREE fragment register sets: fragment n = 4 j + i (i = 0: rows 0 / 1 at
                 // plane 0, 1: rows 2 / 3 at plane 0 = rows 0 / 1 at plane 1, 2: ... plane 1 / 2, 3: rows 2 / 3 at plane 2) lives
                 // in set n mod 3, whose previous tenant n - 3 has just had its last use when n is issued.  Every fragment
@@ -846,7 +847,13 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 // four; with two sets the distance was one group (96 cycles), less than the LDS round trip while the other
                 // half stages (PMC: a third of the wave cycles of this launch waiting, LDS conflicts or not).
                 f16x8 Xs[3][2][2], Wc2[2][NTW];
-                auto tj = [&](int j, int iz) __attribute__((always_inline)) { return tt[(3 * iz + j) * 4]; };
+                // the nine tap offsets of the phase in ONE batch of table reads ahead of the first fragment read: a table read
+                // between two fragment reads is met with lgkmcnt(0) (the counter retires in order), i.e. it drains every
+                // fragment read in flight and the distance gained above is lost
+                int tapv[9];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) tapv[q] = tt[q * 4];
+                auto tj = [&](int j, int iz) __attribute__((always_inline)) { return tapv[3 * iz + j]; };
                 auto issue = [&](auto N) __attribute__((always_inline)) {          // fragment n = 4 j + i into set n mod 3
                     constexpr int n = decltype(N)::value, j = n >> 2, i = n & 3;
                     if constexpr (j < 3) rdX(Xs[n % 3], i == 0 ? 0 : 2, tj(j, i == 0 ? 0 : i - 1));
@@ -1779,13 +1786,18 @@ static int launch4_k(alq_ctx *ctx, const Igemm4Plan &plan, const Igemm4Args &a, 
 }
 
 // every constant a trait states equals the launch's (and the optional pointers are present / absent as stated)
+#ifdef ALQ_STAMPS
+#define G4_STAMPED 1      // the diagnostic build stamps the folded instantiations too (its a.dbg is set)
+#else
+#define G4_STAMPED 0
+#endif
 template <class G>
 static bool g4_matches(const Igemm4Args &a) {
     bool ok = true;
 #define X(f) ok = ok && a.f == G::f;
     G4_FIXED_INTS(X)
 #undef X
-#define X(f) ok = ok && ((a.f != nullptr) == G::has_##f);
+#define X(f) ok = ok && ((a.f != nullptr) == G::has_##f || (G4_STAMPED && std::strcmp(#f, "dbg") == 0));
     G4_FIXED_PTRS(X)
 #undef X
     return ok;

@@ -29,7 +29,7 @@ def main():
     ld, sk = netspec.net_c()
     in_shape = (32, 32, 32, 1)
     pars = netspec.he_init(ld, in_shape, seed=14, skips=sk)
-    N = 256
+    N = int(os.environ.get("STAMP_BATCH", "256"))
     model = device.DeviceModel(sess, ld, in_shape, sk, max_batch=N)
     model.set_weights(pars)
     x = sess.empty((N, 32 ** 3), torch.float32)

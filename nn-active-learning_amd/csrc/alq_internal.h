@@ -229,6 +229,10 @@ struct Igemm2Fuse {
     unsigned *out_amax = nullptr;
     int amax_from = 0;         // only columns >= amax_from count for out_amax (the slice the next launch reads)
     const unsigned *in_amax = nullptr, *in_amax2 = nullptr;
+    // igemm4 only: a host-known bound on max |x| of the stored input tensor (e.g. a cotangent under the unit cotangent, bounded
+    // through the weights' L1 norms): enables the fp16x2 contraction with ONE scale for the launch.  A bound far above the
+    // values costs no accuracy: (h, l) fp16 pairs carry 22 bits over 29 binades and an absolute 2^-36 of the scaled range below
+    float in_bound = 0.f;
     // igemm4 only (pair form, 8 output channels, one patch per tile): the output feeds nothing but a 2-output fc head -
     // the epilogue emits per (tile, wave) partials of the logit difference against fc_W [fc_F] = W0 - W1
     // (activation-memory order) and the sign byte of every voxel instead of storing the tensor

@@ -1845,6 +1845,7 @@ static bool g4_wants_f16(const Igemm4Plan &plan, const View &in, const Igemm2Fus
     if (!fuse || g_no_f16x2 || !plan.d_W16 || plan.multi) return false;
     if (fuse->in_bits) return fuse->in_vec_amax > 0.f;
     if (fuse->fc_W) return fuse->in_amax != nullptr;
+    if (fuse->in_bound > 0.f && !fuse->in_amax) return plan.a.PT == 1 && plan.NTW <= 2;
     return fuse->in_amax != nullptr && plan.a.PT == 1 && (!in.split || fuse->in_amax2) && plan.NTW <= 2;
 }
 
@@ -1893,6 +1894,15 @@ static int igemm4_launch_impl(alq_ctx *ctx, const Igemm4Plan &plan, const View &
     if (fuse && fuse->in_amax && !fuse->in_bits && !fuse->fc_W && plan.d_W16 && !plan.multi && a.PT == 1 && !no16 &&
         (!in.split || fuse->in_amax2) && plan.NTW <= 2) {
         a.in_amax = fuse->in_amax; a.in_amax2 = fuse->in_amax2;
+        a.W = plan.d_W16;
+        f16 = true;
+    }
+    // a stored input tensor with a host-known bound on its magnitude: fp16x2 with one launch-wide scale
+    if (!f16 && fuse && fuse->in_bound > 0.f && !fuse->in_amax && !fuse->in_bits && !fuse->fc_W && plan.d_W16 && !plan.multi &&
+        a.PT == 1 && !no16 && plan.NTW <= 2) {
+        int ex = 0;
+        (void)std::frexp(fuse->in_bound, &ex);       // bound < 2^ex
+        a.f16_ein = 14 - ex;
         a.W = plan.d_W16;
         f16 = true;
     }

@@ -71,6 +71,12 @@ struct Layer {
     const unsigned *dout_amax = nullptr;   // per-patch max |cotangent of this layer's output| of the running backward pass, or null
     unsigned *amax_fwd = nullptr;          // [max_batch] per-patch max |output| of a forward pass that asked for it
     float dout_vec_amax = 0.f;
+    // Static bounds for the fp16x2 contraction of backward launches (no data pass needed): bwd_l1 = max over the input
+    // channels of sum_{taps, output channels} |W| (set with the weights), i.e. |cotangent of the input| <= bwd_l1 * max
+    // |cotangent of the output|; dout_bound = the bound on this layer's output cotangent in the running Fisher pass
+    // (unit cotangent at the logits, chained down by run_backward_main).
+    double bwd_l1 = 0;
+    float dout_bound = 0.f;
     float *fc_part2 = nullptr;         // partial logits per (tile, wave) when the conv below computes them in its epilogue
     int fc_slices2 = 0;
     const unsigned *dout_bits = nullptr;   // set on the conv below for the duration of one backward pass
@@ -113,6 +119,7 @@ struct alq_model {
     int knobs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int no_f16x2 = 0;
     int no_xcd_order = 0;
+    int no_bound16 = 0;           // ALQ_NO_BOUND16 at creation: backward launches take their fp16x2 scale from measured per-patch maxima only
     int no_fixed = 0;             // ALQ_NO_FIXED at creation: runtime-constant igemm4 instantiations only
     int no_presplit = 0;           // ALQ_NO_PRESPLIT (A/B): split the fc head's weight-difference vector in the staging part again
     int f16_fwd_mask = -1;         // ALQ_F16_FWD_MASK (diagnostics): forward fp16x2 consumers by layer bit, -1 = default rule
@@ -908,6 +915,23 @@ static int run_backward_main(alq_model *m, const float *d_x, int N) {
     ALQ_TRY(k_fill_unit_cotangent(ctx, m->dlogits, N));
     for (Layer &l : m->layers) { l.delta_ready = false; l.dsum_partial = false; l.dout_bits = nullptr; l.dout_vec = nullptr; l.dout_vec16 = nullptr; l.dout_amax = nullptr; }
     const bool v4_on = !g_dbg_knobs[4] && !g_dbg_knobs[5];
+    {   // bounds on every layer's output cotangent under the unit cotangent (+1, -1): |d out| of the head = 1; a two-class
+        // head hands max |W0 - W1| down, a conv / conv_transpose its L1 bound, a pool passes the bound on, a ReLU mask
+        // cannot raise it; a tensor with several consumers (skip source) collects the sum.  One fp16x2 scale per LAUNCH
+        // follows from it (igemm4: Igemm2Fuse::in_bound) - no per-patch maxima, no extra pass, batch-invariant results.
+        for (Layer &l : m->layers) l.dout_bound = 0.f;
+        m->layers[nl - 1].dout_bound = 1.f;
+        for (int i = nl - 1; i >= 1; --i) {
+            const Layer &ly = m->layers[i];
+            double inb = ly.dout_bound;
+            if (ly.spec.type == ALQ_FC) inb = (ly.spec.cout == 2 && ly.fc_wv_amax > 0.f && i == nl - 1) ? (double)ly.fc_wv_amax : 0.0;
+            else if (ly.spec.type != ALQ_POOL) inb = ly.bwd_l1 * ly.dout_bound;
+            if (!(inb > 0.0) || ly.dout_bound <= 0.f) inb = 0.0;       // unknown upstream: no bound below either
+            auto add = [&](Layer &p) { p.dout_bound = (p.dout_bound < 0.f || inb <= 0.0) ? -1.f : p.dout_bound + (float)(inb * (1.0 + 1e-6)); };
+            add(m->layers[i - 1]);
+            if (ly.spec.skip_src >= 0) add(m->layers[ly.spec.skip_src]);
+        }
+    }
     // a pool whose producer is the first parameterised layer: 2x2(x2) windows tiling the input exactly
     auto pool_first_ok = [&](const Layer &pl, const Layer &src) {
         return pl.spec.type == ALQ_POOL && src.pidx == 0 && src.spec.type != ALQ_FC && pl.spec.k[1] == 2 && pl.spec.k[2] == 2 &&
@@ -1031,7 +1055,8 @@ static int run_backward_main(alq_model *m, const float *d_x, int N) {
                 // mask-bit launch above: its staging side is the critical one and the maxima cost more than they gave.
                 const bool p4_here = fuse && v4_on && ly.bwd.p4.ok && !ly.bwd.p4.multi && ly.bwd.p4.a.PT == 1 && !g_no_f16x2;
                 bool hand = false;
-                if (p4_here && prev_param && !acc && prev->pidx > 0 && prev->bwd.p4.ok && !prev->bwd.p4.multi && prev->bwd.p4.a.PT == 1 &&
+                // (with a static bound for the launch below, nothing needs to be measured here)
+                if (p4_here && prev_param && !acc && !(prev->dout_bound > 0.f && !m->no_bound16) && prev->pidx > 0 && prev->bwd.p4.ok && !prev->bwd.p4.multi && prev->bwd.p4.a.PT == 1 &&
                     prev->bwd.p4.d_W16 && !prev->dout.split &&
                     ((prev->bwd.p4.NTW == 1 && prev->bwd.p4.fic) || prev->bwd.p4.NTW == 2)) {
                     const size_t len = (size_t)ly.bwd.p4.a.tpg * 4;
@@ -1042,6 +1067,7 @@ static int run_backward_main(alq_model *m, const float *d_x, int N) {
                     hand = true;
                 }
                 if (p4_here && ly.dout_amax) fz.in_amax = ly.dout_amax;
+                if (p4_here && !fz.in_amax && ly.dout_bound > 0.f && !m->no_bound16) fz.in_bound = ly.dout_bound;
                 const unsigned *mine = ly.dout_amax;
                 ly.dout_amax = nullptr;
                 ALQ_TRY(gemm_launch(ctx, ly.bwd, ly.dout, ly.din, nullptr, 0, acc, N, PROF_IGEMM_BWD, fuse, &fused));
@@ -1326,6 +1352,7 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
         m->no_f16x2 = getenv("ALQ_NO_F16X2") != nullptr;
         m->no_xcd_order = getenv("ALQ_NO_XCD_ORDER") != nullptr;
         m->no_fixed = getenv("ALQ_NO_FIXED") != nullptr;
+        m->no_bound16 = getenv("ALQ_NO_BOUND16") != nullptr;
         m->no_presplit = getenv("ALQ_NO_PRESPLIT") != nullptr;
         if (const char *f = getenv("ALQ_F16_FWD_MASK")) m->f16_fwd_mask = atoi(f);
         static const char *names[8] = {"ALQ_DEBUG_REPEAT", "ALQ_DEBUG_FLAGS", "ALQ_NO_BWD_FUSE", "ALQ_NO_FWD_FUSE", "ALQ_NO_V3", "ALQ_NO_V4",
@@ -1409,6 +1436,18 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
     ALQ_HIP(hipMemcpyAsync(ly.d_bias, b, ly.b_elems * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
     const int Ci = ly.in.C, Co = sp.cout;
     const int ntaps = sp.k[0] * sp.k[1] * sp.k[2];
+    if (sp.type == ALQ_CONV || sp.type == ALQ_CONVT) {
+        // conv W[tap][ci][co], conv_transpose W[tap][co][ci]: L1 norm of everything that multiplies into input channel ci
+        double best = 0;
+        for (int ci = 0; ci < Ci; ++ci) {
+            double s = 0;
+            for (int tp = 0; tp < ntaps; ++tp)
+                for (int co = 0; co < Co; ++co)
+                    s += std::fabs((double)(sp.type == ALQ_CONV ? W[((size_t)tp * Ci + ci) * Co + co] : W[((size_t)tp * Co + co) * Ci + ci]));
+            best = std::max(best, s);
+        }
+        ly.bwd_l1 = best;
+    }
     if (sp.type == ALQ_CONV) {
         // TF [tap][ci][co] is already the fwd B matrix [(tap, ci)][co]
         std::vector<float> B(W, W + ly.w_elems);

@@ -1068,6 +1068,14 @@ static int run_backward_main(alq_model *m, const float *d_x, int N) {
                 }
                 if (p4_here && ly.dout_amax) fz.in_amax = ly.dout_amax;
                 if (p4_here && !fz.in_amax && ly.dout_bound > 0.f && !m->no_bound16) fz.in_bound = ly.dout_bound;
+                // a launch without an epilogue request (nothing parameterised below it to mask or sum for) still gets its
+                // fp16x2 scale: an otherwise empty request carries the bound (no mask, no sums: the plain epilogue runs)
+                if (!fuse && !acc && v4_on && ly.bwd.p4.ok && !ly.bwd.p4.multi && ly.bwd.p4.a.PT == 1 && !g_no_f16x2 && !ly.dout_amax &&
+                    ly.dout_bound > 0.f && !m->no_bound16 && !g_dbg_knobs[2]) {
+                    fz = Igemm2Fuse();
+                    fz.in_bound = ly.dout_bound;
+                    fuse = &fz;
+                }
                 const unsigned *mine = ly.dout_amax;
                 ly.dout_amax = nullptr;
                 ALQ_TRY(gemm_launch(ctx, ly.bwd, ly.dout, ly.din, nullptr, 0, acc, N, PROF_IGEMM_BWD, fuse, &fused));

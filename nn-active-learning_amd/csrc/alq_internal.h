@@ -240,6 +240,11 @@ struct Igemm2Fuse {
     long long fc_F = 0;
     float *fc_part = nullptr;
     unsigned *fc_bits = nullptr;
+    // flip-safe fused head (fp16x2 contraction only): see Igemm4Args::flip_tau; flip_l1 = max over the output channels of the L1
+    // norm of their weights
+    unsigned *flip_cnt = nullptr, *flip_list = nullptr;
+    int flip_cap = 0;
+    float flip_l1 = 0.f;
 };
 
 extern unsigned long long *g_igemm2_dbg;
@@ -318,6 +323,13 @@ struct Igemm4Args {
     // (appended: the position of an argument changes how the compiler packs the scalar loads of ALL kernels - a field in
     // the middle cost the mask-bit launch 13 %)
     int zreuse;             // 1: k-step 3 * iz + j reads, for row blocks 2 / 3 of a wave, what k-step 3 * (iz + 1) + j reads for row blocks 0 / 1 (fragment reuse, igemm4.hip)
+    // FCF + F16 (flip-safe fused head): a 4-channel group holding a finished pre-activation with |value| < flip_tau * 2^(14 - scale
+    // exponent) - closer to zero than the fp16x2 contraction's error bound - gets bit 4 of its sign byte set (flip_list non-null
+    // switches it on; the list itself is filled by k_flip_fix's scan, which then re-evaluates the marked groups exactly)
+    float flip_tau;
+    int flip_cap;
+    unsigned *flip_cnt;
+    unsigned *flip_list;
 };
 
 struct G4Geom {
@@ -459,6 +471,9 @@ int k_fc_small_bwd(alq_ctx *, const float *delta, int nout, const float *Wp, int
                    float *dact, const float *mask_act = nullptr, float *dsum = nullptr, int C = 0,
                    bool *fused = nullptr);
 int k_rowsum_field(alq_ctx *, const float *field, int64_t len, int N, float *out);
+int k_flip_fix(alq_ctx *, unsigned *list, unsigned *cnt, int cap, int N, const float *inA, const float *inB, int CA, int CB,
+               int D, int H, int W, int kz, int ky, int kx, int lz, int ly, int lx, const float *W32, const float *bias, int Co,
+               unsigned char *bits, long long F);
 int k_rowmax_u32(alq_ctx *, const unsigned *in, int len, int N, unsigned *out);      // out[n] = max_k in[n][k]
 int k_softmax(alq_ctx *, const float *logits, int c, int N, float *post_cN, int64_t *pred);
 int k_fill_unit_cotangent(alq_ctx *, float *dlogits, int N);

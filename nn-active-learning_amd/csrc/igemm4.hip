@@ -104,8 +104,13 @@ __device__ inline unsigned g4_pack2(float a, float b) {
 // assembly for v_pk_mul / v_pk_fma).  Round 1's "wrong partials with packed multiplies" was refuted in round 2 (packed and
 // scalar builds are bit-identical, profiles/r02_fcf_diag.txt); plain C++ keeps every read of an MFMA result (f16_combine)
 // under the compiler's hazard recognizer.  test_writeback_inside_and_after_the_tick_loop_agree stays as the guard.
+// The contraction into fmas is spelled out: left to -ffp-contract the compiler picks, per instantiation, which product of
+// a.x * b.x + a.y * b.y becomes the fma addend, and the constant-folded and the runtime instantiation of one launch stopped
+// agreeing in the last bit of the logits once the epilogue around this call differed.
 __device__ inline float g4_dot4(const f32x4 &a, const f32x4 &b) {
-    return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+    const float t0 = __builtin_fmaf(a.y, b.y, a.x * b.x);
+    const float t1 = __builtin_fmaf(a.w, b.w, a.z * b.z);
+    return t0 + t1;
 }
 
 // F16 (one column tile): fp16x2 split instead of bf16x3 - x * 2^e = h + l * 2^-11 with fp16 h, l (weights alike, packed
@@ -121,7 +126,7 @@ __device__ inline float g4_dot4(const f32x4 &a, const f32x4 &b) {
     X(plane_bytes) X(in_pstride) X(out_pstride) X(relu) X(accumulate) X(pair) X(store_from) X(cls_ok) X(in_split_ch) X(out_split) \
     X(mask_split) X(tt_ints) X(pd_off) X(td_off) X(wbytes) X(abytes) X(dbg_repeat) X(bits_pstride) X(fc_F) X(amax_from) X(wp) \
     X(src_presplit) X(xcd_order) X(zreuse)
-#define G4_FIXED_PTRS(X) X(bias) X(mask) X(osumA) X(osumB) X(out_amax) X(in_amax) X(in_amax2) X(fc_bits) X(dbg)
+#define G4_FIXED_PTRS(X) X(bias) X(mask) X(osumA) X(osumB) X(out_amax) X(in_amax) X(in_amax2) X(fc_bits) X(dbg) X(flip_list)
 
 // Launch-constant traits of a kernel instantiation.  G4Runtime (the default): every constant is read from the argument
 // block.  A generated G4F_<n> (igemm4_fixed.inc, tests/gen_igemm4_fixed.py) states the constants of ONE launch of a known
@@ -512,6 +517,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     // staging part of the next tick; a kernel whose staging part is the longer one writes its first EPI_SPLIT row
     // blocks at the end of the contraction instead (the channel-sum accumulator travels in sacc_k).
     f32x4 sacc_k = f32x4{0.f, 0.f, 0.f, 0.f};
+    float p_tau = 0.f;                // FCF + F16: flagging threshold of the pending tile (its patch's scale), see Igemm4Args::flip_tau
     float amx_k = 0.f;                // a.out_amax: max |stored value| of the row blocks written so far
     int flush_grp = 0;                // a.out_amax: output group of the running flush (MULTI)
     auto flush = [&](int q_out, int q_full, int q_l, int q_g, auto MS0, auto MS1) __attribute__((always_inline)) {
@@ -579,11 +585,25 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                 // accumulation, no output maxima and nothing of the tensor stored - those launch constants are folded at
                 // compile time (each test of one keeps a kernel argument in SGPRs, of which this kernel has too few)
                 const bool on = live && (FCF || c < AF(Co));
+                unsigned unsure = 0u;      // FCF + F16: bit 4 of the sign byte (see below)
                 if (on) {
                     f32x4 *dst = reinterpret_cast<f32x4 *>(outb + ((unsigned)(obase_e + eoff[ms] + coff[nt]) * 4u));
                     // accumulating launches (a skip source whose direct consumer is a conv) have their own instantiations: the
                     // read-modify-write path in every kernel cost 1 % of a pass it never ran in (same-box A/B of a build without it)
                     if constexpr (ACC) { if (AF(accumulate)) val += *dst; }      // (the one packed fp32 op of the kernel: v_pk_add_f32)
+                    if constexpr (FCF && F16) {
+                        // Flip-safe head: the fp16x2 contraction rounds every operand at 2^-22, four times the noise of an fp32
+                        // GEMM, and a ReLU input within that noise of zero would get its SIGN (the mask bit the backward pass
+                        // works from) decided by it.  Such values are rare (~30 of 262144 per patch): a 4-channel group holding
+                        // one is marked in bit 4 of its sign byte (the consumers read bits 0-3), k_flip_fix collects the marked
+                        // groups and re-evaluates them exactly from the stored fp32 inputs.  No atomics here: a returning atomic
+                        // in half of the tiles' epilogues cost the launch 10 %.
+                        if (AHAS(flip_list)) {
+                            const float mn = fminf(fminf(__builtin_fabsf(val.x), __builtin_fabsf(val.y)),
+                                                   fminf(__builtin_fabsf(val.z), __builtin_fabsf(val.w)));
+                            unsure = mn < p_tau ? 16u : 0u;
+                        }
+                    }
                     if (FCF || AF(relu)) {
                         val.x = __builtin_amdgcn_fmed3f(val.x, 0.f, __builtin_inff());
                         val.y = __builtin_amdgcn_fmed3f(val.y, 0.f, __builtin_inff());
@@ -609,7 +629,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                     unsigned nib = 0;
                     if (on) {
                         fs0 += g4_dot4(val, fwv[ms]);
-                        nib = (val.x > 0.f ? 1u : 0u) | (val.y > 0.f ? 2u : 0u) | (val.z > 0.f ? 4u : 0u) | (val.w > 0.f ? 8u : 0u);
+                        nib = (val.x > 0.f ? 1u : 0u) | (val.y > 0.f ? 2u : 0u) | (val.z > 0.f ? 4u : 0u) | (val.w > 0.f ? 8u : 0u) | unsure;
                     }
                     fbyte[ms] = nib;
                     fon[ms] = on;
@@ -1037,6 +1057,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                     else unit(pd[2], Wl + pd[3] + lane * 16, Al, pd[4]);
                 }
                 if (b_ph == AF(nph) - 1) {
+                    if constexpr (FCF && F16) p_tau = __builtin_ldexpf(a.flip_tau, 14 - c_e);      // max |x| of the patch < 2^(14 - c_e)
                     f16_combine();
                     if constexpr (EPI_SPLIT > 0) flush(c_out, c_full, c_l, c_g, IC<0>{}, IC<EPI_SPLIT>{});
                     have_pend = true;
@@ -1907,6 +1928,7 @@ static int igemm4_launch_impl(alq_ctx *ctx, const Igemm4Plan &plan, const View &
         f16 = true;
     }
     a.fc_W = nullptr; a.fc_part = nullptr; a.fc_bits = nullptr; a.fc_F = 0;
+    a.flip_tau = 0.f; a.flip_cap = 0; a.flip_cnt = nullptr; a.flip_list = nullptr;
     if (fuse && fuse->in_bits) {      // masked-vector input: `in` only gives the geometry
         ALQ_REQUIRE(plan.NTW == 1 && !plan.multi && a.PT == 1 && !in.split && in.c0 == 0 && in.cs == in.C && fuse->in_vec &&
                         ((long long)in.vox() * in.cs) % 32 == 0,
@@ -1964,6 +1986,16 @@ static int igemm4_launch_impl(alq_ctx *ctx, const Igemm4Plan &plan, const View &
             a.fc_W = fuse->fc_W; a.fc_F = (int)fuse->fc_F; a.fc_part = fuse->fc_part;
             a.fc_bits = reinterpret_cast<unsigned char *>(fuse->fc_bits);
             a.store_from = out.C;
+            if (fuse->flip_list && fuse->fc_bits && fuse->flip_l1 > 0.f) {
+                // The fp16x2 contraction's error: each operand is off by <= 2^-22 relative, the l.l product is dropped, the
+                // accumulation is fp32, so |error| <= 2^-20 * max |x| * (L1 norm of the output channel's weights) in the WORST case
+                // (every term at the patch's maximum, every rounding error of one sign) - three orders of magnitude above the
+                // rms error 2^-22 sqrt(sum x^2 w^2) of independent roundings, and a threshold there marks ~150 groups per 32^3
+                // patch (the fix-up then costs 160 us per 2000 patches).  The threshold is 1/16 of the worst case = ~160 rms
+                // errors: ~10 groups per patch, 15 us.
+                a.flip_tau = std::ldexp(fuse->flip_l1, -24);
+                a.flip_cnt = fuse->flip_cnt; a.flip_list = fuse->flip_list; a.flip_cap = fuse->flip_cap;
+            }
         }
     }
     const int pgroups = (N + a.PT - 1) / a.PT;
@@ -1975,6 +2007,7 @@ static int igemm4_launch_impl(alq_ctx *ctx, const Igemm4Plan &plan, const View &
         a.W = plan.d_W16;
         f16 = true;
     }
+    if (!f16) { a.flip_list = nullptr; a.flip_cnt = nullptr; a.flip_cap = 0; a.flip_tau = 0.f; }
     ALQ_REQUIRE(plan.wp == 3 || f16, ALQ_EINVAL, "igemm4: an fp16x2-only plan was asked for a bf16x3 launch");
     ProfScope ps(ctx, f16 ? (int)PROF_IGEMM_F16 : prof_cls, plan.flops_per_patch * N);
     if (accumulate) {

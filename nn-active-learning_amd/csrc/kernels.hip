@@ -1272,6 +1272,96 @@ int k_rowmax_u32(alq_ctx *ctx, const unsigned *in, int len, int N, unsigned *out
     return ALQ_OK;
 }
 
+// Flip-safe fused head, step 1: collect the sign bytes whose bit 4 is set (igemm4's fused-head epilogue marks the 4-channel
+// groups holding a pre-activation that its fp16x2 contraction left within its error bound of zero).  Streams the bit field
+// once (16 bytes per thread); every scan block keeps its own list segment and count: list[block * FLIP_PER_BLOCK + slot] = global
+// byte index, cnt[block] = groups found.
+constexpr int FLIP_BLOCKS = 8192, FLIP_PER_BLOCK = 128;      // scan blocks and list slots per block (expected load: ~8)
+__global__ __launch_bounds__(256) void flip_scan_kernel(const uint4 *bits16, long long n16, unsigned *cnt, unsigned *list) {
+    __shared__ unsigned lc;
+    if (threadIdx.x == 0) lc = 0u;
+    __syncthreads();
+    const long long per = (n16 + gridDim.x - 1) / gridDim.x, a = blockIdx.x * per, b = a + per < n16 ? a + per : n16;
+    for (long long i = a + threadIdx.x; i < b; i += 256) {
+        const uint4 w = bits16[i];
+        if (((w.x | w.y | w.z | w.w) & 0x10101010u) == 0u) continue;
+        const unsigned ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb)
+                if ((ws[q] >> (8 * bb + 4)) & 1u) {
+                    const unsigned slot = atomicAdd(&lc, 1u);          // LDS: a global counter serialised ~65 k hits at ~10 ns each
+                    if (slot < (unsigned)FLIP_PER_BLOCK) list[(long long)blockIdx.x * FLIP_PER_BLOCK + slot] = (unsigned)(i * 16 + q * 4 + bb);
+                }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[blockIdx.x] = lc < (unsigned)FLIP_PER_BLOCK ? lc : (unsigned)FLIP_PER_BLOCK;
+}
+// Step 2: exact re-evaluation of the four pre-activations of every listed group of a stride-1 SAME conv and their sign
+// nibble written back (flag cleared).  One wave per group; products in fp64 (exact for fp32 factors), lane partials and the
+// wave reduction in a fixed order.  Input = two dense channels-last tensors (the parts of a split concat; CB = 0: one).
+// CI / KD / KH / KW > 0: compile-time channel count and kernel box (the index arithmetic of the product loop is divisions by
+// them: with run-time divisors the kernel spent its time there, 240 us per 2000 patches); 0 = run-time values.
+template <int CI, int KD, int KH, int KW>
+__global__ __launch_bounds__(256) void flip_fix_kernel(const unsigned *list, const unsigned *cnt, const float *inA, const float *inB,
+                                                       int CA, int CB, int D, int H, int W, int kz_, int ky_, int kx_, int lz, int ly, int lx,
+                                                       const float *W32, const float *bias, int Co, unsigned char *bits, long long F) {
+    const unsigned seg = blockIdx.x >> 2;                    // four workgroups share the groups scan block `seg` found
+    const unsigned n = cnt[seg];
+    const int Ci = CI > 0 ? CI : CA + CB, kz = KD > 0 ? KD : kz_, ky = KH > 0 ? KH : ky_, kx = KW > 0 ? KW : kx_;
+    const int lane = threadIdx.x & 63, K = kz * ky * kx * Ci;
+    const unsigned gpp = (unsigned)(F >> 2);                 // groups (bytes) per patch
+    for (unsigned r = (blockIdx.x & 3u) * 4u + (threadIdx.x >> 6); r < n; r += 16) {     // one wave per group
+        const unsigned b = list[(long long)seg * FLIP_PER_BLOCK + r];
+        const unsigned p = b / gpp, g = b - p * gpp;
+        const int co = (int)((g * 4u) % (unsigned)Co);       // first of the group's 4 channels
+        int v = (int)((g * 4u) / (unsigned)Co);
+        const int x = v % W; v /= W;
+        const int y = v % H;
+        const int z = v / H;
+        const long long pv = (long long)p * D * H * W;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (int i = lane; i < K; i += 64) {
+            const int ci = i % Ci, t = i / Ci;
+            const int tx = t % kx, ty = (t / kx) % ky, tz = t / (kx * ky);
+            const int iz = z + tz - lz, iy = y + ty - ly, ix = x + tx - lx;
+            if ((unsigned)iz < (unsigned)D && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                const long long vox = pv + ((long long)iz * H + iy) * W + ix;
+                const double xv = (double)(ci < CA ? inA[vox * CA + ci] : inB[vox * CB + (ci - CA)]);
+                const float *wr = W32 + ((long long)t * Ci + ci) * Co + co;
+                s0 += xv * (double)wr[0]; s1 += xv * (double)wr[1]; s2 += xv * (double)wr[2]; s3 += xv * (double)wr[3];
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64);
+            s2 += __shfl_xor(s2, off, 64); s3 += __shfl_xor(s3, off, 64);
+        }
+        if (lane == 0) {
+            const double b0 = bias ? (double)bias[co] : 0.0, b1 = bias ? (double)bias[co + 1] : 0.0;
+            const double b2 = bias ? (double)bias[co + 2] : 0.0, b3 = bias ? (double)bias[co + 3] : 0.0;
+            bits[b] = (unsigned char)((s0 + b0 > 0.0 ? 1u : 0u) | (s1 + b1 > 0.0 ? 2u : 0u) | (s2 + b2 > 0.0 ? 4u : 0u) | (s3 + b3 > 0.0 ? 8u : 0u));
+        }
+    }
+}
+int k_flip_fix(alq_ctx *ctx, unsigned *list, unsigned *cnt, int cap, int N, const float *inA, const float *inB, int CA, int CB,
+               int D, int H, int W, int kz, int ky, int kx, int lz, int ly, int lx, const float *W32, const float *bias, int Co,
+               unsigned char *bits, long long F) {
+    ProfScope ps(ctx, PROF_ELEMWISE, 0);
+    const long long n16 = (long long)N * (F >> 2) / 16;
+    (void)cap;
+    hipLaunchKernelGGL(flip_scan_kernel, dim3(FLIP_BLOCKS), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4 *>(bits), n16, cnt, list);
+    if (CA + CB == 16 && kz == 3 && ky == 3 && kx == 3)
+        hipLaunchKernelGGL((flip_fix_kernel<16, 3, 3, 3>), dim3(FLIP_BLOCKS * 4), dim3(256), 0, ctx->stream, list, cnt, inA, inB, CA, CB, D, H, W,
+                           kz, ky, kx, lz, ly, lx, W32, bias, Co, bits, F);
+    else
+        hipLaunchKernelGGL((flip_fix_kernel<0, 0, 0, 0>), dim3(FLIP_BLOCKS * 4), dim3(256), 0, ctx->stream, list, cnt, inA, inB, CA, CB, D, H, W,
+                           kz, ky, kx, lz, ly, lx, W32, bias, Co, bits, F);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
 int k_fc_small_dsum_bits(alq_ctx *ctx, const unsigned *maskbits, const float *wv, int64_t F, int N, float *dsum) {
     ProfScope ps(ctx, PROF_FC_SMALL, 0);
     ALQ_REQUIRE(F % 32 == 0, ALQ_EINVAL, "fc_small_dsum_bits: F %% 32");

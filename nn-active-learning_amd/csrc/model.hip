@@ -77,6 +77,10 @@ struct Layer {
     // (unit cotangent at the logits, chained down by run_backward_main).
     double bwd_l1 = 0;
     float dout_bound = 0.f;
+    // flip-safe fused head (the conv under a two-class head): plain fp32 copy of the weights in TF layout [tap][ci][co] for the
+    // exact re-evaluation, and max over co of sum_{tap, ci} |W|
+    float *d_W32 = nullptr;
+    float fwd_l1 = 0.f;
     float *fc_part2 = nullptr;         // partial logits per (tile, wave) when the conv below computes them in its epilogue
     int fc_slices2 = 0;
     const unsigned *dout_bits = nullptr;   // set on the conv below for the duration of one backward pass
@@ -99,6 +103,9 @@ struct alq_model {
     bool last_head_fused = false;    // the last forward pass did not store the last conv's output
     // per-patch max |x| (float bits) of the two producers of the fused-head conv's input, for its fp16x2 contraction
     unsigned *amax_a = nullptr, *amax_b = nullptr, *amax_tiles = nullptr;
+    unsigned *flip_cnt = nullptr, *flip_list = nullptr;     // candidates of the flip-safe fused head (igemm4 FCF + F16)
+    int flip_cap = 0;
+    int no_flipfix = 0;                                      // ALQ_NO_FLIPFIX at creation (A/B: the head's sign bits as the fp16x2 contraction leaves them)
     size_t amax_tiles_len = 0;
     int in_dims[4] = {1, 1, 1, 1};
     int nclass = 0;
@@ -805,7 +812,25 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                     // epilogue, the tensor itself is not stored
                     fz.fc_W = nx->fc_wv; fz.fc_F = nx->F; fz.fc_part = nx->fc_part2; fz.fc_bits = with_sums ? nx->fc_maskbits : nullptr;
                     take_amax(fz, i);
+                    // flip-safe head: only where the launch will contract with the fp16x2 split (input maxima known) and the
+                    // sign bits are wanted (Fisher pass); stride-1 conv on one dense tensor or a split concat of two
+                    const bool flipfix = with_sums && fz.fc_bits && fz.in_amax && !g_no_f16x2 && !m->no_flipfix && ly.d_W32 && ly.fwd_l1 > 0.f &&
+                                         sp.s[0] == 1 && sp.s[1] == 1 && sp.s[2] == 1 && in.c0 == 0 &&
+                                         ((in.split == 0 && in.cs == in.C) || (in.split > 0 && in.cs == in.split && in.C == 2 * in.split));
+                    if (flipfix) {
+                        if (!m->flip_list) {
+                            m->flip_cap = 8192 * 128;            // kernels.hip: FLIP_BLOCKS segments of FLIP_PER_BLOCK groups
+                            ALQ_TRY(m->dalloc(&m->flip_cnt, (size_t)8192));
+                            ALQ_TRY(m->dalloc(&m->flip_list, (size_t)m->flip_cap));
+                        }
+                        fz.flip_cnt = m->flip_cnt; fz.flip_list = m->flip_list; fz.flip_cap = m->flip_cap; fz.flip_l1 = ly.fwd_l1;
+                    }
                     ALQ_TRY(igemm4_launch(ctx, ly.fwd[0].p4, in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM3_FWD, &fz));
+                    if (flipfix)
+                        ALQ_TRY(k_flip_fix(ctx, m->flip_list, m->flip_cnt, m->flip_cap, N, in.p, in.split ? in.p + in.delta : nullptr,
+                                           in.split ? in.split : in.C, in.split ? in.C - in.split : 0, in.D, in.H, in.W, sp.k[0], sp.k[1], sp.k[2],
+                                           ly.lo[0], ly.lo[1], ly.lo[2], ly.d_W32, ly.d_bias, sp.cout,
+                                           reinterpret_cast<unsigned char *>(nx->fc_maskbits), nx->F));
                     fused = true;
                     fc_head_fused = true;
                     m->last_head_fused = true;
@@ -1361,6 +1386,7 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
         m->no_xcd_order = getenv("ALQ_NO_XCD_ORDER") != nullptr;
         m->no_fixed = getenv("ALQ_NO_FIXED") != nullptr;
         m->no_bound16 = getenv("ALQ_NO_BOUND16") != nullptr;
+        m->no_flipfix = getenv("ALQ_NO_FLIPFIX") != nullptr;
         m->no_presplit = getenv("ALQ_NO_PRESPLIT") != nullptr;
         if (const char *f = getenv("ALQ_F16_FWD_MASK")) m->f16_fwd_mask = atoi(f);
         static const char *names[8] = {"ALQ_DEBUG_REPEAT", "ALQ_DEBUG_FLAGS", "ALQ_NO_BWD_FUSE", "ALQ_NO_FWD_FUSE", "ALQ_NO_V3", "ALQ_NO_V4",
@@ -1455,6 +1481,21 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
             best = std::max(best, s);
         }
         ly.bwd_l1 = best;
+    }
+    if (sp.type == ALQ_CONV) {
+        double best = 0;
+        for (int co = 0; co < Co; ++co) {
+            double s = 0;
+            for (int tp = 0; tp < ntaps; ++tp)
+                for (int ci = 0; ci < Ci; ++ci) s += std::fabs((double)W[((size_t)tp * Ci + ci) * Co + co]);
+            best = std::max(best, s);
+        }
+        ly.fwd_l1 = (float)(best * (1.0 + 1e-6));
+        const int li = (int)(lyp - &m->layers[0]);
+        if (li + 2 == (int)m->layers.size() && m->layers[li + 1].fc_part2) {      // the conv under a fused two-class head
+            if (!ly.d_W32) ALQ_TRY(m->dalloc(&ly.d_W32, (size_t)ly.w_elems));
+            ALQ_HIP(hipMemcpyAsync(ly.d_W32, W, ly.w_elems * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
+        }
     }
     if (sp.type == ALQ_CONV) {
         // TF [tap][ci][co] is already the fwd B matrix [(tap, ci)][co]

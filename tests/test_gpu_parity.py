@@ -950,3 +950,32 @@ def test_constant_folded_instantiations_are_bit_identical(sess):
     a, b = run({}), run({'ALQ_NO_FIXED': '1'})
     for k in a:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+def test_default_engines_against_fp64_flip_safe_head(sess):
+    """NET-C at 32^3, the bench's weights and its first 16 synthetic patches, default engines (fp16x2 in the fused-head
+    conv's forward and in every backward launch, bf16x3 elsewhere) against an fp64 evaluation of the network.  The head
+    conv's fp16x2 contraction alone would decide the sign of a ReLU input within its noise of zero in one of these
+    patches (|error of g| 1.3e-4, ALQ_NO_FLIPFIX=1); the flip-safe head re-evaluates such inputs exactly
+    (k_flip_fix), and every layer score of every patch is within 2e-6 of fp64."""
+    import ctypes as C
+    from nnal_amd._lib import check
+    torch = sess.torch
+    n = 16
+    ld, sk = netspec.net_c()
+    in_shape = (32, 32, 32, 1)
+    pars = netspec.he_init(ld, in_shape, seed=14, skips=sk)
+    model = _device_model(sess, ld, in_shape, sk, pars, max_batch=8)
+    x = sess.empty((n, 32 ** 3), torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, 32 ** 3, C.c_void_p(x.data_ptr())))
+    xs = x.cpu().numpy().reshape((n,) + in_shape).astype(np.float64)
+    torch.set_num_threads(16)
+    pars64 = {k: [v[0].astype(np.float64), v[1].astype(np.float64)] for k, v in pars.items()}
+    om64 = OracleModel(ld, in_shape, pars64, skips=sk, dtype=torch.float64)
+    p64, S64, sizes = factored_ref.factored_unit_scores(om64, xs)
+    g64, h64, _ = factored_ref.fisher_from_unit(p64[1], S64, sizes, 1e-3)
+    r = model.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1'))
+    np.testing.assert_allclose(r['p1'].cpu().numpy(), p64[1], rtol=0, atol=2e-6)
+    assert np.abs(r['g0'].cpu().numpy() - g64).max() <= 2e-6
+    assert np.abs(r['g1'].cpu().numpy() - h64).max() <= 2e-6
+    model.close()

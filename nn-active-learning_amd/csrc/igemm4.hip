@@ -1698,13 +1698,15 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan, int wp) 
     plan->flops_per_patch = g.flops_per_patch;
     plan->ok = true;
     plan->alt16.reset();
-    if (WP == 3 && !multi && L.xw == 0 && getenv("ALQ_ALT16")) {
+    if (WP == 3 && !multi && L.xw == 0 && !getenv("ALQ_NO_ALT16")) {
         // This plan reads its fragments with bank conflicts (no conflict-free layout fits beside three weight pieces: the
-        // pair-form 16 -> 8 channel convs at 32^3 / 16^3, 3-way conflicts on every X fragment read, PMC 56 % of the LDS-active
+        // pair-form 16 -> 8 channel convs at 32^3 / 16^3, 3-way conflicts on every X fragment read, PMC 51 - 56 % of the LDS-active
         // cycles).  Launches that contract with the fp16x2 split need two pieces only: with that budget the tile gets the
         // padded 2 x 2 x 4 layout and the twin is conflict-free (PMC: 56 % -> 8 %, LDS active 72 % -> 39 % of CU-busy).
-        // OPT-IN (ALQ_ALT16=1) because it does not pay: same-box A/B 155.7 k vs 154.9 k patches/s - the launch is bound by
-        // the SIMD's issue slots (MFMA + VALU instruction counts), the LDS array was never the limiter.
+        // Rounds 1 - 2 measured no gain from it (the launches were bound by their instruction streams: 155.7 k vs 154.9 k
+        // patches/s) and kept it opt-in; with the launch constants folded and the 16 -> 8 backward launch on the fp16x2 split it
+        // pays (round 3, same-box kernel A/B per 2000 patches: fused-head conv 2415 -> 2311 us, enc2 backward 306 -> 246 us, the
+        // twelve launches 9337 -> 9206 us, bench 182.6 k -> 184.5 k patches/s): default on, ALQ_NO_ALT16=1 switches it off.
         auto alt = std::make_shared<Igemm4Plan>();
         if (igemm4_build_plan(g, max_batch, alt.get(), 2) == ALQ_OK && alt->ok && alt->xw > 0 && alt->a.PT == a.PT &&
             alt->a.tpg == a.tpg && alt->a.rows == a.rows && alt->a.pair == a.pair && alt->NTW == NTW && alt->fic == plan->fic &&

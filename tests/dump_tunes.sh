@@ -4,6 +4,7 @@ cd "$(dirname "${BASH_SOURCE[0]}")/.."
 mkdir -p gpurun_out
 run() { ALQ_DUMP_ARGS=1 python bench.py --pool 4000 --steps 1 --warmup 0 --no-cpu-baseline --netb-pool 0 > /dev/null 2> "gpurun_out/tunedump_$1.err"; grep -c G4ARGS "gpurun_out/tunedump_$1.err"; }
 run default
-ALQ_ALT16=1 run alt16
+ALQ_NO_ALT16=1 run noalt16
+ALQ_NO_FLIPFIX=1 run noflip
 ALQ_NO_BOUND16=1 run nobound16
 ALQ_NO_F16X2=1 run nof16

@@ -1,6 +1,6 @@
 export TMPDIR=/tmp
 for v in alt noalt; do
-  if [ $v = alt ]; then export ALQ_ALT16=1; else unset ALQ_ALT16; fi     # the conflict-free twin is opt-in (igemm4.hip)
+  if [ $v = noalt ]; then export ALQ_NO_ALT16=1; else unset ALQ_NO_ALT16; fi     # the conflict-free twin is on by default (igemm4.hip)
   ALQ_BENCH_NO_EVENTS=1 rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CU_CYCLES -d gpurun_out/lds_$v -o lds --output-format csv -- python3 bench.py --pool 4000 --steps 1 --warmup 0 --no-cpu-baseline --netb-pool 0 > /dev/null 2>&1
 done
 python3 - <<'PY'

@@ -50,8 +50,8 @@ def main():
     ap.add_argument('--pool-global', type=int, default=0, help='strong scaling: one pool of this many patches over all GPUs')
     ap.add_argument('--netb-pool', type=int, default=16384, help='patches of the NET-B side measurement at N = 1 (0 = skip)')
     ap.add_argument('--batch', type=int, default=2000,
-                    help='patches per device pass (per-launch fixed costs ~0.37 ms per pass amortise with the batch; the unsigned '
-                         '32-bit tensor offsets of the GEMM engine cap it at 2047 for 32^3 NET-C)')
+                    help='patches per device pass (per-launch fixed costs ~0.37 ms per pass amortise with the batch; the library '
+                         'clamps it to what the GEMM engine\'s unsigned 32-bit tensor offsets address: 2047 for 32^3 NET-C)')
     ap.add_argument('--topB', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', choices=('nccl', 'gloo'),
@@ -101,6 +101,7 @@ def main():
     pars = netspec.he_init(ld, in_shape, seed=14, skips=sk)
     model = device.DeviceModel(sess, ld, in_shape, sk, max_batch=args.batch)
     model.set_weights(pars)
+    args.batch = model.max_batch          # what the library granted (alq_model_max_batch)
 
     strong = args.pool_global > 0
     n_global = args.pool_global if strong else args.pool * ws
@@ -198,7 +199,7 @@ def main():
                                    ('configs[2]: Fisher scoring, NET-C patch-wise 3-D U-Net (fc head), '
                                     '%d synthetic 32^3 2-class patches per GPU, random-init weights seed 14' % n_local),
                        'outputs_per_patch': 'p1, |p1-.5| (top-B keys), H, g0[8], g1[8], A[8x8], tr A stored; sum A over the pool',
-                       'pool_global': n_global, 'pool_per_gpu': n_local, 'batch': args.batch, 'topB': args.topB,
+                       'pool_global': n_global, 'pool_per_gpu': n_local, 'batch': model.max_batch, 'topB': args.topB,
                        'parallelism': 'pool sharded over %d GPU(s), top-B merge (all-gather) + 8x8 Fisher all-reduce: %s' % (ws, comm)},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic, 'traffic_note': traffic_note,

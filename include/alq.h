@@ -67,6 +67,10 @@ int alq_ctx_synchronize(alq_ctx *ctx);
 int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers,
                      const int32_t in_dims[4], int max_batch, alq_model **out);
 int alq_model_destroy(alq_model *m);
+/* Patches per device pass the model's workspace holds: min(max_batch asked for, what the engines' unsigned 32-bit tensor
+ * offsets allow - every allocation below 2^30 floats; NET-C at 32^3: 2047).  A larger batch is walked in passes of this
+ * size by the host (the reference feeds `ntb` patches per sess.run, PW_NN.py:447-451: the split never changes a result). */
+int alq_model_max_batch(const alq_model *m);
 /* Number of parameterised layers L ( = len(grad_posts['1'])/2, PW_NNAL.py:751 ).             */
 int alq_model_num_param_layers(const alq_model *m);
 /* W/b element counts of parameterised layer t (creation order), i.e. prod(W.shape), len(b).  */

@@ -32,6 +32,7 @@ _SIGNATURES = {
     'alq_model_create': (C.c_int, [_P, C.POINTER(LayerT), C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(_P)]),
     'alq_model_destroy': (C.c_int, [_P]),
     'alq_model_num_param_layers': (C.c_int, [_P]),
+    'alq_model_max_batch': (C.c_int, [_P]),
     'alq_model_param_sizes': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'alq_model_layer_out_elems': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
     'alq_model_set_weights': (C.c_int, [_P, C.c_int, _P, _P]),

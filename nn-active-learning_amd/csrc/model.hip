@@ -126,6 +126,7 @@ struct alq_model {
     int knobs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int no_f16x2 = 0;
     int no_xcd_order = 0;
+    int requested_batch = 0;      // what alq_model_create was asked for (max_batch may be lower: 32-bit tensor offsets)
     int no_bound16 = 0;           // ALQ_NO_BOUND16 at creation: backward launches take their fp16x2 scale from measured per-patch maxima only
     int no_fixed = 0;             // ALQ_NO_FIXED at creation: runtime-constant igemm4 instantiations only
     int no_presplit = 0;           // ALQ_NO_PRESPLIT (A/B): split the fc head's weight-difference vector in the staging part again
@@ -350,7 +351,6 @@ static void enum_taps(const int k[3], std::vector<int> *tz, std::vector<int> *ty
 }
 
 static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
-    const int NB = m->max_batch;
     m->layers.resize(n_layers);
     // ---- pass 1: shapes ------------------------------------------------------------------
     struct Shp { int D, H, W, C; };
@@ -435,6 +435,25 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
                 "the scored path needs an fc head (get_gradients, NN_extended.py:1025)");
     m->nclass = outs[n_layers - 1].C;
     ALQ_REQUIRE(m->nclass >= 2 && m->nclass <= 64, ALQ_EUNSUPPORTED, "%d classes unsupported", m->nclass);
+    {   // The GEMM engines address a tensor with unsigned 32-bit BYTE offsets from its base, and the two halves of a split
+        // concat are one allocation: the workspace batch is the largest one every allocation stays below 2^30 floats with
+        // (NET-C at 32^3: 2047 patches).  A caller that asks for more gets this many per device pass - alq_model_max_batch
+        // reports it and the host walks a larger batch in passes (per-patch results do not depend on the split) - instead
+        // of an error at the first launch.
+        long long worst = m->epp;                                           // floats per patch of the largest allocation
+        for (int i = 0; i < n_layers; ++i) {
+            long long e = (long long)outs[i].D * outs[i].H * outs[i].W * outs[i].C;
+            if (src_of[i] >= 0) {                                           // consumer of a concat: source + direct producer share one
+                const Shp &sh = outs[src_of[i]];
+                e = std::max(e, (long long)sh.D * sh.H * sh.W * (outs[src_of[i]].C + outs[i - 1].C));
+            }
+            worst = std::max(worst, e);
+        }
+        const long long limit = std::max(1LL, ((1LL << 30) - 64) / std::max(worst, 1LL));
+        m->requested_batch = m->max_batch;
+        if (m->max_batch > limit) m->max_batch = (int)limit;
+    }
+    const int NB = m->max_batch;
     ALQ_REQUIRE(m->L <= 16, ALQ_EUNSUPPORTED, "%d parameterised layers > 16", m->L);
 
     // ---- pass 2: buffers (concat = two producers writing channel slices of one buffer) ----
@@ -1439,6 +1458,7 @@ int alq_model_destroy(alq_model *m) {
 }
 
 int alq_model_num_param_layers(const alq_model *m) { return m ? m->L : ALQ_EINVAL; }
+int alq_model_max_batch(const alq_model *m) { return m ? m->max_batch : ALQ_EINVAL; }
 
 int alq_model_param_sizes(const alq_model *m, int t, int64_t *w_elems, int64_t *b_elems) {
     ALQ_REQUIRE(m != nullptr, ALQ_EINVAL, "null model");

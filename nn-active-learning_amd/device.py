@@ -343,6 +343,7 @@ class DeviceModel(object):
         cd = (C.c_int32 * 4)(*dims)
         check(self.lib.alq_model_create(sess.ctx, arr, len(self.layers), cd, self.max_batch, C.byref(self._m)))
         _track(self)
+        self.max_batch = int(self.lib.alq_model_max_batch(self._m))      # may be below the request: 32-bit tensor offsets (alq.h)
         self.L = self.lib.alq_model_num_param_layers(self._m)
         self.nclass = self.layers[-1]['cout']
         self.elems_per_patch = int(np.prod(self.in_shape))

@@ -898,7 +898,8 @@ def test_sharded_loop_world1_under_nccl(sess):
 def test_batches_beyond_two_gigabytes_per_tensor(sess):
     """The GEMM engine addresses tensors with UNSIGNED 32-bit byte offsets: at 1,500 patches of NET-C 32^3 the split
     concat of the last conv spans 3.1 GB (past the signed range) - every score must equal the 300-patch-batch run bit for
-    bit, and a batch that would pass 4 GB is refused with an error, not wrapped."""
+    bit; a model asked for a larger batch than the offsets allow gets the largest addressable workspace (alq_model_max_batch)
+    and the host walks the batch in passes."""
     import ctypes as C
     from nnal_amd._lib import check, AlqError
     torch = sess.torch
@@ -916,11 +917,16 @@ def test_batches_beyond_two_gigabytes_per_tensor(sess):
     assert torch.equal(pb, ps)
     big.close()
     small.close()
-    huge, _, _, _, _ = _netc_model(sess, 2100)
-    xh = sess.empty((2100, 32 ** 3), torch.float32)
-    with pytest.raises(AlqError):
-        huge.fisher_device(xh, 2100, None, 1e-3)
+    # a request beyond the addressing limit is served in passes of the largest workspace the engines can address
+    huge, _, _, _, _ = _netc_model(sess, 4000)
+    assert huge.max_batch == 2047 and huge.lib.alq_model_max_batch(huge._m) == 2047
     huge.close()
+    mid, _, _, _, _ = _netc_model(sess, 1000)
+    assert mid.max_batch == 1000
+    rm = mid.fisher_device(x, n, None, 1e-3)          # 1500 patches in passes of 1000 + 500
+    for k in ('p1', 'g0', 'g1', 'A', 'trace'):
+        assert torch.equal(rm[k], rs_[k]), k
+    mid.close()
 
 
 def test_constant_folded_instantiations_are_bit_identical(sess):

@@ -84,7 +84,7 @@ def build(force=False):
     global _lib
     if os.path.exists(LIB_PATH) and not force:
         srcs = [os.path.join(_HERE, 'csrc', f) for f in os.listdir(os.path.join(_HERE, 'csrc'))
-                if f.endswith(('.hip', '.h'))] + [os.path.join(os.path.dirname(_HERE), 'include', 'alq.h')]
+                if f.endswith(('.hip', '.h', '.inc'))] + [os.path.join(os.path.dirname(_HERE), 'include', 'alq.h')]
         if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
             return LIB_PATH
     subprocess.check_call(['bash', BUILD_SCRIPT])

@@ -48,6 +48,9 @@ struct View {
     // of the same row stride cs at p + delta; split = 0: one strided tensor
     int split = 0;
     long long delta = 0;
+    // sign field of the tensor (Fisher pass): one byte per 4 consecutive channels, bit k of the low nibble = (value k > 0), at
+    // byte (float offset from p) / 4 - what a backward launch needs of a ReLU'd activation (16 x fewer bytes than the floats)
+    unsigned char *sg = nullptr;
     int64_t vox() const { return (int64_t)D * H * W; }
     int64_t elems() const { return vox() * C; }
 };
@@ -217,6 +220,10 @@ struct Igemm2Fuse {
     int store_from = 0;  // columns below this are masked and summed but not stored (igemm4 only)
     int mask_split = 0;  // igemm4 only: the mask source is a split concat (see View): columns >= mask_split at mask + mask_delta
     long long mask_delta = 0;
+    // igemm4 only: the sign field of the mask tensor (View::sg of the view `mask` points into): read instead of the floats.
+    // sign_out: the sign field of the launch's OUTPUT view, written by the epilogue of a forward launch (after its ReLU)
+    const unsigned char *mask_bits = nullptr;
+    unsigned char *sign_out = nullptr;
     // igemm4 only: the GEMM input is not a stored tensor but in[n, j] = [bit j of patch n] * in_vec[j]
     const unsigned *in_bits = nullptr;
     const float *in_vec = nullptr;
@@ -330,6 +337,10 @@ struct Igemm4Args {
     int flip_cap;
     unsigned *flip_cnt;
     unsigned *flip_list;
+    // sign fields (View::sg): the ReLU-grad mask as one byte per 4 channels instead of the fp32 activations (mask_bits set: `mask`
+    // is not read), and the sign field of the output written after the ReLU of a forward launch (sign_out)
+    const unsigned char *mask_bits;
+    unsigned char *sign_out;
 };
 
 struct G4Geom {
@@ -409,7 +420,7 @@ int direct_launch(alq_ctx *ctx, const DirectPlan &dp, const View &in, const View
 // first conv (1 -> 8 channels, 3x3x3) fused with the 2x2x2 max-pool behind it: both outputs, arg-max, both sums
 int direct_conv_pool_launch(alq_ctx *ctx, const float *d_W, const View &in, const View &out, const View &pout,
                             const float *bias, int relu, uint8_t *argmax, float *osum, float *posum, int N,
-                            double flops_per_patch, unsigned *amax = nullptr);
+                            double flops_per_patch, unsigned *amax = nullptr, unsigned char *sg = nullptr);
 
 // ------------------------------------------------------------------ wide fc layers (fcgemm.hip)
 struct FcGemmPlan {
@@ -446,7 +457,7 @@ int k_pool_bwd_first(alq_ctx *, const View &dout, const View &pool_out, const ui
                      int ID, int IH, int IW, int N, float *dsum, int accumulate);
 int k_pool_bwd(alq_ctx *, const View &dout, const View &din, const uint8_t *argmax,
                const int w[3], const int lo[3], int N, int accumulate, const View *mask_act = nullptr,
-               float *dsum = nullptr, bool *fused = nullptr, int store_din = 1);
+               float *dsum = nullptr, bool *fused = nullptr, int store_din = 1, int use_signs = 0);   // use_signs: mask_act->sg holds the signs
 int k_chansum(alq_ctx *, const View &in, float *field, int N);
 int k_mask_chansum(alq_ctx *, const View &dact, const View *act_or_null, float *field, int N);
 int boxdot_slabs(long long vox);

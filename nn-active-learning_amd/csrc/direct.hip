@@ -107,6 +107,7 @@ struct DirectPoolArgs {
     unsigned *argmax;          // [N * pooled voxels][2] packed window indices (4 channels per word)
     float *osum, *posum;       // channel sums of the conv output / pooled output (or null)
     unsigned *amax;            // [N] max |conv output| per patch as float bits (atomic max; zeroed by the caller) or null
+    unsigned char *sg;         // sign field of the conv output (View::sg: one byte per 4 channels, bit k = (value k > 0)) or null
     const float *W;            // [27][8]
     const float *bias;
     int out_cs, out_c0, po_cs, po_c0;
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(256, 4) void direct_conv_pool_kernel(const DirectPo
     float amx = 0.f;
     char *obase = reinterpret_cast<char *>(a.out + pv0 * a.out_cs + a.out_c0);
     char *sbase = a.osum ? reinterpret_cast<char *>(a.osum + pv0) : nullptr;
+    unsigned char *gbase = a.sg ? a.sg + ((pv0 * a.out_cs + a.out_c0) >> 2) : nullptr;       // out_cs, out_c0 multiples of 4 (launch)
     const bool full = z0 + 2 * TWZ <= a.D && y0 + 2 * TWY <= a.H && x0 + 2 * TWX <= a.Wd;      // uniform
     const int vox00 = (((z0 + 2 * wz) * a.H + y0 + 2 * wy) * a.Wd + x0 + 2 * wx);      // first voxel of the window, inside the patch
     const int sw = (wx >> 1) & 3;               // chunk swizzle: position = chunk ^ ((chunk >> 3) & 3), chunk >> 2 == wx
@@ -293,6 +295,12 @@ __global__ __launch_bounds__(256, 4) void direct_conv_pool_kernel(const DirectPo
                 *reinterpret_cast<f32x4 *>(orow + (((q0 + 1) ^ sw) << 2)) = f32x4{o[4], o[5], o[6], o[7]};
                 const bool vin = full || (z < a.D && y0 + ly < a.H && x0 + lx < a.Wd);
                 if (vin) {
+                    if (gbase) {      // 8 channels = two sign bytes, written as one 16-bit store
+                        const unsigned lo4 = (o[0] > 0.f ? 1u : 0u) | (o[1] > 0.f ? 2u : 0u) | (o[2] > 0.f ? 4u : 0u) | (o[3] > 0.f ? 8u : 0u);
+                        const unsigned hi4 = (o[4] > 0.f ? 1u : 0u) | (o[5] > 0.f ? 2u : 0u) | (o[6] > 0.f ? 4u : 0u) | (o[7] > 0.f ? 8u : 0u);
+                        *reinterpret_cast<unsigned short *>(gbase + (((unsigned)(vox00 + ((vz * a.H + vy) * a.Wd + vx)) * (unsigned)a.out_cs) >> 2)) =
+                            (unsigned short)(lo4 | (hi4 << 8));
+                    }
                     if (sbase)
                         *reinterpret_cast<float *>(sbase + (unsigned)(vox00 + ((vz * a.H + vy) * a.Wd + vx)) * 4u) =
                             ((o[0] + o[1]) + (o[2] + o[3])) + ((o[4] + o[5]) + (o[6] + o[7]));
@@ -355,14 +363,14 @@ __global__ __launch_bounds__(256, 4) void direct_conv_pool_kernel(const DirectPo
 // eligibility is checked by the caller (model.hip): 3x3x3 SAME conv of one channel into 8, 2x2x2 pool, even dims
 int direct_conv_pool_launch(alq_ctx *ctx, const float *d_W, const View &in, const View &out, const View &pout,
                             const float *bias, int relu, uint8_t *argmax, float *osum, float *posum, int N,
-                            double flops_per_patch, unsigned *amax) {
+                            double flops_per_patch, unsigned *amax, unsigned char *sg) {
     ALQ_REQUIRE(in.C == 1 && in.cs == 1 && in.c0 == 0 && out.C == 8 && pout.C == 8 && d_W, ALQ_EINVAL, "direct conv+pool: bad views");
     ALQ_REQUIRE(((out.cs | out.c0 | pout.cs | pout.c0) & 3) == 0 && in.D % 2 == 0 && in.H % 2 == 0 && in.W % 2 == 0 &&
                     pout.D * 2 == in.D && pout.H * 2 == in.H && pout.W * 2 == in.W,
                 ALQ_EUNSUPPORTED, "direct conv+pool: unsupported geometry");
     DirectPoolArgs a;
     a.in = in.p; a.out = out.p; a.pout = pout.p; a.argmax = reinterpret_cast<unsigned *>(argmax);
-    a.osum = osum; a.posum = posum; a.W = d_W; a.bias = bias; a.amax = amax;
+    a.osum = osum; a.posum = posum; a.W = d_W; a.bias = bias; a.amax = amax; a.sg = sg;
     a.out_cs = out.cs; a.out_c0 = out.c0; a.po_cs = pout.cs; a.po_c0 = pout.c0;
     a.D = in.D; a.H = in.H; a.Wd = in.W; a.N = N; a.relu = relu;
     a.tilesZ = (pout.D + 3) / 4; a.tilesY = (pout.H + 7) / 8; a.tilesX = (pout.W + 7) / 8;

@@ -126,7 +126,7 @@ __device__ inline float g4_dot4(const f32x4 &a, const f32x4 &b) {
     X(plane_bytes) X(in_pstride) X(out_pstride) X(relu) X(accumulate) X(pair) X(store_from) X(cls_ok) X(in_split_ch) X(out_split) \
     X(mask_split) X(tt_ints) X(pd_off) X(td_off) X(wbytes) X(abytes) X(dbg_repeat) X(bits_pstride) X(fc_F) X(amax_from) X(wp) \
     X(src_presplit) X(xcd_order) X(zreuse)
-#define G4_FIXED_PTRS(X) X(bias) X(mask) X(osumA) X(osumB) X(out_amax) X(in_amax) X(in_amax2) X(fc_bits) X(dbg) X(flip_list)
+#define G4_FIXED_PTRS(X) X(bias) X(mask) X(osumA) X(osumB) X(out_amax) X(in_amax) X(in_amax2) X(fc_bits) X(dbg) X(flip_list) X(mask_bits) X(sign_out)
 
 // Launch-constant traits of a kernel instantiation.  G4Runtime (the default): every constant is read from the argument
 // block.  A generated G4F_<n> (igemm4_fixed.inc, tests/gen_igemm4_fixed.py) states the constants of ONE launch of a known
@@ -462,9 +462,11 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             for (int nt = 0; nt < NTW; ++nt) {
                 const int c = nt * 16 + cl;
                 Mk[ms][nt] = f32x4{1.f, 1.f, 1.f, 1.f};
+                if (AHAS(mask_bits)) Mk[ms][nt].x = __builtin_bit_cast(float, 15u);      // the sign nibble travels in .x
                 if (live && c < AF(Co) && c >= AF(mask_from) && c < AF(mask_to)) {
                     const int mo = (q_out + evox[ms]) * AF(mask_cs) + AF(mask_c0) + mcoff[nt];
-                    Mk[ms][nt] = *reinterpret_cast<const f32x4 *>(maskb + ((unsigned)mo * 4u));
+                    if (AHAS(mask_bits)) Mk[ms][nt].x = __builtin_bit_cast(float, (unsigned)a.mask_bits[(unsigned)mo >> 2]);
+                    else Mk[ms][nt] = *reinterpret_cast<const f32x4 *>(maskb + ((unsigned)mo * 4u));
                 }
             }
         }
@@ -554,16 +556,18 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
         // was 55 % of the two-column-tile backward launches - timing of a build without it).
         f32x4 Mq[(MASK_PF || FCF) ? 1 : 4][NTW];
         if constexpr (!MASK_PF && !FCF) {
-            if (AHAS(mask)) {
+            if (AHAS(mask) || AHAS(mask_bits)) {
 #pragma unroll
                 for (int ms = m0; ms < m1; ++ms)
 #pragma unroll
                     for (int nt = 0; nt < NTW; ++nt) {
                         const int c = nt * 16 + cl;
                         Mq[ms][nt] = f32x4{1.f, 1.f, 1.f, 1.f};
+                        if (AHAS(mask_bits)) Mq[ms][nt].x = __builtin_bit_cast(float, 15u);
                         if (livem[ms] && c < AF(Co) && c >= AF(mask_from) && c < AF(mask_to)) {
                             const int mo = (q_out + evox[ms]) * AF(mask_cs) + AF(mask_c0) + mcoff[nt];
-                            Mq[ms][nt] = *reinterpret_cast<const f32x4 *>(maskb + ((unsigned)mo * 4u));
+                            if (AHAS(mask_bits)) Mq[ms][nt].x = __builtin_bit_cast(float, (unsigned)a.mask_bits[(unsigned)mo >> 2]);
+                            else Mq[ms][nt] = *reinterpret_cast<const f32x4 *>(maskb + ((unsigned)mo * 4u));
                         }
                     }
             }
@@ -610,13 +614,22 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                         val.z = __builtin_amdgcn_fmed3f(val.z, 0.f, __builtin_inff());
                         val.w = __builtin_amdgcn_fmed3f(val.w, 0.f, __builtin_inff());
                     }
-                    if (!FCF && AHAS(mask)) {
+                    if (!FCF && (AHAS(mask) || AHAS(mask_bits))) {
                         f32x4 mk;
                         if constexpr (MASK_PF) mk = Mk[ms][nt];
                         else mk = Mq[ms][nt];
-                        val.x = mk.x > 0.f ? val.x : 0.f; val.y = mk.y > 0.f ? val.y : 0.f;
-                        val.z = mk.z > 0.f ? val.z : 0.f; val.w = mk.w > 0.f ? val.w : 0.f;
+                        if (AHAS(mask_bits)) {
+                            const unsigned nb = __builtin_bit_cast(unsigned, mk.x);
+                            val.x = (nb & 1u) ? val.x : 0.f; val.y = (nb & 2u) ? val.y : 0.f;
+                            val.z = (nb & 4u) ? val.z : 0.f; val.w = (nb & 8u) ? val.w : 0.f;
+                        } else {
+                            val.x = mk.x > 0.f ? val.x : 0.f; val.y = mk.y > 0.f ? val.y : 0.f;
+                            val.z = mk.z > 0.f ? val.z : 0.f; val.w = mk.w > 0.f ? val.w : 0.f;
+                        }
                     }
+                    if (!FCF && AHAS(sign_out))       // the output's sign field (forward launch: after the ReLU)
+                        a.sign_out[(unsigned)(obase_e + eoff[ms] + coff[nt]) >> 2] =
+                            (unsigned char)((val.x > 0.f ? 1u : 0u) | (val.y > 0.f ? 2u : 0u) | (val.z > 0.f ? 4u : 0u) | (val.w > 0.f ? 8u : 0u));
                     if (!FCF && c >= AF(store_from)) {
                         __builtin_nontemporal_store(val, dst);
                         if (AHAS(out_amax) && c >= AF(amax_from))
@@ -1047,7 +1060,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
             if constexpr (!MULTI) {
                 const i32x4 pdA = ld4(AF(pd_off) + (c_pdb + b_ph) * 8), pdB = ld4(AF(pd_off) + (c_pdb + b_ph) * 8 + 4);
                 const int pd[5] = {0, 0, __builtin_amdgcn_readfirstlane(pdA.z), pdA.w, pdB.x};
-                if constexpr (MASK_PF) { if (!FCF && b_ph == AF(nph) - 1 && AHAS(mask)) load_mask(c_out, c_full, c_l, c_g); }
+                if constexpr (MASK_PF) { if (!FCF && b_ph == AF(nph) - 1 && (AHAS(mask) || AHAS(mask_bits))) load_mask(c_out, c_full, c_l, c_g); }
                 // the contracting side has the slack (phase stamps: with the prefetch in the staging part that part was
                 // the longer one and the other half waited for it at the barrier)
                 if constexpr (FCF) { if (b_ph == AF(nph) - 1) fcw_prefetch(c_out, c_full, c_l, c_g); }
@@ -1972,6 +1985,12 @@ static int igemm4_launch_impl(alq_ctx *ctx, const Igemm4Plan &plan, const View &
         ALQ_REQUIRE(!a.pair || (!fuse->osumB && fuse->split == 0), ALQ_EUNSUPPORTED,
                     "igemm4: the pair form sums all 8 channels of a voxel");
         a.mask = fuse->mask; a.mask_cs = fuse->mask_cs; a.mask_c0 = fuse->mask_c0; a.mask_from = fuse->mask_from;
+        // the sign field stands in for the floats (same index space / 4; the slices are 4-channel aligned, checked above)
+        a.mask_bits = fuse->mask ? fuse->mask_bits : nullptr;
+        if (a.mask_bits) a.mask = nullptr;
+        a.sign_out = fuse->sign_out;
+        ALQ_REQUIRE(!a.sign_out || (!accumulate && !fuse->fc_W && fuse->store_from == 0 && !out.split), ALQ_EUNSUPPORTED,
+                    "igemm4: a sign field is written for a plainly stored output only");
         a.mask_to = fuse->mask_to;
         a.mask_split = fuse->mask_split; a.mask_delta = (int)fuse->mask_delta;
         ALQ_REQUIRE(!a.mask_split || a.mask_from == 0, ALQ_EUNSUPPORTED, "igemm4: a split mask covers all columns");

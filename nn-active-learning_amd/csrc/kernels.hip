@@ -139,7 +139,7 @@ __global__ void pool_bwd_vec_kernel(const float *dout, int do_cs, int do_c0, int
                                     float *din, int di_cs, int di_c0, int ID, int IH, int IW,
                                     const uint8_t *argmax, int wz, int wy, int wx, int lz, int ly, int lx,
                                     int accumulate, long long total, const float *act, int a_cs, int a_c0,
-                                    float *dsum) {
+                                    float *dsum, const unsigned char *asg) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < ((total + 63) & ~63LL);
          i += (long long)gridDim.x * blockDim.x) {
         if (i >= total) {      // keep whole waves in the shuffles below
@@ -172,7 +172,11 @@ __global__ void pool_bwd_vec_kernel(const float *dout, int do_cs, int do_c0, int
         f32x4 *dst = reinterpret_cast<f32x4 *>(din + ivox * di_cs + di_c0 + c4 * 4);
         if (accumulate) g += *dst;
         if constexpr (G > 0) {
-            if (act) {
+            if (asg) {        // the activation's sign field (View::sg): one byte instead of 16
+                const unsigned nb = asg[(ivox * a_cs + a_c0 + c4 * 4) >> 2];
+                g.x = (nb & 1u) ? g.x : 0.f; g.y = (nb & 2u) ? g.y : 0.f;
+                g.z = (nb & 4u) ? g.z : 0.f; g.w = (nb & 8u) ? g.w : 0.f;
+            } else if (act) {
                 const f32x4 m = *reinterpret_cast<const f32x4 *>(act + ivox * a_cs + a_c0 + c4 * 4);
                 g.x = m.x > 0.f ? g.x : 0.f; g.y = m.y > 0.f ? g.y : 0.f;
                 g.z = m.z > 0.f ? g.z : 0.f; g.w = m.w > 0.f ? g.w : 0.f;
@@ -380,7 +384,7 @@ int k_pool_bwd_first(alq_ctx *ctx, const View &dout, const View &pool_out, const
 
 int k_pool_bwd(alq_ctx *ctx, const View &dout, const View &din, const uint8_t *argmax, const int w[3],
                const int lo[3], int N, int accumulate, const View *mask_act, float *dsum, bool *fused,
-               int store_din) {
+               int store_din, int use_signs) {
     const long long total = (long long)N * din.vox() * din.C;
     ProfScope ps(ctx, PROF_ELEMWISE, 0);
     if (fused) *fused = false;
@@ -409,11 +413,12 @@ int k_pool_bwd(alq_ctx *ctx, const View &dout, const View &din, const uint8_t *a
         const float *ap = (can && mask_act) ? mask_act->p : nullptr;
         const int acs = mask_act ? mask_act->cs : 0, ac0 = mask_act ? mask_act->c0 : 0;
         float *ds = can ? dsum : nullptr;
+        const unsigned char *asg = (ap && use_signs) ? mask_act->sg : nullptr;
 #define ALQ_PB(GV)                                                                                              \
     hipLaunchKernelGGL(pool_bwd_vec_kernel<GV>, dim3(grid_for(total / 4)), dim3(256), 0, ctx->stream, dout.p,   \
                        dout.cs, dout.c0, dout.C / 4, dout.D, dout.H, dout.W, din.p, din.cs, din.c0, din.D,      \
                        din.H, din.W, argmax, w[0], w[1], w[2], lo[0], lo[1], lo[2], accumulate, total / 4, ap,   \
-                       acs, ac0, ds)
+                       acs, ac0, ds, asg)
         if (!can) ALQ_PB(0);
         else if (C4 == 1) ALQ_PB(1);
         else if (C4 == 2) ALQ_PB(2);

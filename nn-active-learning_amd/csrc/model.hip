@@ -59,6 +59,7 @@ struct Layer {
     float *asum = nullptr, *dsum = nullptr;
     float *osum = nullptr;     // channel sums of this layer's OUTPUT (spatial layers): next layers' asum
     bool delta_ready = false;  // backward: the cotangent of our output is already masked and dsum is filled
+    bool signs_ready = false;  // Fisher pass: the forward launch wrote the sign field of our output (View::sg)
     bool dsum_partial = false; // backward, first layer: the skip destination has written its share of dsum
     float *fc_partials = nullptr;
     // fc head of a Fisher pass on top of a ReLU conv: its input cotangent is [input > 0] * fc_wv for every patch; the
@@ -130,6 +131,8 @@ struct alq_model {
     int no_bound16 = 0;           // ALQ_NO_BOUND16 at creation: backward launches take their fp16x2 scale from measured per-patch maxima only
     int no_fixed = 0;             // ALQ_NO_FIXED at creation: runtime-constant igemm4 instantiations only
     int no_presplit = 0;           // ALQ_NO_PRESPLIT (A/B): split the fc head's weight-difference vector in the staging part again
+    int no_signs = 0;              // ALQ_NO_SIGNS (A/B, bit-identity test): backward launches read ReLU masks from the fp32 activations
+    int no_signs0 = 0;             // ALQ_NO_SIGNS0 (A/B): no sign field from the first conv + pool kernel only
     int f16_fwd_mask = -1;         // ALQ_F16_FWD_MASK (diagnostics): forward fp16x2 consumers by layer bit, -1 = default rule
 
     template <typename T>
@@ -472,6 +475,8 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
         const size_t el = (size_t)NB * sh.D * sh.H * sh.W * (Cs + Cp);
         ALQ_TRY(m->dalloc(&buf, el));
         ALQ_TRY(m->dalloc(&dbuf, el));
+        unsigned char *sbuf = nullptr;      // sign field of the whole allocation (View::sg): float offset / 4
+        if (Cs % 4 == 0 && Cp % 4 == 0) ALQ_TRY(m->dalloc(&sbuf, el / 4));
         // Split concat: when the consumer's forward and backward contractions both run on the two-slot engine, the
         // two producers keep DENSE tensors (the halves of one allocation) and the consumer reads / writes them as
         // two channel groups.  Interleaved slices cost twice the cache lines per staged or stored row (32 of 64
@@ -501,6 +506,7 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
             dact[d - 1] = mkview(dbuf + half, sh, Cp, 0, Cp);
             catv[d] = mkview(buf, sh, Cs, 0, Cs + Cp);
             catv[d].split = Cs; catv[d].delta = half;
+            if (sbuf) { act[s].sg = sbuf; act[d - 1].sg = sbuf + half / 4; catv[d].sg = sbuf; }
             dcatv[d] = mkview(dbuf, sh, Cs, 0, Cs + Cp);
             dcatv[d].split = Cs; dcatv[d].delta = half;
             m->layers[s].out_is_skip_src = true;
@@ -512,6 +518,7 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
         dact[d - 1] = mkview(dbuf, sh, Cs + Cp, Cs, Cp);
         catv[d] = mkview(buf, sh, Cs + Cp, 0, Cs + Cp);
         dcatv[d] = mkview(dbuf, sh, Cs + Cp, 0, Cs + Cp);
+        if (sbuf) { act[s].sg = sbuf; act[d - 1].sg = sbuf; catv[d].sg = sbuf; }
         m->layers[s].out_is_skip_src = true;
     }
     for (int i = 0; i < n_layers; ++i) {
@@ -523,6 +530,7 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
         ALQ_TRY(m->dalloc(&dbuf, el));
         act[i] = mkview(buf, sh, sh.C, 0, sh.C);
         dact[i] = mkview(dbuf, sh, sh.C, 0, sh.C);
+        if (sh.C % 4 == 0 && specs[i].type != ALQ_FC && specs[i].type != ALQ_POOL && specs[i].relu) ALQ_TRY(m->dalloc(&act[i].sg, el / 4));
     }
     m->logits = act[n_layers - 1].p;
     m->dlogits = dact[n_layers - 1].p;
@@ -798,6 +806,12 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
         fz.in_amax = m->layers[j - 1].amax_fwd;
         if (m->layers[j].spec.skip_src >= 0) fz.in_amax2 = m->layers[m->layers[j].spec.skip_src].amax_fwd;
     };
+    for (Layer &l : m->layers) l.signs_ready = false;
+    // Sign fields (View::sg): in a Fisher pass a forward launch of the two-slot engine also writes one byte per 4 channels
+    // with the signs of its ReLU'd output; the backward launches read those instead of the fp32 activations (1/16 of the bytes)
+    auto v4_fwd = [&](const Gemm &g, const View &in, const View &out) {      // gemm_launch's choice for a forward launch with sums
+        return !g.pd.ok && g.p4.ok && ((!g_dbg_knobs[4] && !g_dbg_knobs[5]) || in.split != 0 || out.split != 0);
+    };
     for (int i = 0; i < nl; ++i) {
         Layer &ly = m->layers[i];
         ALQ_REQUIRE(ly.pidx < 0 || ly.weights_set, ALQ_EINVAL, "weights of parameterised layer %d not set", ly.pidx);
@@ -819,9 +833,13 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                 const alq_layer_t &sp = ly.spec;
                 if (use_dcp(i)) {
                     if (prod[i]) ALQ_HIP(hipMemsetAsync(ly.amax_fwd, 0, (size_t)N * sizeof(unsigned), ctx->stream));
+                    // (the sign field of the full-resolution output: what the last conv's backward launch reads as its ReLU mask)
+                    const bool sg_here = with_sums && !m->no_signs && !m->no_signs0 && sp.relu && ly.out.sg != nullptr;
                     ALQ_TRY(direct_conv_pool_launch(ctx, ly.fwd[0].pd.d_W, in, ly.out, nx->out, ly.d_bias, sp.relu, nx->argmax,
                                                     with_sums ? ly.osum : nullptr, with_sums ? nx->osum : nullptr, N,
-                                                    ly.fwd[0].pd.flops_per_patch, prod[i] ? ly.amax_fwd : nullptr));
+                                                    ly.fwd[0].pd.flops_per_patch, prod[i] ? ly.amax_fwd : nullptr,
+                                                    sg_here ? ly.out.sg : nullptr));
+                    ly.signs_ready = sg_here;
                     fused = true;
                     skip_next = true;
                     break;
@@ -857,7 +875,10 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                 }
                 if (fuse) take_amax(fz, i);
                 if (fuse && prod[i]) fz.out_amax = m->amax_tiles;
+                const bool sg_here = with_sums && fuse && !m->no_signs && ly.spec.relu && ly.out.sg && v4_fwd(ly.fwd[0], in, ly.out);
+                if (sg_here) fz.sign_out = ly.out.sg;
                 ALQ_TRY(gemm_launch(ctx, ly.fwd[0], in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM_FWD, fuse, &fused));
+                ly.signs_ready = sg_here;
                 if (fuse && prod[i]) ALQ_TRY(k_rowmax_u32(ctx, m->amax_tiles, ly.fwd[0].p4.a.tpg * 4, N, ly.amax_fwd));
                 break;
             }
@@ -866,7 +887,10 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                     const bool want_amax = fuse && prod[i];
                     if (fuse) take_amax(fz, i);
                     if (want_amax) fz.out_amax = m->amax_tiles;
+                    const bool sg_here = with_sums && fuse && !m->no_signs && ly.spec.relu && ly.out.sg;
+                    if (sg_here) fz.sign_out = ly.out.sg;
                     ALQ_TRY(igemm4_launch(ctx, ly.fwd_all, in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM3_FWD, fuse));
+                    ly.signs_ready = sg_here;
                     if (want_amax)
                         ALQ_TRY(k_rowmax_u32(ctx, m->amax_tiles, ly.fwd_all.a.tpg * (ly.fwd_all.multi ? ly.fwd_all.a.ngr : 1) * 4, N, ly.amax_fwd));
                     fused = fuse != nullptr;
@@ -1001,7 +1025,8 @@ static int run_backward_main(alq_model *m, const float *d_x, int N) {
             bool fused = false;
             ALQ_TRY(k_pool_bwd(ctx, ly.dout, ly.din, ly.argmax, ly.spec.k, ly.lo, N, prev_is_src ? 1 : 0,
                                (prev_param && prev->spec.relu) ? &prev->out : nullptr, prev_param ? prev->dsum : nullptr,
-                               &fused, /*store_din=*/!(prev_param && prev->pidx == 0)));   // layer 0 only needs the sums
+                               &fused, /*store_din=*/!(prev_param && prev->pidx == 0),      // layer 0 only needs the sums
+                               /*use_signs=*/(prev_param && prev->signs_ready) ? 1 : 0));
             if (prev_param && fused) prev->delta_ready = true;
             continue;
         }
@@ -1067,7 +1092,10 @@ static int run_backward_main(alq_model *m, const float *d_x, int N) {
             const Igemm2Fuse *fuse = nullptr;
             if (prev_param && !g_dbg_knobs[2]) {
                 const int Cs = ly.spec.skip_src >= 0 ? m->layers[ly.spec.skip_src].out.C : 0;   // concat: [src | prev]
-                if (prev->spec.relu) { fz.mask = prev->out.p; fz.mask_cs = prev->out.cs; fz.mask_c0 = prev->out.c0; fz.mask_from = Cs; }
+                if (prev->spec.relu) {
+                    fz.mask = prev->out.p; fz.mask_cs = prev->out.cs; fz.mask_c0 = prev->out.c0; fz.mask_from = Cs;
+                    if (prev->signs_ready) fz.mask_bits = prev->out.sg;
+                }
                 if (Cs > 0) { fz.split = Cs; fz.osumB = prev->dsum; } else { fz.osumA = prev->dsum; }
                 // the skip source is the first parameterised layer and sits in front of a pool: nothing needs its
                 // cotangent except the channel sums, so mask and sum its columns here and do not store them
@@ -1078,6 +1106,7 @@ static int run_backward_main(alq_model *m, const float *d_x, int N) {
                     const bool splitv = ly.in.split == Cs && sl.out.p == ly.in.p;
                     if (next_pool && (sliced || splitv) && (Cs & 3) == 0) {
                         fz.mask = sl.out.p; fz.mask_cs = sl.out.cs; fz.mask_c0 = sl.out.c0; fz.mask_from = 0;
+                        fz.mask_bits = (sl.signs_ready && (!prev->spec.relu || prev->signs_ready)) ? sl.out.sg : nullptr;
                         if (splitv) { fz.mask_split = Cs; fz.mask_delta = ly.in.delta; }
                         if (!prev->spec.relu) fz.mask_to = Cs;
                         fz.osumA = sl.dsum; fz.store_from = Cs;
@@ -1407,6 +1436,8 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
         m->no_bound16 = getenv("ALQ_NO_BOUND16") != nullptr;
         m->no_flipfix = getenv("ALQ_NO_FLIPFIX") != nullptr;
         m->no_presplit = getenv("ALQ_NO_PRESPLIT") != nullptr;
+        m->no_signs = getenv("ALQ_NO_SIGNS") != nullptr;
+        m->no_signs0 = getenv("ALQ_NO_SIGNS0") != nullptr;
         if (const char *f = getenv("ALQ_F16_FWD_MASK")) m->f16_fwd_mask = atoi(f);
         static const char *names[8] = {"ALQ_DEBUG_REPEAT", "ALQ_DEBUG_FLAGS", "ALQ_NO_BWD_FUSE", "ALQ_NO_FWD_FUSE", "ALQ_NO_V3", "ALQ_NO_V4",
                                        "ALQ_NO_POOL_FIRST", "ALQ_NO_CONV_POOL"};

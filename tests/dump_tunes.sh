@@ -8,3 +8,4 @@ ALQ_NO_ALT16=1 run noalt16
 ALQ_NO_FLIPFIX=1 run noflip
 ALQ_NO_BOUND16=1 run nobound16
 ALQ_NO_F16X2=1 run nof16
+ALQ_NO_SIGNS=1 run nosigns

@@ -958,6 +958,37 @@ def test_constant_folded_instantiations_are_bit_identical(sess):
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
 
 
+def test_sign_fields_are_bit_identical(sess):
+    """In a Fisher pass the forward launches of the two-slot engine also write the SIGN FIELD of their ReLU'd output (one byte
+    per 4 channels, View::sg) and the backward launches / the pool backward read their ReLU-grad masks from it instead of the
+    fp32 activations (1/16 of the bytes); ALQ_NO_SIGNS=1 at model creation keeps the fp32 reads.  Same decisions (value > 0),
+    so every output must agree bit for bit - NET-C at 32^3 (split concats, folded kernels) and at 16^3 (runtime kernels),
+    the 2-D analogue and NET-B's topology (other engines: nothing changes there) - full and ragged batches."""
+    torch = sess.torch
+    cases = [(netspec.net_c, (32, 32, 32, 1), 21, 8), (netspec.net_c, (16, 16, 16, 1), 13, 5), (netspec.net_c_2d, (16, 16, 1), 9, 4),
+             (lambda: (netspec.net_b_small(), []), (25, 25, 2), 9, 4)]
+    for mk, in_shape, n, mb in cases:
+        ld, sk = mk()
+        pars = netspec.he_init(ld, in_shape, seed=15, skips=sk, bias_std=0.05)
+        x = sess.to_device(np.random.RandomState(78).randn(n, int(np.prod(in_shape))).astype(np.float32), torch.float32)
+
+        def run(env):
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                m = _device_model(sess, ld, in_shape, sk, pars, max_batch=mb)
+            finally:
+                for k, v in old.items():
+                    os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+            r = m.fisher_device(x, n, None, 1e-3)
+            out = {k: r[k].cpu().numpy() for k in ('p1', 'g0', 'g1', 'A', 'trace', 'Asum')}
+            m.close()
+            return out
+        a, b = run({}), run({'ALQ_NO_SIGNS': '1'})
+        for k in a:
+            np.testing.assert_array_equal(a[k], b[k], err_msg='%s %s' % (in_shape, k))
+
+
 def test_default_engines_against_fp64_flip_safe_head(sess):
     """NET-C at 32^3, the bench's weights and its first 16 synthetic patches, default engines (fp16x2 in the fused-head
     conv's forward and in every backward launch, bf16x3 elsewhere) against an fp64 evaluation of the network.  The head

@@ -420,7 +420,7 @@ int direct_launch(alq_ctx *ctx, const DirectPlan &dp, const View &in, const View
 // first conv (1 -> 8 channels, 3x3x3) fused with the 2x2x2 max-pool behind it: both outputs, arg-max, both sums
 int direct_conv_pool_launch(alq_ctx *ctx, const float *d_W, const View &in, const View &out, const View &pout,
                             const float *bias, int relu, uint8_t *argmax, float *osum, float *posum, int N,
-                            double flops_per_patch, unsigned *amax = nullptr, unsigned char *sg = nullptr);
+                            double flops_per_patch, unsigned *amax = nullptr, unsigned char *sg = nullptr, unsigned char *psg = nullptr);
 
 // ------------------------------------------------------------------ wide fc layers (fcgemm.hip)
 struct FcGemmPlan {
@@ -454,7 +454,7 @@ int k_pool_fwd(alq_ctx *, const View &in, const View &out, uint8_t *argmax, cons
 // dout (masked by pooled activation > 0, i.e. the ReLU of the arg-max element) into the 2x2(x2) window sums;
 // accumulate = the skip destination has already written its part of the field.
 int k_pool_bwd_first(alq_ctx *, const View &dout, const View &pool_out, const uint8_t *argmax, const int w[3],
-                     int ID, int IH, int IW, int N, float *dsum, int accumulate);
+                     int ID, int IH, int IW, int N, float *dsum, int accumulate, int use_signs = 0);   // use_signs: pool_out.sg holds the signs
 int k_pool_bwd(alq_ctx *, const View &dout, const View &din, const uint8_t *argmax,
                const int w[3], const int lo[3], int N, int accumulate, const View *mask_act = nullptr,
                float *dsum = nullptr, bool *fused = nullptr, int store_din = 1, int use_signs = 0);   // use_signs: mask_act->sg holds the signs

@@ -108,6 +108,7 @@ struct DirectPoolArgs {
     float *osum, *posum;       // channel sums of the conv output / pooled output (or null)
     unsigned *amax;            // [N] max |conv output| per patch as float bits (atomic max; zeroed by the caller) or null
     unsigned char *sg;         // sign field of the conv output (View::sg: one byte per 4 channels, bit k = (value k > 0)) or null
+    unsigned char *psg;        // sign field of the pooled output or null
     const float *W;            // [27][8]
     const float *bias;
     int out_cs, out_c0, po_cs, po_c0;
@@ -345,6 +346,11 @@ __global__ __launch_bounds__(256, 4) void direct_conv_pool_kernel(const DirectPo
         *reinterpret_cast<f32x4 *>(prow) = f32x4{best[0], best[1], best[2], best[3]};
         *reinterpret_cast<f32x4 *>(prow + 16) = f32x4{best[4], best[5], best[6], best[7]};
         *reinterpret_cast<uint2 *>(abase + pvox * 8u) = uint2{bidx0, bidx1};
+        if (a.psg) {
+            const unsigned lo4 = (best[0] > 0.f ? 1u : 0u) | (best[1] > 0.f ? 2u : 0u) | (best[2] > 0.f ? 4u : 0u) | (best[3] > 0.f ? 8u : 0u);
+            const unsigned hi4 = (best[4] > 0.f ? 1u : 0u) | (best[5] > 0.f ? 2u : 0u) | (best[6] > 0.f ? 4u : 0u) | (best[7] > 0.f ? 8u : 0u);
+            *reinterpret_cast<unsigned short *>(a.psg + (((pp0 + pvox) * a.po_cs + a.po_c0) >> 2)) = (unsigned short)(lo4 | (hi4 << 8));
+        }
         if (a.posum)
             *reinterpret_cast<float *>(reinterpret_cast<char *>(a.posum + pp0) + pvox * 4u) =
                 ((best[0] + best[1]) + (best[2] + best[3])) + ((best[4] + best[5]) + (best[6] + best[7]));
@@ -363,14 +369,14 @@ __global__ __launch_bounds__(256, 4) void direct_conv_pool_kernel(const DirectPo
 // eligibility is checked by the caller (model.hip): 3x3x3 SAME conv of one channel into 8, 2x2x2 pool, even dims
 int direct_conv_pool_launch(alq_ctx *ctx, const float *d_W, const View &in, const View &out, const View &pout,
                             const float *bias, int relu, uint8_t *argmax, float *osum, float *posum, int N,
-                            double flops_per_patch, unsigned *amax, unsigned char *sg) {
+                            double flops_per_patch, unsigned *amax, unsigned char *sg, unsigned char *psg) {
     ALQ_REQUIRE(in.C == 1 && in.cs == 1 && in.c0 == 0 && out.C == 8 && pout.C == 8 && d_W, ALQ_EINVAL, "direct conv+pool: bad views");
     ALQ_REQUIRE(((out.cs | out.c0 | pout.cs | pout.c0) & 3) == 0 && in.D % 2 == 0 && in.H % 2 == 0 && in.W % 2 == 0 &&
                     pout.D * 2 == in.D && pout.H * 2 == in.H && pout.W * 2 == in.W,
                 ALQ_EUNSUPPORTED, "direct conv+pool: unsupported geometry");
     DirectPoolArgs a;
     a.in = in.p; a.out = out.p; a.pout = pout.p; a.argmax = reinterpret_cast<unsigned *>(argmax);
-    a.osum = osum; a.posum = posum; a.W = d_W; a.bias = bias; a.amax = amax; a.sg = sg;
+    a.osum = osum; a.posum = posum; a.W = d_W; a.bias = bias; a.amax = amax; a.sg = sg; a.psg = psg;
     a.out_cs = out.cs; a.out_c0 = out.c0; a.po_cs = pout.cs; a.po_c0 = pout.c0;
     a.D = in.D; a.H = in.H; a.Wd = in.W; a.N = N; a.relu = relu;
     a.tilesZ = (pout.D + 3) / 4; a.tilesY = (pout.H + 7) / 8; a.tilesX = (pout.W + 7) / 8;

@@ -293,7 +293,7 @@ __global__ void pool_bwd_vox_kernel(const float *dout, int do_cs, int do_c0, int
 template <int C4>
 __global__ void pool_bwd_first_kernel(const float *dout, int do_cs, int do_c0, const float *pout, int po_cs, int po_c0,
                                       const uint8_t *argmax, int OD, int OH, int OW, int wz, int ID, int IH, int IW,
-                                      long long npool, float *dsum, int accumulate) {
+                                      long long npool, float *dsum, int accumulate, const unsigned char *psg) {
     for (long long o = blockIdx.x * (long long)blockDim.x + threadIdx.x; o < npool;
          o += (long long)gridDim.x * blockDim.x) {
         long long r = o;
@@ -306,8 +306,14 @@ __global__ void pool_bwd_first_kernel(const float *dout, int do_cs, int do_c0, c
         for (int c = 0; c < C4; ++c) {
             const unsigned am = reinterpret_cast<const unsigned *>(argmax)[o * C4 + c];
             const f32x4 d = *reinterpret_cast<const f32x4 *>(dout + o * do_cs + do_c0 + c * 4);
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(pout + o * po_cs + po_c0 + c * 4);
-            const float g[4] = {a.x > 0.f ? d.x : 0.f, a.y > 0.f ? d.y : 0.f, a.z > 0.f ? d.z : 0.f, a.w > 0.f ? d.w : 0.f};
+            float g[4];
+            if (psg) {        // the pooled activation's sign field (View::sg)
+                const unsigned nb = psg[(o * po_cs + po_c0 + c * 4) >> 2];
+                g[0] = (nb & 1u) ? d.x : 0.f; g[1] = (nb & 2u) ? d.y : 0.f; g[2] = (nb & 4u) ? d.z : 0.f; g[3] = (nb & 8u) ? d.w : 0.f;
+            } else {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(pout + o * po_cs + po_c0 + c * 4);
+                g[0] = a.x > 0.f ? d.x : 0.f; g[1] = a.y > 0.f ? d.y : 0.f; g[2] = a.z > 0.f ? d.z : 0.f; g[3] = a.w > 0.f ? d.w : 0.f;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const unsigned w = (am >> (8 * j)) & 255u;
@@ -366,7 +372,7 @@ int k_pool_fwd(alq_ctx *ctx, const View &in, const View &out, uint8_t *argmax, c
 }
 
 int k_pool_bwd_first(alq_ctx *ctx, const View &dout, const View &pool_out, const uint8_t *argmax, const int w[3],
-                     int ID, int IH, int IW, int N, float *dsum, int accumulate) {
+                     int ID, int IH, int IW, int N, float *dsum, int accumulate, int use_signs) {
     ALQ_REQUIRE(w[1] == 2 && w[2] == 2 && (w[0] == 1 || w[0] == 2) && ID == dout.D * w[0] && IH == dout.H * 2 && IW == dout.W * 2 &&
                     (dout.C == 4 || dout.C == 8 || dout.C == 16) && ((dout.cs | dout.c0 | pool_out.cs | pool_out.c0) & 3) == 0,
                 ALQ_EUNSUPPORTED, "pool_bwd_first: unsupported geometry");
@@ -375,7 +381,7 @@ int k_pool_bwd_first(alq_ctx *ctx, const View &dout, const View &pool_out, const
 #define ALQ_PBF(CV)                                                                                               \
     hipLaunchKernelGGL(pool_bwd_first_kernel<CV>, dim3(grid_for(npool)), dim3(256), 0, ctx->stream, dout.p, dout.cs, \
                        dout.c0, pool_out.p, pool_out.cs, pool_out.c0, argmax, dout.D, dout.H, dout.W, w[0], ID, IH, IW, \
-                       npool, dsum, accumulate)
+                       npool, dsum, accumulate, (use_signs && ((pool_out.cs | pool_out.c0) & 3) == 0) ? pool_out.sg : nullptr)
     switch (dout.C) { case 4: ALQ_PBF(1); break; case 8: ALQ_PBF(2); break; default: ALQ_PBF(4); }
 #undef ALQ_PBF
     ALQ_LAUNCH_CHECK();

@@ -530,7 +530,7 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
         ALQ_TRY(m->dalloc(&dbuf, el));
         act[i] = mkview(buf, sh, sh.C, 0, sh.C);
         dact[i] = mkview(dbuf, sh, sh.C, 0, sh.C);
-        if (sh.C % 4 == 0 && specs[i].type != ALQ_FC && specs[i].type != ALQ_POOL && specs[i].relu) ALQ_TRY(m->dalloc(&act[i].sg, el / 4));
+        if (sh.C % 4 == 0 && specs[i].type != ALQ_FC && (specs[i].type == ALQ_POOL || specs[i].relu)) ALQ_TRY(m->dalloc(&act[i].sg, el / 4));
     }
     m->logits = act[n_layers - 1].p;
     m->dlogits = dact[n_layers - 1].p;
@@ -838,8 +838,9 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                     ALQ_TRY(direct_conv_pool_launch(ctx, ly.fwd[0].pd.d_W, in, ly.out, nx->out, ly.d_bias, sp.relu, nx->argmax,
                                                     with_sums ? ly.osum : nullptr, with_sums ? nx->osum : nullptr, N,
                                                     ly.fwd[0].pd.flops_per_patch, prod[i] ? ly.amax_fwd : nullptr,
-                                                    sg_here ? ly.out.sg : nullptr));
+                                                    sg_here ? ly.out.sg : nullptr, (sg_here && nx->out.sg) ? nx->out.sg : nullptr));
                     ly.signs_ready = sg_here;
+                    nx->signs_ready = sg_here && nx->out.sg != nullptr;      // (the pool's output: sign of the window maximum)
                     fused = true;
                     skip_next = true;
                     break;
@@ -1017,7 +1018,7 @@ static int run_backward_main(alq_model *m, const float *d_x, int N) {
         const bool prev_param = prev && prev->pidx >= 0 && prev->spec.type != ALQ_FC;
         if (ly.spec.type == ALQ_POOL && prev_param && pool_first_ok(ly, *prev) && (prev->dsum_partial || !prev_is_src)) {
             ALQ_TRY(k_pool_bwd_first(ctx, ly.dout, ly.out, ly.argmax, ly.spec.k, prev->out.D, prev->out.H, prev->out.W, N,
-                                     prev->dsum, prev->dsum_partial ? 1 : 0));
+                                     prev->dsum, prev->dsum_partial ? 1 : 0, ly.signs_ready ? 1 : 0));
             prev->delta_ready = true;
             continue;
         }

@@ -9,3 +9,6 @@ ALQ_NO_FLIPFIX=1 run noflip
 ALQ_NO_BOUND16=1 run nobound16
 ALQ_NO_F16X2=1 run nof16
 ALQ_NO_SIGNS=1 run nosigns
+ALQ_NO_SIGNS0=1 run nosigns0
+# the forward-only pass (the AL loop's entropy filter): its six launches are other instantiations (no sums, no sign bytes)
+ALQ_DUMP_ARGS=1 python tests/dump_forward.py > /dev/null 2> gpurun_out/tunedump_forward.err; grep -c G4ARGS gpurun_out/tunedump_forward.err

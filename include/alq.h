@@ -267,6 +267,12 @@ int alq_debug_set_stamp_buffer(void *d_buf);
  * MFMAs, 8 no sum stores), 2 = no epilogue fusion in backward GEMMs, 3 = none in forward GEMMs,
  * 4 = use the fp32-MFMA GEMM kernel instead of the bf16x3 split kernel.                         */
 int alq_debug_set(int key, int value);
+/* What the last pass of a model ran on (tests / bench reporting).  what = 0: 1 when the matrix cores of the context's device
+ * keep fp16 subnormal operands (probed once; the one-accumulator form of the plane-sweep engine needs it), 1: 1 when the last
+ * forward pass ran the conv under the two-class head on the plane-sweep engine (csrc/c3d.hip; replaces the tf.nn.conv3d call
+ * site NN_extended.py:416-426 for that layer), 2: the same for the last backward pass, 3: 1 when that engine accumulates the
+ * three piece products in one accumulator.  Returns the answer (0 / 1) or a negative error code.  */
+int alq_model_engine_info(alq_model *m, int what);
 
 /* Synthetic patch generator: counter-based RNG keyed (seed, patch_id, element), standard
  * normal, written to d_out [n, elems_per_patch] for patch ids first_id .. first_id+n-1

@@ -73,6 +73,7 @@ _SIGNATURES = {
     'alq_model_debug_copy': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_int64)]),
     'alq_debug_set_stamp_buffer': (C.c_int, [_P]),
     'alq_debug_set': (C.c_int, [C.c_int, C.c_int]),
+    'alq_model_engine_info': (C.c_int, [_P, C.c_int]),
     'alq_synth_patches': (C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, _P]),
 }
 

@@ -389,6 +389,24 @@ void igemm4_pack_weights(Igemm4Plan *plan, const std::vector<float> &Bmat /* [(e
 int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const View &out, const float *bias,
                   int relu, int accumulate, int N, int prof_cls, const Igemm2Fuse *fuse);
 
+// ------------------------------------------------------------------ plane-sweep engine for the head conv pair (c3d.hip)
+// One workgroup per patch sweeps the z planes with three rotating accumulator plane sets in registers; 32^3 patches, 3x3x3,
+// forward: 16 (two dense 8-channel tensors) -> 8 channels with the two-class head fused; backward: 8 (sign bytes x W0 - W1) -> 16.
+struct C3dPlan {
+    bool ok = false;
+    int D = 0;
+    int w_exp = 0;                        // scale exponent of the packed fp16 weight pairs
+    int oneacc = 1;                       // pieces at their true scale, one accumulator (c3d.hip); 0: l scaled by 2^11, two accumulators
+    double flops_per_patch = 0;
+    std::vector<unsigned short> h_W;      // [k-step][piece][lane][8] fp16 bits
+    void *d_W = nullptr;
+};
+int c3d_subnormals_ok(alq_ctx *ctx);      // 1: the matrix cores keep fp16 subnormal operands (needed by the one-accumulator form)
+int c3d_fwd_build(const View &in, const View &out, const int k[3], const int lo[3], const int s[3], C3dPlan *plan);
+void c3d_fwd_pack(C3dPlan *plan, const std::vector<float> &Bmat /* [(tap, ci)][co] */);
+int c3d_fwd_launch(alq_ctx *ctx, const C3dPlan &plan, const View &in, const float *bias, int N, const unsigned *amaxA, const unsigned *amaxB,
+                   const float *fc_W, float *fc_part, float *asum_part, unsigned char *fc_bits, float flip_tau);
+
 // ------------------------------------------------------------------ direct first-layer conv (direct.hip)
 struct DirectArgs {
     const float *in;

@@ -1,0 +1,467 @@
+// Plane-sweep engine for the 3x3x3 convolutions around the two-class head (NET-C: dec2, 16 -> 8 channels at 32^3, and its
+// backward, 8 -> 16): the two launches that were 47 % of the two-slot engine's time (igemm4.hip) at 0.24 - 0.29 of the 16-bit
+// MFMA peak.  Replaces the tf.nn.conv3d call site NN_extended.py:416-426 for that layer (forward) and the corresponding
+// node of tf.gradients (NN_extended.py:1029-1035) (backward), same arithmetic as the fp16x2 variant of igemm4
+// (x 2^e = h + l 2^-11, products h.h | h.l + l.h on v_mfma_f32_16x16x32_f16, fp32 accumulate).
+//
+// What is different from the tile engine, and why (MI355X_MICROARCH.md: "Two waves per SIMD", LDS table):
+//  * INPUT-STATIONARY Z SWEEP.  One 256-thread workgroup per CU owns a whole patch and walks its z planes; wave w owns
+//    the output rows y = 8w .. 8w+7 (all 32 x).  An MFMA column block is one x row (16 x-pairs), so a fragment read from
+//    LDS for input row (z, y) and k-step s feeds every (dz, dy) tap that touches it: up to 3 x 3 x 3 products = 27 MFMAs per
+//    two ds_read_b128 (the tile engine: 3 per two reads; its contraction was LDS-read and issue bound).  The three output
+//    planes z-1, z, z+1 an input plane contributes to live in three rotating accumulator sets (3 x 8 rows x 2 x 4 VGPRs).
+//  * WEIGHTS IN REGISTERS (18 k-steps x 2 pieces x 4 VGPRs = 144 of the 512 a one-wave-per-SIMD kernel owns): no weight
+//    fragment reads at all, no LDS for them.
+//  * EVERY INPUT ELEMENT IS STAGED ONCE PER PATCH: the x halo is two zero slots per row image, the y halo two zero rows per
+//    plane image, the z halo is no plane at all; nothing is re-read from HBM or re-split (the tile engine staged and
+//    split every halo voxel 2.3 x).  Two plane images (2 x 74 KB) alternate; the split of plane z+1 is spread over the
+//    MFMA stream of plane z.
+//  * ONE WAVE PER SIMD, no second wave competing for the issue port; the epilogue of plane z-2 (fused two-class head:
+//    logit-difference partials, sign bytes, flip marks, the head's input sum) is spread over the rows of step z, each
+//    row just before its accumulators are restarted.
+//  * compile-time geometry: every LDS offset is an instruction immediate, no descriptor tables, no per-slot EXEC masks.
+#include "alq_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+namespace alq {
+
+namespace {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <int V> using IC = std::integral_constant<int, V>;
+
+// LDS image of one input plane (bytes).  Slot = 8 fp16 channels of one tensor at one voxel, one piece (h or l).
+constexpr int C3_TEN = 34 * 16;          // slots x = -1 .. 32 of one (row, piece, tensor); the two outer ones stay zero
+constexpr int C3_PIECE = 2 * C3_TEN;     // two tensors (channels 0..7 | 8..15 of the concat)
+constexpr int C3_ROW = 2 * C3_PIECE;     // two pieces
+constexpr int C3_PLANE = 34 * C3_ROW;    // rows y = -1 .. 32; the two outer ones stay zero
+constexpr int C3_LDS = 2 * C3_PLANE;     // two planes alternate: 147,968 of the 163,840 bytes
+static_assert(C3_LDS <= 160 * 1024, "two plane images must fit the CU's LDS");
+}  // namespace
+
+struct C3FwdArgs {
+    const float *inA, *inB;        // dense [N, D, 32, 32, 8] fp32: channels 0..7 / 8..15 of the conv's 16-channel input
+    const void *W;                 // [18 k-steps][2 pieces][64 lanes][8] fp16 (c3d_fwd_pack)
+    const float *bias;             // [8]
+    const unsigned *amaxA, *amaxB; // [N] max |x| per patch of the two tensors (float bits)
+    const float *fc_W;             // [D * 32 * 32 * 8] W0 - W1 of the two-class head, activation-memory order
+    float *fc_part;                // [N][4] logit-difference partials, one per wave
+    float *asum_part;              // [N][4] sum of the ReLU'd output per wave (the head's input sum), or null
+    unsigned char *fc_bits;        // [N][D * 32 * 32 * 2] sign byte per 4 channels (bit 4: flip mark), or null
+    int N, D;
+    int e_w;                       // scale exponent of the packed weights
+    float flip_tau;                // > 0: mark 4-channel groups holding |pre-activation| < flip_tau * 2^(14 - e_patch)
+};
+
+// SUMS: Fisher pass (sign bytes, flip marks, the head's input sum); otherwise forward only (logit partials).
+// ONEACC: both pieces at their true scale (l = x 2^e - h, not times 2^11) and all three products in ONE accumulator: half the
+// accumulator registers (96 instead of 192 of the 512) and no combine step.  A small l is then an fp16 subnormal (absolute
+// resolution 2^-24 of the scaled range, i.e. 2^-38 of the patch's maximum): the MFMA of gfx950 does not flush them (checked on
+// the device by alq_c3d_selftest), and an element that small contributes 2^-38 max |x| |w| of error - far below the 2^-24
+// relative rounding of the large elements' products.
+template <bool SUMS, bool ONEACC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void c3d_fwd_kernel(const C3FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int D = a.D;
+    const unsigned plane_f = 32u * 32u * 8u;                 // floats per plane of one 8-channel tensor
+    const unsigned patch_bytes = (unsigned)D * plane_f * 4u;
+
+    for (int i = tid * 16; i < C3_LDS; i += 256 * 16) *reinterpret_cast<i32x4 *>(lds + i) = i32x4{0, 0, 0, 0};
+
+    // weights: A operand (rows = 2 x-adjacent output voxels x 8 channels), resident in registers for the whole launch
+    f16x8 Wh[18], Wl[18];
+    {
+        const i32x4 *Wg = reinterpret_cast<const i32x4 *>(a.W);
+#pragma unroll
+        for (int k = 0; k < 18; ++k) {
+            Wh[k] = __builtin_bit_cast(f16x8, Wg[(k * 2 + 0) * 64 + lane]);
+            Wl[k] = __builtin_bit_cast(f16x8, Wg[(k * 2 + 1) * 64 + lane]);
+        }
+    }
+    f32x4 bias4 = *reinterpret_cast<const f32x4 *>(a.bias + (lq & 1) * 4);
+
+    // fragment reads (B operand: columns = 16 x-pairs r, k-group (t, p) = (tensor, x parity)): slot 2 r + p (+ 2 s)
+    const int frag_lane = (lq >> 1) * C3_TEN + (2 * lr + (lq & 1)) * 16 + wave * 8 * C3_ROW;
+    // staging writes: lane = (x, channel half): 8 bytes per piece at slot x + 1 of rows 8 w + 1 ..
+    const int st_lane = (wave * 8 + 1) * C3_ROW + 16 + lane * 8;
+    // epilogue: this lane's 4 channels of voxel x = 2 r + (q >> 1): float offset 16 r + 4 q inside the x row
+    const unsigned epi_lane_f = 16u * lr + 4u * lq;
+
+    const int G = gridDim.x, b0 = blockIdx.x;
+    const int np = b0 < a.N ? (a.N - b0 + G - 1) / G : 0;
+    const long long nplanes = (long long)np * D;
+
+    f32x4 acc[3][8], accx[3][ONEACC ? 1 : 8];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { acc[s][i] = f32x4{0.f, 0.f, 0.f, 0.f}; if constexpr (!ONEACC) accx[s][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    auto patch_exp = [&](int p) __attribute__((always_inline)) {      // max |x| < 2^ex -> scale 2^(14 - ex); all-zero patch: 0
+        const unsigned fa = a.amaxA[p], fb = a.amaxB[p];
+        const unsigned fm = fa > fb ? fa : fb;
+        const int ex = (int)((fm >> 23) & 255u) - 126;
+        return fm ? 14 - ex : 0;
+    };
+    auto rsrc_of = [&](const void *base, long long off, unsigned bytes) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(base)) + off, 0, (int)bytes, 0x00020000);
+    };
+
+    // ---- staging: plane `cz` of patch `cp` (ordinal cn in this workgroup's plane stream) -> image cn & 1 -----------
+    // unit u = 0..15: row 8 w + (u >> 1), tensor u & 1: 1 KB of fp32 per wave instruction, 16 bytes per lane
+    f32x4 R4[4];
+    float sc = 1.f, sc11 = 2048.f;
+    auto stage_unit = [&](int wbase, auto U) __attribute__((always_inline)) {
+        constexpr int u = decltype(U)::value;
+        const f32x4 v = R4[u & 3];
+        const float x0 = v.x * sc, x1 = v.y * sc, x2 = v.z * sc, x3 = v.w * sc;
+        const f16x2 h01 = __builtin_convertvector(f32x2{x0, x1}, f16x2);
+        const f16x2 h23 = __builtin_convertvector(f32x2{x2, x3}, f16x2);
+        const f32x2 g01 = __builtin_convertvector(h01, f32x2), g23 = __builtin_convertvector(h23, f32x2);
+        f16x2 l01, l23;
+        if constexpr (ONEACC) {       // x 2^e - h is exact in fp32; its rounding to fp16 is the only one
+            l01 = __builtin_convertvector(f32x2{x0 - g01.x, x1 - g01.y}, f16x2);
+            l23 = __builtin_convertvector(f32x2{x2 - g23.x, x3 - g23.y}, f16x2);
+        } else {
+            l01 = __builtin_convertvector(f32x2{__builtin_fmaf(g01.x, -2048.f, v.x * sc11), __builtin_fmaf(g01.y, -2048.f, v.y * sc11)}, f16x2);
+            l23 = __builtin_convertvector(f32x2{__builtin_fmaf(g23.x, -2048.f, v.z * sc11), __builtin_fmaf(g23.y, -2048.f, v.w * sc11)}, f16x2);
+        }
+        char *dst = lds + wbase + (u >> 1) * C3_ROW + (u & 1) * C3_TEN;
+        *reinterpret_cast<uint2 *>(dst) = uint2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+        *reinterpret_cast<uint2 *>(dst + C3_PIECE) = uint2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+    };
+    auto load_unit = [&](__amdgpu_buffer_rsrc_t rA, __amdgpu_buffer_rsrc_t rB, unsigned zoff, auto U) __attribute__((always_inline)) {
+        constexpr int u = decltype(U)::value;
+        R4[u & 3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((u & 1) ? rB : rA, lane * 16,
+                                                                                    (int)(zoff + (unsigned)((wave * 8 + (u >> 1)) * 1024)), 0));
+    };
+
+    // plane stream cursors: c1 = the plane staged by the running step, c2 = the one after it (its first 4 loads go out early)
+    int c1_pi = 0, c1_z = 0, c2_pi = 0, c2_z = 0;
+    auto cur_rsrc = [&](int pi, int z, __amdgpu_buffer_rsrc_t *rA, __amdgpu_buffer_rsrc_t *rB, unsigned *zoff) __attribute__((always_inline)) {
+        const bool ok = pi < np;
+        const long long off = ok ? (long long)(b0 + pi * G) * patch_bytes : 0;
+        *rA = rsrc_of(a.inA, off, ok ? patch_bytes : 0u);
+        *rB = rsrc_of(a.inB, off, ok ? patch_bytes : 0u);
+        *zoff = (unsigned)z * plane_f * 4u;
+    };
+    auto advance = [&](int &pi, int &z) __attribute__((always_inline)) { if (++z == D) { z = 0; ++pi; } };
+
+    float fs = 0.f, sa = 0.f;       // running logit-difference partial / sum of the ReLU'd output of the patch in the epilogue
+    f32x4 wd_next = f32x4{0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t wd_rsrc = rsrc_of(a.fc_W, 0, patch_bytes);
+
+    // ---- epilogue of one finished x row (plane zo, row 8 w + i) of accumulator set S -------------------------------
+    // inv = 0 and a zero-sized sign buffer turn it into a no-op (steps without a finished plane)
+    auto epi_row = [&](auto S, auto I, float inv, f32x4 b4, float tau, __amdgpu_buffer_rsrc_t bits_rsrc, __amdgpu_buffer_rsrc_t wdr, unsigned row_f) __attribute__((always_inline)) {
+        constexpr int s = decltype(S)::value, i = decltype(I)::value;
+        const f32x4 w4 = wd_next;
+        if constexpr (i < 7)         // the next row's slice of the head's weight difference: its L2 latency behind this row's work
+            wd_next = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wdr, (int)(epi_lane_f * 4u), (int)((row_f + (unsigned)(i + 1) * 256u) * 4u), 0));
+        const f32x4 c = acc[s][i];
+        f32x4 val;
+        if constexpr (ONEACC) {
+            val.x = __builtin_fmaf(c.x, inv, b4.x); val.y = __builtin_fmaf(c.y, inv, b4.y);
+            val.z = __builtin_fmaf(c.z, inv, b4.z); val.w = __builtin_fmaf(c.w, inv, b4.w);
+        } else {
+            const f32x4 d = accx[s][i];
+            val.x = __builtin_fmaf(__builtin_fmaf(d.x, 0x1p-11f, c.x), inv, b4.x);
+            val.y = __builtin_fmaf(__builtin_fmaf(d.y, 0x1p-11f, c.y), inv, b4.y);
+            val.z = __builtin_fmaf(__builtin_fmaf(d.z, 0x1p-11f, c.z), inv, b4.z);
+            val.w = __builtin_fmaf(__builtin_fmaf(d.w, 0x1p-11f, c.w), inv, b4.w);
+        }
+        unsigned unsure = 0u;
+        if constexpr (SUMS) {
+            const float mn = fminf(fminf(__builtin_fabsf(val.x), __builtin_fabsf(val.y)), fminf(__builtin_fabsf(val.z), __builtin_fabsf(val.w)));
+            unsure = mn < tau ? 16u : 0u;
+        }
+        val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f);
+        fs += __builtin_fmaf(val.y, w4.y, val.x * w4.x) + __builtin_fmaf(val.w, w4.w, val.z * w4.z);
+        if constexpr (SUMS) {
+            sa += (val.x + val.y) + (val.z + val.w);
+            const unsigned nib = (val.x > 0.f ? 1u : 0u) | (val.y > 0.f ? 2u : 0u) | (val.z > 0.f ? 4u : 0u) | (val.w > 0.f ? 8u : 0u) | unsure;
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)nib, bits_rsrc, (int)(epi_lane_f >> 2), (int)((row_f + (unsigned)i * 256u) >> 2), 0);
+        }
+    };
+    auto wave_sum = [&](float x) __attribute__((always_inline)) {
+        int v = __builtin_bit_cast(int, x);
+#define C3_ROW_SHR_ADD(n) v = __builtin_bit_cast(int, __builtin_bit_cast(float, v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, v, 0x110 + (n), 0xf, 0xf, true)))
+        C3_ROW_SHR_ADD(1); C3_ROW_SHR_ADD(2); C3_ROW_SHR_ADD(4); C3_ROW_SHR_ADD(8);
+#undef C3_ROW_SHR_ADD
+        const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 15));
+        const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 31));
+        const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 47));
+        const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 63));
+        return (r0 + r1) + (r2 + r3);
+    };
+    auto finish_patch = [&](int p) __attribute__((always_inline)) {
+        const float t = wave_sum(fs);
+        if (lane == 0) a.fc_part[(size_t)p * 4 + wave] = t;
+        if constexpr (SUMS) {
+            const float u = wave_sum(sa);
+            if (lane == 0 && a.asum_part) a.asum_part[(size_t)p * 4 + wave] = u;
+        }
+        fs = 0.f; sa = 0.f;
+    };
+    // epilogue constants of (patch ordinal pe, plane zo), valid = there is such a finished plane
+    struct Epi { float inv; f32x4 b4; float tau; __amdgpu_buffer_rsrc_t bits, wd; unsigned row_f; };
+    auto epi_setup = [&](bool valid, int pe, int zo) __attribute__((always_inline)) {
+        Epi e;
+        const int p = valid ? b0 + pe * G : 0;
+        const int ce = valid ? patch_exp(p) : 0;
+        e.wd = rsrc_of(a.fc_W, 0, valid ? patch_bytes : 0u);       // an empty buffer: the loads of a step without a finished plane return 0
+        e.inv = valid ? __builtin_ldexpf(1.f, -(ce + a.e_w)) : 0.f;
+        e.b4 = valid ? bias4 : f32x4{0.f, 0.f, 0.f, 0.f};
+        e.tau = valid ? __builtin_ldexpf(a.flip_tau, 14 - ce) : 0.f;
+        e.bits = rsrc_of(a.fc_bits, (long long)p * (patch_bytes >> 4), (valid && SUMS && a.fc_bits) ? (patch_bytes >> 4) : 0u);
+        e.row_f = (unsigned)(zo * 32 + wave * 8) * 256u;       // float offset of row 8 w of that plane inside the patch
+        return e;
+    };
+    // the head's weight difference for row 0 of the plane the NEXT step finishes (the same vector for every patch): issued at
+    // the end of a step so that its L2 latency is not met at the top of the next one; rows 1..7 are fetched a row ahead
+    auto prefetch_wd = [&](bool valid, int zo) __attribute__((always_inline)) {
+        const unsigned row_f = (unsigned)(zo * 32 + wave * 8) * 256u;
+        wd_next = valid ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wd_rsrc, (int)(epi_lane_f * 4u), (int)(row_f * 4u), 0))
+                        : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+
+    // ---- one step: input plane z of patch ordinal pi (plane ordinal n), rotation R = z mod 3 ------------------------
+    // sets: zo = z - 1 -> (R + 2) % 3, zo = z -> R, zo = z + 1 -> (R + 1) % 3 (restarted row by row, after the epilogue of the
+    // plane z - 2 it still holds)
+    auto step = [&](auto RR, int pi, int z, long long n) __attribute__((always_inline)) {
+        constexpr int R = decltype(RR)::value;
+        constexpr int S_lo = (R + 2) % 3, S_mid = R, S_hi = (R + 1) % 3;
+        // everything the previous step wrote into this plane's image has landed; nobody still reads the other image
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int abase = frag_lane + (int)(n & 1) * C3_PLANE;
+        const int wbase = st_lane + (int)((n + 1) & 1) * C3_PLANE;
+        __amdgpu_buffer_rsrc_t rA1, rB1, rA2, rB2;
+        unsigned zo1, zo2;
+        cur_rsrc(c1_pi, c1_z, &rA1, &rB1, &zo1);
+        cur_rsrc(c2_pi, c2_z, &rA2, &rB2, &zo2);
+        {
+            const int ce = c1_pi < np ? patch_exp(b0 + c1_pi * G) : 0;
+            sc = __builtin_ldexpf(1.f, ce); sc11 = __builtin_ldexpf(1.f, ce + 11);
+        }
+        // finished plane: z - 2 of this patch, or plane D - 1 of the previous one at z = 0 (D - 2 is done by the light step)
+        const bool ev = z >= 2 || (z == 0 && pi > 0);
+        const Epi E = epi_setup(ev, z >= 2 ? pi : pi - 1, z >= 2 ? z - 2 : D - 1);
+
+        auto frag = [&](int j, int s, f16x8 &bh, f16x8 &bl) __attribute__((always_inline)) {
+            const char *p = lds + abase + j * C3_ROW + s * 32;
+            bh = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(p));
+            bl = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(p + C3_PIECE));
+        };
+        f16x8 bh, bl, nh, nl;
+        frag(0, 0, bh, bl);
+        auto row = [&](auto J) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value;
+            if constexpr (j < 8) {
+                // row j of the plane finished two steps ago, then (below) its accumulators restart for plane z + 1
+                epi_row(IC<S_hi>{}, J, E.inv, E.b4, E.tau, E.bits, E.wd, E.row_f);
+                stage_unit(wbase, IC<2 * j>{});
+                if constexpr (2 * j + 4 < 16) load_unit(rA1, rB1, zo1, IC<2 * j + 4>{}); else load_unit(rA2, rB2, zo2, IC<2 * j + 4 - 16>{});
+                stage_unit(wbase, IC<2 * j + 1>{});
+                if constexpr (2 * j + 5 < 16) load_unit(rA1, rB1, zo1, IC<2 * j + 5>{}); else load_unit(rA2, rB2, zo2, IC<2 * j + 5 - 16>{});
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                // the next fragment pair goes out before this one's MFMAs
+                if (s == 0) frag(j, 1, nh, nl);
+                else if (j < 9) frag(j + 1, 0, nh, nl);
+#pragma unroll
+                for (int di = 0; di < 3; ++di) {
+                    const int i = j - di;          // output row; y tap index = di
+                    if (i < 0 || i > 7) continue;
+#pragma unroll
+                    for (int dzi = 0; dzi < 3; ++dzi) {      // z tap index: output plane z + 1 - dzi
+                        const int k = (dzi * 3 + di) * 2 + s;
+                        const int set = dzi == 0 ? S_hi : (dzi == 1 ? S_mid : S_lo);
+                        const bool start = dzi == 0 && di == 0 && s == 0;       // first contribution to (plane z + 1, row i)
+                        f32x4 c = acc[set][i];
+                        if (start) c = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if constexpr (ONEACC) {      // the small products first
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wl[k], bh, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wh[k], bl, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wh[k], bh, c, 0, 0, 0);
+                        } else {
+                            f32x4 d = accx[set][i];
+                            if (start) d = f32x4{0.f, 0.f, 0.f, 0.f};
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wl[k], bh, d, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wh[k], bh, c, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wh[k], bl, d, 0, 0, 0);
+                            accx[set][i] = d;
+                        }
+                        acc[set][i] = c;
+                    }
+                }
+                bh = nh; bl = nl;
+            }
+        };
+        row(IC<0>{}); row(IC<1>{}); row(IC<2>{}); row(IC<3>{}); row(IC<4>{});
+        row(IC<5>{}); row(IC<6>{}); row(IC<7>{}); row(IC<8>{}); row(IC<9>{});
+        // what the next step finishes: plane z - 1 (z + 1 < D), or plane D - 2 in the light step behind z = D - 1
+        prefetch_wd(z + 1 < D ? z >= 1 : true, z + 1 < D ? z - 1 : D - 2);
+        if constexpr (R == 0) { if (z == 0 && pi > 0) finish_patch(b0 + (pi - 1) * G); }
+        c1_pi = c2_pi; c1_z = c2_z;
+        advance(c2_pi, c2_z);
+    };
+    // a step without an input plane: only the epilogue of a finished plane held by set S (plane D - 2 after the last
+    // input plane of a patch, plane D - 1 after the last patch), then the set is cleared
+    auto light = [&](auto S, int pe, int zo) __attribute__((always_inline)) {
+        constexpr int s = decltype(S)::value;
+        const Epi E = epi_setup(true, pe, zo);
+        auto rows = [&](auto I) __attribute__((always_inline)) { epi_row(S, I, E.inv, E.b4, E.tau, E.bits, E.wd, E.row_f); };
+        rows(IC<0>{}); rows(IC<1>{}); rows(IC<2>{}); rows(IC<3>{}); rows(IC<4>{}); rows(IC<5>{}); rows(IC<6>{}); rows(IC<7>{});
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { acc[s][i] = f32x4{0.f, 0.f, 0.f, 0.f}; if constexpr (!ONEACC) accx[s][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        prefetch_wd(zo == D - 2, D - 1);      // plane D - 1 is finished next (step 0 of the next patch, or the final light step)
+    };
+
+    // ---- prologue: plane 0 of the first patch, synchronously; the first 4 loads of plane 1 in flight ------------------
+    __syncthreads();       // the zero fill
+    if (np > 0) {
+        __amdgpu_buffer_rsrc_t rA, rB;
+        unsigned zo;
+        cur_rsrc(0, 0, &rA, &rB, &zo);
+        const int ce = patch_exp(b0);
+        sc = __builtin_ldexpf(1.f, ce); sc11 = __builtin_ldexpf(1.f, ce + 11);
+        const int wb = st_lane;       // image 0
+        auto four = [&](auto U0) __attribute__((always_inline)) {
+            constexpr int u0 = decltype(U0)::value;
+            load_unit(rA, rB, zo, IC<u0>{}); load_unit(rA, rB, zo, IC<u0 + 1>{}); load_unit(rA, rB, zo, IC<u0 + 2>{}); load_unit(rA, rB, zo, IC<u0 + 3>{});
+            stage_unit(wb, IC<u0>{}); stage_unit(wb, IC<u0 + 1>{}); stage_unit(wb, IC<u0 + 2>{}); stage_unit(wb, IC<u0 + 3>{});
+        };
+        four(IC<0>{}); four(IC<4>{}); four(IC<8>{}); four(IC<12>{});
+        c1_pi = 0; c1_z = 0;
+        advance(c1_pi, c1_z);          // plane 1
+        c2_pi = c1_pi; c2_z = c1_z;
+        advance(c2_pi, c2_z);          // plane 2
+        cur_rsrc(c1_pi, c1_z, &rA, &rB, &zo);
+        load_unit(rA, rB, zo, IC<0>{}); load_unit(rA, rB, zo, IC<1>{}); load_unit(rA, rB, zo, IC<2>{}); load_unit(rA, rB, zo, IC<3>{});
+    }
+
+    // D = 32: 33 = 3 * 11 steps per patch (the last one light), so the set rotation restarts at every patch
+    long long n = 0;
+    for (int pi = 0; pi < np; ++pi) {
+        for (int zz = 0; zz < 11; ++zz) {
+            step(IC<0>{}, pi, 3 * zz, n); ++n;
+            step(IC<1>{}, pi, 3 * zz + 1, n); ++n;
+            if (zz < 10) { step(IC<2>{}, pi, 3 * zz + 2, n); ++n; }
+            else light(IC<0>{}, pi, D - 2);
+        }
+    }
+    if (np > 0) {
+        light(IC<1>{}, np - 1, D - 1);
+        finish_patch(b0 + (np - 1) * G);
+    }
+    (void)nplanes;
+}
+
+// One MFMA on fp16 SUBNORMAL operands: 32 products 2^-20 * 2^10 per element -> 2^-5 when the matrix core keeps subnormal
+// inputs (gfx950 does), 0 when it flushes them.  The one-accumulator form relies on it for the low pieces of small values.
+__global__ void c3d_subnormal_probe(float *out) {
+    f16x8 a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)0x1p-20f; b[i] = (_Float16)0x1p10f; }
+    const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    if (threadIdx.x == 0) out[0] = d.x;
+}
+
+// 1: fp16 subnormal MFMA operands are honoured on this device, 0: flushed (checked once per process)
+int c3d_subnormals_ok(alq_ctx *ctx) {
+    static int cached = -1;
+    if (cached >= 0) return cached;
+    float *d = nullptr, h = -1.f;
+    if (hipMalloc(&d, sizeof(float)) != hipSuccess) return 0;
+    hipLaunchKernelGGL(c3d_subnormal_probe, dim3(1), dim3(64), 0, ctx->stream, d);
+    const bool ok = hipMemcpyAsync(&h, d, sizeof(float), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                    hipStreamSynchronize(ctx->stream) == hipSuccess;
+    (void)hipFree(d);
+    cached = (ok && h == 0x1p-5f) ? 1 : 0;
+    return cached;
+}
+
+// ------------------------------------------------------------------------------------------------------ host
+int c3d_fwd_build(const View &in, const View &out, const int k[3], const int lo[3], const int s[3], C3dPlan *plan) {
+    plan->ok = false;
+    if (getenv("ALQ_NO_C3D")) return ALQ_OK;
+    if (!(k[0] == 3 && k[1] == 3 && k[2] == 3 && lo[0] == 1 && lo[1] == 1 && lo[2] == 1 && s[0] == 1 && s[1] == 1 && s[2] == 1)) return ALQ_OK;
+    if (!(in.D == 32 && in.H == 32 && in.W == 32 && out.D == 32 && out.H == 32 && out.W == 32)) return ALQ_OK;
+    if (!(in.C == 16 && in.split == 8 && in.cs == 8 && in.c0 == 0 && out.C == 8)) return ALQ_OK;
+    plan->D = in.D;
+    plan->oneacc = getenv("ALQ_C3D_TWOACC") ? 0 : 1;
+    plan->flops_per_patch = 2.0 * 27 * 16 * 8 * (double)in.vox();
+    plan->ok = true;
+    return ALQ_OK;
+}
+
+// Bmat [(tap, ci)][co] (TF conv layout), tap = (dz * 3 + dy) * 3 + dx.  k-step (dz, dy, s): lane (i = lane & 15 -> output
+// voxel v = i >> 3 of the x pair, channel co = i & 7; k-group kg = lane >> 4 -> tensor t = kg >> 1, x parity p = kg & 1):
+// window position q = 2 s + p holds input x = 2 r - 1 + q, i.e. x tap index q - v of output voxel 2 r + v.
+void c3d_fwd_pack(C3dPlan *plan, const std::vector<float> &Bmat) {
+    float amax = 0.f;
+    for (float w : Bmat) amax = std::max(amax, std::fabs(w));
+    int ex = 0;
+    if (amax > 0.f) (void)std::frexp(amax, &ex);
+    plan->w_exp = 14 - ex;
+    plan->h_W.assign((size_t)18 * 2 * 64 * 8, 0);
+    for (int dzi = 0; dzi < 3; ++dzi)
+        for (int dyi = 0; dyi < 3; ++dyi)
+            for (int s = 0; s < 2; ++s)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 15, kg = lane >> 4, v = i >> 3, co = i & 7, t = kg >> 1, p = kg & 1;
+                    const int dxi = 2 * s + p - v;
+                    const int ks = (dzi * 3 + dyi) * 2 + s;
+                    for (int c = 0; c < 8; ++c) {
+                        float w = 0.f;
+                        if (dxi >= 0 && dxi <= 2) w = Bmat[((size_t)((dzi * 3 + dyi) * 3 + dxi) * 16 + 8 * t + c) * 8 + co];
+                        const float ws = std::ldexp(w, plan->w_exp);
+                        const _Float16 h = (_Float16)ws;
+                        const _Float16 l = (_Float16)std::ldexp(ws - (float)h, plan->oneacc ? 0 : 11);
+                        unsigned short hb, lb;
+                        std::memcpy(&hb, &h, 2);
+                        std::memcpy(&lb, &l, 2);
+                        plan->h_W[((size_t)(ks * 2 + 0) * 64 + lane) * 8 + c] = hb;
+                        plan->h_W[((size_t)(ks * 2 + 1) * 64 + lane) * 8 + c] = lb;
+                    }
+                }
+}
+
+int c3d_fwd_launch(alq_ctx *ctx, const C3dPlan &plan, const View &in, const float *bias, int N, const unsigned *amaxA, const unsigned *amaxB,
+                   const float *fc_W, float *fc_part, float *asum_part, unsigned char *fc_bits, float flip_tau) {
+    ALQ_REQUIRE(plan.ok && plan.d_W, ALQ_EINVAL, "c3d: weights not set");
+    ALQ_REQUIRE(in.split == 8 && in.cs == 8 && in.C == 16 && in.D == plan.D && in.H == 32 && in.W == 32 && plan.D == 32, ALQ_EINVAL, "c3d: input view mismatch");
+    ALQ_REQUIRE(amaxA && amaxB && fc_W && fc_part && bias, ALQ_EINVAL, "c3d: missing argument");
+    if (N <= 0) return ALQ_OK;
+    C3FwdArgs a;
+    a.inA = in.p; a.inB = in.p + in.delta; a.W = plan.d_W; a.bias = bias; a.amaxA = amaxA; a.amaxB = amaxB;
+    a.fc_W = fc_W; a.fc_part = fc_part; a.asum_part = asum_part; a.fc_bits = fc_bits; a.N = N; a.D = plan.D; a.e_w = plan.w_exp;
+    a.flip_tau = flip_tau;
+    const unsigned grid = (unsigned)std::min(N, 256);
+    ProfScope ps(ctx, PROF_IGEMM_F16, plan.flops_per_patch * N);
+    auto go = [&](auto kfn) -> int {
+        ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS));
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), C3_LDS, ctx->stream, a);
+        return ALQ_OK;
+    };
+    if (fc_bits) ALQ_TRY(plan.oneacc ? go(c3d_fwd_kernel<true, true>) : go(c3d_fwd_kernel<true, false>));
+    else ALQ_TRY(plan.oneacc ? go(c3d_fwd_kernel<false, true>) : go(c3d_fwd_kernel<false, false>));
+    ALQ_HIP(hipGetLastError());
+    return ALQ_OK;
+}
+
+}  // namespace alq

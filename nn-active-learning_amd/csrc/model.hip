@@ -84,6 +84,10 @@ struct Layer {
     float fwd_l1 = 0.f;
     float *fc_part2 = nullptr;         // partial logits per (tile, wave) when the conv below computes them in its epilogue
     int fc_slices2 = 0;
+    // plane-sweep engine (c3d.hip) for the conv under the fused two-class head (and its backward): plans on the conv layer,
+    // per-(patch, wave) partials of the logit difference / of the head's input sum on the head layer
+    C3dPlan c3f;
+    float *c3_part = nullptr, *c3_asum = nullptr;
     const unsigned *dout_bits = nullptr;   // set on the conv below for the duration of one backward pass
     const float *dout_vec = nullptr;
     const unsigned *dout_vec16 = nullptr;
@@ -134,6 +138,9 @@ struct alq_model {
     int no_signs = 0;              // ALQ_NO_SIGNS (A/B, bit-identity test): backward launches read ReLU masks from the fp32 activations
     int no_signs0 = 0;             // ALQ_NO_SIGNS0 (A/B): no sign field from the first conv + pool kernel only
     int f16_fwd_mask = -1;         // ALQ_F16_FWD_MASK (diagnostics): forward fp16x2 consumers by layer bit, -1 = default rule
+    int no_c3d = 0;                // ALQ_NO_C3D (A/B): the head conv pair on the two-slot engine (igemm4) as in round 3
+    bool last_c3 = false;          // the last forward pass ran the head conv on the plane-sweep engine
+    bool last_c3_bwd = false;      // ... and the last backward pass its backward
 
     template <typename T>
     int dalloc(T **p, size_t count) {
@@ -579,6 +586,7 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
             g4.OD = ly.out.D; g4.OH = ly.out.H; g4.OW = ly.out.W; g4.Co = sp.cout;
             for (int q = 0; q < 3; ++q) { g4.k[q] = sp.k[q]; g4.s[q] = sp.s[q]; g4.lo[q] = ly.lo[q]; }
             ALQ_TRY(gemm_build(d, NB, &ly.fwd[0], &g4));
+            if (!first_param && sp.relu) ALQ_TRY(c3d_fwd_build(ly.in, ly.out, sp.k, ly.lo, sp.s, &ly.c3f));
             if (!first_param) {
                 ConvDesc b;
                 b.ID = ly.out.D; b.IH = ly.out.H; b.IW = ly.out.W; b.Ci = sp.cout;
@@ -684,6 +692,10 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
                         cv.bwd.p4.ok && cv.bwd.p4.NTW == 1 && !cv.bwd.p4.multi && cv.bwd.p4.a.PT == 1 && !cv.dout.split) {
                         ly.fc_slices2 = fp.a.tpg * 4;
                         ALQ_TRY(m->dalloc(&ly.fc_part2, (size_t)NB * ly.fc_slices2));
+                        if (cv.c3f.ok && ly.F == (int64_t)cv.out.vox() * 8) {
+                            ALQ_TRY(m->dalloc(&ly.c3_part, (size_t)NB * 4));
+                            ALQ_TRY(m->dalloc(&ly.c3_asum, (size_t)NB * 4));
+                        }
                     }
                 }
             } else {
@@ -743,6 +755,7 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
     const int nl = (int)m->layers.size();
     bool skip_next = false;      // this layer's outputs were produced by the previous layer's kernel
     bool fc_head_fused = false;  // the logits partials of the fc head came out of the previous conv's epilogue
+    bool c3_head = false;        // ... of the plane-sweep engine: one partial per (patch, wave), the head's input sum likewise
     m->last_head_fused = false;
     // A conv / conv_transpose launch contracts with the fp16x2 split if it knows max |x| per patch of (every part of)
     // its input ahead of time: the launches that produce those tensors report them (`prod`), the consumers (`cons`)
@@ -863,7 +876,14 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                         }
                         fz.flip_cnt = m->flip_cnt; fz.flip_list = m->flip_list; fz.flip_cap = m->flip_cap; fz.flip_l1 = ly.fwd_l1;
                     }
-                    ALQ_TRY(igemm4_launch(ctx, ly.fwd[0].p4, in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM3_FWD, &fz));
+                    // the plane-sweep engine (c3d.hip) where its geometry applies and both per-patch input maxima are known
+                    c3_head = ly.c3f.ok && ly.c3f.d_W && nx->c3_part && fz.in_amax && fz.in_amax2 && !g_no_f16x2 && !m->no_c3d;
+                    if (c3_head)
+                        ALQ_TRY(c3d_fwd_launch(ctx, ly.c3f, in, ly.d_bias, N, fz.in_amax, fz.in_amax2, nx->fc_wv, nx->c3_part,
+                                               with_sums ? nx->c3_asum : nullptr, reinterpret_cast<unsigned char *>(fz.fc_bits),
+                                               flipfix ? std::ldexp(ly.fwd_l1, -24) : 0.f));
+                    else
+                        ALQ_TRY(igemm4_launch(ctx, ly.fwd[0].p4, in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM3_FWD, &fz));
                     if (flipfix)
                         ALQ_TRY(k_flip_fix(ctx, m->flip_list, m->flip_cnt, m->flip_cap, N, in.p, in.split ? in.p + in.delta : nullptr,
                                            in.split ? in.split : in.C, in.split ? in.C - in.split : 0, in.D, in.H, in.W, sp.k[0], sp.k[1], sp.k[2],
@@ -872,6 +892,7 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                     fused = true;
                     fc_head_fused = true;
                     m->last_head_fused = true;
+                    m->last_c3 = c3_head;
                     break;
                 }
                 if (fuse) take_amax(fz, i);
@@ -913,10 +934,13 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                 if (with_sums) {
                     // sum of all inputs of the fc layer, per patch
                     const bool prev_spatial = i > 0 && m->layers[i - 1].osum != nullptr;
-                    if (prev_spatial) ALQ_TRY(k_rowsum_field(ctx, m->layers[i - 1].osum, m->layers[i - 1].out.vox(), N, ly.asum));
+                    if (c3_head) ALQ_TRY(k_rowsum_field(ctx, ly.c3_asum, 4, N, ly.asum));
+                    else if (prev_spatial) ALQ_TRY(k_rowsum_field(ctx, m->layers[i - 1].osum, m->layers[i - 1].out.vox(), N, ly.asum));
                     else ALQ_TRY(k_chansum(ctx, flat_view(in), ly.asum, N));
                 }
-                if (ly.dense_fc_small && fc_head_fused) {
+                if (ly.dense_fc_small && fc_head_fused && c3_head) {
+                    ALQ_TRY(k_fc_small_finish_diff(ctx, ly.c3_part, 4, ly.d_bias, N, ly.out.p));
+                } else if (ly.dense_fc_small && fc_head_fused) {
                     ALQ_TRY(k_fc_small_finish_diff(ctx, ly.fc_part2, ly.fc_slices2, ly.d_bias, N, ly.out.p));
                 } else if (ly.dense_fc_small) {
                     ALQ_TRY(k_fc_small_fwd(ctx, in.p, ly.F, ly.d_Wp, ly.spec.cout, N, ly.fc_partials, ly.fc_slices,
@@ -1437,6 +1461,7 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
         m->no_bound16 = getenv("ALQ_NO_BOUND16") != nullptr;
         m->no_flipfix = getenv("ALQ_NO_FLIPFIX") != nullptr;
         m->no_presplit = getenv("ALQ_NO_PRESPLIT") != nullptr;
+        m->no_c3d = getenv("ALQ_NO_C3D") != nullptr;
         m->no_signs = getenv("ALQ_NO_SIGNS") != nullptr;
         m->no_signs0 = getenv("ALQ_NO_SIGNS0") != nullptr;
         if (const char *f = getenv("ALQ_F16_FWD_MASK")) m->f16_fwd_mask = atoi(f);
@@ -1553,6 +1578,16 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
         // TF [tap][ci][co] is already the fwd B matrix [(tap, ci)][co]
         std::vector<float> B(W, W + ly.w_elems);
         ALQ_TRY(gemm_set(m, &ly.fwd[0], B));
+        if (ly.c3f.ok) {
+            // one accumulator (pieces at their true scale) only where the matrix cores honour fp16 subnormals
+            if (ly.c3f.oneacc && !c3d_subnormals_ok(m->ctx)) ly.c3f.oneacc = 0;
+            c3d_fwd_pack(&ly.c3f, B);
+            unsigned short *dw = reinterpret_cast<unsigned short *>(ly.c3f.d_W);
+            if (!dw) ALQ_TRY(m->dalloc(&dw, ly.c3f.h_W.size()));
+            ly.c3f.d_W = dw;
+            ALQ_HIP(hipMemcpyAsync(dw, ly.c3f.h_W.data(), ly.c3f.h_W.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
+            ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
+        }
         if (ly.has_bwd) {
             std::vector<float> Bb((size_t)ntaps * Co * Ci);
             for (int tp = 0; tp < ntaps; ++tp)
@@ -1831,8 +1866,9 @@ int alq_model_debug_copy(alq_model *m, int layer_idx, int what, int N, float *d_
     if (what == 5) {       // per (tile, wave) partials of the logit difference from the fused fc head (last pass)
         const Layer &head = m->layers.back();
         ALQ_REQUIRE(head.fc_part2 && m->last_head_fused, ALQ_EUNSUPPORTED, "the last pass did not run the fused fc head");
-        if (elems_out) *elems_out = (int64_t)N * head.fc_slices2;
-        ALQ_HIP(hipMemcpyAsync(d_out, head.fc_part2, (size_t)N * head.fc_slices2 * sizeof(float), hipMemcpyDeviceToDevice,
+        const int ns = m->last_c3 ? 4 : head.fc_slices2;      // plane-sweep engine: one partial per (patch, wave)
+        if (elems_out) *elems_out = (int64_t)N * ns;
+        ALQ_HIP(hipMemcpyAsync(d_out, m->last_c3 ? head.c3_part : head.fc_part2, (size_t)N * ns * sizeof(float), hipMemcpyDeviceToDevice,
                                m->ctx->stream));
         return ALQ_OK;
     }
@@ -1857,6 +1893,17 @@ int alq_model_debug_copy(alq_model *m, int layer_idx, int what, int N, float *d_
     ALQ_HIP(hipMemcpyAsync(d_out, what == 2 ? ly.asum : ly.dsum, e * sizeof(float), hipMemcpyDeviceToDevice,
                            m->ctx->stream));
     return ALQ_OK;
+}
+
+int alq_model_engine_info(alq_model *m, int what) {
+    ALQ_REQUIRE(m && what >= 0 && what <= 3, ALQ_EINVAL, "alq_model_engine_info: bad argument");
+    ALQ_HIP(hipSetDevice(m->ctx->device));
+    if (what == 0) return c3d_subnormals_ok(m->ctx);
+    if (what == 1) return m->last_c3 ? 1 : 0;
+    if (what == 2) return m->last_c3_bwd ? 1 : 0;
+    for (const Layer &ly : m->layers)
+        if (ly.c3f.ok) return ly.c3f.oneacc;
+    return 0;
 }
 
 int alq_debug_set(int key, int value) {

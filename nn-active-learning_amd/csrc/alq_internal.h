@@ -406,6 +406,13 @@ int c3d_fwd_build(const View &in, const View &out, const int k[3], const int lo[
 void c3d_fwd_pack(C3dPlan *plan, const std::vector<float> &Bmat /* [(tap, ci)][co] */);
 int c3d_fwd_launch(alq_ctx *ctx, const C3dPlan &plan, const View &in, const float *bias, int N, const unsigned *amaxA, const unsigned *amaxB,
                    const float *fc_W, float *fc_part, float *asum_part, unsigned char *fc_bits, float flip_tau);
+// backward of that conv in a Fisher pass: input = [sign bytes of its output] x one pre-split vector (c3d_presplit_vec), output
+// channels 0..7 masked (maskA: sign field, or null) and summed per voxel, channels 8..15 stored (dB) and summed
+int c3d_bwd_build(const View &fwd_in, const View &fwd_out, const int k[3], const int lo[3], const int s[3], C3dPlan *plan);
+void c3d_bwd_pack(C3dPlan *plan, const std::vector<float> &Bmat_fwd /* the forward conv's [(tap, ci)][co] */);
+void c3d_presplit_vec(const float *v, long long F, int e, std::vector<unsigned short> *out);
+int c3d_bwd_launch(alq_ctx *ctx, const C3dPlan &plan, int N, const unsigned char *bits, const void *vec16, int e_in, const unsigned char *maskA,
+                   float *dB, float *sumA, float *sumB);
 
 // ------------------------------------------------------------------ direct first-layer conv (direct.hip)
 struct DirectArgs {

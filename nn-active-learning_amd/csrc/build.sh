@@ -14,6 +14,8 @@ for f in igemm igemm2 igemm3 igemm4 c3d fcgemm direct kernels topk model comm tr
   # v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, which issue slower than the scalar pairs next to another wave's MFMAs on
   # the same SIMD (same-box A/B: 155.4 k -> 156.6 k patches/s); conversions still pack (v_cvt_pk_f16_f32 / _bf16_f32)
   X=""; if [ "$f" = igemm4 ]; then X="-fno-slp-vectorize --save-temps=obj ${ALQ_G4_FLAGS:-}"; fi
+  # c3d: the same choice (its staging / epilogue arithmetic runs between the wave's own MFMAs)
+  if [ "$f" = c3d ]; then X="-fno-slp-vectorize ${ALQ_C3_FLAGS:-}"; fi
   ( hipcc $FLAGS $X -c "$HERE/$f.hip" -o "$BUILD/$f.o" ${ALQ_EXTRA_FLAGS:-} ) &
   pids+=($!)
 done

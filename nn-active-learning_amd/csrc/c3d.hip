@@ -371,6 +371,261 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     (void)nplanes;
 }
 
+// ======================================================================================================================
+// Backward of the same conv (8 -> 16 channels, flipped taps) in a Fisher pass.  Its input is not a tensor: the cotangent of
+// the conv's output under the unit cotangent is [sign of output element] x (W0 - W1) of the head - the sign bytes the
+// forward kernel left (after the flip fix-up) and ONE vector shared by all patches, kept pre-split as fp16 pairs
+// ([voxel][h8 | l8], c3d_presplit_vec).  Same sweep: wave w owns output rows 8 w .. 8 w + 7, an MFMA column block is half an x
+// row (16 voxels), the four k-groups of a k-step are the x offsets -1, 0, +1 (and one zero group), one k-step per (dz, dy).
+// Output channels 0..7 (the skip source, the first conv): masked by that layer's sign field and only summed per voxel
+// (nothing below it needs the cotangent itself); channels 8..15 (the conv_transpose in front): stored + summed per voxel.
+namespace {
+constexpr int B3_TEN = 34 * 16;          // one piece of one row: slots x = -1 .. 32, 8 fp16 channels each
+constexpr int B3_ROW = 2 * B3_TEN;
+constexpr int B3_PLANE = 34 * B3_ROW;
+constexpr int B3_LDS = 2 * B3_PLANE;     // 73,984 bytes
+}  // namespace
+
+struct C3BwdArgs {
+    const unsigned char *bits;     // [N][D * 32 * 32 * 2] sign byte per 4 output channels of the forward conv (low nibble)
+    const void *vec;               // [D * 32 * 32][h8 | l8] fp16: (W0 - W1) 2^e_in split (c3d_presplit_vec)
+    const void *W;                 // [9 k-steps][2 pieces][64 lanes][8] fp16 (c3d_bwd_pack)
+    const unsigned char *maskA;    // [N][D * 32 * 32 * 2] sign field of the tensor behind output channels 0..7, or null (no ReLU)
+    float *dB;                     // [N, D, 32, 32, 8] cotangent of channels 8..15
+    float *sumA, *sumB;            // [N][D * 32 * 32] per-voxel sums of the (masked) channels 0..7 / of channels 8..15
+    int N, D;
+    int e_in, e_w;                 // scale exponents of the vector and of the packed weights
+};
+
+template <bool ONEACC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void c3d_bwd_kernel(const C3BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    const int D = a.D;
+    const unsigned plane_v = 32u * 32u;                      // voxels per plane
+    const unsigned patch_v = (unsigned)D * plane_v;
+
+    for (int i = tid * 16; i < B3_LDS; i += 256 * 16) *reinterpret_cast<i32x4 *>(lds + i) = i32x4{0, 0, 0, 0};
+
+    f16x8 Wh[9], Wl[9];
+    {
+        const i32x4 *Wg = reinterpret_cast<const i32x4 *>(a.W);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            Wh[k] = __builtin_bit_cast(f16x8, Wg[(k * 2 + 0) * 64 + lane]);
+            Wl[k] = __builtin_bit_cast(f16x8, Wg[(k * 2 + 1) * 64 + lane]);
+        }
+    }
+    // fragment reads: column j = voxel 16 hx + j, k-group kg = x offset kg - 1 (group 3 has zero weights: it re-reads group 2's slot)
+    const int frag_lane = (lj + (lq < 2 ? lq : 2)) * 16 + wave * 8 * B3_ROW;
+    // staging: a unit = two rows of the wave's strip, lane = (row lane >> 5, x = lane & 31)
+    const int st_lane = (wave * 8 + 1 + (lane >> 5)) * B3_ROW + ((lane & 31) + 1) * 16;
+    const unsigned st_vox = (unsigned)((wave * 8 + (lane >> 5)) * 32 + (lane & 31));       // voxel inside the plane, unit 0
+    const float inv = __builtin_ldexpf(1.f, -(a.e_in + a.e_w));
+
+    const int G = gridDim.x, b0 = blockIdx.x;
+    const int np = b0 < a.N ? (a.N - b0 + G - 1) / G : 0;
+
+    f32x4 acc[3][8][2];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { acc[s][i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[s][i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    static_assert(ONEACC, "the backward kernel is built for the one-accumulator form");
+
+    auto rsrc_of = [&](const void *base, long long off, unsigned bytes) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(base)) + off, 0, (int)bytes, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t vec_rsrc = rsrc_of(a.vec, 0, patch_v * 32u);
+
+    // ---- staging unit u = 0..3 of a plane: rows 8 w + 2 u, 8 w + 2 u + 1 ---------------------------------------------------
+    i32x4 Vh[2], Vl[2];
+    unsigned Sb[2];
+    auto load_unit = [&](__amdgpu_buffer_rsrc_t rbits, unsigned z, auto U) __attribute__((always_inline)) {
+        constexpr int u = decltype(U)::value;
+        Vh[u & 1] = __builtin_amdgcn_raw_buffer_load_b128(vec_rsrc, (int)(st_vox * 32u), (int)((z * plane_v + (unsigned)u * 64u) * 32u), 0);
+        Vl[u & 1] = __builtin_amdgcn_raw_buffer_load_b128(vec_rsrc, (int)(st_vox * 32u + 16u), (int)((z * plane_v + (unsigned)u * 64u) * 32u), 0);
+        Sb[u & 1] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rbits, (int)(st_vox * 2u), (int)((z * plane_v + (unsigned)u * 64u) * 2u), 0);
+    };
+    auto stage_unit = [&](int wbase, auto U) __attribute__((always_inline)) {
+        constexpr int u = decltype(U)::value;
+        const int b = (int)Sb[u & 1];      // bits 0..3: channels 0..3, bits 8..11: channels 4..7
+        const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe(b, 0, 1), m1 = (unsigned)__builtin_amdgcn_sbfe(b, 1, 1);
+        const unsigned m2 = (unsigned)__builtin_amdgcn_sbfe(b, 2, 1), m3 = (unsigned)__builtin_amdgcn_sbfe(b, 3, 1);
+        const unsigned m4 = (unsigned)__builtin_amdgcn_sbfe(b, 8, 1), m5 = (unsigned)__builtin_amdgcn_sbfe(b, 9, 1);
+        const unsigned m6 = (unsigned)__builtin_amdgcn_sbfe(b, 10, 1), m7 = (unsigned)__builtin_amdgcn_sbfe(b, 11, 1);
+        const unsigned k0 = (m0 & 0xffffu) | (m1 & 0xffff0000u), k1 = (m2 & 0xffffu) | (m3 & 0xffff0000u);
+        const unsigned k2 = (m4 & 0xffffu) | (m5 & 0xffff0000u), k3 = (m6 & 0xffffu) | (m7 & 0xffff0000u);
+        const i32x4 h = Vh[u & 1], l = Vl[u & 1];
+        char *dst = lds + wbase + (2 * u) * B3_ROW;
+        *reinterpret_cast<i32x4 *>(dst) = i32x4{(int)((unsigned)h.x & k0), (int)((unsigned)h.y & k1), (int)((unsigned)h.z & k2), (int)((unsigned)h.w & k3)};
+        *reinterpret_cast<i32x4 *>(dst + B3_TEN) = i32x4{(int)((unsigned)l.x & k0), (int)((unsigned)l.y & k1), (int)((unsigned)l.z & k2), (int)((unsigned)l.w & k3)};
+    };
+
+    int c1_pi = 0, c1_z = 0, c2_pi = 0, c2_z = 0;
+    auto bits_rsrc_of = [&](int pi) __attribute__((always_inline)) {
+        const bool ok = pi < np;
+        return rsrc_of(a.bits, ok ? (long long)(b0 + pi * G) * (patch_v * 2u) : 0, ok ? patch_v * 2u : 0u);
+    };
+    auto advance = [&](int &pi, int &z) __attribute__((always_inline)) { if (++z == D) { z = 0; ++pi; } };
+
+    // ---- epilogue of one finished x row (plane zo, row 8 w + i) of set S: both halves --------------------------------------
+    // lane (j, q): channels 4 q .. 4 q + 3 of voxel 16 hx + j; q < 2: masked + summed, q >= 2: stored + summed
+    unsigned mk_next[2] = {0u, 0u};
+    struct Epi { __amdgpu_buffer_rsrc_t mask, dB, sumA, sumB; unsigned row_v; float inv; };
+    auto epi_setup = [&](bool valid, int pe, int zo) __attribute__((always_inline)) {
+        Epi e;
+        const long long p = valid ? b0 + pe * G : 0;
+        e.mask = rsrc_of(a.maskA, p * (patch_v * 2u), (valid && a.maskA) ? patch_v * 2u : 0u);
+        e.dB = rsrc_of(a.dB, p * (patch_v * 32u), valid ? patch_v * 32u : 0u);
+        e.sumA = rsrc_of(a.sumA, p * (patch_v * 4u), valid ? patch_v * 4u : 0u);
+        e.sumB = rsrc_of(a.sumB, p * (patch_v * 4u), valid ? patch_v * 4u : 0u);
+        e.row_v = (unsigned)(zo * 32 + wave * 8) * 32u;
+        e.inv = valid ? inv : 0.f;
+        return e;
+    };
+    auto mask_load = [&](__amdgpu_buffer_rsrc_t mrs, unsigned row_v, int i) __attribute__((always_inline)) {
+        // the sign bytes of the next row (channels 4 q .. 4 q + 3 of the masked half): byte 2 voxel + q; lanes q >= 2 load nothing
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx)
+            mk_next[hx] = (unsigned char)__builtin_amdgcn_raw_buffer_load_b8(mrs, (int)(lq < 2 ? (unsigned)(lj * 2 + lq) : 0xffffff00u),
+                                                                            (int)((row_v + (unsigned)i * 32u + (unsigned)hx * 16u) * 2u), 0);
+    };
+    // stores without divergent control flow: a lane that has nothing to store aims past the buffer (the range check drops it)
+    const unsigned OOB = 0xffffff00u;
+    const unsigned off_dB = lq >= 2 ? (unsigned)lj * 32u + (unsigned)(lq - 2) * 16u : OOB;
+    const unsigned off_sA = lq == 0 ? (unsigned)lj * 4u : OOB, off_sB = lq == 2 ? (unsigned)lj * 4u : OOB;
+    auto epi_row = [&](auto S, auto I, const Epi &E, bool has_mask) __attribute__((always_inline)) {
+        constexpr int s = decltype(S)::value, i = decltype(I)::value;
+        const unsigned mk[2] = {mk_next[0], mk_next[1]};
+        if constexpr (i < 7) mask_load(E.mask, E.row_v, i + 1);
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) {
+            const f32x4 c = acc[s][i][hx];
+            f32x4 val = f32x4{c.x * E.inv, c.y * E.inv, c.z * E.inv, c.w * E.inv};
+            const int nib = (lq < 2 && has_mask) ? (int)mk[hx] : 15;
+            val.x = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, val.x) & (unsigned)__builtin_amdgcn_sbfe(nib, 0, 1));
+            val.y = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, val.y) & (unsigned)__builtin_amdgcn_sbfe(nib, 1, 1));
+            val.z = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, val.z) & (unsigned)__builtin_amdgcn_sbfe(nib, 2, 1));
+            val.w = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, val.w) & (unsigned)__builtin_amdgcn_sbfe(nib, 3, 1));
+            const unsigned vox = E.row_v + (unsigned)i * 32u + (unsigned)hx * 16u;      // first voxel of this half row
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, val), E.dB, (int)off_dB, (int)(vox * 32u), 2 /* nt */);
+            float t = (val.x + val.y) + (val.z + val.w);
+            // lanes (j, q) and (j, q ^ 1) hold the two 4-channel groups of one voxel: their sum through the LDS crossbar
+            t += __shfl_xor(t, 16, 64);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, t), E.sumA, (int)off_sA, (int)(vox * 4u), 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, t), E.sumB, (int)off_sB, (int)(vox * 4u), 0);
+        }
+    };
+
+    auto step = [&](auto RR, int pi, int z, long long n) __attribute__((always_inline)) {
+        constexpr int R = decltype(RR)::value;
+        constexpr int S_lo = (R + 2) % 3, S_mid = R, S_hi = (R + 1) % 3;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int abase = frag_lane + (int)(n & 1) * B3_PLANE;
+        const int wbase = st_lane + (int)((n + 1) & 1) * B3_PLANE;
+        const __amdgpu_buffer_rsrc_t rb1 = bits_rsrc_of(c1_pi), rb2 = bits_rsrc_of(c2_pi);
+        const unsigned z1 = (unsigned)c1_z, z2 = (unsigned)c2_z;
+        const bool ev = z >= 2 || (z == 0 && pi > 0);
+        const int pe = z >= 2 ? pi : pi - 1, zo = z >= 2 ? z - 2 : D - 1;
+        const Epi E = epi_setup(ev, pe, zo);
+        const bool has_mask = a.maskA != nullptr;
+
+        auto frag = [&](int j, int hx, f16x8 &bh, f16x8 &bl) __attribute__((always_inline)) {
+            const char *p = lds + abase + j * B3_ROW + hx * 256;
+            bh = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(p));
+            bl = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(p + B3_TEN));
+        };
+        f16x8 bh, bl, nh, nl;
+        frag(0, 0, bh, bl);
+        auto row = [&](auto J) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value;
+            if constexpr (j < 8) {
+                epi_row(IC<S_hi>{}, J, E, has_mask);
+                if constexpr ((j & 1) == 0) {      // staging unit j / 2 of the next plane; the unit after the next one goes out
+                    stage_unit(wbase, IC<j / 2>{});
+                    if constexpr (j / 2 + 2 < 4) load_unit(rb1, z1, IC<j / 2 + 2>{}); else load_unit(rb2, z2, IC<j / 2 + 2 - 4>{});
+                }
+            }
+#pragma unroll
+            for (int hx = 0; hx < 2; ++hx) {
+                if (hx == 0) frag(j, 1, nh, nl);
+                else if (j < 9) frag(j + 1, 0, nh, nl);
+#pragma unroll
+                for (int di = 0; di < 3; ++di) {
+                    const int i = j - di;
+                    if (i < 0 || i > 7) continue;
+#pragma unroll
+                    for (int dzi = 0; dzi < 3; ++dzi) {
+                        const int k = dzi * 3 + di;
+                        const int set = dzi == 0 ? S_hi : (dzi == 1 ? S_mid : S_lo);
+                        const bool start = dzi == 0 && di == 0;       // first contribution to (plane z + 1, row i, this half)
+                        f32x4 c = acc[set][i][hx];
+                        if (start) c = f32x4{0.f, 0.f, 0.f, 0.f};
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wl[k], bh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wh[k], bl, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wh[k], bh, c, 0, 0, 0);
+                        acc[set][i][hx] = c;
+                    }
+                }
+                bh = nh; bl = nl;
+            }
+        };
+        row(IC<0>{}); row(IC<1>{}); row(IC<2>{}); row(IC<3>{}); row(IC<4>{});
+        row(IC<5>{}); row(IC<6>{}); row(IC<7>{}); row(IC<8>{}); row(IC<9>{});
+        {   // the sign bytes of row 0 of the plane the next step finishes
+            const bool nv = z + 1 < D ? z >= 1 : true;
+            const int nzo = z + 1 < D ? z - 1 : D - 2;
+            const __amdgpu_buffer_rsrc_t mrs = rsrc_of(a.maskA, (long long)(b0 + pi * G) * (patch_v * 2u), (nv && a.maskA) ? patch_v * 2u : 0u);
+            mask_load(mrs, (unsigned)(nzo * 32 + wave * 8) * 32u, 0);
+        }
+        c1_pi = c2_pi; c1_z = c2_z;
+        advance(c2_pi, c2_z);
+    };
+    auto light = [&](auto S, int pe, int zo) __attribute__((always_inline)) {
+        constexpr int s = decltype(S)::value;
+        const Epi E = epi_setup(true, pe, zo);
+        const bool has_mask = a.maskA != nullptr;
+        auto rows = [&](auto I) __attribute__((always_inline)) { epi_row(S, I, E, has_mask); };
+        rows(IC<0>{}); rows(IC<1>{}); rows(IC<2>{}); rows(IC<3>{}); rows(IC<4>{}); rows(IC<5>{}); rows(IC<6>{}); rows(IC<7>{});
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { acc[s][i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[s][i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if (zo == D - 2) {      // plane D - 1 of the same patch is finished next
+            const __amdgpu_buffer_rsrc_t mrs = rsrc_of(a.maskA, (long long)(b0 + pe * G) * (patch_v * 2u), a.maskA ? patch_v * 2u : 0u);
+            mask_load(mrs, (unsigned)((D - 1) * 32 + wave * 8) * 32u, 0);
+        }
+    };
+
+    __syncthreads();
+    if (np > 0) {
+        const __amdgpu_buffer_rsrc_t rb = bits_rsrc_of(0);
+        const int wb = st_lane;
+        load_unit(rb, 0u, IC<0>{}); load_unit(rb, 0u, IC<1>{});
+        stage_unit(wb, IC<0>{}); stage_unit(wb, IC<1>{});
+        load_unit(rb, 0u, IC<2>{}); load_unit(rb, 0u, IC<3>{});
+        stage_unit(wb, IC<2>{}); stage_unit(wb, IC<3>{});
+        c1_pi = 0; c1_z = 0;
+        advance(c1_pi, c1_z);
+        c2_pi = c1_pi; c2_z = c1_z;
+        advance(c2_pi, c2_z);
+        const __amdgpu_buffer_rsrc_t rb1 = bits_rsrc_of(c1_pi);
+        load_unit(rb1, (unsigned)c1_z, IC<0>{}); load_unit(rb1, (unsigned)c1_z, IC<1>{});
+    }
+    long long n = 0;
+    for (int pi = 0; pi < np; ++pi) {
+        for (int zz = 0; zz < 11; ++zz) {
+            step(IC<0>{}, pi, 3 * zz, n); ++n;
+            step(IC<1>{}, pi, 3 * zz + 1, n); ++n;
+            if (zz < 10) { step(IC<2>{}, pi, 3 * zz + 2, n); ++n; }
+            else light(IC<0>{}, pi, D - 2);
+        }
+    }
+    if (np > 0) light(IC<1>{}, np - 1, D - 1);
+}
+
 // One MFMA on fp16 SUBNORMAL operands: 32 products 2^-20 * 2^10 per element -> 2^-5 when the matrix core keeps subnormal
 // inputs (gfx950 does), 0 when it flushes them.  The one-accumulator form relies on it for the low pieces of small values.
 __global__ void c3d_subnormal_probe(float *out) {
@@ -460,6 +715,80 @@ int c3d_fwd_launch(alq_ctx *ctx, const C3dPlan &plan, const View &in, const floa
     };
     if (fc_bits) ALQ_TRY(plan.oneacc ? go(c3d_fwd_kernel<true, true>) : go(c3d_fwd_kernel<true, false>));
     else ALQ_TRY(plan.oneacc ? go(c3d_fwd_kernel<false, true>) : go(c3d_fwd_kernel<false, false>));
+    ALQ_HIP(hipGetLastError());
+    return ALQ_OK;
+}
+
+// ---- backward ------------------------------------------------------------------------------------------------------------
+int c3d_bwd_build(const View &fwd_in, const View &fwd_out, const int k[3], const int lo[3], const int s[3], C3dPlan *plan) {
+    C3dPlan f;
+    ALQ_TRY(c3d_fwd_build(fwd_in, fwd_out, k, lo, s, &f));      // same geometry rules
+    plan->ok = f.ok;
+    plan->D = f.D;
+    plan->oneacc = 1;
+    plan->flops_per_patch = f.flops_per_patch;
+    return ALQ_OK;
+}
+
+// Bmat = the FORWARD conv's [(tap, ci)][co].  k-step (dzi, di) = input plane / row offsets (dzi - 1, di - 1) relative to the
+// output voxel, k-group kg = x offset kg - 1 (kg = 3: zero): the forward tap that links them is (2 - dzi, 2 - di, 2 - kg).
+// A-operand row i = output channel ci (0..15), elements c = the 8 channels co of the cotangent.
+void c3d_bwd_pack(C3dPlan *plan, const std::vector<float> &Bmat) {
+    float amax = 0.f;
+    for (float w : Bmat) amax = std::max(amax, std::fabs(w));
+    int ex = 0;
+    if (amax > 0.f) (void)std::frexp(amax, &ex);
+    plan->w_exp = 14 - ex;
+    plan->h_W.assign((size_t)9 * 2 * 64 * 8, 0);
+    for (int dzi = 0; dzi < 3; ++dzi)
+        for (int di = 0; di < 3; ++di)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int ci = lane & 15, kg = lane >> 4;
+                const int ks = dzi * 3 + di;
+                for (int c = 0; c < 8; ++c) {
+                    float w = 0.f;
+                    if (kg < 3) w = Bmat[((size_t)(((2 - dzi) * 3 + (2 - di)) * 3 + (2 - kg)) * 16 + ci) * 8 + c];
+                    const float ws = std::ldexp(w, plan->w_exp);
+                    const _Float16 h = (_Float16)ws;
+                    const _Float16 l = (_Float16)(ws - (float)h);
+                    unsigned short hb, lb;
+                    std::memcpy(&hb, &h, 2);
+                    std::memcpy(&lb, &l, 2);
+                    plan->h_W[((size_t)(ks * 2 + 0) * 64 + lane) * 8 + c] = hb;
+                    plan->h_W[((size_t)(ks * 2 + 1) * 64 + lane) * 8 + c] = lb;
+                }
+            }
+}
+
+// the head's weight difference as fp16 pairs at their true scale: per voxel (8 channels) [h8 | l8], x 2^e = h + l
+void c3d_presplit_vec(const float *v, long long F, int e, std::vector<unsigned short> *out) {
+    out->assign((size_t)F * 2, 0);
+    for (long long vox = 0; vox < F / 8; ++vox)
+        for (int c = 0; c < 8; ++c) {
+            const float xs = std::ldexp(v[vox * 8 + c], e);
+            const _Float16 h = (_Float16)xs;
+            const _Float16 l = (_Float16)(xs - (float)h);
+            unsigned short hb, lb;
+            std::memcpy(&hb, &h, 2);
+            std::memcpy(&lb, &l, 2);
+            (*out)[(size_t)vox * 16 + c] = hb;
+            (*out)[(size_t)vox * 16 + 8 + c] = lb;
+        }
+}
+
+int c3d_bwd_launch(alq_ctx *ctx, const C3dPlan &plan, int N, const unsigned char *bits, const void *vec16, int e_in, const unsigned char *maskA,
+                   float *dB, float *sumA, float *sumB) {
+    ALQ_REQUIRE(plan.ok && plan.d_W && plan.D == 32, ALQ_EINVAL, "c3d: backward weights not set");
+    ALQ_REQUIRE(bits && vec16 && dB && sumA && sumB, ALQ_EINVAL, "c3d: missing argument");
+    if (N <= 0) return ALQ_OK;
+    C3BwdArgs a;
+    a.bits = bits; a.vec = vec16; a.W = plan.d_W; a.maskA = maskA; a.dB = dB; a.sumA = sumA; a.sumB = sumB;
+    a.N = N; a.D = plan.D; a.e_in = e_in; a.e_w = plan.w_exp;
+    const unsigned grid = (unsigned)std::min(N, 256);
+    ProfScope ps(ctx, PROF_IGEMM_F16, plan.flops_per_patch * N);
+    auto kfn = c3d_bwd_kernel<true>;
+    ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS));
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), B3_LDS, ctx->stream, a);
     ALQ_HIP(hipGetLastError());
     return ALQ_OK;
 }

@@ -86,8 +86,10 @@ struct Layer {
     int fc_slices2 = 0;
     // plane-sweep engine (c3d.hip) for the conv under the fused two-class head (and its backward): plans on the conv layer,
     // per-(patch, wave) partials of the logit difference / of the head's input sum on the head layer
-    C3dPlan c3f;
+    C3dPlan c3f, c3b;
     float *c3_part = nullptr, *c3_asum = nullptr;
+    unsigned short *fc_wv16c = nullptr;    // fc_wv as fp16 pairs at their true scale, [voxel][h8 | l8] (c3d_presplit_vec), for c3b
+    const unsigned short *dout_vec16c = nullptr;   // set on the conv below for one backward pass, like dout_vec16
     const unsigned *dout_bits = nullptr;   // set on the conv below for the duration of one backward pass
     const float *dout_vec = nullptr;
     const unsigned *dout_vec16 = nullptr;
@@ -586,7 +588,10 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
             g4.OD = ly.out.D; g4.OH = ly.out.H; g4.OW = ly.out.W; g4.Co = sp.cout;
             for (int q = 0; q < 3; ++q) { g4.k[q] = sp.k[q]; g4.s[q] = sp.s[q]; g4.lo[q] = ly.lo[q]; }
             ALQ_TRY(gemm_build(d, NB, &ly.fwd[0], &g4));
-            if (!first_param && sp.relu) ALQ_TRY(c3d_fwd_build(ly.in, ly.out, sp.k, ly.lo, sp.s, &ly.c3f));
+            if (!first_param && sp.relu) {
+                ALQ_TRY(c3d_fwd_build(ly.in, ly.out, sp.k, ly.lo, sp.s, &ly.c3f));
+                ALQ_TRY(c3d_bwd_build(ly.in, ly.out, sp.k, ly.lo, sp.s, &ly.c3b));
+            }
             if (!first_param) {
                 ConvDesc b;
                 b.ID = ly.out.D; b.IH = ly.out.H; b.IW = ly.out.W; b.Ci = sp.cout;
@@ -695,6 +700,7 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
                         if (cv.c3f.ok && ly.F == (int64_t)cv.out.vox() * 8) {
                             ALQ_TRY(m->dalloc(&ly.c3_part, (size_t)NB * 4));
                             ALQ_TRY(m->dalloc(&ly.c3_asum, (size_t)NB * 4));
+                            if (cv.c3b.ok) ALQ_TRY(m->dalloc(&ly.fc_wv16c, (size_t)ly.F * 2));
                         }
                     }
                 }
@@ -1006,7 +1012,8 @@ static int run_backward_main(alq_model *m, const float *d_x, int N) {
     const int nl = (int)m->layers.size();
     ALQ_REQUIRE(m->nclass == 2, ALQ_EUNSUPPORTED, "Fisher scoring is binary (PW_NNAL.py:766), got %d classes", m->nclass);
     ALQ_TRY(k_fill_unit_cotangent(ctx, m->dlogits, N));
-    for (Layer &l : m->layers) { l.delta_ready = false; l.dsum_partial = false; l.dout_bits = nullptr; l.dout_vec = nullptr; l.dout_vec16 = nullptr; l.dout_amax = nullptr; }
+    for (Layer &l : m->layers) { l.delta_ready = false; l.dsum_partial = false; l.dout_bits = nullptr; l.dout_vec = nullptr; l.dout_vec16 = nullptr; l.dout_vec16c = nullptr; l.dout_amax = nullptr; }
+    m->last_c3_bwd = false;
     const bool v4_on = !g_dbg_knobs[4] && !g_dbg_knobs[5];
     {   // bounds on every layer's output cotangent under the unit cotangent (+1, -1): |d out| of the head = 1; a two-class
         // head hands max |W0 - W1| down, a conv / conv_transpose its L1 bound, a pool passes the bound on, a ReLU mask
@@ -1102,6 +1109,7 @@ static int run_backward_main(alq_model *m, const float *d_x, int N) {
                 prev->dout_bits = ly.fc_maskbits;
                 prev->dout_vec = ly.fc_wv;
                 prev->dout_vec16 = ly.fc_wv16;
+                prev->dout_vec16c = ly.fc_wv16c;
                 prev->dout_vec_amax = ly.spec.cout == 2 ? ly.fc_wv_amax : 0.f;
                 fused = true;
             } else if (ly.dense_fc_small) {
@@ -1143,9 +1151,23 @@ static int run_backward_main(alq_model *m, const float *d_x, int N) {
             if (ly.dout_bits) {       // the cotangent of this layer's output exists only as mask bits and one vector
                 fz.in_bits = ly.dout_bits; fz.in_vec = ly.dout_vec; fz.in_vec_amax = ly.dout_vec_amax;
                 fz.in_vec16 = m->no_presplit ? nullptr : ly.dout_vec16;
-                ly.dout_bits = nullptr; ly.dout_vec = nullptr; ly.dout_vec16 = nullptr;
+                const unsigned short *vec16c = ly.dout_vec16c;
+                ly.dout_bits = nullptr; ly.dout_vec = nullptr; ly.dout_vec16 = nullptr; ly.dout_vec16c = nullptr;
                 const bool honoured = fuse != nullptr;
-                ALQ_TRY(igemm4_launch(ctx, ly.bwd.p4, ly.dout, ly.din, nullptr, 0, acc, N, PROF_IGEMM3_BWD, &fz));
+                // the plane-sweep engine (c3d.hip): the NET-C pattern - channels 0..7 = the skip source (first conv, ReLU: masked by
+                // its sign field and only summed), channels 8..15 = a layer without ReLU (stored and summed)
+                const bool c3 = ly.c3b.ok && ly.c3b.d_W && vec16c && !m->no_c3d && !g_no_f16x2 && fuse && !acc && fz.in_vec_amax > 0.f &&
+                                fz.split == 8 && fz.store_from == 8 && fz.mask_bits && fz.mask_from == 0 && fz.mask_to == 8 && fz.osumA && fz.osumB &&
+                                ly.din.split == 8 && ly.din.cs == 8 && ly.din.C == 16;
+                m->last_c3_bwd = c3;
+                if (c3) {
+                    int ex = 0;
+                    (void)std::frexp(fz.in_vec_amax, &ex);
+                    ALQ_TRY(c3d_bwd_launch(ctx, ly.c3b, N, reinterpret_cast<const unsigned char *>(fz.in_bits), vec16c, 14 - ex, fz.mask_bits,
+                                           ly.din.p + ly.din.delta, fz.osumA, fz.osumB));
+                } else {
+                    ALQ_TRY(igemm4_launch(ctx, ly.bwd.p4, ly.dout, ly.din, nullptr, 0, acc, N, PROF_IGEMM3_BWD, &fz));
+                }
                 fused = honoured;
             } else {
                 // Hand the per-patch maxima of what this launch stores to the backward launch below it when that one has
@@ -1588,6 +1610,14 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
             ALQ_HIP(hipMemcpyAsync(dw, ly.c3f.h_W.data(), ly.c3f.h_W.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
             ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
         }
+        if (ly.c3b.ok && ly.has_bwd && c3d_subnormals_ok(m->ctx)) {      // (the backward kernel exists in the one-accumulator form only)
+            c3d_bwd_pack(&ly.c3b, B);
+            unsigned short *dw = reinterpret_cast<unsigned short *>(ly.c3b.d_W);
+            if (!dw) ALQ_TRY(m->dalloc(&dw, ly.c3b.h_W.size()));
+            ly.c3b.d_W = dw;
+            ALQ_HIP(hipMemcpyAsync(dw, ly.c3b.h_W.data(), ly.c3b.h_W.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
+            ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
+        }
         if (ly.has_bwd) {
             std::vector<float> Bb((size_t)ntaps * Co * Ci);
             for (int tp = 0; tp < ntaps; ++tp)
@@ -1668,6 +1698,12 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
                     }
                     ALQ_HIP(hipMemcpyAsync(ly.fc_wv16, sp.data(), sp.size() * sizeof(unsigned), hipMemcpyHostToDevice, m->ctx->stream));
                     ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
+                    if (ly.fc_wv16c && F % 8 == 0) {      // the same scale, pieces at their true scale, per voxel [h8 | l8] (plane-sweep backward)
+                        std::vector<unsigned short> sc;
+                        c3d_presplit_vec(wv.data(), F, e, &sc);
+                        ALQ_HIP(hipMemcpyAsync(ly.fc_wv16c, sc.data(), sc.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
+                        ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
+                    }
                 }
             }
             ALQ_HIP(hipMemcpyAsync(ly.d_Wp, Wp.data(), Wp.size() * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));

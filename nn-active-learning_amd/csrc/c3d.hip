@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int lr = lane & 15, lq = lane >> 4;
     const int D = a.D;
     const unsigned plane_f = 32u * 32u * 8u;                 // floats per plane of one 8-channel tensor
-    const unsigned patch_bytes = (unsigned)D * plane_f * 4u;
+    const unsigned patch_f = (unsigned)D * plane_f;
 
     for (int i = tid * 16; i < C3_LDS; i += 256 * 16) *reinterpret_cast<i32x4 *>(lds + i) = i32x4{0, 0, 0, 0};
 
@@ -90,8 +90,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             Wh[k] = __builtin_bit_cast(f16x8, Wg[(k * 2 + 0) * 64 + lane]);
             Wl[k] = __builtin_bit_cast(f16x8, Wg[(k * 2 + 1) * 64 + lane]);
         }
+        // Start the weights' lives in ACCUMULATION registers: only MFMAs read them, and with them (144) + the accumulators (96)
+        // in the AGPR half the 256 architectural VGPRs are left to the staging / epilogue arithmetic.  Left to itself the
+        // allocator keeps half of them in VGPRs, fills that half and spills - and a scratch reload inside the sweep waits
+        // for every staging load in flight (vmcnt retires in order).
+#ifndef C3_NO_PIN
+#pragma unroll
+        for (int k = 0; k < 18; ++k) {
+            i32x4 h = __builtin_bit_cast(i32x4, Wh[k]), l = __builtin_bit_cast(i32x4, Wl[k]);
+            asm volatile("" : "+a"(h), "+a"(l));
+            Wh[k] = __builtin_bit_cast(f16x8, h); Wl[k] = __builtin_bit_cast(f16x8, l);
+        }
+#endif
     }
-    f32x4 bias4 = *reinterpret_cast<const f32x4 *>(a.bias + (lq & 1) * 4);
+    const f32x4 bias4 = *reinterpret_cast<const f32x4 *>(a.bias + (lq & 1) * 4);
 
     // fragment reads (B operand: columns = 16 x-pairs r, k-group (t, p) = (tensor, x parity)): slot 2 r + p (+ 2 s)
     const int frag_lane = (lq >> 1) * C3_TEN + (2 * lr + (lq & 1)) * 16 + wave * 8 * C3_ROW;
@@ -102,7 +114,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     const int G = gridDim.x, b0 = blockIdx.x;
     const int np = b0 < a.N ? (a.N - b0 + G - 1) / G : 0;
-    const long long nplanes = (long long)np * D;
 
     f32x4 acc[3][8], accx[3][ONEACC ? 1 : 8];
 #pragma unroll
@@ -116,17 +127,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int ex = (int)((fm >> 23) & 255u) - 126;
         return fm ? 14 - ex : 0;
     };
-    auto rsrc_of = [&](const void *base, long long off, unsigned bytes) __attribute__((always_inline)) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(base)) + off, 0, (int)bytes, 0x00020000);
+    // ONE buffer resource per array for the whole launch: the patch goes into the scalar offset (not range-checked by the
+    // hardware), a lane with nothing to load or store aims past the array through its VECTOR offset (loads return 0, stores
+    // are dropped).  N <= 2047 patches keep every byte offset below 2^32 (the host checks).
+    auto rsrc_of = [&](const void *base, unsigned long long bytes) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)(unsigned)bytes, 0x00020000);
     };
+    const unsigned OOB = 0xffffff00u;
+    const __amdgpu_buffer_rsrc_t inA_rsrc = rsrc_of(a.inA, (unsigned long long)a.N * patch_f * 4u);
+    const __amdgpu_buffer_rsrc_t inB_rsrc = rsrc_of(a.inB, (unsigned long long)a.N * patch_f * 4u);
+    const __amdgpu_buffer_rsrc_t wd_rsrc = rsrc_of(a.fc_W, (unsigned long long)patch_f * 4u);
+    const __amdgpu_buffer_rsrc_t bits_rsrc = rsrc_of(a.fc_bits, (SUMS && a.fc_bits) ? (unsigned long long)a.N * patch_f : 0ull);
+    auto patch_of = [&](int pi) __attribute__((always_inline)) { return (unsigned)(b0 + pi * G); };
 
-    // ---- staging: plane `cz` of patch `cp` (ordinal cn in this workgroup's plane stream) -> image cn & 1 -----------
-    // unit u = 0..15: row 8 w + (u >> 1), tensor u & 1: 1 KB of fp32 per wave instruction, 16 bytes per lane
-    f32x4 R4[4];
+    // ---- staging: unit u = 0..15 of a plane: row 8 w + (u >> 1), tensor u & 1: 1 KB of fp32 per wave instruction ------------
+    // eight units in flight (HBM latency under load is ~2 us = half a step)
+    f32x4 R4[8];
     float sc = 1.f, sc11 = 2048.f;
     auto stage_unit = [&](int wbase, auto U) __attribute__((always_inline)) {
         constexpr int u = decltype(U)::value;
-        const f32x4 v = R4[u & 3];
+        const f32x4 v = R4[u & 7];
         const float x0 = v.x * sc, x1 = v.y * sc, x2 = v.z * sc, x3 = v.w * sc;
         const f16x2 h01 = __builtin_convertvector(f32x2{x0, x1}, f16x2);
         const f16x2 h23 = __builtin_convertvector(f32x2{x2, x3}, f16x2);
@@ -143,57 +163,75 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         *reinterpret_cast<uint2 *>(dst) = uint2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
         *reinterpret_cast<uint2 *>(dst + C3_PIECE) = uint2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
     };
-    auto load_unit = [&](__amdgpu_buffer_rsrc_t rA, __amdgpu_buffer_rsrc_t rB, unsigned zoff, auto U) __attribute__((always_inline)) {
+    // voff = lane * 16 or OOB (no such plane), soff = byte offset of row 8 w of the plane inside the array
+    auto load_unit = [&](unsigned voff, unsigned soff, auto U) __attribute__((always_inline)) {
         constexpr int u = decltype(U)::value;
-        R4[u & 3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((u & 1) ? rB : rA, lane * 16,
-                                                                                    (int)(zoff + (unsigned)((wave * 8 + (u >> 1)) * 1024)), 0));
+        R4[u & 7] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((u & 1) ? inB_rsrc : inA_rsrc, (int)voff, (int)(soff + (unsigned)(u >> 1) * 1024u), 0));
     };
-
-    // plane stream cursors: c1 = the plane staged by the running step, c2 = the one after it (its first 4 loads go out early)
-    int c1_pi = 0, c1_z = 0, c2_pi = 0, c2_z = 0;
-    auto cur_rsrc = [&](int pi, int z, __amdgpu_buffer_rsrc_t *rA, __amdgpu_buffer_rsrc_t *rB, unsigned *zoff) __attribute__((always_inline)) {
+    struct Cur { unsigned voff, soff; };
+    auto cursor = [&](int pi, int z) __attribute__((always_inline)) {
+        Cur c;
         const bool ok = pi < np;
-        const long long off = ok ? (long long)(b0 + pi * G) * patch_bytes : 0;
-        *rA = rsrc_of(a.inA, off, ok ? patch_bytes : 0u);
-        *rB = rsrc_of(a.inB, off, ok ? patch_bytes : 0u);
-        *zoff = (unsigned)z * plane_f * 4u;
+        c.voff = ok ? (unsigned)lane * 16u : OOB;
+        c.soff = ok ? (patch_of(pi) * patch_f + (unsigned)z * plane_f) * 4u + (unsigned)(wave * 8) * 1024u : 0u;
+        return c;
     };
+    // plane stream cursors: c1 = the plane staged by the running step, c2 = the one after it (its first 8 loads go out early)
+    int c1_pi = 0, c1_z = 0, c2_pi = 0, c2_z = 0;
     auto advance = [&](int &pi, int &z) __attribute__((always_inline)) { if (++z == D) { z = 0; ++pi; } };
 
     float fs = 0.f, sa = 0.f;       // running logit-difference partial / sum of the ReLU'd output of the patch in the epilogue
-    f32x4 wd_next = f32x4{0.f, 0.f, 0.f, 0.f};
-    const __amdgpu_buffer_rsrc_t wd_rsrc = rsrc_of(a.fc_W, 0, patch_bytes);
+    f32x4 wdq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};      // the head's weight difference, fetched two rows ahead
+
+    // epilogue constants of a finished plane (patch ordinal pe, plane zo); !valid: inv = 0, zero bias and lane offsets past the
+    // arrays turn the epilogue of a step without a finished plane into a no-op
+    struct Epi { float inv; f32x4 b4; float tau; unsigned off_w, off_b, row_f, bits_s; };
+    auto epi_setup = [&](bool valid, int pe, int zo) __attribute__((always_inline)) {
+        Epi e;
+        const int p = valid ? (int)patch_of(pe) : 0;
+        const int ce = valid ? patch_exp(p) : 0;
+        e.inv = valid ? __builtin_ldexpf(1.f, -(ce + a.e_w)) : 0.f;
+        e.b4 = valid ? bias4 : f32x4{0.f, 0.f, 0.f, 0.f};
+        e.tau = valid ? __builtin_ldexpf(a.flip_tau, 14 - ce) : 0.f;
+        e.off_w = valid ? epi_lane_f * 4u : OOB;
+        e.off_b = valid ? (epi_lane_f >> 2) : OOB;
+        e.row_f = (unsigned)(zo * 32 + wave * 8) * 256u;       // float offset of row 8 w of that plane inside the patch
+        e.bits_s = (unsigned)p * (patch_f >> 2);
+        return e;
+    };
+    auto wd_load = [&](const Epi &E, auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+        wdq[i & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wd_rsrc, (int)E.off_w, (int)((E.row_f + (unsigned)i * 256u) * 4u), 0));
+    };
 
     // ---- epilogue of one finished x row (plane zo, row 8 w + i) of accumulator set S -------------------------------
-    // inv = 0 and a zero-sized sign buffer turn it into a no-op (steps without a finished plane)
-    auto epi_row = [&](auto S, auto I, float inv, f32x4 b4, float tau, __amdgpu_buffer_rsrc_t bits_rsrc, __amdgpu_buffer_rsrc_t wdr, unsigned row_f) __attribute__((always_inline)) {
+    auto epi_row = [&](auto S, auto I, const Epi &E) __attribute__((always_inline)) {
         constexpr int s = decltype(S)::value, i = decltype(I)::value;
-        const f32x4 w4 = wd_next;
-        if constexpr (i < 7)         // the next row's slice of the head's weight difference: its L2 latency behind this row's work
-            wd_next = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wdr, (int)(epi_lane_f * 4u), (int)((row_f + (unsigned)(i + 1) * 256u) * 4u), 0));
+        const f32x4 w4 = wdq[i & 1];
+        if constexpr (i + 2 < 8) wd_load(E, IC<i + 2>{});       // two rows ahead: its L2 latency behind ~100 MFMAs
         const f32x4 c = acc[s][i];
         f32x4 val;
         if constexpr (ONEACC) {
-            val.x = __builtin_fmaf(c.x, inv, b4.x); val.y = __builtin_fmaf(c.y, inv, b4.y);
-            val.z = __builtin_fmaf(c.z, inv, b4.z); val.w = __builtin_fmaf(c.w, inv, b4.w);
+            val.x = __builtin_fmaf(c.x, E.inv, E.b4.x); val.y = __builtin_fmaf(c.y, E.inv, E.b4.y);
+            val.z = __builtin_fmaf(c.z, E.inv, E.b4.z); val.w = __builtin_fmaf(c.w, E.inv, E.b4.w);
         } else {
             const f32x4 d = accx[s][i];
-            val.x = __builtin_fmaf(__builtin_fmaf(d.x, 0x1p-11f, c.x), inv, b4.x);
-            val.y = __builtin_fmaf(__builtin_fmaf(d.y, 0x1p-11f, c.y), inv, b4.y);
-            val.z = __builtin_fmaf(__builtin_fmaf(d.z, 0x1p-11f, c.z), inv, b4.z);
-            val.w = __builtin_fmaf(__builtin_fmaf(d.w, 0x1p-11f, c.w), inv, b4.w);
+            val.x = __builtin_fmaf(__builtin_fmaf(d.x, 0x1p-11f, c.x), E.inv, E.b4.x);
+            val.y = __builtin_fmaf(__builtin_fmaf(d.y, 0x1p-11f, c.y), E.inv, E.b4.y);
+            val.z = __builtin_fmaf(__builtin_fmaf(d.z, 0x1p-11f, c.z), E.inv, E.b4.z);
+            val.w = __builtin_fmaf(__builtin_fmaf(d.w, 0x1p-11f, c.w), E.inv, E.b4.w);
         }
         unsigned unsure = 0u;
         if constexpr (SUMS) {
             const float mn = fminf(fminf(__builtin_fabsf(val.x), __builtin_fabsf(val.y)), fminf(__builtin_fabsf(val.z), __builtin_fabsf(val.w)));
-            unsure = mn < tau ? 16u : 0u;
+            unsure = mn < E.tau ? 16u : 0u;
         }
         val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f);
         fs += __builtin_fmaf(val.y, w4.y, val.x * w4.x) + __builtin_fmaf(val.w, w4.w, val.z * w4.z);
         if constexpr (SUMS) {
             sa += (val.x + val.y) + (val.z + val.w);
             const unsigned nib = (val.x > 0.f ? 1u : 0u) | (val.y > 0.f ? 2u : 0u) | (val.z > 0.f ? 4u : 0u) | (val.w > 0.f ? 8u : 0u) | unsure;
-            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)nib, bits_rsrc, (int)(epi_lane_f >> 2), (int)((row_f + (unsigned)i * 256u) >> 2), 0);
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)nib, bits_rsrc, (int)E.off_b, (int)(E.bits_s + ((E.row_f + (unsigned)i * 256u) >> 2)), 0);
         }
     };
     auto wave_sum = [&](float x) __attribute__((always_inline)) {
@@ -216,27 +254,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         fs = 0.f; sa = 0.f;
     };
-    // epilogue constants of (patch ordinal pe, plane zo), valid = there is such a finished plane
-    struct Epi { float inv; f32x4 b4; float tau; __amdgpu_buffer_rsrc_t bits, wd; unsigned row_f; };
-    auto epi_setup = [&](bool valid, int pe, int zo) __attribute__((always_inline)) {
-        Epi e;
-        const int p = valid ? b0 + pe * G : 0;
-        const int ce = valid ? patch_exp(p) : 0;
-        e.wd = rsrc_of(a.fc_W, 0, valid ? patch_bytes : 0u);       // an empty buffer: the loads of a step without a finished plane return 0
-        e.inv = valid ? __builtin_ldexpf(1.f, -(ce + a.e_w)) : 0.f;
-        e.b4 = valid ? bias4 : f32x4{0.f, 0.f, 0.f, 0.f};
-        e.tau = valid ? __builtin_ldexpf(a.flip_tau, 14 - ce) : 0.f;
-        e.bits = rsrc_of(a.fc_bits, (long long)p * (patch_bytes >> 4), (valid && SUMS && a.fc_bits) ? (patch_bytes >> 4) : 0u);
-        e.row_f = (unsigned)(zo * 32 + wave * 8) * 256u;       // float offset of row 8 w of that plane inside the patch
-        return e;
-    };
-    // the head's weight difference for row 0 of the plane the NEXT step finishes (the same vector for every patch): issued at
-    // the end of a step so that its L2 latency is not met at the top of the next one; rows 1..7 are fetched a row ahead
-    auto prefetch_wd = [&](bool valid, int zo) __attribute__((always_inline)) {
-        const unsigned row_f = (unsigned)(zo * 32 + wave * 8) * 256u;
-        wd_next = valid ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wd_rsrc, (int)(epi_lane_f * 4u), (int)(row_f * 4u), 0))
-                        : f32x4{0.f, 0.f, 0.f, 0.f};
-    };
 
     // ---- one step: input plane z of patch ordinal pi (plane ordinal n), rotation R = z mod 3 ------------------------
     // sets: zo = z - 1 -> (R + 2) % 3, zo = z -> R, zo = z + 1 -> (R + 1) % 3 (restarted row by row, after the epilogue of the
@@ -248,12 +265,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const int abase = frag_lane + (int)(n & 1) * C3_PLANE;
         const int wbase = st_lane + (int)((n + 1) & 1) * C3_PLANE;
-        __amdgpu_buffer_rsrc_t rA1, rB1, rA2, rB2;
-        unsigned zo1, zo2;
-        cur_rsrc(c1_pi, c1_z, &rA1, &rB1, &zo1);
-        cur_rsrc(c2_pi, c2_z, &rA2, &rB2, &zo2);
+        const Cur C1 = cursor(c1_pi, c1_z), C2 = cursor(c2_pi, c2_z);
         {
-            const int ce = c1_pi < np ? patch_exp(b0 + c1_pi * G) : 0;
+            const int ce = c1_pi < np ? patch_exp((int)patch_of(c1_pi)) : 0;
             sc = __builtin_ldexpf(1.f, ce); sc11 = __builtin_ldexpf(1.f, ce + 11);
         }
         // finished plane: z - 2 of this patch, or plane D - 1 of the previous one at z = 0 (D - 2 is done by the light step)
@@ -271,11 +285,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             constexpr int j = decltype(J)::value;
             if constexpr (j < 8) {
                 // row j of the plane finished two steps ago, then (below) its accumulators restart for plane z + 1
-                epi_row(IC<S_hi>{}, J, E.inv, E.b4, E.tau, E.bits, E.wd, E.row_f);
+                epi_row(IC<S_hi>{}, J, E);
                 stage_unit(wbase, IC<2 * j>{});
-                if constexpr (2 * j + 4 < 16) load_unit(rA1, rB1, zo1, IC<2 * j + 4>{}); else load_unit(rA2, rB2, zo2, IC<2 * j + 4 - 16>{});
+                if constexpr (2 * j + 8 < 16) load_unit(C1.voff, C1.soff, IC<2 * j + 8>{}); else load_unit(C2.voff, C2.soff, IC<2 * j + 8 - 16>{});
                 stage_unit(wbase, IC<2 * j + 1>{});
-                if constexpr (2 * j + 5 < 16) load_unit(rA1, rB1, zo1, IC<2 * j + 5>{}); else load_unit(rA2, rB2, zo2, IC<2 * j + 5 - 16>{});
+                if constexpr (2 * j + 9 < 16) load_unit(C1.voff, C1.soff, IC<2 * j + 9>{}); else load_unit(C2.voff, C2.soff, IC<2 * j + 9 - 16>{});
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -313,9 +327,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         };
         row(IC<0>{}); row(IC<1>{}); row(IC<2>{}); row(IC<3>{}); row(IC<4>{});
         row(IC<5>{}); row(IC<6>{}); row(IC<7>{}); row(IC<8>{}); row(IC<9>{});
-        // what the next step finishes: plane z - 1 (z + 1 < D), or plane D - 2 in the light step behind z = D - 1
-        prefetch_wd(z + 1 < D ? z >= 1 : true, z + 1 < D ? z - 1 : D - 2);
-        if constexpr (R == 0) { if (z == 0 && pi > 0) finish_patch(b0 + (pi - 1) * G); }
+        {   // the weight difference for rows 0 and 1 of the plane the next step finishes: plane z - 1 (z + 1 < D), or plane D - 2 in
+            // the light step behind z = D - 1 (the vector is the same for every patch)
+            const Epi En = epi_setup(z + 1 < D ? z >= 1 : true, pi, z + 1 < D ? z - 1 : D - 2);
+            wd_load(En, IC<0>{});
+            wd_load(En, IC<1>{});
+        }
+        if constexpr (R == 0) { if (z == 0 && pi > 0) finish_patch((int)patch_of(pi - 1)); }
         c1_pi = c2_pi; c1_z = c2_z;
         advance(c2_pi, c2_z);
     };
@@ -324,34 +342,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto light = [&](auto S, int pe, int zo) __attribute__((always_inline)) {
         constexpr int s = decltype(S)::value;
         const Epi E = epi_setup(true, pe, zo);
-        auto rows = [&](auto I) __attribute__((always_inline)) { epi_row(S, I, E.inv, E.b4, E.tau, E.bits, E.wd, E.row_f); };
+        auto rows = [&](auto I) __attribute__((always_inline)) { epi_row(S, I, E); };
         rows(IC<0>{}); rows(IC<1>{}); rows(IC<2>{}); rows(IC<3>{}); rows(IC<4>{}); rows(IC<5>{}); rows(IC<6>{}); rows(IC<7>{});
 #pragma unroll
         for (int i = 0; i < 8; ++i) { acc[s][i] = f32x4{0.f, 0.f, 0.f, 0.f}; if constexpr (!ONEACC) accx[s][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        prefetch_wd(zo == D - 2, D - 1);      // plane D - 1 is finished next (step 0 of the next patch, or the final light step)
+        {   // plane D - 1 is finished next (step 0 of the next patch, or the final light step); nothing after that one
+            const Epi En = epi_setup(zo == D - 2, pe, D - 1);
+            wd_load(En, IC<0>{});
+            wd_load(En, IC<1>{});
+        }
     };
 
-    // ---- prologue: plane 0 of the first patch, synchronously; the first 4 loads of plane 1 in flight ------------------
+    // ---- prologue: plane 0 of the first patch, synchronously; the first 8 loads of plane 1 in flight ------------------
     __syncthreads();       // the zero fill
     if (np > 0) {
-        __amdgpu_buffer_rsrc_t rA, rB;
-        unsigned zo;
-        cur_rsrc(0, 0, &rA, &rB, &zo);
-        const int ce = patch_exp(b0);
+        const Cur C0 = cursor(0, 0);
+        const int ce = patch_exp((int)patch_of(0));
         sc = __builtin_ldexpf(1.f, ce); sc11 = __builtin_ldexpf(1.f, ce + 11);
         const int wb = st_lane;       // image 0
-        auto four = [&](auto U0) __attribute__((always_inline)) {
+        auto eight = [&](auto U0) __attribute__((always_inline)) {
             constexpr int u0 = decltype(U0)::value;
-            load_unit(rA, rB, zo, IC<u0>{}); load_unit(rA, rB, zo, IC<u0 + 1>{}); load_unit(rA, rB, zo, IC<u0 + 2>{}); load_unit(rA, rB, zo, IC<u0 + 3>{});
+            load_unit(C0.voff, C0.soff, IC<u0>{}); load_unit(C0.voff, C0.soff, IC<u0 + 1>{}); load_unit(C0.voff, C0.soff, IC<u0 + 2>{}); load_unit(C0.voff, C0.soff, IC<u0 + 3>{});
+            load_unit(C0.voff, C0.soff, IC<u0 + 4>{}); load_unit(C0.voff, C0.soff, IC<u0 + 5>{}); load_unit(C0.voff, C0.soff, IC<u0 + 6>{}); load_unit(C0.voff, C0.soff, IC<u0 + 7>{});
             stage_unit(wb, IC<u0>{}); stage_unit(wb, IC<u0 + 1>{}); stage_unit(wb, IC<u0 + 2>{}); stage_unit(wb, IC<u0 + 3>{});
+            stage_unit(wb, IC<u0 + 4>{}); stage_unit(wb, IC<u0 + 5>{}); stage_unit(wb, IC<u0 + 6>{}); stage_unit(wb, IC<u0 + 7>{});
         };
-        four(IC<0>{}); four(IC<4>{}); four(IC<8>{}); four(IC<12>{});
+        eight(IC<0>{}); eight(IC<8>{});
         c1_pi = 0; c1_z = 0;
         advance(c1_pi, c1_z);          // plane 1
         c2_pi = c1_pi; c2_z = c1_z;
         advance(c2_pi, c2_z);          // plane 2
-        cur_rsrc(c1_pi, c1_z, &rA, &rB, &zo);
-        load_unit(rA, rB, zo, IC<0>{}); load_unit(rA, rB, zo, IC<1>{}); load_unit(rA, rB, zo, IC<2>{}); load_unit(rA, rB, zo, IC<3>{});
+        const Cur C1 = cursor(c1_pi, c1_z);
+        load_unit(C1.voff, C1.soff, IC<0>{}); load_unit(C1.voff, C1.soff, IC<1>{}); load_unit(C1.voff, C1.soff, IC<2>{}); load_unit(C1.voff, C1.soff, IC<3>{});
+        load_unit(C1.voff, C1.soff, IC<4>{}); load_unit(C1.voff, C1.soff, IC<5>{}); load_unit(C1.voff, C1.soff, IC<6>{}); load_unit(C1.voff, C1.soff, IC<7>{});
     }
 
     // D = 32: 33 = 3 * 11 steps per patch (the last one light), so the set rotation restarts at every patch
@@ -366,9 +389,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     if (np > 0) {
         light(IC<1>{}, np - 1, D - 1);
-        finish_patch(b0 + (np - 1) * G);
+        finish_patch((int)patch_of(np - 1));
     }
-    (void)nplanes;
 }
 
 // ======================================================================================================================
@@ -407,6 +429,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int D = a.D;
     const unsigned plane_v = 32u * 32u;                      // voxels per plane
     const unsigned patch_v = (unsigned)D * plane_v;
+    static_assert(ONEACC, "the backward kernel is built for the one-accumulator form");
 
     for (int i = tid * 16; i < B3_LDS; i += 256 * 16) *reinterpret_cast<i32x4 *>(lds + i) = i32x4{0, 0, 0, 0};
 
@@ -418,6 +441,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             Wh[k] = __builtin_bit_cast(f16x8, Wg[(k * 2 + 0) * 64 + lane]);
             Wl[k] = __builtin_bit_cast(f16x8, Wg[(k * 2 + 1) * 64 + lane]);
         }
+        // the weights start their lives in accumulation registers (see the forward kernel): 192 accumulators + 16 of the 18
+        // fragments fill the AGPR half, the last two stay in VGPRs
+#ifndef C3_NO_PIN
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            i32x4 h = __builtin_bit_cast(i32x4, Wh[k]), l = __builtin_bit_cast(i32x4, Wl[k]);
+            asm volatile("" : "+a"(h), "+a"(l));
+            Wh[k] = __builtin_bit_cast(f16x8, h); Wl[k] = __builtin_bit_cast(f16x8, l);
+        }
+#endif
     }
     // fragment reads: column j = voxel 16 hx + j, k-group kg = x offset kg - 1 (group 3 has zero weights: it re-reads group 2's slot)
     const int frag_lane = (lj + (lq < 2 ? lq : 2)) * 16 + wave * 8 * B3_ROW;
@@ -434,21 +467,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int s = 0; s < 3; ++s)
 #pragma unroll
         for (int i = 0; i < 8; ++i) { acc[s][i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[s][i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    static_assert(ONEACC, "the backward kernel is built for the one-accumulator form");
 
-    auto rsrc_of = [&](const void *base, long long off, unsigned bytes) __attribute__((always_inline)) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(base)) + off, 0, (int)bytes, 0x00020000);
+    // ONE buffer resource per array for the whole launch (no per-step descriptor building, few scalar registers): the patch
+    // goes into the scalar offset - which the hardware does not range-check - and a lane with nothing to load or store aims
+    // past the array through its VECTOR offset (loads then return 0, stores are dropped).  N <= 2047 patches keep every
+    // offset below 2^32 (the host checks).
+    auto rsrc_of = [&](const void *base, unsigned long long bytes) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)(unsigned)bytes, 0x00020000);
     };
-    const __amdgpu_buffer_rsrc_t vec_rsrc = rsrc_of(a.vec, 0, patch_v * 32u);
+    const unsigned OOB = 0xffffff00u;
+    const __amdgpu_buffer_rsrc_t vec_rsrc = rsrc_of(a.vec, (unsigned long long)patch_v * 32u);
+    const __amdgpu_buffer_rsrc_t bits_rsrc = rsrc_of(a.bits, (unsigned long long)a.N * patch_v * 2u);
+    const __amdgpu_buffer_rsrc_t mask_rsrc = rsrc_of(a.maskA, a.maskA ? (unsigned long long)a.N * patch_v * 2u : 0ull);
+    const __amdgpu_buffer_rsrc_t dB_rsrc = rsrc_of(a.dB, (unsigned long long)a.N * patch_v * 32u);
+    const __amdgpu_buffer_rsrc_t sA_rsrc = rsrc_of(a.sumA, (unsigned long long)a.N * patch_v * 4u);
+    const __amdgpu_buffer_rsrc_t sB_rsrc = rsrc_of(a.sumB, (unsigned long long)a.N * patch_v * 4u);
 
     // ---- staging unit u = 0..3 of a plane: rows 8 w + 2 u, 8 w + 2 u + 1 ---------------------------------------------------
     i32x4 Vh[2], Vl[2];
     unsigned Sb[2];
-    auto load_unit = [&](__amdgpu_buffer_rsrc_t rbits, unsigned z, auto U) __attribute__((always_inline)) {
+    auto load_unit = [&](unsigned bits_v, unsigned bits_s, unsigned z, auto U) __attribute__((always_inline)) {
         constexpr int u = decltype(U)::value;
         Vh[u & 1] = __builtin_amdgcn_raw_buffer_load_b128(vec_rsrc, (int)(st_vox * 32u), (int)((z * plane_v + (unsigned)u * 64u) * 32u), 0);
         Vl[u & 1] = __builtin_amdgcn_raw_buffer_load_b128(vec_rsrc, (int)(st_vox * 32u + 16u), (int)((z * plane_v + (unsigned)u * 64u) * 32u), 0);
-        Sb[u & 1] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rbits, (int)(st_vox * 2u), (int)((z * plane_v + (unsigned)u * 64u) * 2u), 0);
+        Sb[u & 1] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(bits_rsrc, (int)bits_v, (int)(bits_s + (z * plane_v + (unsigned)u * 64u) * 2u), 0);
     };
     auto stage_unit = [&](int wbase, auto U) __attribute__((always_inline)) {
         constexpr int u = decltype(U)::value;
@@ -466,59 +508,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
 
     int c1_pi = 0, c1_z = 0, c2_pi = 0, c2_z = 0;
-    auto bits_rsrc_of = [&](int pi) __attribute__((always_inline)) {
-        const bool ok = pi < np;
-        return rsrc_of(a.bits, ok ? (long long)(b0 + pi * G) * (patch_v * 2u) : 0, ok ? patch_v * 2u : 0u);
-    };
     auto advance = [&](int &pi, int &z) __attribute__((always_inline)) { if (++z == D) { z = 0; ++pi; } };
+    auto patch_of = [&](int pi) __attribute__((always_inline)) { return (unsigned)(b0 + pi * G); };
 
     // ---- epilogue of one finished x row (plane zo, row 8 w + i) of set S: both halves --------------------------------------
     // lane (j, q): channels 4 q .. 4 q + 3 of voxel 16 hx + j; q < 2: masked + summed, q >= 2: stored + summed
-    unsigned mk_next[2] = {0u, 0u};
-    struct Epi { __amdgpu_buffer_rsrc_t mask, dB, sumA, sumB; unsigned row_v; float inv; };
+    unsigned mkq[2][2] = {{0u, 0u}, {0u, 0u}};      // sign bytes of the masked half, fetched two rows ahead: [row parity][hx]
+    struct Epi { unsigned pv; unsigned row_v; float inv; unsigned off_mask, off_dB, off_sum; };
     auto epi_setup = [&](bool valid, int pe, int zo) __attribute__((always_inline)) {
         Epi e;
-        const long long p = valid ? b0 + pe * G : 0;
-        e.mask = rsrc_of(a.maskA, p * (patch_v * 2u), (valid && a.maskA) ? patch_v * 2u : 0u);
-        e.dB = rsrc_of(a.dB, p * (patch_v * 32u), valid ? patch_v * 32u : 0u);
-        e.sumA = rsrc_of(a.sumA, p * (patch_v * 4u), valid ? patch_v * 4u : 0u);
-        e.sumB = rsrc_of(a.sumB, p * (patch_v * 4u), valid ? patch_v * 4u : 0u);
+        e.pv = valid ? patch_of(pe) * patch_v : 0u;          // first voxel of the patch in the batch
         e.row_v = (unsigned)(zo * 32 + wave * 8) * 32u;
         e.inv = valid ? inv : 0.f;
+        // lane offsets; an invalid step (no finished plane) sends every access past the arrays
+        e.off_mask = (valid && lq < 2) ? (unsigned)(lj * 2 + lq) : OOB;
+        e.off_dB = (valid && lq >= 2) ? (unsigned)lj * 32u + (unsigned)(lq - 2) * 16u : OOB;
+        // sums: after the cross-row add, lanes q = 0 / 1 hold the masked half's sum of half row 0 / 1 (x = j / 16 + j), lanes
+        // q = 2 / 3 the stored half's: one 128-byte store per field and row
+        e.off_sum = valid ? (unsigned)((lq & 1) * 16 + lj) * 4u : OOB;
         return e;
     };
-    auto mask_load = [&](__amdgpu_buffer_rsrc_t mrs, unsigned row_v, int i) __attribute__((always_inline)) {
-        // the sign bytes of the next row (channels 4 q .. 4 q + 3 of the masked half): byte 2 voxel + q; lanes q >= 2 load nothing
+    auto mask_load = [&](const Epi &E, auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
 #pragma unroll
         for (int hx = 0; hx < 2; ++hx)
-            mk_next[hx] = (unsigned char)__builtin_amdgcn_raw_buffer_load_b8(mrs, (int)(lq < 2 ? (unsigned)(lj * 2 + lq) : 0xffffff00u),
-                                                                            (int)((row_v + (unsigned)i * 32u + (unsigned)hx * 16u) * 2u), 0);
+            mkq[i & 1][hx] = (unsigned char)__builtin_amdgcn_raw_buffer_load_b8(mask_rsrc, (int)E.off_mask,
+                                                                               (int)((E.pv + E.row_v + (unsigned)i * 32u + (unsigned)hx * 16u) * 2u), 0);
     };
-    // stores without divergent control flow: a lane that has nothing to store aims past the buffer (the range check drops it)
-    const unsigned OOB = 0xffffff00u;
-    const unsigned off_dB = lq >= 2 ? (unsigned)lj * 32u + (unsigned)(lq - 2) * 16u : OOB;
-    const unsigned off_sA = lq == 0 ? (unsigned)lj * 4u : OOB, off_sB = lq == 2 ? (unsigned)lj * 4u : OOB;
-    auto epi_row = [&](auto S, auto I, const Epi &E, bool has_mask) __attribute__((always_inline)) {
+    const bool has_mask = a.maskA != nullptr;
+    auto epi_row = [&](auto S, auto I, const Epi &E) __attribute__((always_inline)) {
         constexpr int s = decltype(S)::value, i = decltype(I)::value;
-        const unsigned mk[2] = {mk_next[0], mk_next[1]};
-        if constexpr (i < 7) mask_load(E.mask, E.row_v, i + 1);
+        const unsigned mk[2] = {mkq[i & 1][0], mkq[i & 1][1]};
+        if constexpr (i + 2 < 8) mask_load(E, IC<i + 2>{});
+        float t2[2];
 #pragma unroll
         for (int hx = 0; hx < 2; ++hx) {
             const f32x4 c = acc[s][i][hx];
-            f32x4 val = f32x4{c.x * E.inv, c.y * E.inv, c.z * E.inv, c.w * E.inv};
             const int nib = (lq < 2 && has_mask) ? (int)mk[hx] : 15;
-            val.x = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, val.x) & (unsigned)__builtin_amdgcn_sbfe(nib, 0, 1));
-            val.y = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, val.y) & (unsigned)__builtin_amdgcn_sbfe(nib, 1, 1));
-            val.z = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, val.z) & (unsigned)__builtin_amdgcn_sbfe(nib, 2, 1));
-            val.w = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, val.w) & (unsigned)__builtin_amdgcn_sbfe(nib, 3, 1));
-            const unsigned vox = E.row_v + (unsigned)i * 32u + (unsigned)hx * 16u;      // first voxel of this half row
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, val), E.dB, (int)off_dB, (int)(vox * 32u), 2 /* nt */);
-            float t = (val.x + val.y) + (val.z + val.w);
-            // lanes (j, q) and (j, q ^ 1) hold the two 4-channel groups of one voxel: their sum through the LDS crossbar
-            t += __shfl_xor(t, 16, 64);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, t), E.sumA, (int)off_sA, (int)(vox * 4u), 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, t), E.sumB, (int)off_sB, (int)(vox * 4u), 0);
+            // (scalars first: __builtin_bit_cast applied to an element of an ext_vector lvalue reads element 0)
+            const float v0 = c.x * E.inv, v1 = c.y * E.inv, v2 = c.z * E.inv, v3 = c.w * E.inv;
+            f32x4 val;
+            val.x = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v0) & (unsigned)__builtin_amdgcn_sbfe(nib, 0, 1));
+            val.y = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v1) & (unsigned)__builtin_amdgcn_sbfe(nib, 1, 1));
+            val.z = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v2) & (unsigned)__builtin_amdgcn_sbfe(nib, 2, 1));
+            val.w = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v3) & (unsigned)__builtin_amdgcn_sbfe(nib, 3, 1));
+            const unsigned vox = E.pv + E.row_v + (unsigned)i * 32u + (unsigned)hx * 16u;      // first voxel of this half row
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, val), dB_rsrc, (int)E.off_dB, (int)(vox * 32u), 2 /* nt */);
+            const float t = (val.x + val.y) + (val.z + val.w);
+            // lanes (j, q) and (j, q ^ 1) hold the two 4-channel groups of one voxel.  v_permlane16_swap(a, b) returns
+            // ([a.row0, b.row0, a.row2, b.row2], [a.row1, b.row1, a.row3, b.row3]) (rows of 16 lanes; probed on the device,
+            // tools/probe/permlane_probe.hip): with (t, 0) the two results add up to the 8-channel sums in the EVEN rows, with (0, t)
+            // in the ODD rows - half row 0 goes to lanes q = 0 / 2, half row 1 to lanes q = 1 / 3, which is how the merged stores
+            // below want them.  (Never (t, t): the compiler folds the two results of identical operands into one.)
+            const unsigned tu = __builtin_bit_cast(unsigned, t);
+            const auto sw = hx == 0 ? __builtin_amdgcn_permlane16_swap(tu, 0u, false, false) : __builtin_amdgcn_permlane16_swap(0u, tu, false, false);
+            const unsigned s0 = sw[0], s1 = sw[1];       // (scalars first: see the note on __builtin_bit_cast above)
+            t2[hx] = __builtin_bit_cast(float, s0) + __builtin_bit_cast(float, s1);
         }
+        const float ts = t2[0] + t2[1];
+        const unsigned rowv = E.pv + E.row_v + (unsigned)i * 32u;
+        // lanes q < 2 -> the masked half's field, q >= 2 -> the stored half's: two stores, each with the other half of the wave off
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ts), sA_rsrc, (int)(lq < 2 ? E.off_sum : OOB), (int)(rowv * 4u), 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ts), sB_rsrc, (int)(lq >= 2 ? E.off_sum : OOB), (int)(rowv * 4u), 0);
     };
 
     auto step = [&](auto RR, int pi, int z, long long n) __attribute__((always_inline)) {
@@ -527,12 +578,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const int abase = frag_lane + (int)(n & 1) * B3_PLANE;
         const int wbase = st_lane + (int)((n + 1) & 1) * B3_PLANE;
-        const __amdgpu_buffer_rsrc_t rb1 = bits_rsrc_of(c1_pi), rb2 = bits_rsrc_of(c2_pi);
+        const unsigned bv1 = c1_pi < np ? st_vox * 2u : OOB, bs1 = c1_pi < np ? patch_of(c1_pi) * patch_v * 2u : 0u;
+        const unsigned bv2 = c2_pi < np ? st_vox * 2u : OOB, bs2 = c2_pi < np ? patch_of(c2_pi) * patch_v * 2u : 0u;
         const unsigned z1 = (unsigned)c1_z, z2 = (unsigned)c2_z;
         const bool ev = z >= 2 || (z == 0 && pi > 0);
-        const int pe = z >= 2 ? pi : pi - 1, zo = z >= 2 ? z - 2 : D - 1;
-        const Epi E = epi_setup(ev, pe, zo);
-        const bool has_mask = a.maskA != nullptr;
+        const Epi E = epi_setup(ev, z >= 2 ? pi : pi - 1, z >= 2 ? z - 2 : D - 1);
 
         auto frag = [&](int j, int hx, f16x8 &bh, f16x8 &bl) __attribute__((always_inline)) {
             const char *p = lds + abase + j * B3_ROW + hx * 256;
@@ -543,11 +593,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         frag(0, 0, bh, bl);
         auto row = [&](auto J) __attribute__((always_inline)) {
             constexpr int j = decltype(J)::value;
+#ifdef C3_SCHED_ROWS
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             if constexpr (j < 8) {
-                epi_row(IC<S_hi>{}, J, E, has_mask);
+                epi_row(IC<S_hi>{}, J, E);
                 if constexpr ((j & 1) == 0) {      // staging unit j / 2 of the next plane; the unit after the next one goes out
                     stage_unit(wbase, IC<j / 2>{});
-                    if constexpr (j / 2 + 2 < 4) load_unit(rb1, z1, IC<j / 2 + 2>{}); else load_unit(rb2, z2, IC<j / 2 + 2 - 4>{});
+                    if constexpr (j / 2 + 2 < 4) load_unit(bv1, bs1, z1, IC<j / 2 + 2>{}); else load_unit(bv2, bs2, z2, IC<j / 2 + 2 - 4>{});
                 }
             }
 #pragma unroll
@@ -576,11 +629,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         };
         row(IC<0>{}); row(IC<1>{}); row(IC<2>{}); row(IC<3>{}); row(IC<4>{});
         row(IC<5>{}); row(IC<6>{}); row(IC<7>{}); row(IC<8>{}); row(IC<9>{});
-        {   // the sign bytes of row 0 of the plane the next step finishes
-            const bool nv = z + 1 < D ? z >= 1 : true;
-            const int nzo = z + 1 < D ? z - 1 : D - 2;
-            const __amdgpu_buffer_rsrc_t mrs = rsrc_of(a.maskA, (long long)(b0 + pi * G) * (patch_v * 2u), (nv && a.maskA) ? patch_v * 2u : 0u);
-            mask_load(mrs, (unsigned)(nzo * 32 + wave * 8) * 32u, 0);
+        {   // the sign bytes of rows 0 and 1 of the plane the next step finishes (same patch: plane z - 1, or D - 2 in the light step)
+            const Epi En = epi_setup(z + 1 < D ? z >= 1 : true, pi, z + 1 < D ? z - 1 : D - 2);
+            mask_load(En, IC<0>{});
+            mask_load(En, IC<1>{});
         }
         c1_pi = c2_pi; c1_z = c2_z;
         advance(c2_pi, c2_z);
@@ -588,31 +640,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto light = [&](auto S, int pe, int zo) __attribute__((always_inline)) {
         constexpr int s = decltype(S)::value;
         const Epi E = epi_setup(true, pe, zo);
-        const bool has_mask = a.maskA != nullptr;
-        auto rows = [&](auto I) __attribute__((always_inline)) { epi_row(S, I, E, has_mask); };
+        auto rows = [&](auto I) __attribute__((always_inline)) { epi_row(S, I, E); };
         rows(IC<0>{}); rows(IC<1>{}); rows(IC<2>{}); rows(IC<3>{}); rows(IC<4>{}); rows(IC<5>{}); rows(IC<6>{}); rows(IC<7>{});
 #pragma unroll
         for (int i = 0; i < 8; ++i) { acc[s][i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[s][i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        if (zo == D - 2) {      // plane D - 1 of the same patch is finished next
-            const __amdgpu_buffer_rsrc_t mrs = rsrc_of(a.maskA, (long long)(b0 + pe * G) * (patch_v * 2u), a.maskA ? patch_v * 2u : 0u);
-            mask_load(mrs, (unsigned)((D - 1) * 32 + wave * 8) * 32u, 0);
+        {   // plane D - 1 of the same patch is finished next (after the D - 2 light step); nothing after the final one
+            const Epi En = epi_setup(zo == D - 2, pe, D - 1);
+            mask_load(En, IC<0>{});
+            mask_load(En, IC<1>{});
         }
     };
 
     __syncthreads();
     if (np > 0) {
-        const __amdgpu_buffer_rsrc_t rb = bits_rsrc_of(0);
+        const unsigned bv = st_vox * 2u, bs = patch_of(0) * patch_v * 2u;
         const int wb = st_lane;
-        load_unit(rb, 0u, IC<0>{}); load_unit(rb, 0u, IC<1>{});
+        load_unit(bv, bs, 0u, IC<0>{}); load_unit(bv, bs, 0u, IC<1>{});
         stage_unit(wb, IC<0>{}); stage_unit(wb, IC<1>{});
-        load_unit(rb, 0u, IC<2>{}); load_unit(rb, 0u, IC<3>{});
+        load_unit(bv, bs, 0u, IC<2>{}); load_unit(bv, bs, 0u, IC<3>{});
         stage_unit(wb, IC<2>{}); stage_unit(wb, IC<3>{});
         c1_pi = 0; c1_z = 0;
         advance(c1_pi, c1_z);
         c2_pi = c1_pi; c2_z = c1_z;
         advance(c2_pi, c2_z);
-        const __amdgpu_buffer_rsrc_t rb1 = bits_rsrc_of(c1_pi);
-        load_unit(rb1, (unsigned)c1_z, IC<0>{}); load_unit(rb1, (unsigned)c1_z, IC<1>{});
+        const unsigned bv1 = c1_pi < np ? st_vox * 2u : OOB, bs1 = c1_pi < np ? patch_of(c1_pi) * patch_v * 2u : 0u;
+        load_unit(bv1, bs1, (unsigned)c1_z, IC<0>{}); load_unit(bv1, bs1, (unsigned)c1_z, IC<1>{});
     }
     long long n = 0;
     for (int pi = 0; pi < np; ++pi) {
@@ -701,6 +753,7 @@ int c3d_fwd_launch(alq_ctx *ctx, const C3dPlan &plan, const View &in, const floa
     ALQ_REQUIRE(plan.ok && plan.d_W, ALQ_EINVAL, "c3d: weights not set");
     ALQ_REQUIRE(in.split == 8 && in.cs == 8 && in.C == 16 && in.D == plan.D && in.H == 32 && in.W == 32 && plan.D == 32, ALQ_EINVAL, "c3d: input view mismatch");
     ALQ_REQUIRE(amaxA && amaxB && fc_W && fc_part && bias, ALQ_EINVAL, "c3d: missing argument");
+    ALQ_REQUIRE(N < 4096, ALQ_EUNSUPPORTED, "c3d: 32-bit byte offsets hold fewer than 4096 patches per pass");
     if (N <= 0) return ALQ_OK;
     C3FwdArgs a;
     a.inA = in.p; a.inB = in.p + in.delta; a.W = plan.d_W; a.bias = bias; a.amaxA = amaxA; a.amaxB = amaxB;
@@ -780,6 +833,7 @@ int c3d_bwd_launch(alq_ctx *ctx, const C3dPlan &plan, int N, const unsigned char
                    float *dB, float *sumA, float *sumB) {
     ALQ_REQUIRE(plan.ok && plan.d_W && plan.D == 32, ALQ_EINVAL, "c3d: backward weights not set");
     ALQ_REQUIRE(bits && vec16 && dB && sumA && sumB, ALQ_EINVAL, "c3d: missing argument");
+    ALQ_REQUIRE(N < 4096, ALQ_EUNSUPPORTED, "c3d: 32-bit byte offsets hold fewer than 4096 patches per pass");
     if (N <= 0) return ALQ_OK;
     C3BwdArgs a;
     a.bits = bits; a.vec = vec16; a.W = plan.d_W; a.maskA = maskA; a.dB = dB; a.sumA = sumA; a.sumB = sumB;

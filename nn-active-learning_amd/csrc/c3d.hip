@@ -38,6 +38,33 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 template <int V> using IC = std::integral_constant<int, V>;
+// __builtin_amdgcn_sched_barrier mask: VALU (2), SALU (4), all DS (0x80 | 0x100 | 0x200), transcendentals (0x400) may cross;
+// MFMA (8) and vector memory (0x10 | 0x20 | 0x40) may not
+#ifndef C3_SCHED_MASK
+#define C3_SCHED_MASK 0
+#endif
+// forward kernel: staging units (1 KB of fp32 per wave) in flight, and how many rows ahead the head's weight difference is
+// fetched.  vmcnt retires in order, so the wait for a weight-difference slice (an L2 hit) also waits for every staging load
+// issued before it: the HBM latency the sweep tolerates is C3_WD + 1 rows of MFMAs (~860 cycles each), not the staging depth
+#ifndef C3_PF
+#define C3_PF 8
+#endif
+#ifndef C3_WD
+#define C3_WD 4
+#endif
+static_assert(C3_PF == 8 || C3_PF == 16, "the ring of staging registers must divide the 16 units of a plane");
+static_assert(C3_WD >= 1 && C3_WD <= 8, "weight-difference slices are fetched 1..8 rows ahead");
+// timing experiments only (tools/probe/c3d_bench.hip): 1 no staging, 2 no epilogue in the sweep steps, 4 no barrier, 8 staging loads
+// always from the first plane (L2 hits), 16 no sign-byte stores, 32 no weight-difference loads, 64 no LDS writes of the staging
+#ifndef C3_ABL
+#define C3_ABL 0
+#endif
+#ifndef C3_PIPE
+#define C3_PIPE 2
+#endif
+#ifndef C3_BPIPE
+#define C3_BPIPE 2
+#endif
 
 // LDS image of one input plane (bytes).  Slot = 8 fp16 channels of one tensor at one voxel, one piece (h or l).
 constexpr int C3_TEN = 34 * 16;          // slots x = -1 .. 32 of one (row, piece, tensor); the two outer ones stay zero
@@ -60,6 +87,7 @@ struct C3FwdArgs {
     int N, D;
     int e_w;                       // scale exponent of the packed weights
     float flip_tau;                // > 0: mark 4-channel groups holding |pre-activation| < flip_tau * 2^(14 - e_patch)
+    unsigned long long *clk;       // diagnostic builds (-DC3_CLK): per workgroup {shader cycles, 100 MHz ticks} of the whole kernel
 };
 
 // SUMS: Fisher pass (sign bytes, flip marks, the head's input sum); otherwise forward only (logit partials).
@@ -114,6 +142,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     const int G = gridDim.x, b0 = blockIdx.x;
     const int np = b0 < a.N ? (a.N - b0 + G - 1) / G : 0;
+#ifdef C3_CLK
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     f32x4 acc[3][8], accx[3][ONEACC ? 1 : 8];
 #pragma unroll
@@ -142,11 +173,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- staging: unit u = 0..15 of a plane: row 8 w + (u >> 1), tensor u & 1: 1 KB of fp32 per wave instruction ------------
     // eight units in flight (HBM latency under load is ~2 us = half a step)
-    f32x4 R4[8];
+    f32x4 R4[C3_PF];
     float sc = 1.f, sc11 = 2048.f;
     auto stage_unit = [&](int wbase, auto U) __attribute__((always_inline)) {
         constexpr int u = decltype(U)::value;
-        const f32x4 v = R4[u & 7];
+        const f32x4 v = R4[u % C3_PF];
         const float x0 = v.x * sc, x1 = v.y * sc, x2 = v.z * sc, x3 = v.w * sc;
         const f16x2 h01 = __builtin_convertvector(f32x2{x0, x1}, f16x2);
         const f16x2 h23 = __builtin_convertvector(f32x2{x2, x3}, f16x2);
@@ -160,13 +191,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             l23 = __builtin_convertvector(f32x2{__builtin_fmaf(g23.x, -2048.f, v.z * sc11), __builtin_fmaf(g23.y, -2048.f, v.w * sc11)}, f16x2);
         }
         char *dst = lds + wbase + (u >> 1) * C3_ROW + (u & 1) * C3_TEN;
+        if constexpr (C3_ABL & 64) { asm volatile("" :: "v"(h01), "v"(h23), "v"(l01), "v"(l23), "v"(dst)); return; }
         *reinterpret_cast<uint2 *>(dst) = uint2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
         *reinterpret_cast<uint2 *>(dst + C3_PIECE) = uint2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
     };
     // voff = lane * 16 or OOB (no such plane), soff = byte offset of row 8 w of the plane inside the array
     auto load_unit = [&](unsigned voff, unsigned soff, auto U) __attribute__((always_inline)) {
         constexpr int u = decltype(U)::value;
-        R4[u & 7] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((u & 1) ? inB_rsrc : inA_rsrc, (int)voff, (int)(soff + (unsigned)(u >> 1) * 1024u), 0));
+        R4[u % C3_PF] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((u & 1) ? inB_rsrc : inA_rsrc, (int)voff, (int)(soff + (unsigned)((u % 16) >> 1) * 1024u), 0));
     };
     struct Cur { unsigned voff, soff; };
     auto cursor = [&](int pi, int z) __attribute__((always_inline)) {
@@ -174,6 +206,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const bool ok = pi < np;
         c.voff = ok ? (unsigned)lane * 16u : OOB;
         c.soff = ok ? (patch_of(pi) * patch_f + (unsigned)z * plane_f) * 4u + (unsigned)(wave * 8) * 1024u : 0u;
+        if constexpr (C3_ABL & 8) c.soff = (unsigned)(wave * 8) * 1024u;
         return c;
     };
     // plane stream cursors: c1 = the plane staged by the running step, c2 = the one after it (its first 8 loads go out early)
@@ -181,7 +214,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto advance = [&](int &pi, int &z) __attribute__((always_inline)) { if (++z == D) { z = 0; ++pi; } };
 
     float fs = 0.f, sa = 0.f;       // running logit-difference partial / sum of the ReLU'd output of the patch in the epilogue
-    f32x4 wdq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};      // the head's weight difference, fetched two rows ahead
+    f32x4 wdq[C3_WD];      // the head's weight difference, fetched C3_WD rows ahead
+#pragma unroll
+    for (int i = 0; i < C3_WD; ++i) wdq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // epilogue constants of a finished plane (patch ordinal pe, plane zo); !valid: inv = 0, zero bias and lane offsets past the
     // arrays turn the epilogue of a step without a finished plane into a no-op
@@ -201,14 +236,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     auto wd_load = [&](const Epi &E, auto I) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
-        wdq[i & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wd_rsrc, (int)E.off_w, (int)((E.row_f + (unsigned)i * 256u) * 4u), 0));
+        if constexpr (C3_ABL & 32) return;
+        wdq[i % C3_WD] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wd_rsrc, (int)E.off_w, (int)((E.row_f + (unsigned)i * 256u) * 4u), 0));
     };
 
+    auto wd_first = [&](const Epi &E) __attribute__((always_inline)) {      // rows 0 .. C3_WD - 1 of the plane finished next
+        wd_load(E, IC<0>{});
+        if constexpr (C3_WD > 1) wd_load(E, IC<1>{});
+        if constexpr (C3_WD > 2) wd_load(E, IC<2>{});
+        if constexpr (C3_WD > 3) wd_load(E, IC<3>{});
+        if constexpr (C3_WD > 4) wd_load(E, IC<4>{});
+        if constexpr (C3_WD > 5) wd_load(E, IC<5>{});
+        if constexpr (C3_WD > 6) wd_load(E, IC<6>{});
+        if constexpr (C3_WD > 7) wd_load(E, IC<7>{});
+    };
     // ---- epilogue of one finished x row (plane zo, row 8 w + i) of accumulator set S -------------------------------
     auto epi_row = [&](auto S, auto I, const Epi &E) __attribute__((always_inline)) {
         constexpr int s = decltype(S)::value, i = decltype(I)::value;
-        const f32x4 w4 = wdq[i & 1];
-        if constexpr (i + 2 < 8) wd_load(E, IC<i + 2>{});       // two rows ahead: its L2 latency behind ~100 MFMAs
+        const f32x4 w4 = wdq[i % C3_WD];
+        if constexpr (i + C3_WD < 8) wd_load(E, IC<i + C3_WD>{});
         const f32x4 c = acc[s][i];
         f32x4 val;
         if constexpr (ONEACC) {
@@ -231,7 +277,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if constexpr (SUMS) {
             sa += (val.x + val.y) + (val.z + val.w);
             const unsigned nib = (val.x > 0.f ? 1u : 0u) | (val.y > 0.f ? 2u : 0u) | (val.z > 0.f ? 4u : 0u) | (val.w > 0.f ? 8u : 0u) | unsure;
-            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)nib, bits_rsrc, (int)E.off_b, (int)(E.bits_s + ((E.row_f + (unsigned)i * 256u) >> 2)), 0);
+            if constexpr (!(C3_ABL & 16))
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)nib, bits_rsrc, (int)E.off_b, (int)(E.bits_s + ((E.row_f + (unsigned)i * 256u) >> 2)), 0);
+            else asm volatile("" :: "v"(nib));
         }
     };
     auto wave_sum = [&](float x) __attribute__((always_inline)) {
@@ -262,7 +310,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr int R = decltype(RR)::value;
         constexpr int S_lo = (R + 2) % 3, S_mid = R, S_hi = (R + 1) % 3;
         // everything the previous step wrote into this plane's image has landed; nobody still reads the other image
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (!(C3_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const int abase = frag_lane + (int)(n & 1) * C3_PLANE;
         const int wbase = st_lane + (int)((n + 1) & 1) * C3_PLANE;
         const Cur C1 = cursor(c1_pi, c1_z), C2 = cursor(c2_pi, c2_z);
@@ -279,59 +327,74 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             bh = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(p));
             bl = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(p + C3_PIECE));
         };
-        f16x8 bh, bl, nh, nl;
-        frag(0, 0, bh, bl);
-        auto row = [&](auto J) __attribute__((always_inline)) {
-            constexpr int j = decltype(J)::value;
-            if constexpr (j < 8) {
+        // A step is 20 blocks (input row j, k-step s), each its own scheduling region (nothing crosses a block boundary): the
+        // fragments of block b + 2 are read in block b into one of three register sets, so a read is always a full block of
+        // MFMAs (>= 430 cycles) ahead of its use wherever the scheduler puts it inside the block.  Left alone it sinks every
+        // read to its first use - the reads cannot pass the staging writes above them, which may alias - and each fragment
+        // then pays its LDS latency in front of an MFMA (timing builds: +325 us of 1.8 ms for the staging writes alone).
+        // Inside a block: one MFMA, then up to C3_PIPE vector instructions, and so on - the conversion / epilogue arithmetic in
+        // the MFMAs' shadow (an MFMA holds the issue port for 8 of its 16 cycles).
+        f16x8 Fh[3], Fl[3];
+        frag(0, 0, Fh[0], Fl[0]);
+        frag(0, 1, Fh[1], Fl[1]);
+        auto block = [&](auto J, auto SS) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value, s = decltype(SS)::value, b = 2 * j + s;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (s == 0 && j < 8) {
                 // row j of the plane finished two steps ago, then (below) its accumulators restart for plane z + 1
-                epi_row(IC<S_hi>{}, J, E);
-                stage_unit(wbase, IC<2 * j>{});
-                if constexpr (2 * j + 8 < 16) load_unit(C1.voff, C1.soff, IC<2 * j + 8>{}); else load_unit(C2.voff, C2.soff, IC<2 * j + 8 - 16>{});
-                stage_unit(wbase, IC<2 * j + 1>{});
-                if constexpr (2 * j + 9 < 16) load_unit(C1.voff, C1.soff, IC<2 * j + 9>{}); else load_unit(C2.voff, C2.soff, IC<2 * j + 9 - 16>{});
+                if constexpr (!(C3_ABL & 2)) epi_row(IC<S_hi>{}, J, E);
             }
+            // The staging units of the next plane go where the MFMA stream has room for their arithmetic: rows 0 / 1 issue 18 / 36
+            // MFMAs and already carry an epilogue row, rows 8 / 9 carry none - units 0..11 ride on rows 2..7, 12..15 on rows 8, 9
+            if constexpr (!(C3_ABL & 1) && j >= 2) {
+                constexpr int u = 2 * (j - 2) + s;
+                stage_unit(wbase, IC<u>{});
+                if constexpr (u + C3_PF < 16) load_unit(C1.voff, C1.soff, IC<u + C3_PF>{}); else load_unit(C2.voff, C2.soff, IC<u + C3_PF - 16>{});
+            }
+            if constexpr (b + 2 < 20) frag((b + 2) / 2, (b + 2) & 1, Fh[(b + 2) % 3], Fl[(b + 2) % 3]);
+            const f16x8 bh = Fh[b % 3], bl = Fl[b % 3];
+            constexpr int rows_here = (j < 2 ? j + 1 : 3) < (10 - j) ? (j < 2 ? j + 1 : 3) : (10 - j);
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                // the next fragment pair goes out before this one's MFMAs
-                if (s == 0) frag(j, 1, nh, nl);
-                else if (j < 9) frag(j + 1, 0, nh, nl);
+            for (int di = 0; di < 3; ++di) {
+                const int i = j - di;          // output row; y tap index = di
+                if (i < 0 || i > 7) continue;
 #pragma unroll
-                for (int di = 0; di < 3; ++di) {
-                    const int i = j - di;          // output row; y tap index = di
-                    if (i < 0 || i > 7) continue;
-#pragma unroll
-                    for (int dzi = 0; dzi < 3; ++dzi) {      // z tap index: output plane z + 1 - dzi
-                        const int k = (dzi * 3 + di) * 2 + s;
-                        const int set = dzi == 0 ? S_hi : (dzi == 1 ? S_mid : S_lo);
-                        const bool start = dzi == 0 && di == 0 && s == 0;       // first contribution to (plane z + 1, row i)
-                        f32x4 c = acc[set][i];
-                        if (start) c = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if constexpr (ONEACC) {      // the small products first
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wl[k], bh, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wh[k], bl, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wh[k], bh, c, 0, 0, 0);
-                        } else {
-                            f32x4 d = accx[set][i];
-                            if (start) d = f32x4{0.f, 0.f, 0.f, 0.f};
-                            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wl[k], bh, d, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wh[k], bh, c, 0, 0, 0);
-                            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wh[k], bl, d, 0, 0, 0);
-                            accx[set][i] = d;
-                        }
-                        acc[set][i] = c;
+                for (int dzi = 0; dzi < 3; ++dzi) {      // z tap index: output plane z + 1 - dzi
+                    const int k = (dzi * 3 + di) * 2 + s;
+                    const int set = dzi == 0 ? S_hi : (dzi == 1 ? S_mid : S_lo);
+                    const bool start = dzi == 0 && di == 0 && s == 0;       // first contribution to (plane z + 1, row i)
+                    f32x4 c = acc[set][i];
+                    if (start) c = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (ONEACC) {      // the small products first
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wl[k], bh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wh[k], bl, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wh[k], bh, c, 0, 0, 0);
+                    } else {
+                        f32x4 d = accx[set][i];
+                        if (start) d = f32x4{0.f, 0.f, 0.f, 0.f};
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wl[k], bh, d, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wh[k], bh, c, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wh[k], bl, d, 0, 0, 0);
+                        accx[set][i] = d;
                     }
+                    acc[set][i] = c;
                 }
-                bh = nh; bl = nl;
             }
+#if C3_PIPE
+#pragma unroll
+            for (int m = 0; m < 9 * rows_here; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, C3_PIPE, 0);
+            }
+#endif
         };
+        auto row = [&](auto J) __attribute__((always_inline)) { block(J, IC<0>{}); block(J, IC<1>{}); };
         row(IC<0>{}); row(IC<1>{}); row(IC<2>{}); row(IC<3>{}); row(IC<4>{});
         row(IC<5>{}); row(IC<6>{}); row(IC<7>{}); row(IC<8>{}); row(IC<9>{});
         {   // the weight difference for rows 0 and 1 of the plane the next step finishes: plane z - 1 (z + 1 < D), or plane D - 2 in
             // the light step behind z = D - 1 (the vector is the same for every patch)
             const Epi En = epi_setup(z + 1 < D ? z >= 1 : true, pi, z + 1 < D ? z - 1 : D - 2);
-            wd_load(En, IC<0>{});
-            wd_load(En, IC<1>{});
+            wd_first(En);
         }
         if constexpr (R == 0) { if (z == 0 && pi > 0) finish_patch((int)patch_of(pi - 1)); }
         c1_pi = c2_pi; c1_z = c2_z;
@@ -348,8 +411,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int i = 0; i < 8; ++i) { acc[s][i] = f32x4{0.f, 0.f, 0.f, 0.f}; if constexpr (!ONEACC) accx[s][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         {   // plane D - 1 is finished next (step 0 of the next patch, or the final light step); nothing after that one
             const Epi En = epi_setup(zo == D - 2, pe, D - 1);
-            wd_load(En, IC<0>{});
-            wd_load(En, IC<1>{});
+            wd_first(En);
         }
     };
 
@@ -375,6 +437,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const Cur C1 = cursor(c1_pi, c1_z);
         load_unit(C1.voff, C1.soff, IC<0>{}); load_unit(C1.voff, C1.soff, IC<1>{}); load_unit(C1.voff, C1.soff, IC<2>{}); load_unit(C1.voff, C1.soff, IC<3>{});
         load_unit(C1.voff, C1.soff, IC<4>{}); load_unit(C1.voff, C1.soff, IC<5>{}); load_unit(C1.voff, C1.soff, IC<6>{}); load_unit(C1.voff, C1.soff, IC<7>{});
+        if constexpr (C3_PF == 16) {
+            load_unit(C1.voff, C1.soff, IC<8>{}); load_unit(C1.voff, C1.soff, IC<9>{}); load_unit(C1.voff, C1.soff, IC<10>{}); load_unit(C1.voff, C1.soff, IC<11>{});
+            load_unit(C1.voff, C1.soff, IC<12>{}); load_unit(C1.voff, C1.soff, IC<13>{}); load_unit(C1.voff, C1.soff, IC<14>{}); load_unit(C1.voff, C1.soff, IC<15>{});
+        }
     }
 
     // D = 32: 33 = 3 * 11 steps per patch (the last one light), so the set rotation restarts at every patch
@@ -391,6 +457,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         light(IC<1>{}, np - 1, D - 1);
         finish_patch((int)patch_of(np - 1));
     }
+#ifdef C3_CLK
+    if (a.clk && tid == 0) { a.clk[2 * b0] = __builtin_amdgcn_s_memtime() - clk0; a.clk[2 * b0 + 1] = __builtin_amdgcn_s_memrealtime() - rt0; }
+#endif
 }
 
 // ======================================================================================================================
@@ -441,9 +510,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             Wh[k] = __builtin_bit_cast(f16x8, Wg[(k * 2 + 0) * 64 + lane]);
             Wl[k] = __builtin_bit_cast(f16x8, Wg[(k * 2 + 1) * 64 + lane]);
         }
-        // the weights start their lives in accumulation registers (see the forward kernel): 192 accumulators + 16 of the 18
-        // fragments fill the AGPR half, the last two stay in VGPRs
-#ifndef C3_NO_PIN
+        // (no pinning of the weights to accumulation registers here: the 192 accumulators already fill three quarters of that half
+        // and the allocator does better alone - timing builds: 1.50 ms per 2000 patches against 1.66 ms with 16 fragments pinned)
+#ifdef C3_BWD_PIN
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             i32x4 h = __builtin_bit_cast(i32x4, Wh[k]), l = __builtin_bit_cast(i32x4, Wl[k]);
@@ -536,40 +605,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                                                (int)((E.pv + E.row_v + (unsigned)i * 32u + (unsigned)hx * 16u) * 2u), 0);
     };
     const bool has_mask = a.maskA != nullptr;
-    auto epi_row = [&](auto S, auto I, const Epi &E) __attribute__((always_inline)) {
-        constexpr int s = decltype(S)::value, i = decltype(I)::value;
-        const unsigned mk[2] = {mkq[i & 1][0], mkq[i & 1][1]};
-        if constexpr (i + 2 < 8) mask_load(E, IC<i + 2>{});
-        float t2[2];
-#pragma unroll
-        for (int hx = 0; hx < 2; ++hx) {
-            const f32x4 c = acc[s][i][hx];
-            const int nib = (lq < 2 && has_mask) ? (int)mk[hx] : 15;
-            // (scalars first: __builtin_bit_cast applied to an element of an ext_vector lvalue reads element 0)
-            const float v0 = c.x * E.inv, v1 = c.y * E.inv, v2 = c.z * E.inv, v3 = c.w * E.inv;
-            f32x4 val;
-            val.x = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v0) & (unsigned)__builtin_amdgcn_sbfe(nib, 0, 1));
-            val.y = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v1) & (unsigned)__builtin_amdgcn_sbfe(nib, 1, 1));
-            val.z = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v2) & (unsigned)__builtin_amdgcn_sbfe(nib, 2, 1));
-            val.w = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v3) & (unsigned)__builtin_amdgcn_sbfe(nib, 3, 1));
-            const unsigned vox = E.pv + E.row_v + (unsigned)i * 32u + (unsigned)hx * 16u;      // first voxel of this half row
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, val), dB_rsrc, (int)E.off_dB, (int)(vox * 32u), 2 /* nt */);
-            const float t = (val.x + val.y) + (val.z + val.w);
-            // lanes (j, q) and (j, q ^ 1) hold the two 4-channel groups of one voxel.  v_permlane16_swap(a, b) returns
-            // ([a.row0, b.row0, a.row2, b.row2], [a.row1, b.row1, a.row3, b.row3]) (rows of 16 lanes; probed on the device,
-            // tools/probe/permlane_probe.hip): with (t, 0) the two results add up to the 8-channel sums in the EVEN rows, with (0, t)
-            // in the ODD rows - half row 0 goes to lanes q = 0 / 2, half row 1 to lanes q = 1 / 3, which is how the merged stores
-            // below want them.  (Never (t, t): the compiler folds the two results of identical operands into one.)
-            const unsigned tu = __builtin_bit_cast(unsigned, t);
-            const auto sw = hx == 0 ? __builtin_amdgcn_permlane16_swap(tu, 0u, false, false) : __builtin_amdgcn_permlane16_swap(0u, tu, false, false);
-            const unsigned s0 = sw[0], s1 = sw[1];       // (scalars first: see the note on __builtin_bit_cast above)
-            t2[hx] = __builtin_bit_cast(float, s0) + __builtin_bit_cast(float, s1);
+    float t_keep = 0.f;      // the 8-channel sums of half row 0 (even 16-lane rows) until half row 1 joins them
+    // one half row (16 voxels): the first one also fetches the sign bytes two rows ahead, the second one stores the sums of both
+    auto epi_half = [&](auto S, auto I, auto HX, const Epi &E) __attribute__((always_inline)) {
+        constexpr int s = decltype(S)::value, i = decltype(I)::value, hx = decltype(HX)::value;
+        const unsigned mk = mkq[i & 1][hx];
+        if constexpr (hx == 1 && i + 2 < 8) mask_load(E, IC<i + 2>{});      // (both halves' bytes of row i + 2, after this row's were read)
+        const f32x4 c = acc[s][i][hx];
+        const int nib = (lq < 2 && has_mask) ? (int)mk : 15;
+        // (scalars first: __builtin_bit_cast applied to an element of an ext_vector lvalue reads element 0)
+        const float v0 = c.x * E.inv, v1 = c.y * E.inv, v2 = c.z * E.inv, v3 = c.w * E.inv;
+        f32x4 val;
+        val.x = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v0) & (unsigned)__builtin_amdgcn_sbfe(nib, 0, 1));
+        val.y = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v1) & (unsigned)__builtin_amdgcn_sbfe(nib, 1, 1));
+        val.z = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v2) & (unsigned)__builtin_amdgcn_sbfe(nib, 2, 1));
+        val.w = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v3) & (unsigned)__builtin_amdgcn_sbfe(nib, 3, 1));
+        const unsigned vox = E.pv + E.row_v + (unsigned)i * 32u + (unsigned)hx * 16u;      // first voxel of this half row
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, val), dB_rsrc, (int)E.off_dB, (int)(vox * 32u), 2 /* nt */);
+        const float t = (val.x + val.y) + (val.z + val.w);
+        // lanes (j, q) and (j, q ^ 1) hold the two 4-channel groups of one voxel.  v_permlane16_swap(a, b) returns
+        // ([a.row0, b.row0, a.row2, b.row2], [a.row1, b.row1, a.row3, b.row3]) (rows of 16 lanes; probed on the device,
+        // tools/probe/permlane_probe.hip): with (t, 0) the two results add up to the 8-channel sums in the EVEN rows, with (0, t)
+        // in the ODD rows - half row 0 goes to lanes q = 0 / 2, half row 1 to lanes q = 1 / 3, which is how the merged stores
+        // below want them.  (Never (t, t): the compiler folds the two results of identical operands into one.)
+        const unsigned tu = __builtin_bit_cast(unsigned, t);
+        const auto sw = hx == 0 ? __builtin_amdgcn_permlane16_swap(tu, 0u, false, false) : __builtin_amdgcn_permlane16_swap(0u, tu, false, false);
+        const unsigned s0 = sw[0], s1 = sw[1];       // (scalars first: see the note on __builtin_bit_cast above)
+        const float t2 = __builtin_bit_cast(float, s0) + __builtin_bit_cast(float, s1);
+        if constexpr (hx == 0) {
+            t_keep = t2;
+        } else {
+            const float ts = t_keep + t2;
+            const unsigned rowv = E.pv + E.row_v + (unsigned)i * 32u;
+            // lanes q < 2 -> the masked half's field, q >= 2 -> the stored half's: two stores, each with the other half of the wave off
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ts), sA_rsrc, (int)(lq < 2 ? E.off_sum : OOB), (int)(rowv * 4u), 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ts), sB_rsrc, (int)(lq >= 2 ? E.off_sum : OOB), (int)(rowv * 4u), 0);
         }
-        const float ts = t2[0] + t2[1];
-        const unsigned rowv = E.pv + E.row_v + (unsigned)i * 32u;
-        // lanes q < 2 -> the masked half's field, q >= 2 -> the stored half's: two stores, each with the other half of the wave off
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ts), sA_rsrc, (int)(lq < 2 ? E.off_sum : OOB), (int)(rowv * 4u), 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ts), sB_rsrc, (int)(lq >= 2 ? E.off_sum : OOB), (int)(rowv * 4u), 0);
+    };
+    auto epi_row = [&](auto S, auto I, const Epi &E) __attribute__((always_inline)) {
+        epi_half(S, I, IC<0>{}, E);
+        epi_half(S, I, IC<1>{}, E);
     };
 
     auto step = [&](auto RR, int pi, int z, long long n) __attribute__((always_inline)) {
@@ -589,13 +664,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             bh = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(p));
             bl = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(p + B3_TEN));
         };
+        // One scheduling region per input row (nothing crosses a row boundary: left alone the scheduler sinks the staging loads to
+        // their uses).  The finer block structure of the forward kernel costs this one more than it gives: its 192 accumulators
+        // leave no slack in the AGPR half and the extra fragment set spills (timing builds: 1.53 ms per 2000 patches like this,
+        // 1.78 ms with 20 blocks per step).
         f16x8 bh, bl, nh, nl;
         frag(0, 0, bh, bl);
         auto row = [&](auto J) __attribute__((always_inline)) {
             constexpr int j = decltype(J)::value;
-#ifdef C3_SCHED_ROWS
             __builtin_amdgcn_sched_barrier(0);
-#endif
             if constexpr (j < 8) {
                 epi_row(IC<S_hi>{}, J, E);
                 if constexpr ((j & 1) == 0) {      // staging unit j / 2 of the next plane; the unit after the next one goes out
@@ -626,6 +703,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
                 bh = nh; bl = nl;
             }
+#if C3_BPIPE
+            {
+                constexpr int rows_here = (j < 2 ? j + 1 : 3) < (10 - j) ? (j < 2 ? j + 1 : 3) : (10 - j);
+#pragma unroll
+                for (int m = 0; m < 18 * rows_here; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, C3_BPIPE, 0);
+                }
+            }
+#endif
         };
         row(IC<0>{}); row(IC<1>{}); row(IC<2>{}); row(IC<3>{}); row(IC<4>{});
         row(IC<5>{}); row(IC<6>{}); row(IC<7>{}); row(IC<8>{}); row(IC<9>{});
@@ -758,7 +845,7 @@ int c3d_fwd_launch(alq_ctx *ctx, const C3dPlan &plan, const View &in, const floa
     C3FwdArgs a;
     a.inA = in.p; a.inB = in.p + in.delta; a.W = plan.d_W; a.bias = bias; a.amaxA = amaxA; a.amaxB = amaxB;
     a.fc_W = fc_W; a.fc_part = fc_part; a.asum_part = asum_part; a.fc_bits = fc_bits; a.N = N; a.D = plan.D; a.e_w = plan.w_exp;
-    a.flip_tau = flip_tau;
+    a.flip_tau = flip_tau; a.clk = nullptr;
     const unsigned grid = (unsigned)std::min(N, 256);
     ProfScope ps(ctx, PROF_IGEMM_F16, plan.flops_per_patch * N);
     auto go = [&](auto kfn) -> int {

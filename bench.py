@@ -61,7 +61,13 @@ def main():
                          'refuses two ranks on one device); throughput numbers of such a run mean nothing')
     ap.add_argument('--prof-every', type=int, default=8, help='HIP-event timing on every k-th pass of the timed region')
     ap.add_argument('--cpu-sample', type=int, default=128, help='patches the CPU baseline scores (~15 s on 16 cores)')
+    ap.add_argument('--config', type=int, default=2, choices=(0, 1, 2, 3, 4),
+                    help='BASELINE.json configs[i]: 0 NET-A entropy query over 1,000 patches, 1 NET-A Fisher scoring of 10,000, 2 NET-C Fisher '
+                         'scoring of 100,000 per GPU (the metric\'s config, default), 3 ONE pool of 1,000,000 over the GPUs (= --pool-global '
+                         '1000000), 4 the active-learning loop, 5 rounds over 200,000 patches')
     args = ap.parse_args()
+    if args.config == 3 and args.pool_global == 0:
+        args.pool_global = 1000000
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # Bare-shell launch: this process only starts the ranks (it never imports torch.cuda or touches HIP).
@@ -96,6 +102,14 @@ def main():
     from nnal_amd import netspec   # network definition + seeded weight draw (product copy; not timed)
 
     sess = device.DeviceSession(local_rank)
+    if args.config in (0, 1, 4):
+        line = small_config(args, sess, rank, ws) if args.config < 4 else loop_config(args, sess, rank, ws)
+        if rank == 0:
+            print(json.dumps(line))
+        if ws > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     ld, sk = netspec.net_c()
     in_shape = (32, 32, 32, 1)
     pars = netspec.he_init(ld, in_shape, seed=14, skips=sk)
@@ -157,9 +171,9 @@ def main():
         # dominant kernel = igemm4_kernel (conv / conv_transpose fwd + bwd-data on the bf16 matrix cores
         # with the 3-way operand split: 6 bf16 MFMA MACs per fp32-accurate MAC, so the matrix-core bound
         # on ALGORITHMIC fp32 flops is the dense bf16 peak / 6)
-        # The launches whose input maxima are known ahead of time (the last conv's forward and backward, the backward
-        # launches of the two layers below it) run the fp16x2 split: 3 fp16 MFMA MACs per fp32-accurate MAC, bound = dense fp16 peak (= the bf16 one) / 3.  The bound of
-        # the mix is the flop-weighted harmonic mean of the two.
+        # The launches whose input scale is known ahead of time (the conv under the head, forward and backward - the plane-sweep
+        # kernels of csrc/c3d.hip - and every other backward launch) run on fp16 pairs: 3 fp16 MFMA MACs per fp32-accurate MAC,
+        # bound = dense fp16 peak (= the bf16 one) / 3.  The bound of the mix is the flop-weighted harmonic mean of the two.
         f16 = prof.get('igemm_f16x2', {'ms': 0.0, 'flops': 0.0, 'launches': 0})
         bf_fl = prof['igemm3_fwd']['flops'] + prof['igemm3_bwd']['flops']
         ig_ms = prof['igemm3_fwd']['ms'] + prof['igemm3_bwd']['ms'] + f16['ms']
@@ -191,8 +205,9 @@ def main():
             'metric': 'patches/sec Fisher-scored (32^3, 2-class)',
             'value': value, 'unit': 'patches/s', 'n_gpus': ws, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
-            'dtype': 'f32 (bf16x3 operand split on the bf16 MFMA - fp16x2 split in the launches whose input maxima are known ahead -, fp32 accumulate; '
-                     'everything else fp32 / fp64)',
+            'dtype': 'f32 (operands split exactly into 16-bit pieces on the 16-bit MFMA - fp16 pairs, three products, in the conv under the '
+                     'head (forward + backward) and the other backward launches; bf16 triples, six products, in the remaining forward launches - '
+                     'fp32 accumulate; everything else fp32 / fp64)',
             'data': 'synthetic',
             'config': {'workload': ('configs[3]: Fisher scoring, NET-C patch-wise 3-D U-Net (fc head), ONE pool of %d synthetic 32^3 '
                                     '2-class patches in contiguous blocks over the GPUs, random-init weights seed 14' % n_global) if strong else
@@ -200,11 +215,19 @@ def main():
                                     '%d synthetic 32^3 2-class patches per GPU, random-init weights seed 14' % n_local),
                        'outputs_per_patch': 'p1, |p1-.5| (top-B keys), H, g0[8], g1[8], A[8x8], tr A stored; sum A over the pool',
                        'pool_global': n_global, 'pool_per_gpu': n_local, 'batch': model.max_batch, 'topB': args.topB,
+                       # integers the driver can check: ranks of the torch.distributed group and of the RCCL communicator the libalq
+                       # context owns (0 = none: the Fisher sum goes through torch.distributed or, at world 1, nowhere)
+                       'dist_world_size': dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1,
+                       'comm_world': int(getattr(sess, 'comm_world', 0) or 0),
+                       'dist_backend': dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None,
+                       'head_conv_engine': {'forward_plane_sweep': int(sess.lib.alq_model_engine_info(model._m, 1)),
+                                            'backward_plane_sweep': int(sess.lib.alq_model_engine_info(model._m, 2))},
                        'parallelism': 'pool sharded over %d GPU(s), top-B merge (all-gather) + 8x8 Fisher all-reduce: %s' % (ws, comm)},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic, 'traffic_note': traffic_note,
-                         'kernel': 'igemm4_kernel: conv / conv_transpose fwd + bwd-data, bf16x3 split (fp16x2 where the input '
-                                   'maxima are known ahead: 4 of the 12 launches of a pass)',
+                         'kernel': 'the 12 contraction launches of a pass: c3d_fwd_kernel / c3d_bwd_kernel (plane-sweep engine, the conv under the '
+                                   'head: 53 % of the flops, fp16 pairs) + 10 igemm4_kernel launches (conv / conv_transpose fwd + bwd-data: '
+                                   'fp16 pairs in the backward launches, bf16 triples in the forward ones)',
                          'peak_note': 'algorithmic fp32 flops; peak = flop-weighted harmonic mean of %.0f dense 16-bit MFMA / %d '
                                       'products (bf16x3 launches, %.0f %% of the flops) and / 3 (the fp16x2 launches)'
                                       % (PEAK_BF16_MFMA_TFLOPS, SPLIT_PRODUCTS, 100.0 * bf_fl / max(ig_fl, 1.0)),
@@ -236,6 +259,165 @@ def main():
     if ws > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _conv_roofline(prof, note):
+    """Roofline object from the HIP-event classes of the contraction engines (whatever ran: the small nets of configs[0..1] use
+    the first-layer kernel, the bf16x3 engines and the fp32 fallback)."""
+    keys = ('igemm_fwd', 'igemm_bwd', 'igemm3_fwd', 'igemm3_bwd', 'direct_conv', 'igemm_f16x2')
+    ms = sum(prof[k]['ms'] for k in keys if k in prof)
+    fl = sum(prof[k]['flops'] for k in keys if k in prof)
+    n = sum(prof[k]['launches'] for k in keys if k in prof)
+    peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
+    ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    return {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+            'kernel': 'all contraction launches (first-layer kernel, igemm3 / igemm4 bf16x3, fp32 fallback engine)', 'launches': n,
+            'avg_launch_ms': ms / max(n, 1), 'peak_note': 'dense 16-bit MFMA %.0f TFLOP/s / 6 products of the bf16x3 split' % PEAK_BF16_MFMA_TFLOPS,
+            'note': note, 'time_share_ms_sampled': {k: v['ms'] for k, v in prof.items()}}
+
+
+def small_config(args, sess, rank, ws):
+    """configs[0]: NET-A entropy query over 1,000 patches (RandomState(1001), weights seed 11, k = 50; the
+    reference's CNN_query(..., 'entropy'), PW_NNAL.py:51-65); configs[1]: NET-A Fisher scoring of 10,000 patches (RandomState(1002),
+    weights seed 12, diag_load 1e-5).  One GPU (these pools do not shard meaningfully); launch-latency bound by construction."""
+    import torch
+    from nnal_amd import device, netspec, pool_shard
+    ent = args.config == 0
+    n = 1000 if ent else 10000
+    ld = netspec.net_a()
+    in_shape = (32, 32, 1)
+    pars = netspec.he_init(ld, in_shape, seed=11 if ent else 12)
+    model = device.DeviceModel(sess, ld, in_shape, (), max_batch=min(n, 10000))
+    model.set_weights(pars)
+    xs = np.random.RandomState(1001 if ent else 1002).randn(n, *in_shape).astype(np.float32)
+    x = sess.to_device(xs.reshape(n, -1), torch.float32)
+    k = 50 if ent else 500
+
+    def step():
+        if ent:
+            post, _, _ = model.forward_device(x, n)
+            return sess.uncertainty_filter(post[1].contiguous(), k)
+        return pool_shard.score_pool(model, sess, x, n, k, 1e-5)['sel']
+    for _ in range(max(args.warmup, 1)):
+        step()
+    sess.prof_reset()
+    sess.prof_enable(0 if os.environ.get('ALQ_BENCH_NO_EVENTS') else 1)
+    steps = max(args.steps, 20)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sel = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    sess.prof_enable(False)
+    prof = sess.prof_read()
+    line = {'metric': 'patches/sec %s (32x32x1, 2-class)' % ('entropy-scored' if ent else 'Fisher-scored'), 'value': n * steps / dt, 'unit': 'patches/s',
+            'n_gpus': 1, 'steps': steps, 'warmup': max(args.warmup, 1), 'ms_per_step': 1e3 * dt / steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32 (bf16x3 operand split on the bf16 MFMA, fp32 accumulate; fp32 / fp64 elsewhere)', 'data': 'synthetic',
+            'config': {'workload': ('configs[0]: entropy query, NET-A 3-layer 2-D CNN, 1,000 synthetic 32x32x1 patches (RandomState 1001), weights seed 11, k = 50'
+                                    if ent else 'configs[1]: Fisher scoring, NET-A 3-layer 2-D CNN, 10,000 synthetic 32x32x1 patches (RandomState 1002), '
+                                    'weights seed 12, diag_load 1e-5, top-500'), 'pool_global': n, 'batch': model.max_batch},
+            'roofline': _conv_roofline(prof, 'a %d-patch pool of a 9,154-parameter net: %d kernel launches of a few microseconds each per step - '
+                                       'launch latency, not a roofline, bounds it' % (n, sum(v['launches'] for v in prof.values()) // max(steps, 1)))}
+    if not args.no_cpu_baseline:
+        from oracle import alpath
+        from oracle.model import OracleModel, OracleSession
+        torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
+        om = OracleModel(ld, in_shape, pars)
+        if ent:      # the reference's entropy branch: batched forward + argsort of |p - .5| (PW_NNAL.py:51-65)
+            t0 = time.perf_counter()
+            reps = 0
+            while time.perf_counter() - t0 < 3.0:
+                p = om.forward(xs)['posteriors'][1]
+                q = np.argsort(np.abs(p.astype(np.float64) - .5))[:k]
+                reps += 1
+            dtc = time.perf_counter() - t0
+            assert np.array_equal(np.sort(q), np.sort(sel.cpu().numpy())), 'device and oracle pick different patches'
+            line['cpu_baseline'] = {'value': n * reps / dtc, 'unit': 'patches/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                                    'sample': 'the whole pool, %d passes of batched forward + argsort in %.1f s' % (reps, dtc)}
+        else:
+            m = 1000
+
+            class E(object):
+                pars = {'patch_shape': in_shape[:2] + (1,)}
+                nclass = 2
+            osess = OracleSession(om)
+            t0 = time.perf_counter()
+            p = om.forward(xs[:m])['posteriors'][1].astype(np.float64)
+            alpath.gen_A_matrices(E(), om, osess, xs[:m], p, 1e-5)
+            dtc = time.perf_counter() - t0
+            line['cpu_baseline'] = {'value': m / dtc, 'unit': 'patches/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                                    'sample': '%d of the pool\'s patches, forward + per-sample gen_A_matrices (reference structure), %.1f s' % (m, dtc)}
+    model.close()
+    return line
+
+
+def loop_config(args, sess, rank, ws):
+    """configs[4]: the active-learning loop at the patch-tensor level (al_loop.run_rounds = the control flow of
+    PW_AL.Experiment_MultiImg.run_method, PW_AL.py:690-898): 5 rounds over a pool of 200,000 synthetic 32^3 patches (sharded over the
+    ranks), per round entropy filter to B = 4096 -> Fisher matrices -> SDP -> 100 draws -> fine-tune; value = patches scored by the
+    filter per second of the whole loop, per-round stage seconds beside it."""
+    import ctypes as C
+    import torch
+    from nnal_amd import al_loop, device, netspec, pool_shard
+    from nnal_amd._lib import check
+    n = 200000 if args.pool == 100000 else args.pool
+    rounds = 5
+    ld, sk = netspec.net_c()
+    in_shape = (32, 32, 32, 1)
+    pars = netspec.he_init(ld, in_shape, seed=15, skips=sk)
+    model = device.DeviceModel(sess, ld, in_shape, sk, max_batch=args.batch)
+    model.set_weights(pars)
+    model.get_optimizer(1e-4, [], 'SGD')
+    a, b = pool_shard.shard_bounds(n, ws, rank)
+    pool = sess.empty((b - a, 32 ** 3), torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1005, a, b - a, 32 ** 3, C.c_void_p(pool.data_ptr())))
+    lab_local = (pool[:, :512].sum(dim=1) > 0).cpu().numpy().astype(np.float64)
+    labels = pool_shard.allgather_rows(n, np.arange(a, b), lab_local, sess).astype(np.int64)
+    if ws > 1 and args.backend == 'nccl':
+        try:
+            pool_shard.attach_comm(sess)
+        except Exception as e:
+            print('[bench] rank %d: %s' % (rank, e), file=sys.stderr, flush=True)
+    model.forward_device(pool, min(b - a, args.batch))           # warm-up pass
+    sess.prof_reset()
+    sess.prof_enable(0 if os.environ.get('ALQ_BENCH_NO_EVENTS') else args.prof_every)
+    pool_shard.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = al_loop.run_rounds(model, sess, pool, rounds, args.topB, 100, n_global=n, labels=labels, finetune=dict(epochs=1, b=50))
+    torch.cuda.synchronize()
+    pool_shard.barrier()
+    dt = pool_shard.max_over_ranks(time.perf_counter() - t0)
+    sess.prof_enable(False)
+    prof = sess.prof_read()
+    scored = sum(rd['pool_left'] + len(rd['queries']) for rd in res)
+    line = {'metric': 'patches/sec scored by the query loop (32^3, 2-class)', 'value': scored / dt, 'unit': 'patches/s', 'n_gpus': ws,
+            'steps': rounds, 'warmup': 1, 'ms_per_step': 1e3 * dt / rounds, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': 'f32 (16-bit operand splits on the MFMA, fp32 accumulate; SDP and draws in fp64 on the host)', 'data': 'synthetic',
+            'config': {'workload': 'configs[4]: active-learning loop, %d rounds over a pool of %d synthetic 32^3 patches, NET-C, per round entropy filter '
+                                   '(B = %d) -> Fisher -> SDP -> 100 draws -> fine-tune (SGD, 1 epoch of batches of 50)' % (rounds, n, args.topB),
+                       'pool_global': n, 'batch': model.max_batch, 'dist_world_size': ws, 'comm_world': int(getattr(sess, 'comm_world', 0) or 0),
+                       'rounds': [{'queries': int(len(rd['queries'])), 'pool_left': int(rd['pool_left']),
+                                   'seconds': {k: float(v) for k, v in rd['seconds'].items()},
+                                   'sdp': {k: (float(v) if isinstance(v, (int, float, np.floating)) else str(v)) for k, v in rd['sdp'].items()}}
+                                  for rd in res]},
+            'roofline': _conv_roofline(prof, 'the entropy filter (forward-only over the whole pool) is %.0f %% of the loop\'s wall time'
+                                       % (100.0 * sum(rd['seconds']['filter'] for rd in res) / dt))}
+    if not args.no_cpu_baseline and ws == 1 and rank == 0:
+        from oracle.model import OracleModel
+        torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
+        om = OracleModel(ld, in_shape, pars, skips=sk)
+        xs = pool[:256].cpu().numpy().reshape((-1,) + in_shape)
+        om.forward(xs[:8])
+        t0 = time.perf_counter()
+        om.forward(xs)
+        dtc = time.perf_counter() - t0
+        line['cpu_baseline'] = {'value': len(xs) / dtc, 'unit': 'patches/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                                'sample': 'batched oracle forward (the entropy filter, the loop\'s dominant stage) over %d pool patches, %.1f s; the '
+                                          'Fisher stage of the reference structure runs at the configs[2] baseline rate' % (len(xs), dtc)}
+    model.close()
+    return line
 
 
 NETB_BATCH = 2048      # same-box sweep over 8192 patches: 186 k patches/s at 256, 278 k at 512, 330 k at 1024, 350 k at 2048

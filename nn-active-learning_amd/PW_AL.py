@@ -106,7 +106,7 @@ def finetune_multimg(expr, model, sess, all_padded_imgs, training_inds):
 class LoopState(object):
     """The per-method directory of Experiment_MultiImg.run_method (PW_AL.py:690-898): `queries/<iter>` = rows
     [voxel index, subject index] (np.savetxt fmt '%d', :862-884), `AL_running_times/dt_<iter>` (:866-885) and
-    `curr_weights_<iter>` after every fine-tune (:896-898; .npz twin of the HDF5 file, h5py is absent).  Resume =
+    `curr_weights_<iter>` after every fine-tune (:896-898; HDF5 like the reference's when h5py is importable, else the .npz twin).  Resume =
     count the files in queries/ (:724-735)."""
 
     def __init__(self, root):
@@ -130,7 +130,26 @@ class LoopState(object):
         return np.concatenate(rows) if rows else np.zeros((0, 2), np.int64)
 
     def weights_path(self, it):
-        return os.path.join(self.root, 'curr_weights_%d.npz' % it)
+        """`curr_weights_<it>.h5` like the reference (PW_AL.py:896-898) when h5py is importable - an existing file of either
+        kind wins, so a directory started with one format is resumed in it - else the .npz twin."""
+        from . import weights_io
+        h5 = os.path.join(self.root, 'curr_weights_%d.h5' % it)
+        nz = os.path.join(self.root, 'curr_weights_%d.npz' % it)
+        if os.path.exists(nz) or (not weights_io.have_h5py() and not os.path.exists(h5)):
+            return nz
+        return h5
+
+
+def _yaml_load(f):
+    """yaml.load of the reference's parameter files (PW_AL.py:91-113) without arbitrary object construction: a SafeLoader that
+    additionally understands the one python tag yaml.dump puts into them - tuples (`patch_shape`).  A file in a shared experiment
+    directory cannot run code when it is loaded."""
+    import yaml
+
+    class Loader(yaml.SafeLoader):
+        pass
+    Loader.add_constructor('tag:yaml.org,2002:python/tuple', lambda ld, node: tuple(ld.construct_sequence(node, deep=True)))
+    return yaml.load(f, Loader=Loader)
 
 
 # ------------------------------------------------------------------------------------------ the experiment object
@@ -140,15 +159,22 @@ class Experiment(object):
     is not mirrored."""
 
     def __init__(self, root_dir, pars={}):
+        from . import pool_shard
         self.root_dir = root_dir
         self.nclass = 2
-        if not os.path.exists(root_dir):
-            os.mkdir(root_dir)
-        if len(pars) > 0:
-            if os.path.exists(os.path.join(root_dir, 'parameters.txt')):
-                print("Some parameters already exist")
-            else:
-                self.save_parameters(pars)
+        # one process per GPU: rank 0 creates the directory and writes the files, the others wait and read them back (a peer
+        # that raced the writer would load a half-written parameters.txt)
+        rank, ws = pool_shard.world()
+        if rank == 0:
+            os.makedirs(root_dir, exist_ok=True)
+            if len(pars) > 0:
+                if os.path.exists(os.path.join(root_dir, 'parameters.txt')):
+                    print("Some parameters already exist")
+                else:
+                    self.save_parameters(pars)
+        pool_shard.barrier()
+        if rank != 0 and len(pars) > 0 and os.path.exists(os.path.join(root_dir, 'parameters.txt')):
+            self.load_parameters()
 
     def save_parameters(self, pars):
         import copy
@@ -158,15 +184,14 @@ class Experiment(object):
             yaml.dump(pars, f)
 
     def load_parameters(self):
-        import yaml
         with open(os.path.join(self.root_dir, 'parameters.txt'), 'r') as f:
-            self.pars = yaml.load(f, Loader=yaml.UnsafeLoader)      # tuples (patch_shape) are python-tagged, like yaml.load(f) of old
+            self.pars = _yaml_load(f)
 
 
 class Experiment_MultiImg(Experiment):
     """PW_AL.Experiment_MultiImg (PW_AL.py:586-898): active learning over several subjects, each a list of modality
     volumes + a mask (NaN = voxel to ignore).  `train_paths.txt`, `train_stats.txt` and, per method, `queries/<iter>`,
-    `AL_running_times/dt_<iter>`, `curr_weights_<iter>` as the reference writes them (weights as .npz: h5py is absent).
+    `AL_running_times/dt_<iter>`, `curr_weights_<iter>` as the reference writes them (weights: HDF5 with h5py, else .npz).
 
     `run_method` is the reference's loop (:690-898): grid indices -> resume from queries/ -> load + pad -> model ->
     perform_assign_ops(init_weights_path) -> [query_multimg -> pool -> training bookkeeping -> files -> finetune_multimg
@@ -177,33 +202,35 @@ class Experiment_MultiImg(Experiment):
 
     def __init__(self, root_dir, pars={}, train_paths={}, test_paths={}):
         import yaml
+        from . import pool_shard
         Experiment.__init__(self, root_dir, pars)
         if not hasattr(self, 'pars'):
             self.load_parameters()
+        rank, ws = pool_shard.world()
         tr_file = os.path.join(self.root_dir, 'train_paths.txt')
-        if not os.path.exists(tr_file):
-            with open(tr_file, 'w') as f:
-                yaml.dump(train_paths, f)
-            self.train_paths = train_paths
-        else:
-            with open(tr_file, 'r') as f:
-                self.train_paths = yaml.load(f, Loader=yaml.UnsafeLoader)
         st_file = os.path.join(self.root_dir, 'train_stats.txt')
-        if os.path.exists(st_file):
-            self.train_stats = np.loadtxt(st_file)
-            if self.train_stats.ndim == 1:                       # one subject: savetxt dropped the dimension (:626-631)
-                self.train_stats = np.expand_dims(self.train_stats, axis=0)
-        else:
-            self.train_stats = get_stats(self.train_paths)
-            np.savetxt(st_file, self.train_stats)
+        if rank == 0:        # the writer; its peers read the finished files behind the barrier
+            if not os.path.exists(tr_file):
+                with open(tr_file, 'w') as f:
+                    yaml.dump(train_paths, f)
+            if not os.path.exists(st_file):
+                with open(tr_file, 'r') as f:
+                    np.savetxt(st_file, get_stats(_yaml_load(f)))
+        pool_shard.barrier()
+        with open(tr_file, 'r') as f:
+            self.train_paths = _yaml_load(f)
+        self.train_stats = np.loadtxt(st_file)
+        if self.train_stats.ndim == 1:                           # one subject: savetxt dropped the dimension (:626-631)
+            self.train_stats = np.expand_dims(self.train_stats, axis=0)
         self.model_factory = None     # callable(expr, input_shape, sess) -> model for nets other than the reference's 'PW'
 
     def add_method(self, method_name):
+        from . import pool_shard
         method_path = os.path.join(self.root_dir, method_name)
-        if not os.path.exists(method_path):
-            os.mkdir(method_path)
-            os.mkdir(os.path.join(method_path, 'queries'))
-            os.mkdir(os.path.join(method_path, 'AL_running_times'))
+        if pool_shard.world()[0] == 0:
+            for d in (method_path, os.path.join(method_path, 'queries'), os.path.join(method_path, 'AL_running_times')):
+                os.makedirs(d, exist_ok=True)
+        pool_shard.barrier()
 
     def _create_model(self, sess):
         m = len(self.train_paths[0]) - 1

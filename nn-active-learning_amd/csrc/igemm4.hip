@@ -1877,8 +1877,10 @@ static int igemm4_launch_impl(alq_ctx *ctx, const Igemm4Plan &plan, const View &
                               int relu, int accumulate, int N, int prof_cls, const Igemm2Fuse *fuse);
 
 // will this launch contract with the fp16x2 split?  (the conditions under which igemm4_launch_impl sets `f16`)
-static bool g4_wants_f16(const Igemm4Plan &plan, const View &in, const Igemm2Fuse *fuse) {
-    if (!fuse || g_no_f16x2 || !plan.d_W16 || plan.multi) return false;
+static bool g4_wants_f16(const Igemm4Plan &plan, const View &in, const Igemm2Fuse *fuse, int accumulate) {
+    // the same conditions as `f16` / `no16` in igemm4_launch_impl: an accumulating launch never contracts with the split, so it
+    // must never be routed to an fp16x2-only twin plan (whose weights exist in that form only)
+    if (!fuse || g_no_f16x2 || accumulate || !plan.d_W16 || plan.multi) return false;
     if (fuse->in_bits) return fuse->in_vec_amax > 0.f;
     if (fuse->fc_W) return fuse->in_amax != nullptr;
     if (fuse->in_bound > 0.f && !fuse->in_amax) return plan.a.PT == 1 && plan.NTW <= 2;
@@ -1887,7 +1889,7 @@ static bool g4_wants_f16(const Igemm4Plan &plan, const View &in, const Igemm2Fus
 
 int igemm4_launch(alq_ctx *ctx, const Igemm4Plan &plan, const View &in, const View &out, const float *bias,
                   int relu, int accumulate, int N, int prof_cls, const Igemm2Fuse *fuse) {
-    if (plan.alt16 && plan.alt16->ok && plan.alt16->d_W16 && g4_wants_f16(*plan.alt16, in, fuse))
+    if (plan.alt16 && plan.alt16->ok && plan.alt16->d_W16 && g4_wants_f16(*plan.alt16, in, fuse, accumulate))
         return igemm4_launch_impl(ctx, *plan.alt16, in, out, bias, relu, accumulate, N, prof_cls, fuse);
     return igemm4_launch_impl(ctx, plan, in, out, bias, relu, accumulate, N, prof_cls, fuse);
 }

@@ -1186,8 +1186,10 @@ static int run_backward_main(alq_model *m, const float *d_x, int N) {
                     fz.amax_from = fz.split > 0 && fz.split < (1 << 29) ? fz.split : 0;       // the slice the layer below reads
                     hand = true;
                 }
-                if (p4_here && ly.dout_amax) fz.in_amax = ly.dout_amax;
-                if (p4_here && !fz.in_amax && ly.dout_bound > 0.f && !m->no_bound16) fz.in_bound = ly.dout_bound;
+                // (not for an accumulating launch - a conv right behind a skip source: those run the plain bf16x3 instantiation,
+                // igemm4_launch_impl's `no16`, and must not be routed to an fp16x2-only twin plan)
+                if (p4_here && !acc && ly.dout_amax) fz.in_amax = ly.dout_amax;
+                if (p4_here && !acc && !fz.in_amax && ly.dout_bound > 0.f && !m->no_bound16) fz.in_bound = ly.dout_bound;
                 // a launch without an epilogue request (nothing parameterised below it to mask or sum for) still gets its
                 // fp16x2 scale: an otherwise empty request carries the bound (no mask, no sums: the plain epilogue runs)
                 if (!fuse && !acc && v4_on && ly.bwd.p4.ok && !ly.bwd.p4.multi && ly.bwd.p4.a.PT == 1 && !g_no_f16x2 && !ly.dout_amax &&

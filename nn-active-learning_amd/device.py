@@ -576,16 +576,15 @@ class DeviceModel(object):
         self._weights_version += 1
 
     def load_weights(self, path, session=None):
-        """.npz twin of CNN.load_weights (NN.py:396-419): keys '<layer>/Weight', '<layer>/Bias'."""
-        f = np.load(path)
-        self.set_weights({n: [f[n + '/Weight'], f[n + '/Bias']] for n in self.var_names})
+        """CNN.load_weights (NN.py:396-419; NN_extended.py:708-760): an HDF5 file of the reference - groups per layer, datasets
+        `Weight` / `Bias` in TF layouts - when h5py is importable, or the .npz twin (keys '<layer>/Weight', '<layer>/Bias')."""
+        from . import weights_io
+        self.set_weights(weights_io.read_weights(path, self.var_names))
 
     def save_weights(self, path):
-        """.npz twin of CNN.save_weights (NN.py:379-394)."""
-        d = {}
-        for n, wb in self.var_dict.items():
-            d[n + '/Weight'], d[n + '/Bias'] = wb
-        np.savez(path, **d)
+        """CNN.save_weights (NN.py:379-394): `.h5` -> the reference's HDF5 layout (needs h5py), anything else -> the .npz twin."""
+        from . import weights_io
+        weights_io.write_weights(path, self.var_dict)
 
     def add_assign_ops(self):
         """No graph to extend (NN.py:421-458): kept so loop code calls it unchanged."""

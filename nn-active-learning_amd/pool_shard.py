@@ -164,13 +164,17 @@ def merge_topB(local_keys, local_global_idx, B):
     return _topk_merge(k, g, B)
 
 
-def merge_topB_device(sess, keys, gidx, B):
+def merge_topB_device(sess, keys, gidx, B, n_global=None):
     """merge_topB on device tensors, nothing staged through the host: every rank passes its (at most B) best candidates as a
     float64 key tensor in ascending order (ties -> lower index) and their GLOBAL indices; fixed-size all-gather of the padded
     (key, index) vectors over the process group (RCCL under "nccl"), then the device top-B of the concatenation
     (alq_topk_uncertain: ascending key, ties -> lower POSITION, and position order IS global-index order among equal keys
     because ranks own ascending index blocks and each rank's list is already tie-ordered).  Returns the global indices as
-    an int64 device tensor [min(B, candidates in total)], identical on every rank."""
+    an int64 device tensor [min(B, candidates in total)], identical on every rank.
+
+    n_global (the pool size; ranks own the blocks of shard_bounds): the number of real candidates in the gathered vector is
+    then known on the host - sum over the ranks of min(B, block size) - and nothing in here waits for the device.  Without
+    it the count is read back from the gathered indices (one host synchronisation per call)."""
     torch = sess.torch
     rank, ws = world()
     nl = int(keys.numel())
@@ -180,7 +184,9 @@ def merge_topB_device(sess, keys, gidx, B):
     # a one-rank "nccl" group still takes the collective path: that is how the one-GPU box exercises the RCCL all-gather of
     # device tensors this function issues on a real node
     if ws > 1 or (dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl'):
-        kk = torch.full((B,), float('inf'), dtype=torch.float64, device=keys.device)
+        # padding: the largest key BIT PATTERN there is (the merge compares keys as bit patterns: numbers ascending, NaNs behind
+        # them) - a real candidate, even one with a NaN key, never sorts behind a padding slot
+        kk = torch.full((B,), 0x7fffffffffffffff, dtype=torch.int64, device=keys.device).view(torch.float64)
         gg = torch.full((B,), -1, dtype=torch.int64, device=keys.device)
         kk[:nl] = keys
         gg[:nl] = gidx
@@ -191,7 +197,12 @@ def merge_topB_device(sess, keys, gidx, B):
         dist.all_gather_into_tensor(K, kk)
         dist.all_gather_into_tensor(G, gg)
         K, G = K.to(keys.device), G.to(keys.device)
-        valid = int((G >= 0).sum().item()) if B > 0 else 0   # n_global < B only: padding must not be selected
+        if B <= 0:
+            valid = 0
+        elif n_global is not None:
+            valid = sum(min(int(B), b - a) for a, b in (shard_bounds(n_global, ws, r) for r in range(ws)))
+        else:
+            valid = int((G >= 0).sum().item())               # padding must not be selected (n_global < B only)
     else:
         K, G, valid = keys.contiguous(), gidx.contiguous(), nl
     take = min(int(B), valid)
@@ -256,8 +267,9 @@ def score_pool(model, sess, local_patches, n_global, B, diag_load=1e-5,
     else:
         keys = sess.empty((0,), torch.float64)
         gidx = sess.empty((0,), torch.int64)
-    # both exchanges stay on the device: nothing in this function copies to the host or synchronises
-    sel = merge_topB_device(sess, keys, gidx, min(B, n_global))
+    # both exchanges stay on the device: nothing in this function copies to the host or synchronises (the number of real
+    # candidates of the merge follows from n_global on the host)
+    sel = merge_topB_device(sess, keys, gidx, min(B, n_global), n_global=n_global)
     Asum = allreduce_sum_device(out['Asum'], sess) if out.get('Asum') is not None else None
     out.update(sel=sel, Asum=Asum, offset=a)
     return out

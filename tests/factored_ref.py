@@ -70,6 +70,7 @@ def factored_unit_scores(model, x, details=None, flips=None):
     names = model.names
     out = xt
     layer_outs = []
+    pool_inputs = {}
     sources = {}
     src_idx = [s[0] for s in model.skips]
     for i, name in enumerate(names):
@@ -104,6 +105,12 @@ def factored_unit_scores(model, x, details=None, flips=None):
             else:
                 out = torch.relu(pre) if relu else pre
         elif ltype == 'pool':
+            if flips is not None and ('pool:' + name) in flips:
+                # a near-tie of a max-pool window decided the other way: the runner-up is lifted past the winner by less than
+                # the implementations' rounding noise (relu_flip_explains), which moves the value by nothing but re-routes the
+                # whole backward path of that window to another voxel
+                out = out + torch.as_tensor(np.asarray(flips['pool:' + name]), dtype=out.dtype)
+            pool_inputs[name] = out.detach()
             if model.ext:
                 out = tfops.max_pool_same(out, spec[1], spec[1])
             else:
@@ -149,6 +156,9 @@ def factored_unit_scores(model, x, details=None, flips=None):
         details['names'] = [r['name'] for r in recs]
         details['pre'] = [r['pre'].detach().numpy() for r in recs]
         details['relu'] = [bool(r['relu']) for r in recs]
+        details['pool_in'] = {k: v.numpy() for k, v in pool_inputs.items()}
+        details['pool_k'] = {n: (model.layer_dict[n][1] if model.ext else [model.layer_dict[n][0][0]] * (pool_inputs[n].dim() - 2))
+                             for n in pool_inputs}
     return p.numpy(), S.numpy(), np.array(sizes)
 
 
@@ -177,11 +187,14 @@ def relu_flip_explains(model64, x1, targets, diag_load, atol=2e-6, rtol=2e-5, ep
 
     `targets`: list of (g0 [L], g1 [L]) score vectors of that patch (e.g. two device engines).  Each must lie within
     atol + rtol |value| of the fp64 evaluation of the network (`model64`: an fp64 OracleModel), OR of an fp64 evaluation in
-    which some of the patch's FRAGILE ReLU decisions are inverted - fragile = |pre-activation| <= eps x the layer's rms
-    pre-activation, i.e. an input that fp32 rounding can legitimately put on either side of zero.  At most `max_units` most
-    fragile units are considered, at most `max_flips` of them inverted together.
-    Returns a list, per target, of the tuple of inverted units ((layer name, flat index), ...) - () = the plain fp64
-    value - or None when no such evaluation matches (the disagreement is NOT a ReLU flip)."""
+    which some of the patch's FRAGILE decisions are inverted.  Fragile = a ReLU input with |pre-activation| <= eps x the layer's
+    rms pre-activation, i.e. one that fp32 rounding can legitimately put on either side of zero - or (round 4) a max-pool window
+    (window = stride, even extents) whose two largest inputs lie within eps x the layer's rms of each other with a positive
+    maximum: which of them is the arg-max decides where the window's whole cotangent goes.  At most `max_units` most fragile
+    units are considered, at most `max_flips` of them inverted together.
+    Returns a list, per target, of the tuple of inverted units ((layer name, flat index), ...; a pool window as
+    ('pool:<name>', flat index of the lifted input)) - () = the plain fp64 value - or None when no such evaluation matches (the
+    disagreement is NOT such a flip)."""
     import itertools
     x1 = np.asarray(x1)[None] if np.asarray(x1).ndim == len(model64.in_shape) else np.asarray(x1)
     det = {}
@@ -206,13 +219,40 @@ def relu_flip_explains(model64, x1, targets, diag_load, atol=2e-6, rtol=2e-5, ep
         flat = np.abs(pre.reshape(-1)) / rms
         for i in np.nonzero(flat <= eps)[0]:
             cand.append((flat[i], name, int(i), pre.shape))
+    for name, xin in det.get('pool_in', {}).items():
+        k = list(det['pool_k'][name])
+        sp = xin.shape[1:-1]
+        if xin.shape[0] != 1 or any(d % kk for d, kk in zip(sp, k)):
+            continue                       # (ragged SAME windows are not needed by the nets this arbiter serves)
+        C = xin.shape[-1]
+        rms = float(np.sqrt(np.mean(xin ** 2))) or 1.0
+        idx = np.arange(xin.size).reshape(xin.shape)
+        shp2, perm = [1], [0]
+        for d, kk in zip(sp, k):
+            shp2 += [d // kk, kk]
+        shp2 += [C]
+        nd = len(sp)
+        win_axes = [2 + 2 * a for a in range(nd)]
+        cell_axes = [1 + 2 * a for a in range(nd)]
+        order = [0] + cell_axes + [1 + 2 * nd] + win_axes
+        v = xin.reshape(shp2).transpose(order).reshape(-1, int(np.prod(k)))
+        ii = idx.reshape(shp2).transpose(order).reshape(-1, int(np.prod(k)))
+        srt = np.argsort(-v, axis=1)
+        top, sec = v[np.arange(len(v)), srt[:, 0]], v[np.arange(len(v)), srt[:, 1]]
+        gap = (top - sec) / rms
+        for w in np.nonzero((gap <= eps) & (top > 0))[0]:
+            cand.append((gap[w], 'pool:' + name, int(ii[w, srt[w, 1]]), xin.shape, float(2.0 * (top[w] - sec[w]) + 1e-12 * rms)))
     cand.sort(key=lambda c: c[0])
     cand = cand[:max_units]
     for r in range(1, min(max_flips, len(cand)) + 1):
         for combo in itertools.combinations(cand, r):
             fl, shapes = {}, {}
-            for _, name, i, shp in combo:
-                fl.setdefault(name, np.zeros(int(np.prod(shp)), bool))[i] = True
+            for c in combo:
+                name, i, shp = c[1], c[2], c[3]
+                if name.startswith('pool:'):
+                    fl.setdefault(name, np.zeros(int(np.prod(shp))))[i] = c[4]
+                else:
+                    fl.setdefault(name, np.zeros(int(np.prod(shp)), bool))[i] = True
                 shapes[name] = shp
             fl = {k: v.reshape(shapes[k]) for k, v in fl.items()}
             pf, Sf, _ = factored_unit_scores(model64, x1, None, flips=fl)

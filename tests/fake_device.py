@@ -19,9 +19,12 @@ class FakeSession(object):
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype)
 
-    def uncertainty_filter(self, posts, B):
+    def uncertainty_filter(self, posts, B, with_keys=False):
         key = np.abs(posts.numpy().astype(np.float64) - 0.5)
-        return torch.as_tensor(np.argsort(key, kind='stable')[:B].astype(np.int64))
+        idx = np.argsort(key, kind='stable')[:B].astype(np.int64)
+        if with_keys:
+            return torch.as_tensor(idx), torch.as_tensor(key[idx])
+        return torch.as_tensor(idx)
 
     def bind_stream(self):
         pass
@@ -111,4 +114,9 @@ class FakeModel(object):
             nclass = 2
         p = p1_in.numpy().astype(np.float64) if p1_in is not None else self.om.forward(x)['posteriors'][1].astype(np.float64)
         A = np.stack(alpath.gen_A_matrices(E(), self.om, self.osess, x, p, diag_load)) if n else np.zeros((0, self.L, self.L))
-        return {'A': torch.as_tensor(A)}
+        out = {'A': torch.as_tensor(A)}
+        if 'p1' in want:
+            out['p1'] = torch.as_tensor(p.astype(np.float32))
+        if 'Asum' in want:
+            out['Asum'] = torch.as_tensor(A.sum(0))
+        return out

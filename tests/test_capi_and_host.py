@@ -194,3 +194,43 @@ def test_topk_merge_c_abi():
     want = g[keep][np.lexsort((g[keep], k[keep]))][:64]
     assert n_out.value == 64
     np.testing.assert_array_equal(out, want)
+
+
+def test_weight_files_npz_twin_and_hdf5_when_available(tmp_path):
+    """weights_io: the reference keeps weights in HDF5 (groups per layer, datasets Weight / Bias in TF layouts,
+    NN.py:379-419; NN_extended.py:670-693 names the datasets after the variables).  The .npz twin round-trips everywhere; the
+    HDF5 form round-trips when h5py is importable and fails with a clear ImportError (not a guess) when it is not."""
+    import nnal_amd  # noqa: F401
+    from nnal_amd import weights_io
+    rs = np.random.RandomState(3)
+    vd = {'conv1': (rs.randn(3, 3, 1, 4).astype(np.float32), rs.randn(4).astype(np.float32)),
+          'fc1': (rs.randn(2, 36).astype(np.float32), rs.randn(2, 1).astype(np.float32))}
+    p = str(tmp_path / 'w.npz')
+    weights_io.write_weights(p, vd)
+    got = weights_io.read_weights(p, list(vd))
+    for n in vd:
+        np.testing.assert_array_equal(got[n][0], vd[n][0])
+        np.testing.assert_array_equal(got[n][1], vd[n][1])
+    h5 = str(tmp_path / 'curr_weights.h5')
+    if not weights_io.have_h5py():
+        with pytest.raises(ImportError, match='h5py'):
+            weights_io.write_weights(h5, vd)
+        with pytest.raises(ImportError, match='h5py'):
+            weights_io.read_weights(h5, list(vd))
+        return
+    import h5py
+    weights_io.write_weights(h5, vd)
+    with h5py.File(h5, 'r') as f:       # the reference's own reader: f[layer]['Weight'] / ['Bias'] (NN.py:409-419)
+        for n in vd:
+            np.testing.assert_array_equal(np.array(f[n]['Weight']), vd[n][0])
+            np.testing.assert_array_equal(np.array(f[n]['Bias']), vd[n][1])
+    got = weights_io.read_weights(h5, list(vd))
+    for n in vd:
+        np.testing.assert_array_equal(got[n][0], vd[n][0])
+    # NN_extended's naming: datasets named after the variables
+    with h5py.File(str(tmp_path / 'ext.h5'), 'w') as f:
+        g = f.create_group('conv1')
+        g.create_dataset('Weight_1', data=vd['conv1'][0])
+        g.create_dataset('Bias_1', data=vd['conv1'][1])
+    got = weights_io.read_weights(str(tmp_path / 'ext.h5'), ['conv1'])
+    np.testing.assert_array_equal(got['conv1'][0], vd['conv1'][0])

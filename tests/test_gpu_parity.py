@@ -984,13 +984,16 @@ def test_sign_fields_are_bit_identical(sess):
             out = {k: r[k].cpu().numpy() for k in ('p1', 'g0', 'g1', 'A', 'trace', 'Asum')}
             m.close()
             return out
-        a, b = run({}), run({'ALQ_NO_SIGNS': '1'})
+        # (ALQ_NO_C3D in both arms: the plane-sweep backward kernel of round 4 exists for the sign-field form only - without the
+        # fields the launch falls back to the two-slot engine, another summation order; the bit identity is a statement about
+        # ONE engine reading its masks from two sources)
+        a, b = run({'ALQ_NO_C3D': '1'}), run({'ALQ_NO_SIGNS': '1', 'ALQ_NO_C3D': '1'})
         for k in a:
             np.testing.assert_array_equal(a[k], b[k], err_msg='%s %s' % (in_shape, k))
 
 
-def test_default_engines_against_fp64_flip_safe_head(sess):
-    """NET-C at 32^3, the bench's weights and its first 16 synthetic patches, default engines (fp16x2 in the fused-head
+def test_default_engines_against_fp64_flip_safe_head(sess, n=64):
+    """NET-C at 32^3, the bench's weights and its first 64 synthetic patches (16 until round 4), default engines (fp16x2 in the fused-head
     conv's forward and in every backward launch, bf16x3 elsewhere) against an fp64 evaluation of the network.  The head
     conv's fp16x2 contraction alone would decide the sign of a ReLU input within its noise of zero in one of these
     patches (|error of g| 1.3e-4, ALQ_NO_FLIPFIX=1); the flip-safe head re-evaluates such inputs exactly
@@ -998,7 +1001,6 @@ def test_default_engines_against_fp64_flip_safe_head(sess):
     import ctypes as C
     from nnal_amd._lib import check
     torch = sess.torch
-    n = 16
     ld, sk = netspec.net_c()
     in_shape = (32, 32, 32, 1)
     pars = netspec.he_init(ld, in_shape, seed=14, skips=sk)
@@ -1013,6 +1015,156 @@ def test_default_engines_against_fp64_flip_safe_head(sess):
     g64, h64, _ = factored_ref.fisher_from_unit(p64[1], S64, sizes, 1e-3)
     r = model.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1'))
     np.testing.assert_allclose(r['p1'].cpu().numpy(), p64[1], rtol=0, atol=2e-6)
-    assert np.abs(r['g0'].cpu().numpy() - g64).max() <= 2e-6
-    assert np.abs(r['g1'].cpu().numpy() - h64).max() <= 2e-6
+    g0, g1 = r['g0'].cpu().numpy(), r['g1'].cpu().numpy()
+    off = np.nonzero((np.maximum(np.abs(g0 - g64), np.abs(g1 - h64)) > 2e-6).any(axis=1))[0]
+    # The head conv's own decisions are exact given its inputs; what remains (round 4, 64 patches instead of 16: ~6 % of the
+    # patches hold such a unit, tools/gpu_fullbatch_dbg.py) is a pre-activation within rounding of zero whose INPUTS - the
+    # outputs of fp32-level launches upstream - put it on the other side than the fp64 network has it.  A ReLU derivative is a
+    # step, so the scores jump by up to ~1e-3; every fp32 implementation has these patches (the exact-fp32 engine: others).
+    # Each one must be explained by the fp64 arbiter, and there must be few.
+    assert len(off) <= max(2, n // 8), off
+    for i in off:
+        found = factored_ref.relu_flip_explains(om64, xs[i], [(g0[i], g1[i])], 1e-3)
+        assert found[0], 'patch %d: scores differ from fp64 and no near-zero ReLU input explains it' % i
     model.close()
+
+
+@pytest.mark.parametrize('in_shape,n', [((16, 16, 16, 1), 5), ((32, 32, 32, 1), 3)])
+def test_accumulating_conv_behind_a_skip_source(sess, in_shape, n):
+    """A conv directly behind a skip source (8 -> 16 channels): its backward launch ACCUMULATES into the skip source's cotangent
+    (the concat's consumer wrote its slice first) and must run the plain bf16x3 instantiation - never be routed to an fp16x2-only
+    twin plan through a cotangent bound or per-patch maxima (round-3 advisor finding on model.hip / igemm4.hip).  Layer scores
+    against an fp64 evaluation."""
+    torch = sess.torch
+    from collections import OrderedDict
+    k3 = [3, 3, 3]
+    ld = OrderedDict([('c1', ['conv', [8, k3], 'MA']), ('c2', ['conv', [16, k3], 'MA']), ('c3', ['conv', [8, k3], 'MA']),
+                      ('c4', ['conv', [8, k3], 'MA']), ('fc', ['fc', [2]])])
+    sk = [[0, [3], 'con']]          # c4 reads [c1 | c3]; c2 sits right behind the skip source c1
+    pars = netspec.he_init(ld, in_shape, seed=41, skips=sk)
+    model = _device_model(sess, ld, in_shape, sk, pars, max_batch=4)
+    x = np.random.RandomState(83).randn(n, *in_shape).astype(np.float32)
+    xd = sess.to_device(x.reshape(n, -1), torch.float32)
+    r = model.fisher_device(xd, n, None, 1e-3)
+    torch.set_num_threads(16)
+    pars64 = {k: [v[0].astype(np.float64), v[1].astype(np.float64)] for k, v in pars.items()}
+    om64 = OracleModel(ld, in_shape, pars64, skips=sk, dtype=torch.float64)
+    p64, S64, sizes = factored_ref.factored_unit_scores(om64, x.astype(np.float64))
+    g64, h64, A64 = factored_ref.fisher_from_unit(p64[1], S64, sizes, 1e-3)
+    assert np.abs(r['p1'].cpu().numpy() - p64[1]).max() <= 5e-6
+    for got, ref in ((r['g0'].cpu().numpy(), g64), (r['g1'].cpu().numpy(), h64)):
+        scale = np.abs(ref).max(axis=0, keepdims=True)
+        assert (np.abs(got - ref) <= 5e-4 * scale + 1e-9).all(), np.abs(got - ref).max()
+    model.close()
+
+
+def _netc32_models(sess, envs, max_batch, seed=14, bias_std=0.0):
+    """NET-C at 32^3 with the bench's weights under several creation-time environments (engine switches are read when a model
+    is created)."""
+    ld, sk = netspec.net_c()
+    in_shape = (32, 32, 32, 1)
+    pars = netspec.he_init(ld, in_shape, seed=seed, skips=sk, bias_std=bias_std) if bias_std else netspec.he_init(ld, in_shape, seed=seed, skips=sk)
+    models = []
+    for env in envs:
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            models.append(_device_model(sess, ld, in_shape, sk, pars, max_batch=max_batch))
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    return ld, sk, in_shape, pars, models
+
+
+def _fp64_arbitrate(ld, sk, in_shape, pars, x_np, rows, results, names, max_rows=12):
+    """Every listed patch must have every engine's (g0, g1) at the fp64 value of the network or at an fp64 value with fragile
+    ReLU decisions inverted (factored_ref.relu_flip_explains); returns the number of patches that needed a flip."""
+    import torch
+    torch.set_num_threads(16)
+    assert len(rows) <= max_rows, 'too many disagreeing patches for the fp64 arbiter: %d' % len(rows)
+    pars64 = {k: [v[0].astype(np.float64), v[1].astype(np.float64)] for k, v in pars.items()}
+    om64 = OracleModel(ld, in_shape, pars64, skips=sk, dtype=torch.float64)
+    flips = 0
+    for i in rows:
+        found = factored_ref.relu_flip_explains(om64, x_np[i].reshape(in_shape).astype(np.float64), [(r['g0'][i], r['g1'][i]) for r in results], 1e-3)
+        for name, f in zip(names, found):
+            assert f is not None, 'patch %d, engine %s: scores differ from fp64 and no near-zero ReLU input explains it' % (i, name)
+        flips += any(bool(f) for f in found)
+    return flips
+
+
+def test_plane_sweep_engine_against_the_two_slot_engine(sess):
+    """The conv under the two-class head and its backward on the plane-sweep engine (csrc/c3d.hip, default) against the two-slot
+    engine's launches of round 3 (ALQ_NO_C3D=1): same fp16x2 arithmetic in another summation order and, in the one-accumulator
+    form, another place for the low pieces.  600 patches of the bench's pool (workgroups with one, two and three patches: the
+    patch seams of the sweep), Fisher pass and forward-only pass.  Posteriors within 2e-6; every layer score within 2e-6 + 2e-5
+    relative of the other engine's, or the patch goes to the fp64 arbiter (a ReLU input within rounding of zero may land on
+    either side)."""
+    import ctypes as C
+    from nnal_amd._lib import check
+    torch = sess.torch
+    n = 600
+    ld, sk, in_shape, pars, (m_new, m_old) = _netc32_models(sess, [{}, {'ALQ_NO_C3D': '1'}], max_batch=n)
+    x = sess.empty((n, 32 ** 3), torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, 32 ** 3, C.c_void_p(x.data_ptr())))
+    out = []
+    for m in (m_new, m_old):
+        r = m.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1', 'A', 'Asum'))
+        d = {k: r[k].cpu().numpy() for k in ('p1', 'g0', 'g1', 'A', 'Asum')}
+        d['post'] = m.forward_device(x, n)[0].cpu().numpy()
+        out.append(d)
+    assert sess.lib.alq_model_engine_info(m_new._m, 1) == 1 and sess.lib.alq_model_engine_info(m_new._m, 2) == 1, 'plane-sweep engine did not run'
+    assert sess.lib.alq_model_engine_info(m_old._m, 1) == 0 and sess.lib.alq_model_engine_info(m_old._m, 2) == 0
+    a, b = out
+    np.testing.assert_allclose(a['p1'], b['p1'], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(a['post'], b['post'], rtol=0, atol=2e-6)
+    bad = set()
+    for k in ('g0', 'g1'):
+        err = np.abs(a[k] - b[k])
+        bad |= set(np.nonzero((err > 2e-6 + 2e-5 * np.abs(b[k])).any(axis=1))[0].tolist())
+    xs = x.cpu().numpy()
+    flips = _fp64_arbitrate(ld, sk, in_shape, pars, xs, sorted(bad), [a, b], ['plane sweep', 'two-slot'])
+    assert flips <= 8, flips
+    good = np.array(sorted(set(range(n)) - bad))
+    np.testing.assert_allclose(a['A'][good], b['A'][good], rtol=2e-5, atol=1e-12 + 2e-6 * np.abs(b['A']).max())
+    m_new.close()
+    m_old.close()
+
+
+def test_default_engines_against_the_exact_fp32_engine_full_batch(sess):
+    """One full 2000-patch batch of the bench's pool: the default engines (fp16x2 pairs in the plane-sweep kernels and in the other
+    backward launches, bf16x3 elsewhere) against the exact-fp32 MFMA engine (alq_debug_set(4, 1): fp32 fma chains, no operand
+    split) ON THE DEVICE (round-3 verdict, item 3; reference outputs: PW_NNAL.py:757-814).  Posteriors within 2e-6 for all 2000
+    patches; layer scores within 2e-6 for all but the patches that hold a ReLU input within rounding of zero, of which a seeded
+    sample goes to the fp64 arbiter and must be explained by such a unit."""
+    import ctypes as C
+    from nnal_amd._lib import check
+    torch = sess.torch
+    n = 2000
+    ld, sk, in_shape, pars, (m,) = _netc32_models(sess, [{}], max_batch=n)
+    x = sess.empty((n, 32 ** 3), torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, 32 ** 3, C.c_void_p(x.data_ptr())))
+    r = m.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1'))
+    a = {k: r[k].cpu().numpy() for k in ('p1', 'g0', 'g1')}
+    check(sess.lib.alq_debug_set(4, 1))
+    try:
+        r = m.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1'))
+        b = {k: r[k].cpu().numpy() for k in ('p1', 'g0', 'g1')}
+    finally:
+        check(sess.lib.alq_debug_set(4, 0))
+    # posteriors: continuous in the rounding noise, so a hard bar
+    np.testing.assert_allclose(a['p1'], b['p1'], rtol=0, atol=2e-6)
+    bad = set()
+    for k in ('g0', 'g1'):
+        bad |= set(np.nonzero((np.abs(a[k] - b[k]) > 2e-6).any(axis=1))[0].tolist())
+    # The scores are NOT continuous: a ReLU input within rounding of zero that two fp32-level engines put on different sides
+    # switches a whole backward path on or off (measured with tools/gpu_fullbatch_dbg.py: ~6 % of the 32^3 patches hold such a
+    # unit, |delta g| up to 7e-4 then, and each engine - the exact-fp32 one included - has its own set against fp64).  So: few
+    # flagged patches, a sanity bound on them, and a seeded sample of them through the fp64 arbiter (every one of them would be
+    # ten minutes of CPU), which must explain each sampled patch by such a unit.
+    assert len(bad) <= n // 10, len(bad)
+    assert max(np.abs(a[k] - b[k]).max() for k in ('g0', 'g1')) <= 5e-3
+    sample = sorted(np.random.RandomState(5).choice(sorted(bad), size=min(10, len(bad)), replace=False).tolist()) if bad else []
+    xs = x.cpu().numpy()
+    _fp64_arbitrate(ld, sk, in_shape, pars, xs, sample, [a, b], ['default engines', 'fp32 MFMA'], max_rows=10)
+    m.close()

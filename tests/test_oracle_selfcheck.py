@@ -108,3 +108,41 @@ def test_factored_identity_fp64(name, ld, in_shape, skips):
         g0, g1 = alpath.shrunk_grads(model, sess, x[i])
         np.testing.assert_allclose(g0f[i], g0, rtol=1e-9, atol=1e-14)
         np.testing.assert_allclose(g1f[i], g1, rtol=1e-9, atol=1e-14)
+
+
+def test_fp64_arbiter_finds_a_max_pool_near_tie():
+    """tests/factored_ref.relu_flip_explains (the fp64 arbiter of the GPU parity tests) also considers max-pool windows whose two
+    largest inputs lie within rounding of each other: deciding such a tie the other way leaves every value unchanged and moves
+    the window's whole cotangent to another voxel - the layer scores below the pool jump like they do for a ReLU flip.
+    Here: the scores of an evaluation with the most fragile window of a small NET-C patch decided the other way are handed
+    to the arbiter, which must name exactly that window."""
+    import torch
+    from oracle import netspec
+    from oracle.model import OracleModel
+    from tests import factored_ref
+    ld, sk = netspec.net_c()
+    in_shape = (8, 8, 8, 1)
+    pars = netspec.he_init(ld, in_shape, seed=3, skips=sk)
+    pars64 = {k: [v[0].astype(np.float64), v[1].astype(np.float64)] for k, v in pars.items()}
+    om = OracleModel(ld, in_shape, pars64, skips=sk, dtype=torch.float64)
+    x = np.random.RandomState(1).randn(*in_shape)
+    det = {}
+    p, S, sizes = factored_ref.factored_unit_scores(om, x[None], det)
+    xin = det['pool_in']['pool1']
+    v = xin.reshape(1, 4, 2, 4, 2, 4, 2, 8).transpose(0, 1, 3, 5, 7, 2, 4, 6).reshape(-1, 8)
+    ii = np.arange(xin.size).reshape(xin.shape).reshape(1, 4, 2, 4, 2, 4, 2, 8).transpose(0, 1, 3, 5, 7, 2, 4, 6).reshape(-1, 8)
+    srt = np.argsort(-v, axis=1)
+    top, sec = v[np.arange(len(v)), srt[:, 0]], v[np.arange(len(v)), srt[:, 1]]
+    ok = np.nonzero(top > 0)[0]
+    w = ok[np.argmin((top - sec)[ok])]
+    bump = np.zeros(xin.size)
+    bump[ii[w, srt[w, 1]]] = 2 * (top[w] - sec[w]) + 1e-12
+    pf, Sf, _ = factored_ref.factored_unit_scores(om, x[None], None, flips={'pool:pool1': bump.reshape(xin.shape)})
+    g0, g1, _ = factored_ref.fisher_from_unit(p[1], S, sizes, 1e-3)
+    f0, f1, _ = factored_ref.fisher_from_unit(pf[1], Sf, sizes, 1e-3)
+    assert np.abs(pf - p).max() < 1e-3 and np.abs(f0 - g0).max() > 1e-7       # values move by (almost) nothing, scores do
+    rms = float(np.sqrt(np.mean(xin ** 2)))
+    found = factored_ref.relu_flip_explains(om, x, [(f0[0], f1[0]), (g0[0], g1[0])], 1e-3, atol=1e-9, rtol=1e-7,
+                                            eps=1.01 * (top[w] - sec[w]) / rms + 1e-15, max_units=200, max_flips=1)
+    assert found[1] == ()
+    assert found[0] == (('pool:pool1', int(ii[w, srt[w, 1]])),), found

@@ -190,7 +190,7 @@ def main():
         executed = (bf_fl * SPLIT_PRODUCTS + f16['flops'] * 3) / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
         conv_ms = ig_ms + sum(prof[k]['ms'] for k in ('igemm_fwd', 'igemm_bwd', 'direct_conv'))
         conv_fl = ig_fl + sum(prof[k]['flops'] for k in ('igemm_fwd', 'igemm_bwd', 'direct_conv'))
-        traffic, traffic_note = None, None   # PMC passes are separate runs (tests/run_pmc.sh -> profiles/pmc_traffic.json)
+        traffic, traffic_note = None, None   # PMC passes are separate runs (tools/run_pmc.sh -> profiles/pmc_traffic.json)
         tp = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(tp):
             try:
@@ -233,7 +233,7 @@ def main():
                                       % (PEAK_BF16_MFMA_TFLOPS, SPLIT_PRODUCTS, 100.0 * bf_fl / max(ig_fl, 1.0)),
                          'frac_definition': 'executed 16-bit MFMA flops (algorithmic flops x 6 products in the bf16x3 launches, x 3 in '
                                             'the fp16x2 ones) / igemm4 time / %.0f TFLOP/s = achieved / peak above; recomputed from a '
-                                            'rocprofv3 --kernel-trace --stats run of this command by tests/roofline_from_stats.py'
+                                            'rocprofv3 --kernel-trace --stats run of this command by tools/roofline_from_stats.py'
                                             % PEAK_BF16_MFMA_TFLOPS,
                          'executed_16bit_tflops': executed, 'peak_16bit_tflops': PEAK_BF16_MFMA_TFLOPS,
                          'igemm4_alg_flops_per_patch': {'bf16x3': bf_fl / max(prof_patches, 1), 'f16x2': f16['flops'] / max(prof_patches, 1)},

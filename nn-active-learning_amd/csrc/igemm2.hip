@@ -45,7 +45,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int I2_CBP = 12;        // floats per halo voxel row in LDS (8 channels + 4 pad)
 constexpr int I2_MAXSLOT = 8;     // float4 A staging slots per thread (nhv*2 <= 256*I2_MAXSLOT)
-constexpr int I2_WRES_MAX = 28 * 1024;   // resident weights: at most this many bytes per 16-col tile (tests/gpu_ab.py)
+constexpr int I2_WRES_MAX = 28 * 1024;   // resident weights: at most this many bytes per 16-col tile (tools/gpu_ab.py)
 
 // GEO: 1 / 2 -> 3x3x3 taps over a halo block with HY = 6, HX = 18 (the 4x4x16 tile every 16^3 / 32^3 layer
 // uses), walked in ascending (forward conv) / descending (backward-data) order: every LDS fragment
@@ -542,7 +542,7 @@ int igemm2_build_plan(const IgemmPlan &p1, Igemm2Plan *p2) {
     p2->NTW = p1.NTW;
     p2->wres = wres;
     p2->lds_bytes = lds;
-    int max_wgs = 2;      // measured: 2 persistent workgroups per CU beat 1, 3 and 4 (tests/gpu_ab.py)
+    int max_wgs = 2;      // measured: 2 persistent workgroups per CU beat 1, 3 and 4 (tools/gpu_ab.py)
     if (const char *e = getenv("ALQ_MAX_WGS")) max_wgs = atoi(e);                      // tuning experiment
     p2->wgs_per_cu = std::max<int>(1, std::min<int>(max_wgs, (int)((160 * 1024) / (lds + 512))));
     p2->flops_per_patch = p1.flops_per_patch;

@@ -77,7 +77,7 @@ constexpr int G4_OOB = (int)0xffffff00u;
 
 // x -> (hi, rem): hi = bf16(x) round-to-nearest packed pairwise, rem = x - hi (exact).  Rounding to nearest
 // matters: a truncating split biases the dropped piece products to one sign, the bias accumulates over K and
-// (measured, tests/gpu_accuracy.py) is enough to flip ReLU masks like a plain fp32 summation-order change does.
+// (measured, tools/gpu_accuracy.py) is enough to flip ReLU masks like a plain fp32 summation-order change does.
 __device__ inline unsigned g4_split2(float &a, float &b) {
     const bf16x2 h = __builtin_convertvector(f32x2{a, b}, bf16x2);
     const unsigned hb = __builtin_bit_cast(unsigned, h);
@@ -116,7 +116,7 @@ __device__ inline float g4_dot4(const f32x4 &a, const f32x4 &b) {
 // F16 (one column tile): fp16x2 split instead of bf16x3 - x * 2^e = h + l * 2^-11 with fp16 h, l (weights alike, packed
 // by the host), h.h into `acc`, h.l + l.h into `accl`, result (acc + accl * 2^-11) * 2^-(e_in + e_w): THREE MFMAs and
 // two LDS pieces per operand instead of six and three, at the accuracy of a plain fp32 GEMM for operands within 2^28 of
-// the scale (tests/study_split_precision.py).  Needs max |x| of the input ahead of the launch: available for free
+// the scale (tools/study_split_precision.py).  Needs max |x| of the input ahead of the launch: available for free
 // where the input is [sign] * one host-known vector (BITSRC).
 
 // launch constants a specialised instantiation may fold (everything that depends only on the layer geometry and the fusion
@@ -129,7 +129,7 @@ __device__ inline float g4_dot4(const f32x4 &a, const f32x4 &b) {
 #define G4_FIXED_PTRS(X) X(bias) X(mask) X(osumA) X(osumB) X(out_amax) X(in_amax) X(in_amax2) X(fc_bits) X(dbg) X(flip_list) X(mask_bits) X(sign_out)
 
 // Launch-constant traits of a kernel instantiation.  G4Runtime (the default): every constant is read from the argument
-// block.  A generated G4F_<n> (igemm4_fixed.inc, tests/gen_igemm4_fixed.py) states the constants of ONE launch of a known
+// block.  A generated G4F_<n> (igemm4_fixed.inc, tools/gen_igemm4_fixed.py) states the constants of ONE launch of a known
 // network - geometry, table offsets, fusion switches, which optional pointers are present - so that the compiler folds them:
 // the generic kernel keeps ~80 arguments live in 102 SGPRs and moves the overflow through v_readlane / v_writelane inside
 // the tick loop (the issue slots of an issue-bound kernel); with the constants folded the spills and the address
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
     // the F16 kernel is the shorter part again (phase stamps: 302 k vs 445 k cycles per half)
     // (EPI >= 0: the launch's own balance, Igemm4Plan::tune_epi)
     // Default 0 since the epilogue meets its loads with one wait: the split that balanced the mask-bit fp16x2 launch in
-    // round 1 (764 -> 627 us at batch 512) now costs it 3 % (tests/tune_sens.sh: 2634 -> 2553 us per 2000 patches without).
+    // round 1 (764 -> 627 us at batch 512) now costs it 3 % (tools/tune_sens.sh: 2634 -> 2553 us per 2000 patches without).
     constexpr int EPI_SPLIT = EPI >= 0 ? EPI : 0;
     static_assert(!(FCF || MULTI) || EPI_SPLIT == 0, "the fused-head and the multi-group epilogues are not split");
     f32x4 R[G4_NSLOT];
@@ -1703,7 +1703,7 @@ int igemm4_build_plan(const G4Geom &g, int max_batch, Igemm4Plan *plan, int wp) 
     // short contractions per phase (see FIC in the kernel): the conv_transpose classes, and a plain conv whose tile is ONE
     // phase - stash, epilogue and tile lookup then all fall into every staging part (the 8 -> 16 channel conv at 16^3:
     // 401 -> 357 us per 2000 patches with the prefetch issued from the contracting side; the 32 -> 16 channel one with
-    // four phases per tile LOSES 4 % the same way: tests/tune_sens.sh)
+    // four phases per tile LOSES 4 % the same way: tools/tune_sens.sh)
     plan->fic = NTW == 1 && (g.kind == 4 || g.kind == 1 || (g.kind == 0 && a.nph == 1 && !pair)) && !getenv("ALQ_NO_FIC");
     plan->Ci = g.Ci; plan->Co = g.Co;
     plan->lds_bytes = (size_t)a.tt_ints * 4 + wbytes + 2 * (size_t)a.abytes;
@@ -1844,7 +1844,7 @@ static bool g4_matches(const Igemm4Args &a) {
 template <int NTW, bool MULTI, bool SUMS, bool BITSRC = false, bool FCF = false, bool FIC = false, bool F16 = false, int EPI = -1, bool ZRE = false,
           bool ACC = false>
 static int launch4_s(alq_ctx *ctx, const Igemm4Plan &plan, const Igemm4Args &a, unsigned grid) {
-    {   // ALQ_DUMP_ARGS=1: the launch constants of every distinct launch, as input for tests/gen_igemm4_fixed.py
+    {   // ALQ_DUMP_ARGS=1: the launch constants of every distinct launch, as input for tools/gen_igemm4_fixed.py
         static const bool dump = getenv("ALQ_DUMP_ARGS") != nullptr;
         if (dump) g4_dump_args("%d %d %d %d %d %d %d %d %d %d", a, NTW, (int)MULTI, (int)SUMS, (int)BITSRC, (int)FCF, (int)FIC, (int)F16, EPI, (int)ZRE, (int)ACC);
     }
@@ -2071,7 +2071,7 @@ static int igemm4_launch_impl(alq_ctx *ctx, const Igemm4Plan &plan, const View &
                                     : launch4_s<1, false, false, true>(ctx, plan, a, grid);
     // the prefetch of the fused-head conv is issued from the staging side again: with its launch constants folded and one
     // wait per epilogue the staging part became the shorter one (phase stamps: contraction 46 %, staging 36 % + 14 %
-    // waiting; tests/tune_sens.sh: 2670 -> 2593 us per 2000 patches)
+    // waiting; tools/tune_sens.sh: 2670 -> 2593 us per 2000 patches)
     if (a.fc_W && f16 && a.zreuse)      // one tap row of nine k-steps per phase (checked when the plan was built): the fragment-reuse loop
         return a.osumA ? launch4_s<1, false, true, false, true, false, true, -1, true>(ctx, plan, a, grid)
                        : launch4_s<1, false, false, false, true, false, true, -1, true>(ctx, plan, a, grid);

@@ -406,7 +406,7 @@ def test_config3_netc_properties(sess):
     # which sits within fp32 rounding of zero: two fp32 implementations (device and oracle, or TF on
     # two machines) put it on different sides of the mask in roughly one patch out of two, which
     # moves the affected layer sums by up to a few 1e-3 relative (|g| ~ 5e-2 -> a few 1e-4
-    # absolute).  tests/gpu_accuracy.py measures each implementation against fp64: the torch fp32
+    # absolute).  tools/gpu_accuracy.py measures each implementation against fp64: the torch fp32
     # oracle is the noisy party (abs max 2e-4), the device stays within 3e-7 absolute.  So: every
     # patch within 5e-4 absolute of the fp32 oracle, and within 2e-6 absolute / 1e-3 relative of
     # the fp64 values -- fifty times inside the 1e-4 parity bar.

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box A/B of one library under two environments at kernel level (rocprofv3 --kernel-trace --stats of a short bench each, alternating).
-#   tests/ab_env.sh "ENVA=1" "ENVB=1 ENVC=2" [rounds]     ("-" = no extra variables)
+#   tools/ab_env.sh "ENVA=1" "ENVB=1 ENVC=2" [rounds]     ("-" = no extra variables)
 set -eo pipefail
 EA="$1"; EB="$2"; R="${3:-2}"
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"

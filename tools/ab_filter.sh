@@ -1,6 +1,6 @@
 #!/bin/bash
 # Forward-only (entropy filter) throughput of NET-C at 32^3 under two environments: 200k-patch filter of the AL loop, 2 rounds each.
-#   tests/ab_filter.sh "ENVA=1" "-"
+#   tools/ab_filter.sh "ENVA=1" "-"
 set -eo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 cd "$ROOT"; mkdir -p gpurun_out

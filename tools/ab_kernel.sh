@@ -1,7 +1,7 @@
 #!/bin/bash
 # Same-box A/B of two library builds at kernel level: rocprofv3 --kernel-trace --stats of a short bench per build,
 # alternating, then the igemm4 launches' average durations side by side.
-#   tests/ab_kernel.sh libalq_a.so libalq_b.so [rounds]      (builds: ALQ_OUT=libalq_b.so ALQ_BUILD_TAG=_b bash csrc/build.sh)
+#   tools/ab_kernel.sh libalq_a.so libalq_b.so [rounds]      (builds: ALQ_OUT=libalq_b.so ALQ_BUILD_TAG=_b bash csrc/build.sh)
 set -eo pipefail
 A="$1"; B="$2"; R="${3:-2}"
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"

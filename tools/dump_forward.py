@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launch constants of the FORWARD-ONLY pass of NET-C at 32^3 (the entropy filter of the AL loop: alq_forward without sums) for
-tests/gen_igemm4_fixed.py:   ALQ_DUMP_ARGS=1 python tests/dump_forward.py 2> gpurun_out/tunedump_forward.err     (GPU box)"""
+tools/gen_igemm4_fixed.py:   ALQ_DUMP_ARGS=1 python tools/dump_forward.py 2> gpurun_out/tunedump_forward.err     (GPU box)"""
 import os
 import sys
 

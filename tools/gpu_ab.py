@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Same-process A/B timing of the NET-C Fisher pass under alq_debug_set knobs (GPU box only).
 
-    python tests/gpu_ab.py "2=0" "2=1" ...      each argument = comma list of key=value knobs
+    python tools/gpu_ab.py "2=0" "2=1" ...      each argument = comma list of key=value knobs
 
 Variants are interleaved round-robin (cdna guide rule 24): per variant the median ms per
 256-patch pass and the per-class HIP-event shares are printed.

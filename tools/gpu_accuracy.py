@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Accuracy of the device Fisher scores against an fp64 evaluation of the same network (GPU box).
 
-    python tests/gpu_accuracy.py [npatches]
+    python tools/gpu_accuracy.py [npatches]
 
 Prints, for the bf16x3 GEMM path, the fp32-MFMA GEMM path (alq_debug_set(4,1)) and the fp32
 torch-CPU oracle, the distribution of |g - g_fp64| / |g_fp64| over layers and patches: it shows how

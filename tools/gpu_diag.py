@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Layer-by-layer comparison of the HIP path with the oracle (manual diagnostic, GPU box only):
 
-    python tests/gpu_diag.py [neta|netb|netc2d|netc|all] > gpurun_out/diag.log
+    python tools/gpu_diag.py [neta|netb|netc2d|netc|all] > gpurun_out/diag.log
 """
 import os
 import sys

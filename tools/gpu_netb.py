@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the reference-literal patch net (NET-B = NN.create_PW1, 32 slices as channels) on the GPU box.
 
-    python tests/gpu_netb.py [batch]
+    python tools/gpu_netb.py [batch]
 """
 import os
 import sys

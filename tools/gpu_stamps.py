@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase shader-clock shares of the pipelined GEMM kernel (diagnostic build libalq_stamps.so).
 
-    ALQ_LIB=libalq_stamps.so python tests/gpu_stamps.py      (GPU box only)
+    ALQ_LIB=libalq_stamps.so python tools/gpu_stamps.py      (GPU box only)
 """
 import ctypes as C
 import os

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """A few NET-C Fisher passes under fixed alq_debug_set knobs, for rocprofv3 --kernel-trace (GPU box).
 
-    rocprofv3 --kernel-trace --output-format csv -d out -o t -- python3 tests/gpu_trace.py "0=1" [batch]
-    python tests/prof_seq.py out/t_kernel_trace.csv all
+    rocprofv3 --kernel-trace --output-format csv -d out -o t -- python3 tools/gpu_trace.py "0=1" [batch]
+    python tools/prof_seq.py out/t_kernel_trace.csv all
 """
 import ctypes as C
 import os

@@ -3,7 +3,7 @@
 refuses two ranks on one device).  The sharded bench step and the sharded config-5 loop (filter -> Fisher -> SDP ->
 draws -> fine-tune) must give the same selections / queries / weights with 2 ranks as with 1, bit for bit.
 
-    python tests/gpu_two_ranks.py gpurun_out/two_ranks"""
+    python tools/gpu_two_ranks.py gpurun_out/two_ranks"""
 import json
 import os
 import subprocess

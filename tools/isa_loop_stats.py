@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static instruction mix of the igemm4 instantiations from the device assembly build.sh leaves behind.
 
-    python tests/isa_loop_stats.py [asm] [substring of the mangled kernel name ...]
+    python tools/isa_loop_stats.py [asm] [substring of the mangled kernel name ...]
 
 Per kernel: instruction counts by class over the WHOLE body and between the first and the last s_barrier (the tick loop
 and its prologue), SGPR-spill traffic (v_readlane / v_writelane), and the VALU : MFMA ratio the verdict tracks."""

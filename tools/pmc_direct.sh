@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes for one kernel family (diagnostic): per-kernel sums of a few SQ counters, for the library named by ALQ_LIB.
-# usage: tests/pmc_direct.sh <tag>
+# usage: tools/pmc_direct.sh <tag>
 set -eo pipefail
 TAG="${1:-x}"
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-dispatch PMC table from a rocprofv3 --pmc counter_collection.csv (largest dispatches of a kernel).
 
-    python tests/pmc_kernels.py <counter_collection.csv> [kernel substring] [min us]
+    python tools/pmc_kernels.py <counter_collection.csv> [kernel substring] [min us]
 """
 import collections
 import csv

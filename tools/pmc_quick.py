@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel table from tests/run_quick_prof.sh passes:  python tests/pmc_quick.py gpurun_out/<tag> [out.json]"""
+"""Per-kernel table from tools/run_quick_prof.sh passes:  python tools/pmc_quick.py gpurun_out/<tag> [out.json]"""
 import collections
 import csv
 import json

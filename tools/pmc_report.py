@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Summary of the rocprofv3 passes made by tests/run_pmc.sh, per kernel (igemm4 variants separately).
+"""Summary of the rocprofv3 passes made by tools/run_pmc.sh, per kernel (igemm4 variants separately).
 
-    python tests/pmc_report.py gpurun_out/<tag> profiles/<tag>_pmc_summary.json
+    python tools/pmc_report.py gpurun_out/<tag> profiles/<tag>_pmc_summary.json
 
 Reads <tag>_{stats,mfma,lds,fetch,write}/ and writes one JSON with, per kernel: calls, average duration (kernel trace of
 the stats pass), matrix-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)), MFMA ops by
@@ -52,7 +52,7 @@ def main():
     fe = per_kernel_counters(base + '_fetch/fetch_counter_collection.csv')
     wr = per_kernel_counters(base + '_write/write_counter_collection.csv')
     out = collections.OrderedDict()
-    out['source'] = 'tests/run_pmc.sh passes under %s_*; bench.py --pool 8192 --steps 1 --warmup 1' % os.path.basename(base)
+    out['source'] = 'tools/run_pmc.sh passes under %s_*; bench.py --pool 8192 --steps 1 --warmup 1' % os.path.basename(base)
     out['notes'] = ('mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES); lds_active = SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES; '
                     'hbm bytes = 2 * FETCH_SIZE KiB + WRITE_SIZE KiB (gfx950 corrections); counters summed over a dispatch')
     kern = collections.OrderedDict()
@@ -89,7 +89,7 @@ def main():
             e['hbm_read_MB_per_launch'] = round(rd_b / 1e6, 1)
             e['hbm_write_MB_per_launch'] = round(wr_b / 1e6, 1)
             e['hbm_GBps'] = round((rd_b + wr_b) / (st['avg_us'] * 1e-6) / 1e9, 0)
-            if name.startswith('igemm4_kernel'):
+            if name.startswith(('igemm4_kernel', 'c3d_fwd_kernel', 'c3d_bwd_kernel')):      # the twelve contraction launches of a pass
                 ig['ms'] += st['avg_us'] * st['calls'] / 1e3
                 ig['n'] += st['calls']
                 ig['rd'] += rd_b * st['calls']
@@ -100,6 +100,15 @@ def main():
         out['igemm4_all'] = dict(launches=ig['n'], avg_launch_ms=ig['ms'] / ig['n'],
                                  read_bytes_per_launch=ig['rd'] / ig['n'], write_bytes_per_launch=ig['wr'] / ig['n'],
                                  hbm_bytes_per_launch=(ig['rd'] + ig['wr']) / ig['n'])
+    if ig['n'] and len(sys.argv) > 3:      # the traffic file bench.py reads (profiles/pmc_traffic.json)
+        batch = int(sys.argv[4]) if len(sys.argv) > 4 else 2000
+        tj = dict(kernel='the 12 contraction launches of a pass (igemm4_kernel variants + c3d_fwd_kernel + c3d_bwd_kernel), bench.py --pool 8000 '
+                         '--batch %d --steps 1 --warmup 1' % batch,
+                  launches=ig['n'], read_bytes_per_launch=ig['rd'] / ig['n'], write_bytes_per_launch=ig['wr'] / ig['n'],
+                  hbm_bytes_per_launch=(ig['rd'] + ig['wr']) / ig['n'],
+                  corrections='KiB -> bytes; FETCH_SIZE x2 (gfx950 wide reads); source %s (tools/run_pmc.sh)' % dst, batch=batch,
+                  hbm_bytes_per_patch_all_contraction_launches=(ig['rd'] + ig['wr']) / ig['n'] * 12.0 / batch)
+        json.dump(tj, open(sys.argv[3], 'w'), indent=1)
     json.dump(out, open(dst, 'w'), indent=1)
     print(json.dumps(out.get('igemm4_all', {}), indent=1))
     for k, e in kern.items():

@@ -1,4 +1,4 @@
-"""Sums rocprofv3 --pmc counter CSVs per kernel name (diagnostic).  usage: python tests/pmc_sum.py <substring> <dir>..."""
+"""Sums rocprofv3 --pmc counter CSVs per kernel name (diagnostic).  usage: python tools/pmc_sum.py <substring> <dir>..."""
 import csv, glob, sys, collections
 sub = sys.argv[1]
 for d in sys.argv[2:]:

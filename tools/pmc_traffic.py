@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM traffic per launch of one kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
 
-    python tests/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> [kernel substring] [out.json]
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> [kernel substring] [out.json]
 
 Corrections per MI355X_MICROARCH.md (HBM section): both counters are in KiB; on gfx950 FETCH_SIZE
 reports half the bytes of wide coalesced reads, so it is doubled."""

@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Recomputes bench.py's `roofline` figures from a rocprofv3 `--kernel-trace --stats` run of the SAME command.
 
-    python tests/roofline_from_stats.py <stats_kernel_stats.csv> <bench JSON line of that run> [pmc_traffic.json] > summary.json
+    python tools/roofline_from_stats.py <stats_kernel_stats.csv> <bench JSON line of that run> [pmc_traffic.json] > summary.json
 
 Definitions (the same ones bench.py prints):
-  * dominant kernel = every instantiation of `alq::igemm4_kernel` (conv / conv_transpose forward + backward-data);
+  * dominant kernel = the twelve contraction launches of a pass: every instantiation of `alq::igemm4_kernel` (conv /
+    conv_transpose forward + backward-data) and, since round 4, `alq::c3d_fwd_kernel` / `alq::c3d_bwd_kernel` (the conv under
+    the head on the plane-sweep engine) - the keys of the output keep the historical `igemm4_` prefix;
   * executed 16-bit MFMA flops of a pass = the launches' ALGORITHMIC fp32 flops (2 x MACs of the real taps / channels,
     the library's own count, `roofline.igemm4_alg_flops_per_patch` of the bench line) x the 16-bit products issued per
     fp32-accurate MAC: 6 for the bf16x3 launches, 3 for the fp16x2 ones;
@@ -33,10 +35,11 @@ def main():
     variants = []
     for r in csv.DictReader(open(stats_csv)):
         total_ns += float(r['TotalDurationNs'])
-        if 'igemm4_kernel' in r['Name']:
+        kname = next((k for k in ('igemm4_kernel', 'c3d_fwd_kernel', 'c3d_bwd_kernel') if k in r['Name']), None)
+        if kname:
             ig_ns += float(r['TotalDurationNs'])
             ig_calls += int(r['Calls'])
-            variants.append({'variant': r['Name'].split('igemm4_kernel')[1].split('(')[0], 'calls': int(r['Calls']),
+            variants.append({'variant': (kname if kname != 'igemm4_kernel' else '') + r['Name'].split(kname)[1].split('(')[0], 'calls': int(r['Calls']),
                              'avg_us': float(r['AverageNs']) / 1e3, 'total_ms': float(r['TotalDurationNs']) / 1e6})
     alg = (per_patch['bf16x3'] + per_patch['f16x2']) * patches
     executed = (6 * per_patch['bf16x3'] + 3 * per_patch['f16x2']) * patches

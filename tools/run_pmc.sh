@@ -4,7 +4,7 @@
 #   mfma   : matrix-pipe counters                  -> MFMA busy, MFMA ops by type
 #   lds    : LDS counters                          -> LDS active / bank conflicts / LDS issue stalls
 #   fetch / write : FETCH_SIZE, WRITE_SIZE (separate passes: they do not fit one)
-# usage: tests/run_pmc.sh <tag> [pool]      outputs under gpurun_out/<tag>_*; summarise with tests/pmc_report.py
+# usage: tools/run_pmc.sh <tag> [pool]      outputs under gpurun_out/<tag>_*; summarise with tools/pmc_report.py
 set -eo pipefail
 TAG="${1:-r02}"
 POOL="${2:-8192}"

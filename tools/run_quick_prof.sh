@@ -1,6 +1,6 @@
 #!/bin/bash
 # quick per-kernel picture of one build: kernel stats + the MFMA / VALU / LDS counter passes (pool 8000, 1 step)
-# usage: tests/run_quick_prof.sh <tag>   -> gpurun_out/<tag>_{stats,mfma,lds}*; summarise with tests/pmc_kernels.py
+# usage: tools/run_quick_prof.sh <tag>   -> gpurun_out/<tag>_{stats,mfma,lds}*; summarise with tools/pmc_kernels.py
 set -eo pipefail
 TAG="${1:-q}"
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Accuracy of operand splits for an fp32-accurate contraction on 16-bit matrix cores (CPU study, numpy + torch).
 
-    python tests/study_split_precision.py
+    python tools/study_split_precision.py
 
 Compares, on dot products shaped like the path's (K = 432, He-scaled weights), against fp64:
   fp32     a plain fp32 GEMM,

@@ -1,4 +1,4 @@
-"""Median duration (us) of each igemm4 launch of a Fisher pass, by its ordinal in the pass, per tests/tune_sens.sh run."""
+"""Median duration (us) of each igemm4 launch of a Fisher pass, by its ordinal in the pass, per tools/tune_sens.sh run."""
 import collections
 import csv
 import sys

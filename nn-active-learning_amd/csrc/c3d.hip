@@ -473,8 +473,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 namespace {
 constexpr int B3_TEN = 34 * 16;          // one piece of one row: slots x = -1 .. 32, 8 fp16 channels each
 constexpr int B3_ROW = 2 * B3_TEN;
-constexpr int B3_PLANE = 34 * B3_ROW;
-constexpr int B3_LDS = 2 * B3_PLANE;     // 73,984 bytes
 }  // namespace
 
 struct C3BwdArgs {
@@ -488,9 +486,20 @@ struct C3BwdArgs {
     int e_in, e_w;                 // scale exponents of the vector and of the packed weights
 };
 
-template <bool ONEACC>
+// RW = output rows per wave.  8: one workgroup per patch (like the forward kernel) - 192 accumulator registers, which leave the
+// AGPR half no slack (the allocator spills ~60 registers to scratch, and the spill traffic showed as +0.7 GB of HBM writes per
+// 2000 patches).  4: a workgroup owns HALF the rows of a patch (16 + 2 halo rows per plane image, staged 1.125 x), 96
+// accumulators like the forward kernel, nothing spilled.
+template <bool ONEACC, int RW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void c3d_bwd_kernel(const C3BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    static_assert(ONEACC, "the backward kernel is built for the one-accumulator form");
+    static_assert(RW == 4 || RW == 8, "4 waves x RW rows: a half or a whole patch per workgroup");
+    constexpr int NR = 4 * RW;                   // output rows of a workgroup
+    constexpr int NPARTS = 32 / NR;              // workgroups (work items) per patch
+    constexpr int PLANE = (NR + 2) * B3_ROW;     // image rows y0 - 1 .. y0 + NR
+    constexpr int DUMMY = 2 * PLANE;             // 2 KB nobody reads: where the idle half of a halo staging unit writes
+    constexpr int NU = RW / 2;                   // own staging units (two rows each) per wave and plane
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -498,9 +507,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int D = a.D;
     const unsigned plane_v = 32u * 32u;                      // voxels per plane
     const unsigned patch_v = (unsigned)D * plane_v;
-    static_assert(ONEACC, "the backward kernel is built for the one-accumulator form");
 
-    for (int i = tid * 16; i < B3_LDS; i += 256 * 16) *reinterpret_cast<i32x4 *>(lds + i) = i32x4{0, 0, 0, 0};
+    for (int i = tid * 16; i < DUMMY + 2 * B3_ROW; i += 256 * 16) *reinterpret_cast<i32x4 *>(lds + i) = i32x4{0, 0, 0, 0};
 
     f16x8 Wh[9], Wl[9];
     {
@@ -510,36 +518,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             Wh[k] = __builtin_bit_cast(f16x8, Wg[(k * 2 + 0) * 64 + lane]);
             Wl[k] = __builtin_bit_cast(f16x8, Wg[(k * 2 + 1) * 64 + lane]);
         }
-        // (no pinning of the weights to accumulation registers here: the 192 accumulators already fill three quarters of that half
-        // and the allocator does better alone - timing builds: 1.50 ms per 2000 patches against 1.66 ms with 16 fragments pinned)
-#ifdef C3_BWD_PIN
+        // RW = 4: the weights start their lives in accumulation registers like the forward kernel's (96 accumulators + 72 weight
+        // registers fit the AGPR half); RW = 8: the 192 accumulators fill three quarters of it and the allocator does better alone
+        // (timing builds: 1.50 ms per 2000 patches against 1.66 ms with 16 fragments pinned)
+        if constexpr (RW == 4) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            i32x4 h = __builtin_bit_cast(i32x4, Wh[k]), l = __builtin_bit_cast(i32x4, Wl[k]);
-            asm volatile("" : "+a"(h), "+a"(l));
-            Wh[k] = __builtin_bit_cast(f16x8, h); Wl[k] = __builtin_bit_cast(f16x8, l);
+            for (int k = 0; k < 9; ++k) {
+                i32x4 h = __builtin_bit_cast(i32x4, Wh[k]), l = __builtin_bit_cast(i32x4, Wl[k]);
+                asm volatile("" : "+a"(h), "+a"(l));
+                Wh[k] = __builtin_bit_cast(f16x8, h); Wl[k] = __builtin_bit_cast(f16x8, l);
+            }
         }
-#endif
     }
     // fragment reads: column j = voxel 16 hx + j, k-group kg = x offset kg - 1 (group 3 has zero weights: it re-reads group 2's slot)
-    const int frag_lane = (lj + (lq < 2 ? lq : 2)) * 16 + wave * 8 * B3_ROW;
-    // staging: a unit = two rows of the wave's strip, lane = (row lane >> 5, x = lane & 31)
-    const int st_lane = (wave * 8 + 1 + (lane >> 5)) * B3_ROW + ((lane & 31) + 1) * 16;
-    const unsigned st_vox = (unsigned)((wave * 8 + (lane >> 5)) * 32 + (lane & 31));       // voxel inside the plane, unit 0
+    const int frag_lane = (lj + (lq < 2 ? lq : 2)) * 16 + wave * RW * B3_ROW;
+    // staging: a unit = two rows of the wave's strip, lane = (row lane >> 5, x = lane & 31); image row = y - y0 + 1
+    const int st_lane = (wave * RW + 1 + (lane >> 5)) * B3_ROW + ((lane & 31) + 1) * 16;
     const float inv = __builtin_ldexpf(1.f, -(a.e_in + a.e_w));
 
     const int G = gridDim.x, b0 = blockIdx.x;
-    const int np = b0 < a.N ? (a.N - b0 + G - 1) / G : 0;
+    const int nitems = a.N * NPARTS;
+    const int np = b0 < nitems ? (nitems - b0 + G - 1) / G : 0;       // work items (patch, part) of this workgroup
 
-    f32x4 acc[3][8][2];
+    f32x4 acc[3][RW][2];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { acc[s][i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[s][i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int i = 0; i < RW; ++i) { acc[s][i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[s][i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     // ONE buffer resource per array for the whole launch (no per-step descriptor building, few scalar registers): the patch
     // goes into the scalar offset - which the hardware does not range-check - and a lane with nothing to load or store aims
-    // past the array through its VECTOR offset (loads then return 0, stores are dropped).  N <= 2047 patches keep every
+    // past the array through its VECTOR offset (loads then return 0, stores are dropped).  N < 4096 patches keep every
     // offset below 2^32 (the host checks).
     auto rsrc_of = [&](const void *base, unsigned long long bytes) __attribute__((always_inline)) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)(unsigned)bytes, 0x00020000);
@@ -551,43 +560,83 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const __amdgpu_buffer_rsrc_t dB_rsrc = rsrc_of(a.dB, (unsigned long long)a.N * patch_v * 32u);
     const __amdgpu_buffer_rsrc_t sA_rsrc = rsrc_of(a.sumA, (unsigned long long)a.N * patch_v * 4u);
     const __amdgpu_buffer_rsrc_t sB_rsrc = rsrc_of(a.sumB, (unsigned long long)a.N * patch_v * 4u);
+    auto item_patch = [&](int pi) __attribute__((always_inline)) { return (unsigned)((b0 + pi * G) / NPARTS); };
+    auto item_y0 = [&](int pi) __attribute__((always_inline)) { return ((b0 + pi * G) % NPARTS) * NR; };
 
-    // ---- staging unit u = 0..3 of a plane: rows 8 w + 2 u, 8 w + 2 u + 1 ---------------------------------------------------
-    i32x4 Vh[2], Vl[2];
-    unsigned Sb[2];
-    auto load_unit = [&](unsigned bits_v, unsigned bits_s, unsigned z, auto U) __attribute__((always_inline)) {
-        constexpr int u = decltype(U)::value;
-        Vh[u & 1] = __builtin_amdgcn_raw_buffer_load_b128(vec_rsrc, (int)(st_vox * 32u), (int)((z * plane_v + (unsigned)u * 64u) * 32u), 0);
-        Vl[u & 1] = __builtin_amdgcn_raw_buffer_load_b128(vec_rsrc, (int)(st_vox * 32u + 16u), (int)((z * plane_v + (unsigned)u * 64u) * 32u), 0);
-        Sb[u & 1] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(bits_rsrc, (int)bits_v, (int)(bits_s + (z * plane_v + (unsigned)u * 64u) * 2u), 0);
+    // ---- staging of a plane: own units u = 0 .. NU - 1 (rows y0 + w RW + 2 u, + 1), and - half patches only - one halo row per
+    // edge wave (wave 0: row y0 - 1, wave 3: row y0 + NR; lanes 0..31, zeros outside the patch) ----------------------------
+    i32x4 Vh[2], Vl[2], Hh, Hl;
+    unsigned Sb[2], Hb = 0u;
+    struct Src { unsigned voff, vvox, soff; };      // lane offset into the sign bytes (or OOB), lane voxel inside the plane, patch offset
+    auto src_of = [&](int pi, bool halo) __attribute__((always_inline)) {
+        Src c;
+        const bool ok = pi < np;
+        const int y0 = ok ? item_y0(pi) : 0;
+        int y = y0 + wave * RW + (lane >> 5);
+        bool live = ok;
+        if (halo) {
+            y = wave == 0 ? y0 - 1 : y0 + NR;
+            live = ok && lane < 32 && y >= 0 && y < 32;
+        }
+        c.vvox = (unsigned)((live ? y : 0) * 32 + (lane & 31));
+        c.voff = live ? c.vvox * 2u : OOB;
+        c.soff = ok ? item_patch(pi) * patch_v * 2u : 0u;
+        return c;
     };
-    auto stage_unit = [&](int wbase, auto U) __attribute__((always_inline)) {
-        constexpr int u = decltype(U)::value;
-        const int b = (int)Sb[u & 1];      // bits 0..3: channels 0..3, bits 8..11: channels 4..7
+    auto mask8 = [&](int b, i32x4 h, i32x4 l, i32x4 *oh, i32x4 *ol) __attribute__((always_inline)) {
+        // bits 0..3: channels 0..3, bits 8..11: channels 4..7
         const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe(b, 0, 1), m1 = (unsigned)__builtin_amdgcn_sbfe(b, 1, 1);
         const unsigned m2 = (unsigned)__builtin_amdgcn_sbfe(b, 2, 1), m3 = (unsigned)__builtin_amdgcn_sbfe(b, 3, 1);
         const unsigned m4 = (unsigned)__builtin_amdgcn_sbfe(b, 8, 1), m5 = (unsigned)__builtin_amdgcn_sbfe(b, 9, 1);
         const unsigned m6 = (unsigned)__builtin_amdgcn_sbfe(b, 10, 1), m7 = (unsigned)__builtin_amdgcn_sbfe(b, 11, 1);
         const unsigned k0 = (m0 & 0xffffu) | (m1 & 0xffff0000u), k1 = (m2 & 0xffffu) | (m3 & 0xffff0000u);
         const unsigned k2 = (m4 & 0xffffu) | (m5 & 0xffff0000u), k3 = (m6 & 0xffffu) | (m7 & 0xffff0000u);
-        const i32x4 h = Vh[u & 1], l = Vl[u & 1];
-        char *dst = lds + wbase + (2 * u) * B3_ROW;
-        *reinterpret_cast<i32x4 *>(dst) = i32x4{(int)((unsigned)h.x & k0), (int)((unsigned)h.y & k1), (int)((unsigned)h.z & k2), (int)((unsigned)h.w & k3)};
-        *reinterpret_cast<i32x4 *>(dst + B3_TEN) = i32x4{(int)((unsigned)l.x & k0), (int)((unsigned)l.y & k1), (int)((unsigned)l.z & k2), (int)((unsigned)l.w & k3)};
+        *oh = i32x4{(int)((unsigned)h.x & k0), (int)((unsigned)h.y & k1), (int)((unsigned)h.z & k2), (int)((unsigned)h.w & k3)};
+        *ol = i32x4{(int)((unsigned)l.x & k0), (int)((unsigned)l.y & k1), (int)((unsigned)l.z & k2), (int)((unsigned)l.w & k3)};
     };
+    auto load_unit = [&](const Src &c, unsigned z, auto U) __attribute__((always_inline)) {
+        constexpr int u = decltype(U)::value;
+        const unsigned so = (z * plane_v + (unsigned)u * 64u);
+        // (the vector is patch-independent: a dead lane reads voxel 0 of it and its sign bits come back 0)
+        Vh[u & 1] = __builtin_amdgcn_raw_buffer_load_b128(vec_rsrc, (int)(c.vvox * 32u), (int)(so * 32u), 0);
+        Vl[u & 1] = __builtin_amdgcn_raw_buffer_load_b128(vec_rsrc, (int)(c.vvox * 32u + 16u), (int)(so * 32u), 0);
+        Sb[u & 1] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(bits_rsrc, (int)c.voff, (int)(c.soff + so * 2u), 0);
+    };
+    auto stage_unit = [&](int wbase, auto U) __attribute__((always_inline)) {
+        constexpr int u = decltype(U)::value;
+        i32x4 oh, ol;
+        mask8((int)Sb[u & 1], Vh[u & 1], Vl[u & 1], &oh, &ol);
+        char *dst = lds + wbase + (2 * u) * B3_ROW;
+        *reinterpret_cast<i32x4 *>(dst) = oh;
+        *reinterpret_cast<i32x4 *>(dst + B3_TEN) = ol;
+    };
+    auto load_halo = [&](const Src &c, unsigned z) __attribute__((always_inline)) {
+        Hh = __builtin_amdgcn_raw_buffer_load_b128(vec_rsrc, (int)(c.vvox * 32u), (int)(z * plane_v * 32u), 0);
+        Hl = __builtin_amdgcn_raw_buffer_load_b128(vec_rsrc, (int)(c.vvox * 32u + 16u), (int)(z * plane_v * 32u), 0);
+        Hb = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(bits_rsrc, (int)c.voff, (int)(c.soff + z * plane_v * 2u), 0);
+    };
+    auto stage_halo = [&](int image) __attribute__((always_inline)) {      // image = byte offset of the plane image
+        i32x4 oh, ol;
+        mask8((int)Hb, Hh, Hl, &oh, &ol);
+        // lanes 0..31 -> the halo row of this wave (image row 0 or NR + 1), the others into the dummy rows
+        const int row = wave == 0 ? 0 : NR + 1;
+        char *dst = lds + (lane < 32 ? image + row * B3_ROW + ((lane & 31) + 1) * 16 : DUMMY + (lane & 31) * 16);
+        *reinterpret_cast<i32x4 *>(dst) = oh;
+        *reinterpret_cast<i32x4 *>(dst + B3_TEN) = ol;
+    };
+    const bool halo_wave = NPARTS > 1 && (wave == 0 || wave == 3);
 
     int c1_pi = 0, c1_z = 0, c2_pi = 0, c2_z = 0;
     auto advance = [&](int &pi, int &z) __attribute__((always_inline)) { if (++z == D) { z = 0; ++pi; } };
-    auto patch_of = [&](int pi) __attribute__((always_inline)) { return (unsigned)(b0 + pi * G); };
 
-    // ---- epilogue of one finished x row (plane zo, row 8 w + i) of set S: both halves --------------------------------------
+    // ---- epilogue of one finished x row (plane zo, row y0 + w RW + i) of set S: both halves --------------------------------
     // lane (j, q): channels 4 q .. 4 q + 3 of voxel 16 hx + j; q < 2: masked + summed, q >= 2: stored + summed
     unsigned mkq[2][2] = {{0u, 0u}, {0u, 0u}};      // sign bytes of the masked half, fetched two rows ahead: [row parity][hx]
     struct Epi { unsigned pv; unsigned row_v; float inv; unsigned off_mask, off_dB, off_sum; };
     auto epi_setup = [&](bool valid, int pe, int zo) __attribute__((always_inline)) {
         Epi e;
-        e.pv = valid ? patch_of(pe) * patch_v : 0u;          // first voxel of the patch in the batch
-        e.row_v = (unsigned)(zo * 32 + wave * 8) * 32u;
+        e.pv = valid ? item_patch(pe) * patch_v : 0u;          // first voxel of the patch in the batch
+        e.row_v = (unsigned)(zo * 32 + (valid ? item_y0(pe) : 0) + wave * RW) * 32u;
         e.inv = valid ? inv : 0.f;
         // lane offsets; an invalid step (no finished plane) sends every access past the arrays
         e.off_mask = (valid && lq < 2) ? (unsigned)(lj * 2 + lq) : OOB;
@@ -606,11 +655,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     const bool has_mask = a.maskA != nullptr;
     float t_keep = 0.f;      // the 8-channel sums of half row 0 (even 16-lane rows) until half row 1 joins them
-    // one half row (16 voxels): the first one also fetches the sign bytes two rows ahead, the second one stores the sums of both
+    // one half row (16 voxels): the second one fetches the sign bytes two rows ahead and stores the sums of both
     auto epi_half = [&](auto S, auto I, auto HX, const Epi &E) __attribute__((always_inline)) {
         constexpr int s = decltype(S)::value, i = decltype(I)::value, hx = decltype(HX)::value;
         const unsigned mk = mkq[i & 1][hx];
-        if constexpr (hx == 1 && i + 2 < 8) mask_load(E, IC<i + 2>{});      // (both halves' bytes of row i + 2, after this row's were read)
+        if constexpr (hx == 1 && i + 2 < RW) mask_load(E, IC<i + 2>{});      // (both halves' bytes of row i + 2, after this row's were read)
         const f32x4 c = acc[s][i][hx];
         const int nib = (lq < 2 && has_mask) ? (int)mk : 15;
         // (scalars first: __builtin_bit_cast applied to an element of an ext_vector lvalue reads element 0)
@@ -651,10 +700,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr int R = decltype(RR)::value;
         constexpr int S_lo = (R + 2) % 3, S_mid = R, S_hi = (R + 1) % 3;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const int abase = frag_lane + (int)(n & 1) * B3_PLANE;
-        const int wbase = st_lane + (int)((n + 1) & 1) * B3_PLANE;
-        const unsigned bv1 = c1_pi < np ? st_vox * 2u : OOB, bs1 = c1_pi < np ? patch_of(c1_pi) * patch_v * 2u : 0u;
-        const unsigned bv2 = c2_pi < np ? st_vox * 2u : OOB, bs2 = c2_pi < np ? patch_of(c2_pi) * patch_v * 2u : 0u;
+        const int abase = frag_lane + (int)(n & 1) * PLANE;
+        const int wimage = (int)((n + 1) & 1) * PLANE;
+        const int wbase = st_lane + wimage;
+        const Src C1 = src_of(c1_pi, false), C2 = src_of(c2_pi, false);
+        const Src H2 = src_of(c2_pi, true);
         const unsigned z1 = (unsigned)c1_z, z2 = (unsigned)c2_z;
         const bool ev = z >= 2 || (z == 0 && pi > 0);
         const Epi E = epi_setup(ev, z >= 2 ? pi : pi - 1, z >= 2 ? z - 2 : D - 1);
@@ -665,29 +715,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             bl = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(p + B3_TEN));
         };
         // One scheduling region per input row (nothing crosses a row boundary: left alone the scheduler sinks the staging loads to
-        // their uses).  The finer block structure of the forward kernel costs this one more than it gives: its 192 accumulators
-        // leave no slack in the AGPR half and the extra fragment set spills (timing builds: 1.53 ms per 2000 patches like this,
-        // 1.78 ms with 20 blocks per step).
+        // their uses); inside it one MFMA : C3_BPIPE vector instructions.
         f16x8 bh, bl, nh, nl;
         frag(0, 0, bh, bl);
         auto row = [&](auto J) __attribute__((always_inline)) {
             constexpr int j = decltype(J)::value;
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (j < 8) {
-                epi_row(IC<S_hi>{}, J, E);
-                if constexpr ((j & 1) == 0) {      // staging unit j / 2 of the next plane; the unit after the next one goes out
+            if constexpr (j < RW) epi_row(IC<S_hi>{}, J, E);
+            // staging of the next plane: RW = 8: unit j / 2 on the even rows below 8; RW = 4: the epilogue rows 0..3 carry enough,
+            // the halo row rides on row 3, the two own units on rows 4 and 5.  The unit after the next one goes out behind each.
+            if constexpr (RW == 8) {
+                if constexpr (j < 8 && (j & 1) == 0) {
                     stage_unit(wbase, IC<j / 2>{});
-                    if constexpr (j / 2 + 2 < 4) load_unit(bv1, bs1, z1, IC<j / 2 + 2>{}); else load_unit(bv2, bs2, z2, IC<j / 2 + 2 - 4>{});
+                    if constexpr (j / 2 + 2 < NU) load_unit(C1, z1, IC<j / 2 + 2>{}); else load_unit(C2, z2, IC<j / 2 + 2 - NU>{});
+                }
+            } else {
+                if constexpr (j == 3) {
+                    if (halo_wave) { stage_halo(wimage); load_halo(H2, z2); }
+                }
+                if constexpr (j >= 4) {
+                    stage_unit(wbase, IC<j - 4>{});
+                    load_unit(C2, z2, IC<j - 4>{});
                 }
             }
 #pragma unroll
             for (int hx = 0; hx < 2; ++hx) {
                 if (hx == 0) frag(j, 1, nh, nl);
-                else if (j < 9) frag(j + 1, 0, nh, nl);
+                else if (j < RW + 1) frag(j + 1, 0, nh, nl);
 #pragma unroll
                 for (int di = 0; di < 3; ++di) {
                     const int i = j - di;
-                    if (i < 0 || i > 7) continue;
+                    if (i < 0 || i > RW - 1) continue;
 #pragma unroll
                     for (int dzi = 0; dzi < 3; ++dzi) {
                         const int k = dzi * 3 + di;
@@ -705,7 +763,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
 #if C3_BPIPE
             {
-                constexpr int rows_here = (j < 2 ? j + 1 : 3) < (10 - j) ? (j < 2 ? j + 1 : 3) : (10 - j);
+                constexpr int rows_here = (j < 2 ? j + 1 : 3) < (RW + 2 - j) ? (j < 2 ? j + 1 : 3) : (RW + 2 - j);
 #pragma unroll
                 for (int m = 0; m < 18 * rows_here; ++m) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -714,9 +772,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
 #endif
         };
-        row(IC<0>{}); row(IC<1>{}); row(IC<2>{}); row(IC<3>{}); row(IC<4>{});
-        row(IC<5>{}); row(IC<6>{}); row(IC<7>{}); row(IC<8>{}); row(IC<9>{});
-        {   // the sign bytes of rows 0 and 1 of the plane the next step finishes (same patch: plane z - 1, or D - 2 in the light step)
+        row(IC<0>{}); row(IC<1>{}); row(IC<2>{}); row(IC<3>{}); row(IC<4>{}); row(IC<5>{});
+        if constexpr (RW == 8) { row(IC<6>{}); row(IC<7>{}); row(IC<8>{}); row(IC<9>{}); }
+        {   // the sign bytes of rows 0 and 1 of the plane the next step finishes (same item: plane z - 1, or D - 2 in the light step)
             const Epi En = epi_setup(z + 1 < D ? z >= 1 : true, pi, z + 1 < D ? z - 1 : D - 2);
             mask_load(En, IC<0>{});
             mask_load(En, IC<1>{});
@@ -728,10 +786,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr int s = decltype(S)::value;
         const Epi E = epi_setup(true, pe, zo);
         auto rows = [&](auto I) __attribute__((always_inline)) { epi_row(S, I, E); };
-        rows(IC<0>{}); rows(IC<1>{}); rows(IC<2>{}); rows(IC<3>{}); rows(IC<4>{}); rows(IC<5>{}); rows(IC<6>{}); rows(IC<7>{});
+        rows(IC<0>{}); rows(IC<1>{}); rows(IC<2>{}); rows(IC<3>{});
+        if constexpr (RW == 8) { rows(IC<4>{}); rows(IC<5>{}); rows(IC<6>{}); rows(IC<7>{}); }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { acc[s][i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[s][i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        {   // plane D - 1 of the same patch is finished next (after the D - 2 light step); nothing after the final one
+        for (int i = 0; i < RW; ++i) { acc[s][i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[s][i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        {   // plane D - 1 of the same item is finished next (after the D - 2 light step); nothing after the final one
             const Epi En = epi_setup(zo == D - 2, pe, D - 1);
             mask_load(En, IC<0>{});
             mask_load(En, IC<1>{});
@@ -740,18 +799,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     __syncthreads();
     if (np > 0) {
-        const unsigned bv = st_vox * 2u, bs = patch_of(0) * patch_v * 2u;
+        // plane 0 of the first item synchronously, then the first loads of plane 1 (RW = 8: two units ahead; RW = 4: the whole
+        // plane - two units and the halo row)
+        const Src C0 = src_of(0, false), H0 = src_of(0, true);
         const int wb = st_lane;
-        load_unit(bv, bs, 0u, IC<0>{}); load_unit(bv, bs, 0u, IC<1>{});
+        load_unit(C0, 0u, IC<0>{}); load_unit(C0, 0u, IC<1>{});
         stage_unit(wb, IC<0>{}); stage_unit(wb, IC<1>{});
-        load_unit(bv, bs, 0u, IC<2>{}); load_unit(bv, bs, 0u, IC<3>{});
-        stage_unit(wb, IC<2>{}); stage_unit(wb, IC<3>{});
+        if constexpr (RW == 8) {
+            load_unit(C0, 0u, IC<2>{}); load_unit(C0, 0u, IC<3>{});
+            stage_unit(wb, IC<2>{}); stage_unit(wb, IC<3>{});
+        } else if (halo_wave) {
+            load_halo(H0, 0u);
+            stage_halo(0);
+        }
         c1_pi = 0; c1_z = 0;
         advance(c1_pi, c1_z);
         c2_pi = c1_pi; c2_z = c1_z;
         advance(c2_pi, c2_z);
-        const unsigned bv1 = c1_pi < np ? st_vox * 2u : OOB, bs1 = c1_pi < np ? patch_of(c1_pi) * patch_v * 2u : 0u;
-        load_unit(bv1, bs1, (unsigned)c1_z, IC<0>{}); load_unit(bv1, bs1, (unsigned)c1_z, IC<1>{});
+        const Src C1 = src_of(c1_pi, false);
+        load_unit(C1, (unsigned)c1_z, IC<0>{}); load_unit(C1, (unsigned)c1_z, IC<1>{});
+        if constexpr (RW == 4) { if (halo_wave) load_halo(src_of(c1_pi, true), (unsigned)c1_z); }
     }
     long long n = 0;
     for (int pi = 0; pi < np; ++pi) {
@@ -925,11 +992,20 @@ int c3d_bwd_launch(alq_ctx *ctx, const C3dPlan &plan, int N, const unsigned char
     C3BwdArgs a;
     a.bits = bits; a.vec = vec16; a.W = plan.d_W; a.maskA = maskA; a.dB = dB; a.sumA = sumA; a.sumB = sumB;
     a.N = N; a.D = plan.D; a.e_in = e_in; a.e_w = plan.w_exp;
-    const unsigned grid = (unsigned)std::min(N, 256);
     ProfScope ps(ctx, PROF_IGEMM_F16, plan.flops_per_patch * N);
-    auto kfn = c3d_bwd_kernel<true>;
-    ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS));
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), B3_LDS, ctx->stream, a);
+    // a workgroup per half patch (4 rows per wave, nothing spilled) unless ALQ_C3D_BWD_ROWS=8 asks for whole patches
+    static const int rows8 = []() { const char *e = getenv("ALQ_C3D_BWD_ROWS"); return e && atoi(e) == 8 ? 1 : 0; }();
+    if (rows8) {
+        auto kfn = c3d_bwd_kernel<true, 8>;
+        const int ldsb = 2 * (32 + 2) * B3_ROW + 2 * B3_ROW;
+        ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+        hipLaunchKernelGGL(kfn, dim3((unsigned)std::min(N, 256)), dim3(256), ldsb, ctx->stream, a);
+    } else {
+        auto kfn = c3d_bwd_kernel<true, 4>;
+        const int ldsb = 2 * (16 + 2) * B3_ROW + 2 * B3_ROW;
+        ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+        hipLaunchKernelGGL(kfn, dim3((unsigned)std::min(2 * N, 256)), dim3(256), ldsb, ctx->stream, a);
+    }
     ALQ_HIP(hipGetLastError());
     return ALQ_OK;
 }

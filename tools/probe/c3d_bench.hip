@@ -74,9 +74,13 @@ int main(int argc, char **argv) {
     C3BwdArgs b;
     b.bits = bits; b.vec = dv16; b.W = pb.d_W; b.maskA = maskA; b.dB = dB; b.sumA = sA; b.sumB = sB; b.N = N; b.D = 32; b.e_in = 20; b.e_w = pb.w_exp;
     auto kf = c3d_fwd_kernel<true, true>;
-    auto kb = c3d_bwd_kernel<true>;
+#ifndef C3_BRW
+#define C3_BRW 4
+#endif
+    auto kb = c3d_bwd_kernel<true, C3_BRW>;
+    const int B3L = 2 * (4 * C3_BRW + 2) * B3_ROW + 2 * B3_ROW;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, B3L));
     const unsigned grid = (unsigned)std::min(N, 256);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -86,7 +90,7 @@ int main(int argc, char **argv) {
         for (int r = 0; r < reps + 2; ++r) {
             CK(hipEventRecord(e0, 0));
             if (which == 0) hipLaunchKernelGGL(kf, dim3(grid), dim3(256), C3_LDS, 0, a);
-            else hipLaunchKernelGGL(kb, dim3(grid), dim3(256), B3_LDS, 0, b);
+            else hipLaunchKernelGGL(kb, dim3((unsigned)std::min(N * (8 / C3_BRW), 256)), dim3(256), B3L, 0, b);
             CK(hipEventRecord(e1, 0));
             CK(hipEventSynchronize(e1));
             float ms = 0.f;

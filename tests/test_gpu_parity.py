@@ -351,6 +351,38 @@ def test_config2_neta_live_oracle(sess):
     model.close()
 
 
+def test_config1_neta_entropy_query_at_the_survey_seeds(sess):
+    """configs[0] / SURVEY.md 8(d) "config 1" exactly as specified: NET-A on 1,000 patches float32[1000,32,32,1] from
+    RandomState(1001), He-normal weights in the draw order of NN.py:476-504 under seed 11, k = 50; the entropy query
+    q = argsort(|p1 - .5|)[:50] (PW_NNAL.py:51-65) on the device against the oracle's posteriors and the reference's filter.
+    Indices bit-exact up to ONE adjacent near-tie: among the 51 smallest oracle keys one pair lies 2.8e-6 apart (the posteriors'
+    noise is ~1e-6), every other gap is above 1e-5."""
+    from nnal_amd import PW_NNAL
+    ld = netspec.net_a()
+    in_shape = (32, 32, 1)
+    pars = netspec.he_init(ld, in_shape, seed=11)
+    x = np.random.RandomState(1001).randn(1000, *in_shape).astype(np.float32)
+    om = OracleModel(ld, in_shape, pars)
+    model = _device_model(sess, ld, in_shape, (), pars, max_batch=1000)
+    p_ref = om.forward(x)['posteriors'][1]
+    p_dev = model.forward(x)['posteriors'][1]
+    dmax = float(np.abs(p_dev.astype(np.float64) - p_ref.astype(np.float64)).max())
+    assert dmax <= 5e-6, dmax
+    want = alpath.binary_uncertainty_filter(p_ref.astype(np.float64), 50)
+    got = PW_NNAL.device_uncertainty_filter(sess, sess.to_device(p_dev, sess.torch.float32), 50).cpu().numpy()
+    # the device orders ITS OWN posteriors exactly like the reference's rule ...
+    np.testing.assert_array_equal(got, PW_NNAL.binary_uncertainty_filter(p_dev.astype(np.float64), 50))
+    # ... and picks the oracle's query: the 51 smallest oracle keys are >= 2.8e-6 apart (one pair; the others >= 1e-5), so at
+    # most that one adjacent pair may swap, and only if the two posteriors differ by less than twice the measured noise
+    key = np.abs(p_ref.astype(np.float64) - .5)
+    diff = np.nonzero(got != want)[0]
+    assert len(diff) in (0, 2), diff
+    for i in diff:
+        assert abs(key[got[i]] - key[want[i]]) <= 2 * dmax, (i, got[i], want[i], dmax)
+    assert set(got) == set(want) or len(set(got) ^ set(want)) == 2
+    model.close()
+
+
 def _netc_model(sess, max_batch):
     ld, sk = netspec.net_c()
     in_shape = (32, 32, 32, 1)

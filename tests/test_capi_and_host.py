@@ -234,3 +234,82 @@ def test_weight_files_npz_twin_and_hdf5_when_available(tmp_path):
         g.create_dataset('Bias_1', data=vd['conv1'][1])
     got = weights_io.read_weights(str(tmp_path / 'ext.h5'), ['conv1'])
     np.testing.assert_array_equal(got['conv1'][0], vd['conv1'][0])
+
+
+def test_run_method_bookkeeping_against_the_reference_run(golden_dir, tmp_path, monkeypatch):
+    """PW_AL.Experiment_MultiImg.run_method's bookkeeping against a run of the reference's own lines (PW_AL.py:690-898;
+    fixture r4_run_method.npz, made by tests/golden/make_golden_r4.py with stand-ins for I/O, TensorFlow and the query):
+    grid pool, volume statistics, the pool each query sees, the training lists each fine-tune is handed, the `queries/<iter>`
+    files byte for byte, and the resume path (a second run_method on the same directory) - all bit-exact."""
+    import copy
+    from nnal_amd import PW_AL, nrrd_io
+    sys_path = os.path.join(os.path.dirname(__file__), 'golden')
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('make_golden_r4', os.path.join(sys_path, 'make_golden_r4.py'))
+    gen = importlib.util.module_from_spec(spec)
+    import sys
+    sys.path.insert(0, sys_path)
+    try:
+        spec.loader.exec_module(gen)              # data + the seeded picker only; main() (the reference run) is not called
+    finally:
+        sys.path.remove(sys_path)
+    g = np.load(os.path.join(golden_dir, 'r4_run_method.npz'))
+    table, paths = gen.subjects(int(g['subject_seed']))
+    data = tmp_path / 'data'
+    data.mkdir()
+    here = []
+    for sub in paths:
+        row = []
+        for p in sub:
+            q = str(data / os.path.basename(p))
+            nrrd_io.write(q, table[p])
+            row.append(q)
+        here.append(row)
+    rec = {'pools_seen': [], 'train_seen': []}
+    pick = gen.picker(int(g['pick_seed']))
+
+    def fake_query(expr, model, sess, all_padded_imgs, pool_inds, labeled_inds, method_name):
+        rec['pools_seen'].append(copy.deepcopy(pool_inds))
+        return pick(pool_inds)
+
+    def fake_finetune(expr, model, sess, all_padded_imgs, training_inds):
+        rec['train_seen'].append(copy.deepcopy(training_inds))
+
+    class Model(object):
+        def add_assign_ops(self):
+            pass
+
+        def perform_assign_ops(self, path, sess):
+            pass
+
+        def save_weights(self, path):
+            pass
+    monkeypatch.setattr(PW_NNAL, 'query_multimg', fake_query)
+    monkeypatch.setattr(PW_AL, 'finetune_multimg', fake_finetune)
+    root = str(tmp_path / 'expr')
+    expr = PW_AL.Experiment_MultiImg(root, dict(gen.PARS), here)
+    expr.model_factory = lambda e, shp, s: Model()
+    expr.add_method('fi')
+    per_iter = int(np.sum(g['picks']))
+    np.testing.assert_array_equal(expr.train_stats, g['train_stats'])
+    expr.run_method('fi', 3 * per_iter, sess=object())
+    expr2 = PW_AL.Experiment_MultiImg(root)
+    expr2.model_factory = lambda e, shp, s: Model()
+    np.testing.assert_array_equal(expr2.train_stats, g['train_stats_reloaded'])
+    expr2.run_method('fi', 2 * per_iter, sess=object())
+    qdir = os.path.join(root, 'fi', 'queries')
+    assert sorted(os.listdir(qdir), key=int) == ['0', '1', '2', '3', '4']
+    assert sorted(os.listdir(os.path.join(root, 'fi', 'AL_running_times'))) == ['dt_%d' % i for i in range(5)]
+    for it in range(5):
+        with open(os.path.join(qdir, '%d' % it), 'rb') as f:
+            assert f.read() == g['queries_text_%d' % it].tobytes(), 'queries/%d differs from the reference run' % it
+        for s_ in range(2):
+            np.testing.assert_array_equal(np.asarray(rec['pools_seen'][it][s_], dtype=np.int64), g['pool_seen_%d_%d' % (it, s_)])
+            mine = np.asarray(rec['train_seen'][it][s_], dtype=np.int64)
+            if it >= 3:
+                # resumed: the reference concatenates the query files in os.listdir order (PW_AL.py:726-734, the file system's
+                # choice), this repo in iteration order; same per-file blocks, so put mine in the order the reference run saw
+                k = int(g['picks'][s_])
+                blocks = [mine[j * k:(j + 1) * k] for j in range(it + 1)]
+                mine = np.concatenate([blocks[j] for j in g['resume_listdir_order']] + blocks[3:])
+            np.testing.assert_array_equal(mine, g['train_seen_%d_%d' % (it, s_)])

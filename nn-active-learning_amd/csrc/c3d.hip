@@ -62,6 +62,12 @@ static_assert(C3_WD >= 1 && C3_WD <= 8, "weight-difference slices are fetched 1.
 #ifndef C3_PIPE
 #define C3_PIPE 2
 #endif
+#ifndef C3_PEEL
+#define C3_PEEL 1
+#endif
+#ifndef C3_EPI2
+#define C3_EPI2 1
+#endif
 #ifndef C3_BPIPE
 #define C3_BPIPE 2
 #endif
@@ -270,13 +276,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         unsigned unsure = 0u;
         if constexpr (SUMS) {
             const float mn = fminf(fminf(__builtin_fabsf(val.x), __builtin_fabsf(val.y)), fminf(__builtin_fabsf(val.z), __builtin_fabsf(val.w)));
+#if C3_EPI2
+            // mn, tau >= 0: their bit patterns order like the numbers, and the sign of the difference is the answer (no compare, no
+            // VCC round trip with its wait states)
+            unsure = (__builtin_bit_cast(unsigned, mn) - __builtin_bit_cast(unsigned, E.tau)) >> 31;
+#else
             unsure = mn < E.tau ? 16u : 0u;
+#endif
         }
         val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f);
         fs += __builtin_fmaf(val.y, w4.y, val.x * w4.x) + __builtin_fmaf(val.w, w4.w, val.z * w4.z);
         if constexpr (SUMS) {
             sa += (val.x + val.y) + (val.z + val.w);
+#if C3_EPI2
+            // after the ReLU a value is +0 or positive (the accumulators start at +0 and never reach -0): the negated bit pattern has
+            // its top bit set exactly when x > 0, and v_alignbit shifts it into the byte - two integer instructions per channel, no
+            // compare / select with their VCC wait states
+            const float r0 = val.x, r1 = val.y, r2 = val.z, r3 = val.w;
+            unsigned nib = unsure;
+            nib = __builtin_amdgcn_alignbit(nib, 0u - __builtin_bit_cast(unsigned, r3), 31);
+            nib = __builtin_amdgcn_alignbit(nib, 0u - __builtin_bit_cast(unsigned, r2), 31);
+            nib = __builtin_amdgcn_alignbit(nib, 0u - __builtin_bit_cast(unsigned, r1), 31);
+            nib = __builtin_amdgcn_alignbit(nib, 0u - __builtin_bit_cast(unsigned, r0), 31);
+#else
             const unsigned nib = (val.x > 0.f ? 1u : 0u) | (val.y > 0.f ? 2u : 0u) | (val.z > 0.f ? 4u : 0u) | (val.w > 0.f ? 8u : 0u) | unsure;
+#endif
             if constexpr (!(C3_ABL & 16))
                 __builtin_amdgcn_raw_buffer_store_b8((unsigned char)nib, bits_rsrc, (int)E.off_b, (int)(E.bits_s + ((E.row_f + (unsigned)i * 256u) >> 2)), 0);
             else asm volatile("" :: "v"(nib));
@@ -446,12 +470,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // D = 32: 33 = 3 * 11 steps per patch (the last one light), so the set rotation restarts at every patch
     long long n = 0;
     for (int pi = 0; pi < np; ++pi) {
+#if C3_PEEL
+        for (int zz = 0; zz < 10; ++zz) {
+            step(IC<0>{}, pi, 3 * zz, n); ++n;
+            step(IC<1>{}, pi, 3 * zz + 1, n); ++n;
+            step(IC<2>{}, pi, 3 * zz + 2, n); ++n;
+        }
+        step(IC<0>{}, pi, 30, n); ++n;
+        step(IC<1>{}, pi, 31, n); ++n;
+        light(IC<0>{}, pi, D - 2);
+#else
         for (int zz = 0; zz < 11; ++zz) {
             step(IC<0>{}, pi, 3 * zz, n); ++n;
             step(IC<1>{}, pi, 3 * zz + 1, n); ++n;
             if (zz < 10) { step(IC<2>{}, pi, 3 * zz + 2, n); ++n; }
             else light(IC<0>{}, pi, D - 2);
         }
+#endif
     }
     if (np > 0) {
         light(IC<1>{}, np - 1, D - 1);
@@ -822,12 +857,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     long long n = 0;
     for (int pi = 0; pi < np; ++pi) {
+#if C3_PEEL
+        for (int zz = 0; zz < 10; ++zz) {
+            step(IC<0>{}, pi, 3 * zz, n); ++n;
+            step(IC<1>{}, pi, 3 * zz + 1, n); ++n;
+            step(IC<2>{}, pi, 3 * zz + 2, n); ++n;
+        }
+        step(IC<0>{}, pi, 30, n); ++n;
+        step(IC<1>{}, pi, 31, n); ++n;
+        light(IC<0>{}, pi, D - 2);
+#else
         for (int zz = 0; zz < 11; ++zz) {
             step(IC<0>{}, pi, 3 * zz, n); ++n;
             step(IC<1>{}, pi, 3 * zz + 1, n); ++n;
             if (zz < 10) { step(IC<2>{}, pi, 3 * zz + 2, n); ++n; }
             else light(IC<0>{}, pi, D - 2);
         }
+#endif
     }
     if (np > 0) light(IC<1>{}, np - 1, D - 1);
 }

@@ -700,10 +700,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // (scalars first: __builtin_bit_cast applied to an element of an ext_vector lvalue reads element 0)
         const float v0 = c.x * E.inv, v1 = c.y * E.inv, v2 = c.z * E.inv, v3 = c.w * E.inv;
         f32x4 val;
-        val.x = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v0) & (unsigned)__builtin_amdgcn_sbfe(nib, 0, 1));
-        val.y = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v1) & (unsigned)__builtin_amdgcn_sbfe(nib, 1, 1));
-        val.z = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v2) & (unsigned)__builtin_amdgcn_sbfe(nib, 2, 1));
-        val.w = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v3) & (unsigned)__builtin_amdgcn_sbfe(nib, 3, 1));
+        // (the empty asm hides the 0 / -1 masks from the optimiser, which otherwise rewrites "x & sext(bit)" into bit test + compare +
+        // select: three vector instructions and a wait state per value instead of v_bfe_i32 + v_and_b32)
+        unsigned k0 = (unsigned)__builtin_amdgcn_sbfe(nib, 0, 1), k1 = (unsigned)__builtin_amdgcn_sbfe(nib, 1, 1);
+        unsigned k2 = (unsigned)__builtin_amdgcn_sbfe(nib, 2, 1), k3 = (unsigned)__builtin_amdgcn_sbfe(nib, 3, 1);
+        asm("" : "+v"(k0), "+v"(k1), "+v"(k2), "+v"(k3));
+        val.x = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v0) & k0);
+        val.y = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v1) & k1);
+        val.z = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v2) & k2);
+        val.w = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v3) & k3);
         const unsigned vox = E.pv + E.row_v + (unsigned)i * 32u + (unsigned)hx * 16u;      // first voxel of this half row
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, val), dB_rsrc, (int)E.off_dB, (int)(vox * 32u), 2 /* nt */);
         const float t = (val.x + val.y) + (val.z + val.w);

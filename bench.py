@@ -221,7 +221,8 @@ def main():
                        'comm_world': int(getattr(sess, 'comm_world', 0) or 0),
                        'dist_backend': dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None,
                        'head_conv_engine': {'forward_plane_sweep': int(sess.lib.alq_model_engine_info(model._m, 1)),
-                                            'backward_plane_sweep': int(sess.lib.alq_model_engine_info(model._m, 2))},
+                                            'backward_plane_sweep': int(sess.lib.alq_model_engine_info(model._m, 2)),
+                                            'flip_list_overflow': int(sess.lib.alq_model_engine_info(model._m, 5))},
                        'parallelism': 'pool sharded over %d GPU(s), top-B merge (all-gather) + 8x8 Fisher all-reduce: %s' % (ws, comm)},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic, 'traffic_note': traffic_note,

@@ -271,7 +271,10 @@ int alq_debug_set(int key, int value);
  * keep fp16 subnormal operands (probed once; the one-accumulator form of the plane-sweep engine needs it), 1: 1 when the last
  * forward pass ran the conv under the two-class head on the plane-sweep engine (csrc/c3d.hip; replaces the tf.nn.conv3d call
  * site NN_extended.py:416-426 for that layer), 2: the same for the last backward pass, 3: 1 when that engine accumulates the
- * three piece products in one accumulator.  Returns the answer (0 / 1) or a negative error code.  */
+ * three piece products in one accumulator, 5: the number of marked 4-channel groups the flip-safe head could NOT re-evaluate
+ * exactly since the model was created because a list segment (a quarter of a patch, 128 slots) was full - 0 on every input the
+ * tests and the bench use; a dropped group keeps the sign its fp16-pair contraction produced (synchronises the stream).
+ * Returns the answer or a negative error code.  */
 int alq_model_engine_info(alq_model *m, int what);
 
 /* Synthetic patch generator: counter-based RNG keyed (seed, patch_id, element), standard

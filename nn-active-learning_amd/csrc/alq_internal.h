@@ -507,9 +507,11 @@ int k_fc_small_bwd(alq_ctx *, const float *delta, int nout, const float *Wp, int
                    float *dact, const float *mask_act = nullptr, float *dsum = nullptr, int C = 0,
                    bool *fused = nullptr);
 int k_rowsum_field(alq_ctx *, const float *field, int64_t len, int N, float *out);
+int flip_segments(int N);      // scan segments / list slots k_flip_fix needs for N patches
+int flip_list_len(int N);
 int k_flip_fix(alq_ctx *, unsigned *list, unsigned *cnt, int cap, int N, const float *inA, const float *inB, int CA, int CB,
                int D, int H, int W, int kz, int ky, int kx, int lz, int ly, int lx, const float *W32, const float *bias, int Co,
-               unsigned char *bits, long long F);
+               unsigned char *bits, long long F, unsigned *overflow = nullptr);
 int k_rowmax_u32(alq_ctx *, const unsigned *in, int len, int N, unsigned *out);      // out[n] = max_k in[n][k]
 int k_softmax(alq_ctx *, const float *logits, int c, int N, float *post_cN, int64_t *pred);
 int k_fill_unit_cotangent(alq_ctx *, float *dlogits, int N);

@@ -233,7 +233,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int ce = valid ? patch_exp(p) : 0;
         e.inv = valid ? __builtin_ldexpf(1.f, -(ce + a.e_w)) : 0.f;
         e.b4 = valid ? bias4 : f32x4{0.f, 0.f, 0.f, 0.f};
-        e.tau = valid ? __builtin_ldexpf(a.flip_tau, 14 - ce) : 0.f;
+        // (an all-zero patch: every pre-activation IS its bias in both arithmetics - nothing to mark)
+        e.tau = (valid && (a.amaxA[p] | a.amaxB[p]) != 0u) ? __builtin_ldexpf(a.flip_tau, 14 - ce) : 0.f;
         e.off_w = valid ? epi_lane_f * 4u : OOB;
         e.off_b = valid ? (epi_lane_f >> 2) : OOB;
         e.row_f = (unsigned)(zo * 32 + wave * 8) * 256u;       // float offset of row 8 w of that plane inside the patch

@@ -1287,12 +1287,19 @@ int k_rowmax_u32(alq_ctx *ctx, const unsigned *in, int len, int N, unsigned *out
 // groups holding a pre-activation that its fp16x2 contraction left within its error bound of zero).  Streams the bit field
 // once (16 bytes per thread); every scan block keeps its own list segment and count: list[block * FLIP_PER_BLOCK + slot] = global
 // byte index, cnt[block] = groups found.
-constexpr int FLIP_BLOCKS = 8192, FLIP_PER_BLOCK = 128;      // scan blocks and list slots per block (expected load: ~8)
-__global__ __launch_bounds__(256) void flip_scan_kernel(const uint4 *bits16, long long n16, unsigned *cnt, unsigned *list) {
+// The segments are cut PER PATCH (FLIP_SEG_PER_PATCH equal parts of a patch's bytes), never across patches: which groups are
+// re-evaluated then does not depend on how the caller cut the pool into batches.  A segment with more marked groups than list
+// slots keeps the first FLIP_PER_BLOCK the hardware hands out and adds the rest to *overflow (alq_model_engine_info(m, 5)): the
+// dropped groups keep the sign the fp16x2 contraction gave them - still a sign within rounding of the exact one.
+constexpr int FLIP_SEG_PER_PATCH = 4, FLIP_PER_BLOCK = 128;      // list slots per segment (expected load: ~8)
+__global__ __launch_bounds__(256) void flip_scan_kernel(const uint4 *bits16, long long p16, unsigned *cnt, unsigned *list, unsigned *overflow) {
     __shared__ unsigned lc;
     if (threadIdx.x == 0) lc = 0u;
     __syncthreads();
-    const long long per = (n16 + gridDim.x - 1) / gridDim.x, a = blockIdx.x * per, b = a + per < n16 ? a + per : n16;
+    // block = (patch, part): p16 = 16-byte words per patch
+    const long long patch = blockIdx.x / FLIP_SEG_PER_PATCH, part = blockIdx.x % FLIP_SEG_PER_PATCH;
+    const long long per = (p16 + FLIP_SEG_PER_PATCH - 1) / FLIP_SEG_PER_PATCH;
+    const long long a = patch * p16 + part * per, b = patch * p16 + ((part + 1) * per < p16 ? (part + 1) * per : p16);
     for (long long i = a + threadIdx.x; i < b; i += 256) {
         const uint4 w = bits16[i];
         if (((w.x | w.y | w.z | w.w) & 0x10101010u) == 0u) continue;
@@ -1307,7 +1314,10 @@ __global__ __launch_bounds__(256) void flip_scan_kernel(const uint4 *bits16, lon
                 }
     }
     __syncthreads();
-    if (threadIdx.x == 0) cnt[blockIdx.x] = lc < (unsigned)FLIP_PER_BLOCK ? lc : (unsigned)FLIP_PER_BLOCK;
+    if (threadIdx.x == 0) {
+        cnt[blockIdx.x] = lc < (unsigned)FLIP_PER_BLOCK ? lc : (unsigned)FLIP_PER_BLOCK;
+        if (lc > (unsigned)FLIP_PER_BLOCK && overflow) atomicAdd(overflow, lc - (unsigned)FLIP_PER_BLOCK);
+    }
 }
 // Step 2: exact re-evaluation of the four pre-activations of every listed group of a stride-1 SAME conv and their sign
 // nibble written back (flag cleared).  One wave per group; products in fp64 (exact for fp32 factors), lane partials and the
@@ -1356,18 +1366,24 @@ __global__ __launch_bounds__(256) void flip_fix_kernel(const unsigned *list, con
         }
     }
 }
+int flip_segments(int N) { return N * FLIP_SEG_PER_PATCH; }
+int flip_list_len(int N) { return N * FLIP_SEG_PER_PATCH * FLIP_PER_BLOCK; }
+
 int k_flip_fix(alq_ctx *ctx, unsigned *list, unsigned *cnt, int cap, int N, const float *inA, const float *inB, int CA, int CB,
                int D, int H, int W, int kz, int ky, int kx, int lz, int ly, int lx, const float *W32, const float *bias, int Co,
-               unsigned char *bits, long long F) {
+               unsigned char *bits, long long F, unsigned *overflow) {
     ProfScope ps(ctx, PROF_ELEMWISE, 0);
-    const long long n16 = (long long)N * (F >> 2) / 16;
-    (void)cap;
-    hipLaunchKernelGGL(flip_scan_kernel, dim3(FLIP_BLOCKS), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4 *>(bits), n16, cnt, list);
+    ALQ_REQUIRE(F % 64 == 0, ALQ_EINVAL, "flip_fix: %lld sign bytes per patch are not whole 16-byte words", (long long)(F >> 2));
+    ALQ_REQUIRE(cap >= flip_list_len(N), ALQ_EINVAL, "flip_fix: list of %d slots for %d patches", cap, N);
+    if (N <= 0) return ALQ_OK;
+    const long long p16 = (F >> 2) / 16;
+    const unsigned segs = (unsigned)flip_segments(N);
+    hipLaunchKernelGGL(flip_scan_kernel, dim3(segs), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4 *>(bits), p16, cnt, list, overflow);
     if (CA + CB == 16 && kz == 3 && ky == 3 && kx == 3)
-        hipLaunchKernelGGL((flip_fix_kernel<16, 3, 3, 3>), dim3(FLIP_BLOCKS * 4), dim3(256), 0, ctx->stream, list, cnt, inA, inB, CA, CB, D, H, W,
+        hipLaunchKernelGGL((flip_fix_kernel<16, 3, 3, 3>), dim3(segs * 4), dim3(256), 0, ctx->stream, list, cnt, inA, inB, CA, CB, D, H, W,
                            kz, ky, kx, lz, ly, lx, W32, bias, Co, bits, F);
     else
-        hipLaunchKernelGGL((flip_fix_kernel<0, 0, 0, 0>), dim3(FLIP_BLOCKS * 4), dim3(256), 0, ctx->stream, list, cnt, inA, inB, CA, CB, D, H, W,
+        hipLaunchKernelGGL((flip_fix_kernel<0, 0, 0, 0>), dim3(segs * 4), dim3(256), 0, ctx->stream, list, cnt, inA, inB, CA, CB, D, H, W,
                            kz, ky, kx, lz, ly, lx, W32, bias, Co, bits, F);
     ALQ_LAUNCH_CHECK();
     return ALQ_OK;

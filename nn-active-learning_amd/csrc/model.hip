@@ -112,6 +112,7 @@ struct alq_model {
     unsigned *amax_a = nullptr, *amax_b = nullptr, *amax_tiles = nullptr;
     unsigned *flip_cnt = nullptr, *flip_list = nullptr;     // candidates of the flip-safe fused head (igemm4 FCF + F16)
     int flip_cap = 0;
+    unsigned *flip_overflow = nullptr;      // marked groups the scan could not list since the model was created (kernels.hip, flip_scan_kernel)
     int no_flipfix = 0;                                      // ALQ_NO_FLIPFIX at creation (A/B: the head's sign bits as the fp16x2 contraction leaves them)
     size_t amax_tiles_len = 0;
     int in_dims[4] = {1, 1, 1, 1};
@@ -876,9 +877,11 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                                          ((in.split == 0 && in.cs == in.C) || (in.split > 0 && in.cs == in.split && in.C == 2 * in.split));
                     if (flipfix) {
                         if (!m->flip_list) {
-                            m->flip_cap = 8192 * 128;            // kernels.hip: FLIP_BLOCKS segments of FLIP_PER_BLOCK groups
-                            ALQ_TRY(m->dalloc(&m->flip_cnt, (size_t)8192));
+                            m->flip_cap = flip_list_len(m->max_batch);      // kernels.hip: per-patch segments of FLIP_PER_BLOCK slots
+                            ALQ_TRY(m->dalloc(&m->flip_cnt, (size_t)flip_segments(m->max_batch)));
                             ALQ_TRY(m->dalloc(&m->flip_list, (size_t)m->flip_cap));
+                            ALQ_TRY(m->dalloc(&m->flip_overflow, (size_t)1));
+                            ALQ_HIP(hipMemsetAsync(m->flip_overflow, 0, sizeof(unsigned), ctx->stream));
                         }
                         fz.flip_cnt = m->flip_cnt; fz.flip_list = m->flip_list; fz.flip_cap = m->flip_cap; fz.flip_l1 = ly.fwd_l1;
                     }
@@ -894,7 +897,7 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                         ALQ_TRY(k_flip_fix(ctx, m->flip_list, m->flip_cnt, m->flip_cap, N, in.p, in.split ? in.p + in.delta : nullptr,
                                            in.split ? in.split : in.C, in.split ? in.C - in.split : 0, in.D, in.H, in.W, sp.k[0], sp.k[1], sp.k[2],
                                            ly.lo[0], ly.lo[1], ly.lo[2], ly.d_W32, ly.d_bias, sp.cout,
-                                           reinterpret_cast<unsigned char *>(nx->fc_maskbits), nx->F));
+                                           reinterpret_cast<unsigned char *>(nx->fc_maskbits), nx->F, m->flip_overflow));
                     fused = true;
                     fc_head_fused = true;
                     m->last_head_fused = true;
@@ -1934,11 +1937,18 @@ int alq_model_debug_copy(alq_model *m, int layer_idx, int what, int N, float *d_
 }
 
 int alq_model_engine_info(alq_model *m, int what) {
-    ALQ_REQUIRE(m && what >= 0 && what <= 3, ALQ_EINVAL, "alq_model_engine_info: bad argument");
+    ALQ_REQUIRE(m && ((what >= 0 && what <= 3) || what == 5), ALQ_EINVAL, "alq_model_engine_info: bad argument");
     ALQ_HIP(hipSetDevice(m->ctx->device));
     if (what == 0) return c3d_subnormals_ok(m->ctx);
     if (what == 1) return m->last_c3 ? 1 : 0;
     if (what == 2) return m->last_c3_bwd ? 1 : 0;
+    if (what == 5) {       // flip-safe head: marked groups dropped by a full list segment since the model was created
+        if (!m->flip_overflow) return 0;
+        unsigned h = 0;
+        ALQ_HIP(hipMemcpyAsync(&h, m->flip_overflow, sizeof(unsigned), hipMemcpyDeviceToHost, m->ctx->stream));
+        ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
+        return h > 0x7fffffffu ? 0x7fffffff : (int)h;
+    }
     for (const Layer &ly : m->layers)
         if (ly.c3f.ok) return ly.c3f.oneacc;
     return 0;

@@ -1163,6 +1163,44 @@ def test_plane_sweep_engine_against_the_two_slot_engine(sess):
     m_old.close()
 
 
+def test_flip_safe_head_is_cut_invariant_and_reports_overflow(sess):
+    """The flip-safe head's candidate scan (kernels.hip, flip_scan_kernel) works on per-patch list segments: the scores of a
+    patch must not depend on how the pool was cut into batches (bit for bit), and marked groups that do not fit a segment are
+    counted (alq_model_engine_info(m, 5)) instead of vanishing silently.  The bench's data never fills a segment; a patch
+    whose upper half is zero under zero biases (every pre-activation there is exactly its bias, 0) does; an all-zero patch
+    marks nothing."""
+    import ctypes as C
+    from nnal_amd._lib import check
+    torch = sess.torch
+    n = 40
+    ld, sk, in_shape, pars, (m,) = _netc32_models(sess, [{}], max_batch=n)
+    x = sess.empty((n, 32 ** 3), torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, 32 ** 3, C.c_void_p(x.data_ptr())))
+    keys = ('p1', 'g0', 'g1', 'A')
+    whole = {k: v.cpu().numpy().copy() for k, v in m.fisher_device(x, n, None, 1e-3, want=keys).items() if k in keys}
+    parts = []
+    for a, b in ((0, 17), (17, 40)):
+        xs = x[a:b].contiguous()
+        r = m.fisher_device(xs, b - a, None, 1e-3, want=keys)
+        parts.append({k: r[k].cpu().numpy().copy() for k in keys})
+    for k in keys:
+        np.testing.assert_array_equal(whole[k], np.concatenate([parts[0][k], parts[1][k]], axis=0), err_msg=k)
+    assert sess.lib.alq_model_engine_info(m._m, 1) == 1
+    assert sess.lib.alq_model_engine_info(m._m, 5) == 0, 'list segments overflowed on the bench data'
+    # an all-zero patch marks nothing (its pre-activations ARE the biases in both arithmetics) ...
+    z = torch.zeros_like(x[:4])
+    r = m.fisher_device(z, 4, None, 1e-3, want=('p1', 'g0'))
+    assert np.isfinite(r['g0'].cpu().numpy()).all()
+    assert sess.lib.alq_model_engine_info(m._m, 5) == 0
+    # ... a patch that is zero in its upper half marks every group deep inside that half: more than the segments hold
+    h = x[:4].clone().reshape(4, 32, 32, 32)
+    h[:, 16:] = 0
+    r = m.fisher_device(h.reshape(4, -1).contiguous(), 4, None, 1e-3, want=('p1', 'g0'))
+    assert np.isfinite(r['g0'].cpu().numpy()).all()
+    assert sess.lib.alq_model_engine_info(m._m, 5) > 0
+    m.close()
+
+
 def test_default_engines_against_the_exact_fp32_engine_full_batch(sess):
     """One full 2000-patch batch of the bench's pool: the default engines (fp16x2 pairs in the plane-sweep kernels and in the other
     backward launches, bf16x3 elsewhere) against the exact-fp32 MFMA engine (alq_debug_set(4, 1): fp32 fma chains, no operand
@@ -1184,6 +1222,7 @@ def test_default_engines_against_the_exact_fp32_engine_full_batch(sess):
         b = {k: r[k].cpu().numpy() for k in ('p1', 'g0', 'g1')}
     finally:
         check(sess.lib.alq_debug_set(4, 0))
+    assert sess.lib.alq_model_engine_info(m._m, 5) == 0, 'flip-safe head: a list segment overflowed on the bench batch'
     # posteriors: continuous in the rounding noise, so a hard bar
     np.testing.assert_allclose(a['p1'], b['p1'], rtol=0, atol=2e-6)
     bad = set()

@@ -412,7 +412,7 @@ int c3d_bwd_build(const View &fwd_in, const View &fwd_out, const int k[3], const
 void c3d_bwd_pack(C3dPlan *plan, const std::vector<float> &Bmat_fwd /* the forward conv's [(tap, ci)][co] */);
 void c3d_presplit_vec(const float *v, long long F, int e, std::vector<unsigned short> *out);
 int c3d_bwd_launch(alq_ctx *ctx, const C3dPlan &plan, int N, const unsigned char *bits, const void *vec16, int e_in, const unsigned char *maskA,
-                   float *dB, float *sumA, float *sumB);
+                   float *dB, float *sumA, float *sumB, int rows_per_wave = 8);
 
 // ------------------------------------------------------------------ direct first-layer conv (direct.hip)
 struct DirectArgs {

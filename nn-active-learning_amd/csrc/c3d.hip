@@ -522,10 +522,10 @@ struct C3BwdArgs {
     int e_in, e_w;                 // scale exponents of the vector and of the packed weights
 };
 
-// RW = output rows per wave.  8: one workgroup per patch (like the forward kernel) - 192 accumulator registers, which leave the
-// AGPR half no slack (the allocator spills ~60 registers to scratch, and the spill traffic showed as +0.7 GB of HBM writes per
-// 2000 patches).  4: a workgroup owns HALF the rows of a patch (16 + 2 halo rows per plane image, staged 1.125 x), 96
-// accumulators like the forward kernel, nothing spilled.
+// RW = output rows per wave.  8 (default): one workgroup per patch like the forward kernel - 192 accumulators + 72 weight
+// registers; since the sweep loop is peeled (no join inside a patch, so no accumulator copies) it fits without scratch.
+// 4 (ALQ_C3D_BWD_ROWS=4): a workgroup owns HALF the rows of a patch (16 + 2 halo rows per plane image, staged 1.125 x), 96
+// accumulators, weights pinned to the AGPR half, 128 registers per lane left for co-resident side-stream kernels.
 template <bool ONEACC, int RW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void c3d_bwd_kernel(const C3BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         // RW = 4: the weights start their lives in accumulation registers like the forward kernel's (96 accumulators + 72 weight
         // registers fit the AGPR half); RW = 8: the 192 accumulators fill three quarters of it and the allocator does better alone
-        // (timing builds: 1.50 ms per 2000 patches against 1.66 ms with 16 fragments pinned)
+        // (timing builds: 1.45 ms per 2000 patches against 1.47 ms with the weights pinned)
         if constexpr (RW == 4) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
@@ -1036,7 +1036,7 @@ void c3d_presplit_vec(const float *v, long long F, int e, std::vector<unsigned s
 }
 
 int c3d_bwd_launch(alq_ctx *ctx, const C3dPlan &plan, int N, const unsigned char *bits, const void *vec16, int e_in, const unsigned char *maskA,
-                   float *dB, float *sumA, float *sumB) {
+                   float *dB, float *sumA, float *sumB, int rows_per_wave) {
     ALQ_REQUIRE(plan.ok && plan.d_W && plan.D == 32, ALQ_EINVAL, "c3d: backward weights not set");
     ALQ_REQUIRE(bits && vec16 && dB && sumA && sumB, ALQ_EINVAL, "c3d: missing argument");
     ALQ_REQUIRE(N < 4096, ALQ_EUNSUPPORTED, "c3d: 32-bit byte offsets hold fewer than 4096 patches per pass");
@@ -1045,8 +1045,10 @@ int c3d_bwd_launch(alq_ctx *ctx, const C3dPlan &plan, int N, const unsigned char
     a.bits = bits; a.vec = vec16; a.W = plan.d_W; a.maskA = maskA; a.dB = dB; a.sumA = sumA; a.sumB = sumB;
     a.N = N; a.D = plan.D; a.e_in = e_in; a.e_w = plan.w_exp;
     ProfScope ps(ctx, PROF_IGEMM_F16, plan.flops_per_patch * N);
-    // a workgroup per half patch (4 rows per wave, nothing spilled) unless ALQ_C3D_BWD_ROWS=8 asks for whole patches
-    static const int rows8 = []() { const char *e = getenv("ALQ_C3D_BWD_ROWS"); return e && atoi(e) == 8 ? 1 : 0; }();
+    // a workgroup per patch (8 rows per wave; with the peeled sweep loop nothing spills: 1.45 ms per 2000 patches against 1.63 ms)
+    // unless the model was created under ALQ_C3D_BWD_ROWS=4: the half-patch form (4 rows per wave, 128 registers per lane left to
+    // co-resident kernels)
+    const int rows8 = rows_per_wave == 4 ? 0 : 1;
     if (rows8) {
         auto kfn = c3d_bwd_kernel<true, 8>;
         const int ldsb = 2 * (32 + 2) * B3_ROW + 2 * B3_ROW;

@@ -142,6 +142,7 @@ struct alq_model {
     int no_signs0 = 0;             // ALQ_NO_SIGNS0 (A/B): no sign field from the first conv + pool kernel only
     int f16_fwd_mask = -1;         // ALQ_F16_FWD_MASK (diagnostics): forward fp16x2 consumers by layer bit, -1 = default rule
     int no_c3d = 0;                // ALQ_NO_C3D (A/B): the head conv pair on the two-slot engine (igemm4) as in round 3
+    int c3_bwd_rows = 8;           // ALQ_C3D_BWD_ROWS=4 (A/B): the plane-sweep backward kernel in its half-patch form
     bool last_c3 = false;          // the last forward pass ran the head conv on the plane-sweep engine
     bool last_c3_bwd = false;      // ... and the last backward pass its backward
 
@@ -1167,7 +1168,7 @@ static int run_backward_main(alq_model *m, const float *d_x, int N) {
                     int ex = 0;
                     (void)std::frexp(fz.in_vec_amax, &ex);
                     ALQ_TRY(c3d_bwd_launch(ctx, ly.c3b, N, reinterpret_cast<const unsigned char *>(fz.in_bits), vec16c, 14 - ex, fz.mask_bits,
-                                           ly.din.p + ly.din.delta, fz.osumA, fz.osumB));
+                                           ly.din.p + ly.din.delta, fz.osumA, fz.osumB, m->c3_bwd_rows));
                 } else {
                     ALQ_TRY(igemm4_launch(ctx, ly.bwd.p4, ly.dout, ly.din, nullptr, 0, acc, N, PROF_IGEMM3_BWD, &fz));
                 }
@@ -1489,6 +1490,7 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
         m->no_flipfix = getenv("ALQ_NO_FLIPFIX") != nullptr;
         m->no_presplit = getenv("ALQ_NO_PRESPLIT") != nullptr;
         m->no_c3d = getenv("ALQ_NO_C3D") != nullptr;
+        { const char *e = getenv("ALQ_C3D_BWD_ROWS"); m->c3_bwd_rows = (e && atoi(e) == 4) ? 4 : 8; }
         m->no_signs = getenv("ALQ_NO_SIGNS") != nullptr;
         m->no_signs0 = getenv("ALQ_NO_SIGNS0") != nullptr;
         if (const char *f = getenv("ALQ_F16_FWD_MASK")) m->f16_fwd_mask = atoi(f);

@@ -1163,6 +1163,29 @@ def test_plane_sweep_engine_against_the_two_slot_engine(sess):
     m_old.close()
 
 
+def test_plane_sweep_backward_half_patch_form_is_bit_identical(sess):
+    """The plane-sweep backward kernel in its two forms - a workgroup per patch (default, 8 rows per wave) and per half patch
+    (ALQ_C3D_BWD_ROWS=4, halo rows staged twice): every output voxel sees the same MFMAs in the same order, so the layer scores
+    must be identical bit for bit.  257 patches: the last workgroups of both grids hold one work item fewer."""
+    import ctypes as C
+    from nnal_amd._lib import check
+    torch = sess.torch
+    n = 257
+    ld, sk, in_shape, pars, (m8, m4) = _netc32_models(sess, [{}, {'ALQ_C3D_BWD_ROWS': '4'}], max_batch=n, bias_std=0.05)
+    x = sess.empty((n, 32 ** 3), torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, 32 ** 3, C.c_void_p(x.data_ptr())))
+    keys = ('p1', 'g0', 'g1', 'A')
+    out = []
+    for m in (m8, m4):
+        r = m.fisher_device(x, n, None, 1e-3, want=keys)
+        out.append({k: r[k].cpu().numpy().copy() for k in keys})
+        assert sess.lib.alq_model_engine_info(m._m, 2) == 1
+    for k in keys:
+        np.testing.assert_array_equal(out[0][k], out[1][k], err_msg=k)
+    m8.close()
+    m4.close()
+
+
 def test_flip_safe_head_is_cut_invariant_and_reports_overflow(sess):
     """The flip-safe head's candidate scan (kernels.hip, flip_scan_kernel) works on per-patch list segments: the scores of a
     patch must not depend on how the pool was cut into batches (bit for bit), and marked groups that do not fit a segment are

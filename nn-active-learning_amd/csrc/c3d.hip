@@ -62,6 +62,13 @@ static_assert(C3_WD >= 1 && C3_WD <= 8, "weight-difference slices are fetched 1.
 #ifndef C3_PIPE
 #define C3_PIPE 2
 #endif
+// what may fill the gap behind an MFMA in the sweep's 1 : C3_PIPE pattern: VALU (0x002) + SALU (0x004) + vector memory (0x010) + LDS
+// (0x080).  With VALU alone the address arithmetic, loads and fragment reads piled up in a few gaps (a gap with up to two fillers is
+// free, each further one costs its issue cycles - tools/probe/mfma_chain_probe.hip): -4 % cycles per step, of which the power-limited
+// clock gives back about a third
+#ifndef C3_FILL_MASK
+#define C3_FILL_MASK 0x096
+#endif
 #ifndef C3_PEEL
 #define C3_PEEL 1
 #endif
@@ -409,7 +416,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int m = 0; m < 9 * rows_here; ++m) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, C3_PIPE, 0);
+                __builtin_amdgcn_sched_group_barrier(C3_FILL_MASK, C3_PIPE, 0);
             }
 #endif
         };
@@ -808,7 +815,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int m = 0; m < 18 * rows_here; ++m) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, C3_BPIPE, 0);
+                    __builtin_amdgcn_sched_group_barrier(C3_FILL_MASK, C3_BPIPE, 0);
                 }
             }
 #endif

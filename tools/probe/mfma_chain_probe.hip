@@ -46,7 +46,24 @@ __global__ __launch_bounds__(256) void probe(unsigned long long *out, int mode) 
                 "v_mfma_f32_16x16x32_f16 a[8:11], a[16:19], v[0:3], a[8:11]" F "v_mfma_f32_16x16x32_f16 a[8:11], a[16:19], v[0:3], a[8:11]" F "v_mfma_f32_16x16x32_f16 a[8:11], a[16:19], v[0:3], a[8:11]" F
                 ::: "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","v0","v1","v2","v3","v4","v5","v6","v7");
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));
-    } else {                     // C: renamed accumulators, interleaved (dependent distance 3), with fillers
+    } else if (mode == 5 || mode == 6 || mode == 7) {      // in place, 1.5 fillers per MFMA: spread 2,1,2,1 (5) / clumped 3,0,3,0 (6) / 6,0,0,0 (7)
+#define M(acc) "v_mfma_f32_16x16x32_f16 " acc ", a[16:19], v[0:3], " acc "\n\t"
+#define V1 "v_add_f32 v4, v4, v5\n\t"
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0));
+        if (mode == 5)
+            for (int r = 0; r < REP; ++r)
+                asm volatile(M("a[0:3]") V1 V1 M("a[0:3]") V1 M("a[0:3]") V1 V1 M("a[4:7]") V1 M("a[4:7]") V1 V1 M("a[4:7]") V1 M("a[8:11]") V1 V1 M("a[8:11]") V1 M("a[8:11]") V1 V1 V1
+                             ::: "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a16","a17","a18","a19","v0","v1","v2","v3","v4","v5");
+        else if (mode == 6)
+            for (int r = 0; r < REP; ++r)
+                asm volatile(M("a[0:3]") V1 V1 V1 M("a[0:3]") M("a[0:3]") V1 V1 V1 M("a[4:7]") M("a[4:7]") V1 V1 V1 M("a[4:7]") M("a[8:11]") V1 V1 V1 M("a[8:11]") M("a[8:11]") V1 V1
+                             ::: "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a16","a17","a18","a19","v0","v1","v2","v3","v4","v5");
+        else
+            for (int r = 0; r < REP; ++r)
+                asm volatile(M("a[0:3]") V1 V1 V1 V1 V1 V1 M("a[0:3]") M("a[0:3]") M("a[4:7]") M("a[4:7]") V1 V1 V1 V1 V1 V1 M("a[4:7]") M("a[8:11]") M("a[8:11]") M("a[8:11]") V1 V1
+                             ::: "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a16","a17","a18","a19","v0","v1","v2","v3","v4","v5");
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));
+    } else if (mode == 4) {                     // C: renamed accumulators, interleaved (dependent distance 3), with fillers
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0));
         for (int r = 0; r < REP; ++r)
             asm volatile(
@@ -61,9 +78,17 @@ __global__ __launch_bounds__(256) void probe(unsigned long long *out, int mode) 
 int main() {
     unsigned long long *d, h[8] = {0};
     hipMalloc(&d, 64); hipMemset(d, 0, 64);
-    const char *names[5] = {"A in place", "B renamed (t <- X, t <- t, X <- t)", "B + 2 fillers per MFMA", "A + 2 fillers per MFMA", "C renamed, interleaved, + fillers"};
-    for (int m = 0; m < 5; ++m) { hipLaunchKernelGGL(probe, dim3(256), dim3(256), 0, 0, d, m); hipDeviceSynchronize(); }
-    hipMemcpy(h, d, 64, hipMemcpyDeviceToHost);
-    for (int m = 0; m < 5; ++m) printf("%-40s %6.2f cycles per MFMA\n", names[m], (double)h[m] / (REP * 9.0));
+    const char *names[8] = {"A in place", "B renamed (t <- X, t <- t, X <- t)", "B + 2 fillers per MFMA", "A + 2 fillers per MFMA", "C renamed, interleaved, + fillers", "A + 14 fillers per 9 MFMAs spread 2,1,2,1", "A + 14 per 9 clumped 3,0,3,0", "A + 14 per 9 clumped 6,0,0,6,0,0"};
+    double best[8];
+    for (int m = 0; m < 8; ++m) best[m] = 1e30;
+    for (int round = 0; round < 6; ++round)          // (the first launches run on a cold instruction cache and a ramping clock)
+        for (int m = 0; m < 8; ++m) {
+            hipLaunchKernelGGL(probe, dim3(256), dim3(256), 0, 0, d, m);
+            hipDeviceSynchronize();
+            hipMemcpy(h, d, 64, hipMemcpyDeviceToHost);
+            const double c = (double)h[m] / (REP * 9.0);
+            if (round > 0 && c < best[m]) best[m] = c;
+        }
+    for (int m = 0; m < 8; ++m) printf("%-48s %6.2f cycles per MFMA (best of 5)\n", names[m], best[m]);
     return 0;
 }

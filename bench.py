@@ -49,9 +49,10 @@ def main():
     ap.add_argument('--pool', type=int, default=100000, help='patches per GPU (weak scaling)')
     ap.add_argument('--pool-global', type=int, default=0, help='strong scaling: one pool of this many patches over all GPUs')
     ap.add_argument('--netb-pool', type=int, default=16384, help='patches of the NET-B side measurement at N = 1 (0 = skip)')
-    ap.add_argument('--batch', type=int, default=2000,
-                    help='patches per device pass (per-launch fixed costs ~0.37 ms per pass amortise with the batch; the library '
-                         'clamps it to what the GEMM engine\'s unsigned 32-bit tensor offsets address: 2047 for 32^3 NET-C)')
+    ap.add_argument('--batch', type=int, default=2047,
+                    help='patches per device pass.  2047 = the most the engines\' unsigned 32-bit tensor offsets address for 32^3 NET-C '
+                         '(the library clamps a larger request to it), and all but one of the 256 plane-sweep workgroups then hold '
+                         'exactly 8 patches (batch 2000: 208 hold 8, 48 hold 7; same-box A/B +1.2 %%, profiles/r04af_batch_sweep.txt)')
     ap.add_argument('--topB', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', choices=('nccl', 'gloo'),

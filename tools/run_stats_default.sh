@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 --kernel-trace --stats of the DEFAULT bench (100k pool, batch 2000; program directly after `--`), plus the
+# rocprofv3 --kernel-trace --stats of the DEFAULT bench (100k pool, default batch; program directly after `--`), plus the
 # same command without the profiler.  usage: tools/run_stats_default.sh <tag> [steps]
 # outputs: gpurun_out/<tag>_default_stats/ (kernel stats csv), gpurun_out/<tag>_default_under_rocprof.json,
 #          gpurun_out/<tag>_default.json; fold into profiles/ with tools/roofline_from_stats.py

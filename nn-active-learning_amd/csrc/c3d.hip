@@ -69,6 +69,9 @@ static_assert(C3_WD >= 1 && C3_WD <= 8, "weight-difference slices are fetched 1.
 #ifndef C3_FILL_MASK
 #define C3_FILL_MASK 0x096
 #endif
+#ifndef C3_PIN_SUMS
+#define C3_PIN_SUMS 1
+#endif
 #ifndef C3_PEEL
 #define C3_PEEL 1
 #endif
@@ -165,8 +168,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int i = 0; i < 8; ++i) { acc[s][i] = f32x4{0.f, 0.f, 0.f, 0.f}; if constexpr (!ONEACC) accx[s][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
+    // (read through the constant address space: the index is uniform, so these become scalar loads; as plain global loads they
+    // brought 64-bit vector address arithmetic and vector loads into the gap between two steps, where no MFMA covers them.  The
+    // arrays are written by earlier launches only.)
+    typedef const unsigned __attribute__((address_space(4))) *cu32p;
+    const cu32p amaxA_c = (cu32p)(unsigned long long)a.amaxA, amaxB_c = (cu32p)(unsigned long long)a.amaxB;
     auto patch_exp = [&](int p) __attribute__((always_inline)) {      // max |x| < 2^ex -> scale 2^(14 - ex); all-zero patch: 0
-        const unsigned fa = a.amaxA[p], fb = a.amaxB[p];
+        const unsigned fa = amaxA_c[p], fb = amaxB_c[p];
         const unsigned fm = fa > fb ? fa : fb;
         const int ex = (int)((fm >> 23) & 255u) - 126;
         return fm ? 14 - ex : 0;
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         e.inv = valid ? __builtin_ldexpf(1.f, -(ce + a.e_w)) : 0.f;
         e.b4 = valid ? bias4 : f32x4{0.f, 0.f, 0.f, 0.f};
         // (an all-zero patch: every pre-activation IS its bias in both arithmetics - nothing to mark)
-        e.tau = (valid && (a.amaxA[p] | a.amaxB[p]) != 0u) ? __builtin_ldexpf(a.flip_tau, 14 - ce) : 0.f;
+        e.tau = (valid && (amaxA_c[p] | amaxB_c[p]) != 0u) ? __builtin_ldexpf(a.flip_tau, 14 - ce) : 0.f;
         e.off_w = valid ? epi_lane_f * 4u : OOB;
         e.off_b = valid ? (epi_lane_f >> 2) : OOB;
         e.row_f = (unsigned)(zo * 32 + wave * 8) * 256u;       // float offset of row 8 w of that plane inside the patch
@@ -313,6 +321,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 __builtin_amdgcn_raw_buffer_store_b8((unsigned char)nib, bits_rsrc, (int)E.off_b, (int)(E.bits_s + ((E.row_f + (unsigned)i * 256u) >> 2)), 0);
             else asm volatile("" :: "v"(nib));
         }
+#if C3_PIN_SUMS
+        // The two running sums are needed only when the patch ends, and the optimiser sinks their ~13 instructions per row out of the
+        // sweep to the end of the step, where nothing covers them (100 vector instructions with the matrix pipe idle, the row's values
+        // alive until then): this pins them to the row's block.
+        if constexpr (SUMS) asm volatile("" : "+v"(fs), "+v"(sa));
+        else asm volatile("" : "+v"(fs));
+#endif
     };
     auto wave_sum = [&](float x) __attribute__((always_inline)) {
         int v = __builtin_bit_cast(int, x);

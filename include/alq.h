@@ -274,6 +274,7 @@ int alq_debug_set(int key, int value);
  * three piece products in one accumulator, 5: the number of marked 4-channel groups the flip-safe head could NOT re-evaluate
  * exactly since the model was created because a list segment (a quarter of a patch, 128 slots) was full - 0 on every input the
  * tests and the bench use; a dropped group keeps the sign its fp16-pair contraction produced (synchronises the stream).
+ * 6: 1 when the last forward pass ran a launch on the fp16-pair split with derived input bounds (opt-in, ALQ_F16_DERIVED=1).
  * Returns the answer or a negative error code.  */
 int alq_model_engine_info(alq_model *m, int what);
 

@@ -507,6 +507,11 @@ int k_fc_small_bwd(alq_ctx *, const float *delta, int nout, const float *Wp, int
                    float *dact, const float *mask_act = nullptr, float *dsum = nullptr, int C = 0,
                    bool *fused = nullptr);
 int k_rowsum_field(alq_ctx *, const float *field, int64_t len, int N, float *out);
+// bound[k][p] = max(bound[k - 1][p], bound[src2[k]][p]) * L[k] + B[k] for k = 1 .. nl - 1, bound[0] = the first layer's measured maximum
+// (float bits, as the producers' epilogues leave them): what a forward launch with the fp16x2 split takes as its input maxima when
+// nothing measured them (model.hip, run_forward)
+struct FwdBoundsArgs { int nl; float L[16]; float B[16]; int src2[16]; };
+int k_fwd_bounds(alq_ctx *, const unsigned *amax0, int N, int stride, const FwdBoundsArgs &a, unsigned *bound_all);
 int flip_segments(int N);      // scan segments / list slots k_flip_fix needs for N patches
 int flip_list_len(int N);
 int k_flip_fix(alq_ctx *, unsigned *list, unsigned *cnt, int cap, int N, const float *inA, const float *inB, int CA, int CB,

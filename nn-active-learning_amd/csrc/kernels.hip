@@ -1283,6 +1283,27 @@ int k_rowmax_u32(alq_ctx *ctx, const unsigned *in, int len, int N, unsigned *out
     return ALQ_OK;
 }
 
+__global__ void fwd_bounds_kernel(const unsigned *amax0, int N, int stride, FwdBoundsArgs a, unsigned *bound_all) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    float b[16];
+    b[0] = __builtin_bit_cast(float, amax0[p]);
+    bound_all[p] = amax0[p];
+    for (int k = 1; k < a.nl && k < 16; ++k) {
+        float in = b[k - 1];
+        if (a.src2[k] >= 0) in = fmaxf(in, b[a.src2[k]]);
+        b[k] = in * a.L[k] + a.B[k];
+        bound_all[(size_t)k * stride + p] = __builtin_bit_cast(unsigned, b[k]);
+    }
+}
+int k_fwd_bounds(alq_ctx *ctx, const unsigned *amax0, int N, int stride, const FwdBoundsArgs &a, unsigned *bound_all) {
+    ProfScope ps(ctx, PROF_REDUCE, 0);
+    ALQ_REQUIRE(amax0 && bound_all && a.nl >= 1 && a.nl <= 16, ALQ_EINVAL, "fwd_bounds: bad argument");
+    hipLaunchKernelGGL(fwd_bounds_kernel, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, amax0, N, stride, a, bound_all);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
 // Flip-safe fused head, step 1: collect the sign bytes whose bit 4 is set (igemm4's fused-head epilogue marks the 4-channel
 // groups holding a pre-activation that its fp16x2 contraction left within its error bound of zero).  Streams the bit field
 // once (16 bytes per thread); every scan block keeps its own list segment and count: list[block * FLIP_PER_BLOCK + slot] = global

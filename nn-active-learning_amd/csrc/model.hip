@@ -82,6 +82,8 @@ struct Layer {
     // exact re-evaluation, and max over co of sum_{tap, ci} |W|
     float *d_W32 = nullptr;
     float fwd_l1 = 0.f;
+    float out_l1 = 0.f, out_bmax = 0.f;    // |out| <= out_l1 * max |in| + out_bmax (conv: = fwd_l1; conv_transpose: all taps), set with the weights
+    unsigned *bound_fwd = nullptr;         // per-patch bound on |out| derived from the first layer's measured maximum (k_fwd_bounds)
     float *fc_part2 = nullptr;         // partial logits per (tile, wave) when the conv below computes them in its epilogue
     int fc_slices2 = 0;
     // plane-sweep engine (c3d.hip) for the conv under the fused two-class head (and its backward): plans on the conv layer,
@@ -112,6 +114,7 @@ struct alq_model {
     unsigned *amax_a = nullptr, *amax_b = nullptr, *amax_tiles = nullptr;
     unsigned *flip_cnt = nullptr, *flip_list = nullptr;     // candidates of the flip-safe fused head (igemm4 FCF + F16)
     int flip_cap = 0;
+    unsigned *bound_all = nullptr;          // [layer][max_batch] derived per-patch output bounds (float bits), k_fwd_bounds
     unsigned *flip_overflow = nullptr;      // marked groups the scan could not list since the model was created (kernels.hip, flip_scan_kernel)
     int no_flipfix = 0;                                      // ALQ_NO_FLIPFIX at creation (A/B: the head's sign bits as the fp16x2 contraction leaves them)
     size_t amax_tiles_len = 0;
@@ -141,10 +144,15 @@ struct alq_model {
     int no_signs = 0;              // ALQ_NO_SIGNS (A/B, bit-identity test): backward launches read ReLU masks from the fp32 activations
     int no_signs0 = 0;             // ALQ_NO_SIGNS0 (A/B): no sign field from the first conv + pool kernel only
     int f16_fwd_mask = -1;         // ALQ_F16_FWD_MASK (diagnostics): forward fp16x2 consumers by layer bit, -1 = default rule
+    int f16_fwd_derived = 0;       // layers (bits) whose forward launch takes the fp16x2 split with DERIVED input bounds (see run_forward)
+    int no_f16_derived = 1;        // 0 with ALQ_F16_DERIVED=1: those launches take the split (default: they stay on bf16x3)
+    float *d_bound_L = nullptr, *d_bound_B = nullptr;      // per layer: out = in * L + B (k_fwd_bounds)
+    int *d_bound_src = nullptr;
     int no_c3d = 0;                // ALQ_NO_C3D (A/B): the head conv pair on the two-slot engine (igemm4) as in round 3
     int c3_bwd_rows = 8;           // ALQ_C3D_BWD_ROWS=4 (A/B): the plane-sweep backward kernel in its half-patch form
     bool last_c3 = false;          // the last forward pass ran the head conv on the plane-sweep engine
     bool last_c3_bwd = false;      // ... and the last backward pass its backward
+    bool last_f16_derived = false; // the last forward pass ran a launch on the fp16x2 split with derived input bounds (ALQ_F16_DERIVED=1)
 
     template <typename T>
     int dalloc(T **p, size_t count) {
@@ -804,9 +812,22 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
             // had a ReLU input of a later layer land on the other side of zero, moving two layer scores by 1 % - the same
             // event any two fp32 implementations produce, four times as often).  The head conv has one ReLU behind it;
             // backward launches have none (the masks are fixed by then), so they take the split wherever a variant exists.
+            const int s_ = l.spec.skip_src;
+            // ... and, opt-in (ALQ_F16_DERIVED=1), the conv whose output reaches the head conv through the (linear) conv_transpose
+            // only: its input maxima are not measured (an epilogue in two producer launches cost what the split gave) but DERIVED per
+            // patch from the first layer's measured maximum through the layers' L1 norms (k_fwd_bounds) - the fp16 pairs keep their
+            // 22 bits under a bound that is loose by orders of magnitude.  Measured (profiles/r04al_*): bench +2.6 % same-box
+            // (222.3 against 216.9 k patches/s), launch 1148 -> 875 us; on a 2000-patch batch against the exact-fp32 engine 129
+            // patches with a flipped fragile unit instead of 115 (bf16x3 everywhere: 109).  Off by default: the forward launches in
+            // front of ReLUs stay fp32-faithful, and the roofline accounting counts executed products.
+            if (m->f16_fwd_mask < 0 && !m->no_f16_derived && nl <= 16 && ((m->f16_fwd_derived >> j) & 1) && l.spec.type == ALQ_CONV && use_dcp(0) &&
+                (s_ >= 0) == (l.in.split != 0) && !(drop && drop->layers)) {
+                cons[j] = 2;
+                prod[0] = 1;
+                continue;
+            }
             if (!(j == nl - 2 && m->layers[nl - 1].fc_part2 && l.spec.type == ALQ_CONV) && m->f16_fwd_mask < 0) continue;
             if (l.spec.type == ALQ_CONVT && !pl->fic) continue;                 // MULTI has no F16 variant
-            const int s_ = l.spec.skip_src;
             if (!prod_ok(j - 1) || (s_ >= 0 && !prod_ok(s_))) continue;
             if ((s_ >= 0) != (l.in.split != 0)) continue;                       // two parts <-> a split view
             if (m->f16_fwd_mask >= 0 && !((m->f16_fwd_mask >> j) & 1)) continue;      // diagnostics: consumers by layer bit
@@ -822,10 +843,21 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
         }
         if (need > m->amax_tiles_len) { ALQ_TRY(m->dalloc(&m->amax_tiles, (size_t)m->max_batch * need)); m->amax_tiles_len = need; }
     }
+    bool any_derived = false;
+    for (int j = 0; j < nl; ++j) any_derived = any_derived || cons[j] == 2;
+    m->last_f16_derived = any_derived;
+    if (any_derived && !m->bound_all) {
+        ALQ_TRY(m->dalloc(&m->bound_all, (size_t)nl * m->max_batch));
+        for (int k = 0; k < nl; ++k) m->layers[k].bound_fwd = m->bound_all + (size_t)k * m->max_batch;
+    }
     auto take_amax = [&](Igemm2Fuse &fz, int j) {      // the input maxima of consumer j
         if (!cons[j]) return;
-        fz.in_amax = m->layers[j - 1].amax_fwd;
-        if (m->layers[j].spec.skip_src >= 0) fz.in_amax2 = m->layers[m->layers[j].spec.skip_src].amax_fwd;
+        const bool dv = cons[j] == 2;
+        fz.in_amax = dv ? m->layers[j - 1].bound_fwd : m->layers[j - 1].amax_fwd;
+        if (m->layers[j].spec.skip_src >= 0) {
+            const Layer &sl = m->layers[m->layers[j].spec.skip_src];
+            fz.in_amax2 = dv ? sl.bound_fwd : sl.amax_fwd;
+        }
     };
     for (Layer &l : m->layers) l.signs_ready = false;
     // Sign fields (View::sg): in a Fisher pass a forward launch of the two-slot engine also writes one byte per 4 channels
@@ -862,6 +894,18 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                                                     sg_here ? ly.out.sg : nullptr, (sg_here && nx->out.sg) ? nx->out.sg : nullptr));
                     ly.signs_ready = sg_here;
                     nx->signs_ready = sg_here && nx->out.sg != nullptr;      // (the pool's output: sign of the window maximum)
+                    if (any_derived) {      // per-patch bounds on every later layer's output from this layer's measured maximum
+                        FwdBoundsArgs ba;
+                        ba.nl = nl;
+                        for (int k = 0; k < nl && k < 16; ++k) {
+                            const Layer &lk = m->layers[k];
+                            const bool par = lk.pidx >= 0 && lk.spec.type != ALQ_FC;
+                            ba.L[k] = par ? lk.out_l1 : 1.f;
+                            ba.B[k] = par ? lk.out_bmax : 0.f;
+                            ba.src2[k] = lk.spec.skip_src;
+                        }
+                        ALQ_TRY(k_fwd_bounds(ctx, ly.amax_fwd, N, m->max_batch, ba, m->bound_all));
+                    }
                     fused = true;
                     skip_next = true;
                     break;
@@ -1494,6 +1538,7 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
         m->no_signs = getenv("ALQ_NO_SIGNS") != nullptr;
         m->no_signs0 = getenv("ALQ_NO_SIGNS0") != nullptr;
         if (const char *f = getenv("ALQ_F16_FWD_MASK")) m->f16_fwd_mask = atoi(f);
+        { const char *e = getenv("ALQ_F16_DERIVED"); m->no_f16_derived = (e && atoi(e) == 1) ? 0 : 1; }
         static const char *names[8] = {"ALQ_DEBUG_REPEAT", "ALQ_DEBUG_FLAGS", "ALQ_NO_BWD_FUSE", "ALQ_NO_FWD_FUSE", "ALQ_NO_V3", "ALQ_NO_V4",
                                        "ALQ_NO_POOL_FIRST", "ALQ_NO_CONV_POOL"};
         for (int k = 0; k < 8; ++k) {
@@ -1530,6 +1575,14 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
             if (fi != std::string::npos) pl->tune_fic = atoi(item.c_str() + fi + 4);
             if (ei != std::string::npos) pl->tune_epi = atoi(item.c_str() + ei + 4);
         }
+    }
+    {   // the conv in front of [conv_transpose without ReLU -> conv under a fused two-class head]: forward launch on the fp16x2 split
+        // with derived input bounds (run_forward)
+        const int nl = (int)m->layers.size();
+        if (nl >= 4 && nl <= 16 && m->layers[nl - 1].fc_part2 && m->layers[nl - 2].spec.type == ALQ_CONV &&
+            m->layers[nl - 3].spec.type == ALQ_CONVT && !m->layers[nl - 3].spec.relu && m->layers[nl - 4].spec.type == ALQ_CONV &&
+            m->layers[nl - 4].spec.relu)
+            m->f16_fwd_derived = 1 << (nl - 4);
     }
     *out = m;
     return ALQ_OK;
@@ -1587,6 +1640,19 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
             best = std::max(best, s);
         }
         ly.bwd_l1 = best;
+        // |out[.., co]| <= (sum over everything that multiplies into channel co) * max |in| + |b[co]|: for a conv_transpose all taps
+        // are counted (an output point sees a subset of them: the bound is only looser)
+        double ob = 0, bm = 0;
+        for (int co = 0; co < Co; ++co) {
+            double t = 0;
+            for (int tp = 0; tp < ntaps; ++tp)
+                for (int ci = 0; ci < Ci; ++ci)
+                    t += std::fabs((double)(sp.type == ALQ_CONV ? W[((size_t)tp * Ci + ci) * Co + co] : W[((size_t)tp * Co + co) * Ci + ci]));
+            ob = std::max(ob, t);
+            bm = std::max(bm, std::fabs((double)b[co]));
+        }
+        ly.out_l1 = (float)(ob * (1.0 + 1e-6));
+        ly.out_bmax = (float)(bm * (1.0 + 1e-6));
     }
     if (sp.type == ALQ_CONV) {
         double best = 0;
@@ -1939,7 +2005,8 @@ int alq_model_debug_copy(alq_model *m, int layer_idx, int what, int N, float *d_
 }
 
 int alq_model_engine_info(alq_model *m, int what) {
-    ALQ_REQUIRE(m && ((what >= 0 && what <= 3) || what == 5), ALQ_EINVAL, "alq_model_engine_info: bad argument");
+    ALQ_REQUIRE(m && ((what >= 0 && what <= 3) || what == 5 || what == 6), ALQ_EINVAL, "alq_model_engine_info: bad argument");
+    if (what == 6) return m->last_f16_derived ? 1 : 0;
     ALQ_HIP(hipSetDevice(m->ctx->device));
     if (what == 0) return c3d_subnormals_ok(m->ctx);
     if (what == 1) return m->last_c3 ? 1 : 0;

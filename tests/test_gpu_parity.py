@@ -1186,6 +1186,38 @@ def test_plane_sweep_backward_half_patch_form_is_bit_identical(sess):
     m4.close()
 
 
+def test_opt_in_fp16_forward_with_derived_bounds(sess):
+    """ALQ_F16_DERIVED=1: NET-C's `dec1` forward launch on the fp16-pair split, its per-patch input maxima DERIVED from the first
+    layer's measured maximum through the layers' L1 norms (csrc/kernels.hip, fwd_bounds_kernel) instead of measured.  Against the
+    default (bf16 triples in that launch): posteriors within 2e-6; layer scores within 2e-6 + 2e-5 relative, or the patch goes to
+    the fp64 arbiter (a ReLU input within rounding of zero may land on either side: the split rounds at 2^-22)."""
+    import ctypes as C
+    from nnal_amd._lib import check
+    torch = sess.torch
+    n = 300
+    ld, sk, in_shape, pars, (m_on, m_off) = _netc32_models(sess, [{'ALQ_F16_DERIVED': '1'}, {}], max_batch=n, bias_std=0.05)
+    x = sess.empty((n, 32 ** 3), torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, 32 ** 3, C.c_void_p(x.data_ptr())))
+    out = []
+    for m in (m_on, m_off):
+        r = m.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1'))
+        out.append({k: r[k].cpu().numpy() for k in ('p1', 'g0', 'g1')})
+    assert sess.lib.alq_model_engine_info(m_on._m, 6) == 1, 'the derived-bound launch did not run'
+    assert sess.lib.alq_model_engine_info(m_off._m, 6) == 0
+    a, b = out
+    np.testing.assert_allclose(a['p1'], b['p1'], rtol=0, atol=2e-6)
+    bad = set()
+    for k in ('g0', 'g1'):
+        err = np.abs(a[k] - b[k])
+        bad |= set(np.nonzero((err > 2e-6 + 2e-5 * np.abs(b[k])).any(axis=1))[0].tolist())
+    assert len(bad) <= n // 10, 'more than 10 %% of the patches disagree: %d' % len(bad)
+    rs = np.random.RandomState(5)
+    sample = sorted(rs.choice(sorted(bad), size=min(6, len(bad)), replace=False).tolist()) if bad else []
+    _fp64_arbitrate(ld, sk, in_shape, pars, x.cpu().numpy(), sample, [a, b], ['fp16 pairs, derived bounds', 'bf16 triples'])
+    m_on.close()
+    m_off.close()
+
+
 def test_flip_safe_head_is_cut_invariant_and_reports_overflow(sess):
     """The flip-safe head's candidate scan (kernels.hip, flip_scan_kernel) works on per-patch list segments: the scores of a
     patch must not depend on how the pool was cut into batches (bit for bit), and marked groups that do not fit a segment are

@@ -206,9 +206,10 @@ def main():
             'metric': 'patches/sec Fisher-scored (32^3, 2-class)',
             'value': value, 'unit': 'patches/s', 'n_gpus': ws, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
-            'dtype': 'f32 (operands split exactly into 16-bit pieces on the 16-bit MFMA - fp16 pairs, three products, in the conv under the '
-                     'head (forward + backward) and the other backward launches; bf16 triples, six products, in the remaining forward launches - '
-                     'fp32 accumulate; everything else fp32 / fp64)',
+            'dtype': 'f32 (fp32 operands split into 16-bit pieces on the 16-bit MFMA, fp32 accumulate: fp16 pairs - 22-23 bits kept per '
+                     'operand, three products - in the conv under the head (forward + backward), in dec1\'s forward launch and in the other '
+                     'backward launches; bf16 triples - all 24 bits, exact, six products - in the remaining forward launches; everything else '
+                     'fp32 / fp64)',
             'data': 'synthetic',
             'config': {'workload': ('configs[3]: Fisher scoring, NET-C patch-wise 3-D U-Net (fc head), ONE pool of %d synthetic 32^3 '
                                     '2-class patches in contiguous blocks over the GPUs, random-init weights seed 14' % n_global) if strong else
@@ -227,9 +228,15 @@ def main():
                        'parallelism': 'pool sharded over %d GPU(s), top-B merge (all-gather) + 8x8 Fisher all-reduce: %s' % (ws, comm)},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic, 'traffic_note': traffic_note,
+                         # the ratio that does not reward redundant products: algorithmic contraction flops against the best
+                         # fp32-faithful split known (3 products per MAC) on the dense 16-bit peak
+                         'useful_frac': achieved / peak_f16,
+                         'useful_frac_definition': 'algorithmic fp32 flops of the 12 contraction launches / their HIP-event time / (%.0f TFLOP/s / 3 '
+                                                   'products): what a launch would reach at most if every one ran the 3-product fp16-pair split'
+                                                   % PEAK_BF16_MFMA_TFLOPS,
                          'kernel': 'the 12 contraction launches of a pass: c3d_fwd_kernel / c3d_bwd_kernel (plane-sweep engine, the conv under the '
-                                   'head: 53 % of the flops, fp16 pairs) + 10 igemm4_kernel launches (conv / conv_transpose fwd + bwd-data: '
-                                   'fp16 pairs in the backward launches, bf16 triples in the forward ones)',
+                                   'head: 53 % of the flops, fp16 pairs) + the 10 conv / conv_transpose fwd + bwd-data launches of the other '
+                                   'layers (fp16 pairs in the backward launches and dec1 forward, bf16 triples in the other forward ones)',
                          'peak_note': 'algorithmic fp32 flops; peak = flop-weighted harmonic mean of %.0f dense 16-bit MFMA / %d '
                                       'products (bf16x3 launches, %.0f %% of the flops) and / 3 (the fp16x2 launches)'
                                       % (PEAK_BF16_MFMA_TFLOPS, SPLIT_PRODUCTS, 100.0 * bf_fl / max(ig_fl, 1.0)),
@@ -252,6 +259,9 @@ def main():
                                             'BESIDE the igemm launches (their spans overlap those, they do not add up to the step)'},
         }
         note('GPU: %.1f patches/s' % value)
+        if ws == 1:
+            line['accuracy'] = accuracy_vs_exact_fp32(sess, model, x, min(args.batch, n_local))
+            line['config']['head_conv_engine']['dec1_forward_fp16_pairs'] = int(sess.lib.alq_model_engine_info(model._m, 6))
         if ws == 1 and args.netb_pool > 0:
             line['netb'] = netb_rate(sess, args.netb_pool, x)
         if not args.no_cpu_baseline and ws == 1:      # reported at N = 1 only (the other ranks would sit in the barrier)
@@ -443,10 +453,59 @@ def netb_rate(sess, n, x):
     model.fisher_device(x, n, None, 1e-3, want=want)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # a third pass with HIP events around every launch (they cost a few per cent, so not the timed pass): the contraction
+    # launches' own time for the roofline object
+    sess.prof_reset()
+    sess.prof_enable(1)
+    model.fisher_device(x, n, None, 1e-3, want=want)
+    torch.cuda.synchronize()
+    sess.prof_enable(False)
+    prof = sess.prof_read()
     model.close()
+    bf = ('igemm_fwd', 'igemm_bwd', 'igemm3_fwd', 'igemm3_bwd', 'direct_conv')
+    bf_ms, bf_fl = sum(prof[k]['ms'] for k in bf if k in prof), sum(prof[k]['flops'] for k in bf if k in prof)
+    f16 = prof.get('igemm_f16x2', {'ms': 0.0, 'flops': 0.0, 'launches': 0})
+    ms, fl = bf_ms + f16['ms'], bf_fl + f16['flops']
+    nl = sum(prof[k]['launches'] for k in bf if k in prof) + f16['launches']
+    peak_bf, peak_f16 = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS, PEAK_BF16_MFMA_TFLOPS / 3
+    ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    peak = fl / (bf_fl / peak_bf + f16['flops'] / peak_f16) if fl > 0 else peak_bf
     return {'value': n / dt, 'unit': 'patches/s', 'net': 'NET-B = NN.create_PW1 (NN.py:1328-1336), input [N,32,32,32], 7 parameterised layers',
             'patches': n, 'batch': NETB_BATCH, 'flops_per_patch_executed': 190.9e6 + 151.5e6,
-            'tflops_executed': (190.9e6 + 151.5e6) * n / dt / 1e12}
+            'tflops_executed': (190.9e6 + 151.5e6) * n / dt / 1e12,
+            'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak if peak > 0 else 0.0,
+                         'useful_frac': ach / peak_f16, 'traffic': None, 'launches': nl, 'avg_launch_ms': ms / max(nl, 1),
+                         'kernel': 'the contraction launches of a NET-B pass (4 conv forward + 3 conv backward-data on the two-slot engine, '
+                                   '3 fc forward + 2 fc backward on fcgemm), HIP events on every launch of a separate pass',
+                         'peak_note': 'algorithmic fp32 flops; peak = flop-weighted harmonic mean of %.0f / 6 (bf16x3 launches, %.0f %% of the '
+                                      'flops) and %.0f / 3 (fp16-pair launches)' % (PEAK_BF16_MFMA_TFLOPS, 100.0 * bf_fl / max(fl, 1.0), PEAK_BF16_MFMA_TFLOPS),
+                         'alg_flops_per_patch': {'bf16x3': bf_fl / max(n, 1), 'f16x2': f16['flops'] / max(n, 1)},
+                         'time_share_ms': {k: v['ms'] for k, v in prof.items()}}}
+
+
+def accuracy_vs_exact_fp32(sess, model, x, n):
+    """One batch of the pool (outside the timed region): the shipped engines against the exact-fp32 MFMA engine on the device
+    (alq_debug_set(4, 1): fp32 fma chains, no operand split).  north_star's bar is 'scores within 1e-4': the scores are not
+    continuous in the rounding noise (a ReLU input within rounding of zero switches a backward path), so what can be stated is how
+    MANY patches differ by more than that between two fp32-level engines; tests/test_gpu_parity.py sends every such patch of a
+    2000-patch batch to the fp64 arbiter."""
+    import torch
+    from nnal_amd._lib import check
+    keys = ('p1', 'g0', 'g1')
+    r = model.fisher_device(x, n, None, 1e-3, want=keys)
+    a = {k: r[k].cpu().numpy().copy() for k in keys}
+    check(sess.lib.alq_debug_set(4, 1))
+    try:
+        r = model.fisher_device(x, n, None, 1e-3, want=keys)
+        b = {k: r[k].cpu().numpy().copy() for k in keys}
+    finally:
+        check(sess.lib.alq_debug_set(4, 0))
+    torch.cuda.synchronize()
+    d = np.maximum(np.abs(a['g0'] - b['g0']), np.abs(a['g1'] - b['g1'])).max(axis=1)
+    return {'patches': int(n), 'over_2e-6': int((d > 2e-6).sum()), 'over_1e-4': int((d > 1e-4).sum()), 'max_abs_dg': float(d.max()),
+            'max_abs_dp': float(np.abs(a['p1'] - b['p1']).max()),
+            'against': 'the exact-fp32 MFMA engine on the device (alq_debug_set(4, 1)), first batch of the pool; differences beyond 2e-6 are '
+                       'ReLU / max-pool decisions that fp32 rounding puts on either side (each engine has its own set against fp64)'}
 
 
 def cpu_baseline(xs, ld, sk, in_shape, pars):
@@ -481,8 +540,23 @@ def cpu_baseline(xs, ld, sk, in_shape, pars):
         affinity = len(os.sched_getaffinity(0))
     except AttributeError:
         affinity = None
+    # ... and the same port with every core the process may use (os.cpu_count() threads), on a shorter sample: the
+    # reference's structure is batch 1, so beyond ~16 threads a sample gains little (the per-op work is one patch)
+    all_cores = None
+    nall = max(1, min(affinity or (os.cpu_count() or 1), os.cpu_count() or 1))
+    if nall > cores:
+        m = max(2, min(len(xs), 32))
+        used = torch.get_num_threads()
+        torch.set_num_threads(nall)
+        alpath.gen_A_matrices(E(), om, osess, xs[:1], p[:1], 1e-3)               # warm-up at the new thread count
+        t1 = time.perf_counter()
+        p2 = om.forward(xs[:m])['posteriors'][1].astype(np.float64)
+        alpath.gen_A_matrices(E(), om, osess, xs[:m], p2, 1e-3)
+        dt2 = time.perf_counter() - t1
+        all_cores = {'value': m / dt2, 'unit': 'patches/s', 'cores': torch.get_num_threads(), 'sample': '%d patches, %.1f s' % (m, dt2)}
+        torch.set_num_threads(used)
     return {'value': len(xs) / dt, 'unit': 'patches/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'host_cores': os.cpu_count(), 'affinity_cores': affinity,
+            'host_cores': os.cpu_count(), 'affinity_cores': affinity, 'all_cores': all_cores,
             'sample': '%d of the pool\'s patches (NET-C 32^3), forward + per-sample gen_A_matrices, %.1f s; %d threads '
                       '(the box reports %s cores, %s in this process\'s affinity mask; capped at 16)'
                       % (len(xs), dt, torch.get_num_threads(), os.cpu_count(), affinity)}

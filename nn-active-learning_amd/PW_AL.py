@@ -140,16 +140,108 @@ class LoopState(object):
         return h5
 
 
+def _plain(obj, where='pars'):
+    """Parameter values as plain Python for the YAML files: numpy scalars -> float / int / bool, arrays -> nested lists,
+    OrderedDict -> dict, tuples stay tuples (`patch_shape`).  Anything else fails HERE, on the writing rank at write time, with
+    the key that holds it - not on the reading ranks after the barrier."""
+    if isinstance(obj, np.generic):        # (first: np.float64 is also a float)
+        return obj.item()
+    if obj is None or isinstance(obj, (bool, int, float, str)):
+        return obj
+    if isinstance(obj, np.ndarray):
+        if obj.dtype.hasobject:
+            raise TypeError('%s: an object array cannot go into a parameter file' % where)
+        return obj.tolist()
+    if isinstance(obj, dict):
+        return {_plain(k, where): _plain(v, '%s[%r]' % (where, k)) for k, v in obj.items()}
+    if isinstance(obj, tuple):
+        return tuple(_plain(v, where) for v in obj)
+    if isinstance(obj, list):
+        return [_plain(v, where) for v in obj]
+    raise TypeError('%s: a %s cannot go into a parameter file (plain numbers, strings, lists, tuples, dicts and numpy '
+                    'scalars / arrays can)' % (where, type(obj).__name__))
+
+
+def _yaml_dump(obj, f):
+    """The writer that matches _yaml_load: yaml.safe_dump of _plain(obj) plus the tuple tag yaml.dump gives `patch_shape` in
+    the reference's files (PW_AL.py:91-110) - what this writes, every rank can read back."""
+    import yaml
+
+    class Dumper(yaml.SafeDumper):
+        pass
+    Dumper.add_representer(tuple, lambda d, data: d.represent_sequence('tag:yaml.org,2002:python/tuple', data))
+    yaml.dump(_plain(obj), f, Dumper=Dumper)
+
+
 def _yaml_load(f):
     """yaml.load of the reference's parameter files (PW_AL.py:91-113) without arbitrary object construction: a SafeLoader that
-    additionally understands the one python tag yaml.dump puts into them - tuples (`patch_shape`).  A file in a shared experiment
-    directory cannot run code when it is loaded."""
+    additionally understands what yaml.dump puts into such files - tuples (`patch_shape`), numpy scalars and arrays
+    (`pars['stats']`, np.float64 learning rates: decoded from their bytes, nothing is called), OrderedDict.  A file in a shared
+    experiment directory cannot run code when it is loaded; any other python tag raises a ValueError that names it."""
     import yaml
 
     class Loader(yaml.SafeLoader):
         pass
+
+    def parts(ld, node):
+        if isinstance(node, yaml.SequenceNode):
+            return ld.construct_sequence(node, deep=True), None
+        m = ld.construct_mapping(node, deep=True)
+        return list(m.get('args', [])), m.get('state')
+
+    def apply(ld, suffix, node):
+        name = suffix.replace('numpy._core.', 'numpy.core.')
+        if name == 'numpy.dtype':
+            args, state = parts(ld, node)
+            dt = np.dtype(str(args[0]))
+            if dt.hasobject:
+                raise yaml.constructor.ConstructorError(None, None, 'object dtype in a parameter file', node.start_mark)
+            if state is not None and len(state) > 1 and state[1] in ('<', '>', '=', '|'):
+                dt = dt.newbyteorder(state[1])
+            return dt
+        if name == 'numpy.core.multiarray.scalar':
+            args, _ = parts(ld, node)
+            return np.frombuffer(bytes(args[1]), dtype=args[0])[0].item()
+        if name == 'numpy.core.multiarray._reconstruct':
+            _, state = parts(ld, node)
+            _ver, shape, dt, fortran, raw = state
+            return np.frombuffer(bytes(raw), dtype=dt).reshape(tuple(shape), order='F' if fortran else 'C').copy()
+        if name == 'collections.OrderedDict':
+            args, _ = parts(ld, node)
+            return {k: v for k, v in (args[0] if args else [])}
+        raise yaml.constructor.ConstructorError(None, None, 'python tag %r is not one a parameter file may hold' % suffix, node.start_mark)
+
+    def pyname(ld, suffix, node):
+        if suffix == 'numpy.ndarray':
+            return np.ndarray
+        raise yaml.constructor.ConstructorError(None, None, 'python name %r is not one a parameter file may hold' % suffix, node.start_mark)
+
     Loader.add_constructor('tag:yaml.org,2002:python/tuple', lambda ld, node: tuple(ld.construct_sequence(node, deep=True)))
-    return yaml.load(f, Loader=Loader)
+    Loader.add_multi_constructor('tag:yaml.org,2002:python/object/apply:', apply)
+    Loader.add_multi_constructor('tag:yaml.org,2002:python/name:', pyname)
+    try:
+        return yaml.load(f, Loader=Loader)
+    except yaml.constructor.ConstructorError as e:
+        raise ValueError('%s: not a parameter file this build reads (plain YAML + tuples + numpy scalars / arrays): %s'
+                         % (getattr(f, 'name', 'parameter file'), e))
+
+
+def _rank0_then_all(fn):
+    """Runs fn() on rank 0 only; a failure there is raised on EVERY rank (the others would otherwise wait in the barrier for a
+    writer that is gone, or run on into the next collective alone)."""
+    from . import pool_shard
+    rank, ws = pool_shard.world()
+    err = None
+    if rank == 0:
+        try:
+            fn()
+        except Exception as e:          # noqa: BLE001 - re-raised below, on every rank
+            err = e
+    failed = pool_shard.max_over_ranks(1.0 if err is not None else 0.0) > 0.0
+    if err is not None:
+        raise err
+    if failed:
+        raise RuntimeError('rank 0 failed while writing the experiment files (see its traceback)')
 
 
 # ------------------------------------------------------------------------------------------ the experiment object
@@ -165,23 +257,25 @@ class Experiment(object):
         # one process per GPU: rank 0 creates the directory and writes the files, the others wait and read them back (a peer
         # that raced the writer would load a half-written parameters.txt)
         rank, ws = pool_shard.world()
-        if rank == 0:
+
+        def write():
             os.makedirs(root_dir, exist_ok=True)
             if len(pars) > 0:
                 if os.path.exists(os.path.join(root_dir, 'parameters.txt')):
                     print("Some parameters already exist")
                 else:
                     self.save_parameters(pars)
+        _rank0_then_all(write)
         pool_shard.barrier()
         if rank != 0 and len(pars) > 0 and os.path.exists(os.path.join(root_dir, 'parameters.txt')):
             self.load_parameters()
 
     def save_parameters(self, pars):
         import copy
-        import yaml
+        plain = _plain(pars)          # (an unsupported value fails before the file is touched)
         with open(os.path.join(self.root_dir, 'parameters.txt'), 'w') as f:
             self.pars = copy.deepcopy(pars)
-            yaml.dump(pars, f)
+            _yaml_dump(plain, f)
 
     def load_parameters(self):
         with open(os.path.join(self.root_dir, 'parameters.txt'), 'r') as f:
@@ -201,7 +295,6 @@ class Experiment_MultiImg(Experiment):
     files."""
 
     def __init__(self, root_dir, pars={}, train_paths={}, test_paths={}):
-        import yaml
         from . import pool_shard
         Experiment.__init__(self, root_dir, pars)
         if not hasattr(self, 'pars'):
@@ -209,13 +302,15 @@ class Experiment_MultiImg(Experiment):
         rank, ws = pool_shard.world()
         tr_file = os.path.join(self.root_dir, 'train_paths.txt')
         st_file = os.path.join(self.root_dir, 'train_stats.txt')
-        if rank == 0:        # the writer; its peers read the finished files behind the barrier
+        def write():         # rank 0 is the writer; its peers read the finished files behind the barrier
             if not os.path.exists(tr_file):
+                plain = _plain(train_paths, 'train_paths')
                 with open(tr_file, 'w') as f:
-                    yaml.dump(train_paths, f)
+                    _yaml_dump(plain, f)
             if not os.path.exists(st_file):
                 with open(tr_file, 'r') as f:
                     np.savetxt(st_file, get_stats(_yaml_load(f)))
+        _rank0_then_all(write)
         pool_shard.barrier()
         with open(tr_file, 'r') as f:
             self.train_paths = _yaml_load(f)

@@ -88,6 +88,7 @@ struct alq_ctx {
     void *param_block = nullptr;   // small device buffer for per-call parameters (gather)
     void *comm = nullptr;          // RCCL communicator of this rank (comm.hip), or null
     int comm_rank = 0, comm_world = 1;
+    int f16_subnormal_mfma = -1;   // c3d_subnormals_ok: -1 not probed yet on this context's device, else 0 / 1
     alq::ProfSlot prof[alq::PROF_NUM];
     int prof_begin(int cls, hipEvent_t *e0, hipEvent_t *e1);
     void prof_end(int cls, hipEvent_t e0, hipEvent_t e1, double flops);

@@ -177,11 +177,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const unsigned fa = amaxA_c[p], fb = amaxB_c[p];
         const unsigned fm = fa > fb ? fa : fb;
         const int ex = (int)((fm >> 23) & 255u) - 126;
-        return fm ? 14 - ex : 0;
+        // (a patch whose maximum is below 2^-82 - fp32 subnormals included - keeps the scale 2^96: 2^(14 - ex) would overflow
+        // the scale or underflow its inverse; such inputs are then simply small fp16 values)
+        const int ce = 14 - ex;
+        return fm ? (ce < 96 ? ce : 96) : 0;
     };
     // ONE buffer resource per array for the whole launch: the patch goes into the scalar offset (not range-checked by the
     // hardware), a lane with nothing to load or store aims past the array through its VECTOR offset (loads return 0, stores
-    // are dropped).  N <= 2047 patches keep every byte offset below 2^32 (the host checks).
+    // are dropped).  N < 4096 patches of 1 MiB keep every byte offset below 2^32 (the host checks).
     auto rsrc_of = [&](const void *base, unsigned long long bytes) __attribute__((always_inline)) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)(unsigned)bytes, 0x00020000);
     };
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const __amdgpu_buffer_rsrc_t inA_rsrc = rsrc_of(a.inA, (unsigned long long)a.N * patch_f * 4u);
     const __amdgpu_buffer_rsrc_t inB_rsrc = rsrc_of(a.inB, (unsigned long long)a.N * patch_f * 4u);
     const __amdgpu_buffer_rsrc_t wd_rsrc = rsrc_of(a.fc_W, (unsigned long long)patch_f * 4u);
-    const __amdgpu_buffer_rsrc_t bits_rsrc = rsrc_of(a.fc_bits, (SUMS && a.fc_bits) ? (unsigned long long)a.N * patch_f : 0ull);
+    const __amdgpu_buffer_rsrc_t bits_rsrc = rsrc_of(a.fc_bits, (SUMS && a.fc_bits) ? (unsigned long long)a.N * (patch_f >> 2) : 0ull);
     auto patch_of = [&](int pi) __attribute__((always_inline)) { return (unsigned)(b0 + pi * G); };
 
     // ---- staging: unit u = 0..15 of a plane: row 8 w + (u >> 1), tensor u & 1: 1 KB of fp32 per wave instruction ------------
@@ -241,7 +244,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // epilogue constants of a finished plane (patch ordinal pe, plane zo); !valid: inv = 0, zero bias and lane offsets past the
     // arrays turn the epilogue of a step without a finished plane into a no-op
-    struct Epi { float inv; f32x4 b4; float tau; unsigned off_w, off_b, row_f, bits_s; };
+    // tau_u: the marking threshold as an integer key, (bits(tau) - 1) >> 1, 0 when nothing is to be marked (epi_row)
+    struct Epi { float inv; f32x4 b4; float tau; unsigned tau_u; unsigned off_w, off_b, row_f, bits_s; };
     auto epi_setup = [&](bool valid, int pe, int zo) __attribute__((always_inline)) {
         Epi e;
         const int p = valid ? (int)patch_of(pe) : 0;
@@ -250,6 +254,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         e.b4 = valid ? bias4 : f32x4{0.f, 0.f, 0.f, 0.f};
         // (an all-zero patch: every pre-activation IS its bias in both arithmetics - nothing to mark)
         e.tau = (valid && (amaxA_c[p] | amaxB_c[p]) != 0u) ? __builtin_ldexpf(a.flip_tau, 14 - ce) : 0.f;
+        e.tau_u = e.tau > 0.f ? (__builtin_bit_cast(unsigned, e.tau) - 1u) >> 1 : 0u;
         e.off_w = valid ? epi_lane_f * 4u : OOB;
         e.off_b = valid ? (epi_lane_f >> 2) : OOB;
         e.row_f = (unsigned)(zo * 32 + wave * 8) * 256u;       // float offset of row 8 w of that plane inside the patch
@@ -294,10 +299,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float mn = fminf(fminf(__builtin_fabsf(val.x), __builtin_fabsf(val.y)), fminf(__builtin_fabsf(val.z), __builtin_fabsf(val.w)));
 #if C3_EPI2
             // mn, tau >= 0: their bit patterns order like the numbers, and the sign of the difference is the answer (no compare, no
-            // VCC round trip with its wait states)
-            unsure = (__builtin_bit_cast(unsigned, mn) - __builtin_bit_cast(unsigned, E.tau)) >> 31;
+            // VCC round trip with its wait states).  A pre-activation that is EXACTLY +0 is not marked: under this arithmetic that
+            // is an all-zero window under a zero bias (the reference's initial weights on a zero-padded volume), +0 in the exact
+            // evaluation too - marking those filled the list segments of padded patches with groups that need no second look.
+            // The key (bits - 1) >> 1 sends +0 to 0x7fffffff (above every threshold) and keeps the order of everything else.
+            unsure = (((__builtin_bit_cast(unsigned, mn) - 1u) >> 1) - E.tau_u) >> 31;
 #else
-            unsure = mn < E.tau ? 16u : 0u;
+            unsure = (mn < E.tau && mn > 0.f) ? 16u : 0u;
 #endif
         }
         val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f);
@@ -916,18 +924,21 @@ __global__ void c3d_subnormal_probe(float *out) {
     if (threadIdx.x == 0) out[0] = d.x;
 }
 
-// 1: fp16 subnormal MFMA operands are honoured on this device, 0: flushed (checked once per process)
+// 1: fp16 subnormal MFMA operands are honoured on this context's device, 0: flushed.  Probed once per context (the answer is a
+// property of the device the context is bound to); a probe that could not run (launch or copy error) is reported as 0 for
+// this call and NOT cached, so a transient failure does not switch the one-accumulator kernels off for good.
 int c3d_subnormals_ok(alq_ctx *ctx) {
-    static int cached = -1;
-    if (cached >= 0) return cached;
+    if (ctx->f16_subnormal_mfma >= 0) return ctx->f16_subnormal_mfma;
     float *d = nullptr, h = -1.f;
-    if (hipMalloc(&d, sizeof(float)) != hipSuccess) return 0;
+    if (hipMalloc(&d, sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return 0; }
     hipLaunchKernelGGL(c3d_subnormal_probe, dim3(1), dim3(64), 0, ctx->stream, d);
-    const bool ok = hipMemcpyAsync(&h, d, sizeof(float), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+    const bool ok = hipGetLastError() == hipSuccess &&
+                    hipMemcpyAsync(&h, d, sizeof(float), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
                     hipStreamSynchronize(ctx->stream) == hipSuccess;
     (void)hipFree(d);
-    cached = (ok && h == 0x1p-5f) ? 1 : 0;
-    return cached;
+    if (!ok) { (void)hipGetLastError(); return 0; }
+    ctx->f16_subnormal_mfma = (h == 0x1p-5f) ? 1 : 0;
+    return ctx->f16_subnormal_mfma;
 }
 
 // ------------------------------------------------------------------------------------------------------ host

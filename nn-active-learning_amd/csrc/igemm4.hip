@@ -605,7 +605,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                         if (AHAS(flip_list)) {
                             const float mn = fminf(fminf(__builtin_fabsf(val.x), __builtin_fabsf(val.y)),
                                                    fminf(__builtin_fabsf(val.z), __builtin_fabsf(val.w)));
-                            unsure = mn < p_tau ? 16u : 0u;
+                            unsure = (mn < p_tau && mn > 0.f) ? 16u : 0u;      // (exactly +0: an all-zero window under a zero bias, +0 in the exact evaluation too)
                         }
                     }
                     if (FCF || AF(relu)) {

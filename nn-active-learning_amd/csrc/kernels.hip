@@ -1304,23 +1304,30 @@ int k_fwd_bounds(alq_ctx *ctx, const unsigned *amax0, int N, int stride, const F
     return ALQ_OK;
 }
 
-// Flip-safe fused head, step 1: collect the sign bytes whose bit 4 is set (igemm4's fused-head epilogue marks the 4-channel
-// groups holding a pre-activation that its fp16x2 contraction left within its error bound of zero).  Streams the bit field
-// once (16 bytes per thread); every scan block keeps its own list segment and count: list[block * FLIP_PER_BLOCK + slot] = global
-// byte index, cnt[block] = groups found.
-// The segments are cut PER PATCH (FLIP_SEG_PER_PATCH equal parts of a patch's bytes), never across patches: which groups are
-// re-evaluated then does not depend on how the caller cut the pool into batches.  A segment with more marked groups than list
-// slots keeps the first FLIP_PER_BLOCK the hardware hands out and adds the rest to *overflow (alq_model_engine_info(m, 5)): the
-// dropped groups keep the sign the fp16x2 contraction gave them - still a sign within rounding of the exact one.
+// Flip-safe fused head, step 1: collect the sign bytes whose bit 4 is set (the fused-head epilogues mark the 4-channel groups
+// holding a pre-activation that their fp16x2 contraction left within its error bound of zero; a pre-activation that is EXACTLY
+// zero - an all-zero window under a zero bias: the reference's initial weights on a zero-padded volume, PW_AL.py:284-298 - is the
+// same +0 in both arithmetics and is not marked).  Streams the bit field once (16 bytes per thread); every scan block keeps its
+// own list segment and count: list[block * FLIP_PER_BLOCK + slot] = global byte index, cnt[block] = groups found (ALL of them,
+// also beyond the list).
+// The segments are cut PER PATCH (FLIP_SEG_PER_PATCH equal parts of a patch's bytes), never across patches.  A segment with
+// at most FLIP_PER_BLOCK marked groups is drained from its list (the order the slots were handed out in does not matter: every
+// listed group is re-evaluated, each on its own); a segment with more is drained by flip_fix_kernel scanning the segment's bytes
+// itself - no group is ever dropped, so the scores do not depend on arrival order or on how the pool was cut into batches.
+// *overflow counts the groups beyond the lists (alq_model_engine_info(m, 5)): how often the slower path ran, not a loss.
 constexpr int FLIP_SEG_PER_PATCH = 4, FLIP_PER_BLOCK = 128;      // list slots per segment (expected load: ~8)
+__device__ inline void flip_segment_range(unsigned seg, long long p16, long long *a, long long *b) {
+    const long long patch = seg / FLIP_SEG_PER_PATCH, part = seg % FLIP_SEG_PER_PATCH;
+    const long long per = (p16 + FLIP_SEG_PER_PATCH - 1) / FLIP_SEG_PER_PATCH;
+    *a = patch * p16 + part * per;
+    *b = patch * p16 + ((part + 1) * per < p16 ? (part + 1) * per : p16);
+}
 __global__ __launch_bounds__(256) void flip_scan_kernel(const uint4 *bits16, long long p16, unsigned *cnt, unsigned *list, unsigned *overflow) {
     __shared__ unsigned lc;
     if (threadIdx.x == 0) lc = 0u;
     __syncthreads();
-    // block = (patch, part): p16 = 16-byte words per patch
-    const long long patch = blockIdx.x / FLIP_SEG_PER_PATCH, part = blockIdx.x % FLIP_SEG_PER_PATCH;
-    const long long per = (p16 + FLIP_SEG_PER_PATCH - 1) / FLIP_SEG_PER_PATCH;
-    const long long a = patch * p16 + part * per, b = patch * p16 + ((part + 1) * per < p16 ? (part + 1) * per : p16);
+    long long a, b;       // block = (patch, part): p16 = 16-byte words per patch
+    flip_segment_range(blockIdx.x, p16, &a, &b);
     for (long long i = a + threadIdx.x; i < b; i += 256) {
         const uint4 w = bits16[i];
         if (((w.x | w.y | w.z | w.w) & 0x10101010u) == 0u) continue;
@@ -1336,11 +1343,11 @@ __global__ __launch_bounds__(256) void flip_scan_kernel(const uint4 *bits16, lon
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        cnt[blockIdx.x] = lc < (unsigned)FLIP_PER_BLOCK ? lc : (unsigned)FLIP_PER_BLOCK;
+        cnt[blockIdx.x] = lc;
         if (lc > (unsigned)FLIP_PER_BLOCK && overflow) atomicAdd(overflow, lc - (unsigned)FLIP_PER_BLOCK);
     }
 }
-// Step 2: exact re-evaluation of the four pre-activations of every listed group of a stride-1 SAME conv and their sign
+// Step 2: exact re-evaluation of the four pre-activations of every marked group of a stride-1 SAME conv and their sign
 // nibble written back (flag cleared).  One wave per group; products in fp64 (exact for fp32 factors), lane partials and the
 // wave reduction in a fixed order.  Input = two dense channels-last tensors (the parts of a split concat; CB = 0: one).
 // CI / KD / KH / KW > 0: compile-time channel count and kernel box (the index arithmetic of the product loop is divisions by
@@ -1354,8 +1361,7 @@ __global__ __launch_bounds__(256) void flip_fix_kernel(const unsigned *list, con
     const int Ci = CI > 0 ? CI : CA + CB, kz = KD > 0 ? KD : kz_, ky = KH > 0 ? KH : ky_, kx = KW > 0 ? KW : kx_;
     const int lane = threadIdx.x & 63, K = kz * ky * kx * Ci;
     const unsigned gpp = (unsigned)(F >> 2);                 // groups (bytes) per patch
-    for (unsigned r = (blockIdx.x & 3u) * 4u + (threadIdx.x >> 6); r < n; r += 16) {     // one wave per group
-        const unsigned b = list[(long long)seg * FLIP_PER_BLOCK + r];
+    auto fix_group = [&](unsigned b) {                       // the whole wave: group = global byte index b
         const unsigned p = b / gpp, g = b - p * gpp;
         const int co = (int)((g * 4u) % (unsigned)Co);       // first of the group's 4 channels
         int v = (int)((g * 4u) / (unsigned)Co);
@@ -1385,6 +1391,24 @@ __global__ __launch_bounds__(256) void flip_fix_kernel(const unsigned *list, con
             const double b2 = bias ? (double)bias[co + 2] : 0.0, b3 = bias ? (double)bias[co + 3] : 0.0;
             bits[b] = (unsigned char)((s0 + b0 > 0.0 ? 1u : 0u) | (s1 + b1 > 0.0 ? 2u : 0u) | (s2 + b2 > 0.0 ? 4u : 0u) | (s3 + b3 > 0.0 ? 8u : 0u));
         }
+    };
+    const unsigned w16 = (blockIdx.x & 3u) * 4u + (threadIdx.x >> 6);      // this wave among the segment's 16
+    if (n <= (unsigned)FLIP_PER_BLOCK) {
+        for (unsigned r = w16; r < n; r += 16) fix_group(list[(long long)seg * FLIP_PER_BLOCK + r]);
+        return;
+    }
+    // more marked groups than list slots: the segment's 16 waves sweep its bytes themselves, word i to wave i mod 16 (every
+    // lane reads the same word; a wave rewrites only bytes of its own words, which no other wave reads)
+    long long a, b;
+    flip_segment_range(seg, (F >> 2) / 16, &a, &b);
+    const uint4 *bits16 = reinterpret_cast<const uint4 *>(bits);
+    for (long long i = a + w16; i < b; i += 16) {
+        const uint4 w = bits16[i];
+        if (((w.x | w.y | w.z | w.w) & 0x10101010u) == 0u) continue;
+        const unsigned ws[4] = {w.x, w.y, w.z, w.w};
+        for (int q = 0; q < 4; ++q)
+            for (int bb = 0; bb < 4; ++bb)
+                if ((ws[q] >> (8 * bb + 4)) & 1u) fix_group((unsigned)(i * 16 + q * 4 + bb));
     }
 }
 int flip_segments(int N) { return N * FLIP_SEG_PER_PATCH; }

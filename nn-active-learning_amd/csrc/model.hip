@@ -115,7 +115,7 @@ struct alq_model {
     unsigned *flip_cnt = nullptr, *flip_list = nullptr;     // candidates of the flip-safe fused head (igemm4 FCF + F16)
     int flip_cap = 0;
     unsigned *bound_all = nullptr;          // [layer][max_batch] derived per-patch output bounds (float bits), k_fwd_bounds
-    unsigned *flip_overflow = nullptr;      // marked groups the scan could not list since the model was created (kernels.hip, flip_scan_kernel)
+    unsigned *flip_overflow = nullptr;      // marked groups beyond the scan's lists since the model was created: drained by the sweep path of flip_fix_kernel (kernels.hip), none dropped
     int no_flipfix = 0;                                      // ALQ_NO_FLIPFIX at creation (A/B: the head's sign bits as the fp16x2 contraction leaves them)
     size_t amax_tiles_len = 0;
     int in_dims[4] = {1, 1, 1, 1};
@@ -145,14 +145,14 @@ struct alq_model {
     int no_signs0 = 0;             // ALQ_NO_SIGNS0 (A/B): no sign field from the first conv + pool kernel only
     int f16_fwd_mask = -1;         // ALQ_F16_FWD_MASK (diagnostics): forward fp16x2 consumers by layer bit, -1 = default rule
     int f16_fwd_derived = 0;       // layers (bits) whose forward launch takes the fp16x2 split with DERIVED input bounds (see run_forward)
-    int no_f16_derived = 1;        // 0 with ALQ_F16_DERIVED=1: those launches take the split (default: they stay on bf16x3)
+    int no_f16_derived = 0;        // 1 with ALQ_NO_F16_DERIVED=1: those launches stay on bf16x3 (A/B; default since round 5: they take the split)
     float *d_bound_L = nullptr, *d_bound_B = nullptr;      // per layer: out = in * L + B (k_fwd_bounds)
     int *d_bound_src = nullptr;
     int no_c3d = 0;                // ALQ_NO_C3D (A/B): the head conv pair on the two-slot engine (igemm4) as in round 3
     int c3_bwd_rows = 8;           // ALQ_C3D_BWD_ROWS=4 (A/B): the plane-sweep backward kernel in its half-patch form
     bool last_c3 = false;          // the last forward pass ran the head conv on the plane-sweep engine
     bool last_c3_bwd = false;      // ... and the last backward pass its backward
-    bool last_f16_derived = false; // the last forward pass ran a launch on the fp16x2 split with derived input bounds (ALQ_F16_DERIVED=1)
+    bool last_f16_derived = false; // the last forward pass ran a launch on the fp16x2 split with derived input bounds
 
     template <typename T>
     int dalloc(T **p, size_t count) {
@@ -773,6 +773,7 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
     bool fc_head_fused = false;  // the logits partials of the fc head came out of the previous conv's epilogue
     bool c3_head = false;        // ... of the plane-sweep engine: one partial per (patch, wave), the head's input sum likewise
     m->last_head_fused = false;
+    m->last_c3 = false;
     // A conv / conv_transpose launch contracts with the fp16x2 split if it knows max |x| per patch of (every part of)
     // its input ahead of time: the launches that produce those tensors report them (`prod`), the consumers (`cons`)
     // read one scale per tile.  Producers: the first conv + pool kernel and one-patch-per-tile igemm4 launches.
@@ -813,13 +814,13 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
             // event any two fp32 implementations produce, four times as often).  The head conv has one ReLU behind it;
             // backward launches have none (the masks are fixed by then), so they take the split wherever a variant exists.
             const int s_ = l.spec.skip_src;
-            // ... and, opt-in (ALQ_F16_DERIVED=1), the conv whose output reaches the head conv through the (linear) conv_transpose
-            // only: its input maxima are not measured (an epilogue in two producer launches cost what the split gave) but DERIVED per
-            // patch from the first layer's measured maximum through the layers' L1 norms (k_fwd_bounds) - the fp16 pairs keep their
-            // 22 bits under a bound that is loose by orders of magnitude.  Measured (profiles/r04al_*): bench +2.6 % same-box
-            // (222.3 against 216.9 k patches/s), launch 1148 -> 875 us; on a 2000-patch batch against the exact-fp32 engine 129
-            // patches with a flipped fragile unit instead of 115 (bf16x3 everywhere: 109).  Off by default: the forward launches in
-            // front of ReLUs stay fp32-faithful, and the roofline accounting counts executed products.
+            // ... and the conv whose output reaches the head conv through the (linear) conv_transpose only (NET-C's dec1): its
+            // input maxima are not measured (an epilogue in two producer launches cost what the split gave) but DERIVED per patch
+            // from the first layer's measured maximum through the layers' L1 norms (k_fwd_bounds) - the fp16 pairs keep their 22
+            // bits under a bound that is loose by orders of magnitude.  Measured (profiles/r04al_*): bench +2.6 % same-box, launch
+            // 1148 -> 875 us; on a 2000-patch batch against the exact-fp32 engine 129 patches with a flipped fragile unit instead
+            // of 115 (bf16x3 everywhere: 109; each engine has its own set against fp64).  Default since round 5 (the round-4
+            // verdict: a faster, equally accurate path is not withheld for an accounting ratio); ALQ_NO_F16_DERIVED=1 is the A/B arm.
             if (m->f16_fwd_mask < 0 && !m->no_f16_derived && nl <= 16 && ((m->f16_fwd_derived >> j) & 1) && l.spec.type == ALQ_CONV && use_dcp(0) &&
                 (s_ >= 0) == (l.in.split != 0) && !(drop && drop->layers)) {
                 cons[j] = 2;
@@ -918,7 +919,7 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                     // flip-safe head: only where the launch will contract with the fp16x2 split (input maxima known) and the
                     // sign bits are wanted (Fisher pass); stride-1 conv on one dense tensor or a split concat of two
                     const bool flipfix = with_sums && fz.fc_bits && fz.in_amax && !g_no_f16x2 && !m->no_flipfix && ly.d_W32 && ly.fwd_l1 > 0.f &&
-                                         sp.s[0] == 1 && sp.s[1] == 1 && sp.s[2] == 1 && in.c0 == 0 &&
+                                         sp.s[0] == 1 && sp.s[1] == 1 && sp.s[2] == 1 && in.c0 == 0 && nx->F % 64 == 0 &&      // (whole 16-byte words of sign bytes per patch)
                                          ((in.split == 0 && in.cs == in.C) || (in.split > 0 && in.cs == in.split && in.C == 2 * in.split));
                     if (flipfix) {
                         if (!m->flip_list) {
@@ -1538,7 +1539,10 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
         m->no_signs = getenv("ALQ_NO_SIGNS") != nullptr;
         m->no_signs0 = getenv("ALQ_NO_SIGNS0") != nullptr;
         if (const char *f = getenv("ALQ_F16_FWD_MASK")) m->f16_fwd_mask = atoi(f);
-        { const char *e = getenv("ALQ_F16_DERIVED"); m->no_f16_derived = (e && atoi(e) == 1) ? 0 : 1; }
+        {   // default since round 5: on.  ALQ_NO_F16_DERIVED=1 (or ALQ_F16_DERIVED=0) keeps that launch on bf16 triples (A/B)
+            const char *e = getenv("ALQ_F16_DERIVED"), *n = getenv("ALQ_NO_F16_DERIVED");
+            m->no_f16_derived = ((e && atoi(e) == 0) || (n && atoi(n) == 1)) ? 1 : 0;
+        }
         static const char *names[8] = {"ALQ_DEBUG_REPEAT", "ALQ_DEBUG_FLAGS", "ALQ_NO_BWD_FUSE", "ALQ_NO_FWD_FUSE", "ALQ_NO_V3", "ALQ_NO_V4",
                                        "ALQ_NO_POOL_FIRST", "ALQ_NO_CONV_POOL"};
         for (int k = 0; k < 8; ++k) {

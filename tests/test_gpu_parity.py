@@ -22,6 +22,7 @@ from tests import factored_ref  # noqa: E402
 #   * the TYPICAL value much tighter: median relative error <= 1e-4, 90th percentile <= rtol.
 P_ATOL = 2e-5          # posteriors (fp32 softmax of fp32 logits)
 SCORE_ATOL = 1e-4      # north_star: "scores within 1e-4 fp32"
+OVER_1E4_MAX = 40      # patches of a 2000-patch bench batch whose scores may differ from the exact-fp32 engine's by more than 1e-4 (flips; measured: see the test)
 
 
 def assert_scores_close(dev, ref, atol, rtol, floor, med=1e-4):
@@ -51,7 +52,18 @@ def sess():
 
 
 def _load(golden_dir, name):
-    return np.load(os.path.join(golden_dir, name))
+    g = np.load(os.path.join(golden_dir, name))
+    if 'x' in g.files or 'x_sha256' not in g.files:
+        return g
+    # a fixture that holds the hash of its patches instead of the patches (tests/golden/make_golden_r5.py): the first
+    # n * prod(in_shape) draws of numpy's frozen legacy stream RandomState(xseed).randn
+    import hashlib
+    d = {k: g[k] for k in g.files}
+    x = np.random.RandomState(int(g['xseed'])).randn(int(g['n']), *[int(v) for v in g['in_shape']]).astype(np.float32)
+    assert hashlib.sha256(x.tobytes()).hexdigest() == str(g['x_sha256']), 'regenerated patches differ from the fixture\'s'
+    np.testing.assert_array_equal(x.reshape(-1)[:8], g['x_first8'])
+    d['x'] = x
+    return d
 
 
 def _device_model(sess, ld, in_shape, skips, pars, feature_layer=None, max_batch=64):
@@ -1186,8 +1198,8 @@ def test_plane_sweep_backward_half_patch_form_is_bit_identical(sess):
     m4.close()
 
 
-def test_opt_in_fp16_forward_with_derived_bounds(sess):
-    """ALQ_F16_DERIVED=1: NET-C's `dec1` forward launch on the fp16-pair split, its per-patch input maxima DERIVED from the first
+def test_fp16_forward_with_derived_bounds_against_bf16_triples(sess):
+    """Default since round 5 (ALQ_NO_F16_DERIVED=1 is the other arm): NET-C's `dec1` forward launch on the fp16-pair split, its per-patch input maxima DERIVED from the first
     layer's measured maximum through the layers' L1 norms (csrc/kernels.hip, fwd_bounds_kernel) instead of measured.  Against the
     default (bf16 triples in that launch): posteriors within 2e-6; layer scores within 2e-6 + 2e-5 relative, or the patch goes to
     the fp64 arbiter (a ReLU input within rounding of zero may land on either side: the split rounds at 2^-22)."""
@@ -1195,7 +1207,7 @@ def test_opt_in_fp16_forward_with_derived_bounds(sess):
     from nnal_amd._lib import check
     torch = sess.torch
     n = 300
-    ld, sk, in_shape, pars, (m_on, m_off) = _netc32_models(sess, [{'ALQ_F16_DERIVED': '1'}, {}], max_batch=n, bias_std=0.05)
+    ld, sk, in_shape, pars, (m_on, m_off) = _netc32_models(sess, [{}, {'ALQ_NO_F16_DERIVED': '1'}], max_batch=n, bias_std=0.05)
     x = sess.empty((n, 32 ** 3), torch.float32)
     check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, 32 ** 3, C.c_void_p(x.data_ptr())))
     out = []
@@ -1218,12 +1230,15 @@ def test_opt_in_fp16_forward_with_derived_bounds(sess):
     m_off.close()
 
 
-def test_flip_safe_head_is_cut_invariant_and_reports_overflow(sess):
+def test_flip_safe_head_is_cut_invariant_and_drains_every_marked_group(sess):
     """The flip-safe head's candidate scan (kernels.hip, flip_scan_kernel) works on per-patch list segments: the scores of a
-    patch must not depend on how the pool was cut into batches (bit for bit), and marked groups that do not fit a segment are
-    counted (alq_model_engine_info(m, 5)) instead of vanishing silently.  The bench's data never fills a segment; a patch
-    whose upper half is zero under zero biases (every pre-activation there is exactly its bias, 0) does; an all-zero patch
-    marks nothing."""
+    patch must not depend on how the pool was cut into batches (bit for bit).  Round 5: NO marked group is ever dropped - a
+    segment with more marked groups than list slots is drained by flip_fix_kernel sweeping the segment's bytes itself
+    (alq_model_engine_info(m, 5) counts the groups that took that path) - and a pre-activation that is exactly +0 (an all-zero
+    window under a zero bias: what the reference's initial weights give on the zero padding of a volume, PW_AL.py:284-298) is not
+    marked at all.  So: the bench's data and a half-zero patch fill no segment; a patch whose upper half is scaled to 1e-7 (tiny
+    but non-zero pre-activations, all within the marking threshold) overflows the lists and is still scored, identically in
+    five repeats and in agreement with the exact-fp32 engine."""
     import ctypes as C
     from nnal_amd._lib import check
     torch = sess.torch
@@ -1247,21 +1262,124 @@ def test_flip_safe_head_is_cut_invariant_and_reports_overflow(sess):
     r = m.fisher_device(z, 4, None, 1e-3, want=('p1', 'g0'))
     assert np.isfinite(r['g0'].cpu().numpy()).all()
     assert sess.lib.alq_model_engine_info(m._m, 5) == 0
-    # ... a patch that is zero in its upper half marks every group deep inside that half: more than the segments hold
+    # ... and neither does the zero half of a half-zero patch (exact +0 under zero biases): the lists keep room for the real
+    # candidates of the other half, five repeats agree bit for bit
     h = x[:4].clone().reshape(4, 32, 32, 32)
     h[:, 16:] = 0
-    r = m.fisher_device(h.reshape(4, -1).contiguous(), 4, None, 1e-3, want=('p1', 'g0'))
-    assert np.isfinite(r['g0'].cpu().numpy()).all()
-    assert sess.lib.alq_model_engine_info(m._m, 5) > 0
+    hz = h.reshape(4, -1).contiguous()
+    first = None
+    for _ in range(5):
+        r = m.fisher_device(hz, 4, None, 1e-3, want=('p1', 'g0', 'g1'))
+        cur = {k: r[k].cpu().numpy().copy() for k in ('p1', 'g0', 'g1')}
+        assert np.isfinite(cur['g0']).all()
+        if first is None:
+            first = cur
+        for k in cur:
+            np.testing.assert_array_equal(first[k], cur[k], err_msg=k)
+    assert sess.lib.alq_model_engine_info(m._m, 5) == 0, 'the zero half of a patch filled the list segments'
+    # a patch whose upper half is tiny but not zero: every group there lies within the marking threshold -> far more marked groups
+    # than list slots -> the sweep path; nothing is dropped, so repeats agree and the scores are those of exact sign decisions
+    t = x[:4].clone().reshape(4, 32, 32, 32)
+    t[:, 16:] *= 1e-7
+    tz = t.reshape(4, -1).contiguous()
+    first = None
+    for _ in range(5):
+        r = m.fisher_device(tz, 4, None, 1e-3, want=('p1', 'g0', 'g1'))
+        cur = {k: r[k].cpu().numpy().copy() for k in ('p1', 'g0', 'g1')}
+        if first is None:
+            first = cur
+        for k in cur:
+            np.testing.assert_array_equal(first[k], cur[k], err_msg=k)
+    assert sess.lib.alq_model_engine_info(m._m, 5) > 0, 'the sweep path of flip_fix_kernel did not run'
+    check(sess.lib.alq_debug_set(4, 1))
+    try:
+        r = m.fisher_device(tz, 4, None, 1e-3, want=('p1', 'g0', 'g1'))
+        ex = {k: r[k].cpu().numpy().copy() for k in ('p1', 'g0', 'g1')}
+    finally:
+        check(sess.lib.alq_debug_set(4, 0))
+    np.testing.assert_allclose(first['p1'], ex['p1'], rtol=0, atol=2e-6)
+    bad = set()
+    for k in ('g0', 'g1'):
+        bad |= set(np.nonzero((np.abs(first[k] - ex[k]) > 2e-6 + 2e-5 * np.abs(ex[k])).any(axis=1))[0].tolist())
+    _fp64_arbitrate(ld, sk, in_shape, pars, tz.cpu().numpy(), sorted(bad), [first, ex], ['default engines', 'fp32 MFMA'], max_rows=4)
     m.close()
 
 
+def test_bench_shape_32_patches_vs_reference_loop_golden(sess, golden_dir):
+    """Round 5: the bench shape (NET-C, 32^3, two classes) on 32 patches through the REFERENCE's own per-sample loop
+    (`PW_NNAL.gen_A_matrices`, PW_NNAL.py:757-814, and `shrink_gradient`, run by tests/golden/make_golden_r5.py) against the device.
+    Posteriors within 5e-6.  A patch whose layer scores differ from the golden's by more than 2e-6 + 2e-5 relative is FLAGGED and
+    goes to the fp64 arbiter with BOTH score sets (the fp32 torch oracle behind the golden flips fragile ReLU / pool decisions like
+    any fp32 implementation does): each must be the fp64 value or an fp64 value with fragile decisions inverted.  Stated counts:
+    flagged <= 8 of 32, beyond north_star's 1e-4 <= 4 of 32; every other patch holds the tight bars, A matrices included."""
+    from nnal_amd import PW_NNAL
+    g = _load(golden_dir, 'r5_fisher_netc_32cube_n32.npz')
+    ld, skips, in_shape, pars = build_fisher_model(g, 'c')
+    n = int(g['n'])
+    assert n >= 32
+    model = _device_model(sess, ld, in_shape, skips, pars, max_batch=n)
+    x, p1 = g['x'], g['p1']
+    dl = float(g['diag_load'])
+    A = np.stack(PW_NNAL.gen_A_matrices(Expr({'patch_shape': in_shape[:3]}), model, sess, x, p1, dl))
+    assert A.shape == g['A'].shape and A.dtype == np.float64
+    res = model.fisher(x, p1, dl)
+    np.testing.assert_allclose(res['p1'], p1, rtol=0, atol=5e-6)
+    assert ((p1 > 1e-6) & (p1 < 1 - 1e-6)).all()          # no saturated branch in this fixture: both class gradients stand
+    d = np.zeros(n)
+    flagged = np.zeros(n, bool)
+    for k in ('g0', 'g1'):
+        err = np.abs(res[k] - g[k])
+        d = np.maximum(d, err.max(axis=1))
+        flagged |= (err > 2e-6 + 2e-5 * np.abs(g[k])).any(axis=1)
+    over = d > SCORE_ATOL
+    print('n32 golden: flagged %d, over 1e-4 %d, max |dg| %.3e' % (flagged.sum(), over.sum(), d.max()))
+    assert flagged.sum() <= 8, np.nonzero(flagged)[0]
+    assert over.sum() <= 4 and d.max() <= 2e-3, (np.nonzero(over)[0], d.max())
+    rows = np.nonzero(flagged)[0].tolist()
+    _fp64_arbitrate(ld, skips, in_shape, pars, x.reshape(n, -1), rows, [res, {'g0': g['g0'], 'g1': g['g1']}], ['device', 'reference loop (fp32 oracle)'], max_rows=8)
+    ok = ~flagged
+    assert_scores_close(A[ok], g['A'][ok], SCORE_ATOL * 0.1, A_RTOL, 1e-6)
+    assert_scores_close(res['trace'][ok], np.trace(g['A'], axis1=1, axis2=2)[ok], SCORE_ATOL, A_RTOL, 1e-6)
+    np.testing.assert_allclose(res['Asum'], A.sum(0), rtol=1e-9, atol=1e-12)        # the pool sum is the sum of the A_i it returned
+    model.close()
+
+
+def test_shipped_batch_2047_is_bit_identical_to_small_batches(sess):
+    """The bench's default batch (2047 patches per pass: the most the 32-bit tensor offsets allow; the last plane-sweep workgroup
+    then holds 7 patches instead of 8) against a model created for 300 patches per pass: the first 300 and the last 300 patches of
+    the 2047 (the seam workgroup included), bit for bit - p1, g0, g1, A, tr A."""
+    import ctypes as C
+    from nnal_amd._lib import check
+    torch = sess.torch
+    n = 2047
+    ld, sk, in_shape, pars, (m_big,) = _netc32_models(sess, [{}], max_batch=n)
+    assert sess.lib.alq_model_max_batch(m_big._m) == n
+    x = sess.empty((n, 32 ** 3), torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, 32 ** 3, C.c_void_p(x.data_ptr())))
+    keys = ('p1', 'g0', 'g1', 'A', 'trace')
+    r = m_big.fisher_device(x, n, None, 1e-3, want=keys)
+    big = {k: r[k].cpu().numpy().copy() for k in keys}
+    assert sess.lib.alq_model_engine_info(m_big._m, 1) == 1 and sess.lib.alq_model_engine_info(m_big._m, 2) == 1
+    m_big.close()
+    _, _, _, _, (m_small,) = _netc32_models(sess, [{}], max_batch=300)
+    for a, b in ((0, 300), (n - 300, n)):
+        xs = x[a:b].contiguous()
+        r = m_small.fisher_device(xs, b - a, None, 1e-3, want=keys)
+        for k in keys:
+            np.testing.assert_array_equal(big[k][a:b], r[k].cpu().numpy(), err_msg='%s, patches %d..%d' % (k, a, b))
+    m_small.close()
+
+
 def test_default_engines_against_the_exact_fp32_engine_full_batch(sess):
-    """One full 2000-patch batch of the bench's pool: the default engines (fp16x2 pairs in the plane-sweep kernels and in the other
-    backward launches, bf16x3 elsewhere) against the exact-fp32 MFMA engine (alq_debug_set(4, 1): fp32 fma chains, no operand
-    split) ON THE DEVICE (round-3 verdict, item 3; reference outputs: PW_NNAL.py:757-814).  Posteriors within 2e-6 for all 2000
-    patches; layer scores within 2e-6 for all but the patches that hold a ReLU input within rounding of zero, of which a seeded
-    sample goes to the fp64 arbiter and must be explained by such a unit."""
+    """One full 2000-patch batch of the bench's pool: the default engines (fp16 pairs in the plane-sweep kernels, in dec1's forward
+    launch and in the backward launches, bf16 triples elsewhere) against the exact-fp32 MFMA engine (alq_debug_set(4, 1): fp32 fma
+    chains, no operand split) ON THE DEVICE (reference outputs: PW_NNAL.py:757-814).  Posteriors within 2e-6 for all 2000 patches.
+    The layer scores are NOT continuous in the rounding noise - a ReLU input (or a max-pool near-tie) within rounding of a decision
+    boundary switches a whole backward path - so north_star's "scores within 1e-4" cannot hold for every patch between ANY two
+    fp32-level engines.  What holds, as numbers (round-4 verdict, item 2a): patches beyond 2e-6 <= 7 %, patches beyond north_star's
+    1e-4 <= OVER_1E4_MAX, no patch beyond 1e-3 - and EVERY patch beyond 1e-4 goes to the fp64 arbiter, which must explain it by
+    fragile decisions (tests/factored_ref.relu_flip_explains; test_fp64_arbiter_rejects_wrong_scores_and_non_fragile_flips shows
+    it refuses anything else)."""
     import ctypes as C
     from nnal_amd._lib import check
     torch = sess.torch
@@ -1271,6 +1389,7 @@ def test_default_engines_against_the_exact_fp32_engine_full_batch(sess):
     check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, 32 ** 3, C.c_void_p(x.data_ptr())))
     r = m.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1'))
     a = {k: r[k].cpu().numpy() for k in ('p1', 'g0', 'g1')}
+    assert sess.lib.alq_model_engine_info(m._m, 6) == 1, 'dec1 forward did not take the fp16-pair split'
     check(sess.lib.alq_debug_set(4, 1))
     try:
         r = m.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1'))
@@ -1280,17 +1399,13 @@ def test_default_engines_against_the_exact_fp32_engine_full_batch(sess):
     assert sess.lib.alq_model_engine_info(m._m, 5) == 0, 'flip-safe head: a list segment overflowed on the bench batch'
     # posteriors: continuous in the rounding noise, so a hard bar
     np.testing.assert_allclose(a['p1'], b['p1'], rtol=0, atol=2e-6)
-    bad = set()
-    for k in ('g0', 'g1'):
-        bad |= set(np.nonzero((np.abs(a[k] - b[k]) > 2e-6).any(axis=1))[0].tolist())
-    # The scores are NOT continuous: a ReLU input within rounding of zero that two fp32-level engines put on different sides
-    # switches a whole backward path on or off (measured with tools/gpu_fullbatch_dbg.py: ~6 % of the 32^3 patches hold such a
-    # unit, |delta g| up to 7e-4 then, and each engine - the exact-fp32 one included - has its own set against fp64).  So: few
-    # flagged patches, a sanity bound on them, and a seeded sample of them through the fp64 arbiter (every one of them would be
-    # ten minutes of CPU), which must explain each sampled patch by such a unit.
-    assert len(bad) <= n // 10, len(bad)
-    assert max(np.abs(a[k] - b[k]).max() for k in ('g0', 'g1')) <= 5e-3
-    sample = sorted(np.random.RandomState(5).choice(sorted(bad), size=min(10, len(bad)), replace=False).tolist()) if bad else []
+    d = np.maximum(np.abs(a['g0'] - b['g0']), np.abs(a['g1'] - b['g1'])).max(axis=1)
+    flagged, over = np.nonzero(d > 2e-6)[0], np.nonzero(d > SCORE_ATOL)[0]
+    print('full batch vs exact fp32: %d patches, over 2e-6: %d, over 1e-4: %d, max |dg| %.3e, max |dp| %.2e' %
+          (n, len(flagged), len(over), d.max(), np.abs(a['p1'] - b['p1']).max()))
+    assert len(flagged) <= (7 * n) // 100, len(flagged)
+    assert len(over) <= OVER_1E4_MAX, (len(over), over.tolist())
+    assert d.max() <= 1e-3, d.max()
     xs = x.cpu().numpy()
-    _fp64_arbitrate(ld, sk, in_shape, pars, xs, sample, [a, b], ['default engines', 'fp32 MFMA'], max_rows=10)
+    _fp64_arbitrate(ld, sk, in_shape, pars, xs, over.tolist(), [a, b], ['default engines', 'fp32 MFMA'], max_rows=OVER_1E4_MAX)
     m.close()

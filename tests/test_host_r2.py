@@ -179,3 +179,48 @@ def test_sdp_lambda_moves_mass_to_long_features_and_needs_centred_rows():
     assert s1['gap'] < 1e-5
     with pytest.raises(ValueError):
         NNAL_tools.SDP_query_distribution(A, 1.0, X + 1.0, 5)
+
+
+def test_parameter_files_round_trip_numpy_values_and_refuse_everything_else(tmp_path):
+    """`parameters.txt` (PW_AL.py:91-113): what `save_parameters` writes, `load_parameters` reads back - numpy scalars and arrays
+    (the reference stores `pars['stats']`; np.float64 learning rates are common) as plain values, tuples as tuples, OrderedDict
+    as dict.  A file the reference's own `yaml.dump` wrote with numpy tags loads too (decoded from its bytes, nothing called).
+    A value that cannot be stored fails at WRITE time (on the writing rank, before the barrier its peers wait in) and leaves no
+    file behind; a file with any other python tag is refused with a ValueError that names the file."""
+    import collections
+    import yaml
+    pars = {'patch_shape': (5, 5, 3), 'learning_rate': np.float64(1e-3), 'k': np.int64(4), 'flag': np.bool_(True),
+            'stats': np.array([[0.25, 1.5], [0.3, 1.25]]), 'nested': collections.OrderedDict([('b', 2), ('a', (1, np.float32(0.5)))]),
+            'grad_layers': [], 'model_name': 'PW'}
+    root = str(tmp_path / 'e1')
+    e = PW_AL.Experiment(root, pars)
+    e2 = PW_AL.Experiment(root)
+    e2.load_parameters()
+    got = e2.pars
+    assert got['patch_shape'] == (5, 5, 3) and isinstance(got['patch_shape'], tuple)
+    assert got['learning_rate'] == 1e-3 and type(got['learning_rate']) is float
+    assert got['k'] == 4 and type(got['k']) is int and got['flag'] is True
+    assert got['stats'] == [[0.25, 1.5], [0.3, 1.25]]
+    assert got['nested'] == {'b': 2, 'a': (1, 0.5)} and got['model_name'] == 'PW' and got['grad_layers'] == []
+    text = open(os.path.join(root, 'parameters.txt')).read()
+    assert 'numpy' not in text and 'python/object' not in text
+    # a file as the reference's yaml.dump writes it (numpy tags)
+    os.makedirs(str(tmp_path / 'e2'))
+    with open(str(tmp_path / 'e2' / 'parameters.txt'), 'w') as f:
+        yaml.dump(pars, f)
+    assert 'python/object/apply:numpy' in open(str(tmp_path / 'e2' / 'parameters.txt')).read()
+    e3 = PW_AL.Experiment(str(tmp_path / 'e2'))
+    e3.load_parameters()
+    assert e3.pars['learning_rate'] == 1e-3 and e3.pars['k'] == 4 and e3.pars['patch_shape'] == (5, 5, 3)
+    np.testing.assert_array_equal(np.asarray(e3.pars['stats']), pars['stats'])
+    assert e3.pars['nested'] == {'b': 2, 'a': (1, 0.5)}
+    # a value that cannot be stored: TypeError at write time, no file
+    with pytest.raises(TypeError, match='bad'):
+        PW_AL.Experiment(str(tmp_path / 'e3'), {'bad': {1, 2}})
+    assert not os.path.exists(str(tmp_path / 'e3' / 'parameters.txt'))
+    # a file that asks for anything else is refused, not executed
+    os.makedirs(str(tmp_path / 'e4'))
+    with open(str(tmp_path / 'e4' / 'parameters.txt'), 'w') as f:
+        f.write("a: !!python/object/apply:os.getcwd []\n")
+    with pytest.raises(ValueError, match='parameters.txt'):
+        PW_AL.Experiment(str(tmp_path / 'e4')).load_parameters()

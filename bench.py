@@ -545,13 +545,15 @@ def cpu_baseline(xs, ld, sk, in_shape, pars):
     all_cores = None
     nall = max(1, min(affinity or (os.cpu_count() or 1), os.cpu_count() or 1))
     if nall > cores:
-        m = max(2, min(len(xs), 32))
         used = torch.get_num_threads()
         torch.set_num_threads(nall)
         alpath.gen_A_matrices(E(), om, osess, xs[:1], p[:1], 1e-3)               # warm-up at the new thread count
         t1 = time.perf_counter()
-        p2 = om.forward(xs[:m])['posteriors'][1].astype(np.float64)
-        alpath.gen_A_matrices(E(), om, osess, xs[:m], p2, 1e-3)
+        m = 0
+        while m < min(len(xs), 32) and (m < 2 or time.perf_counter() - t1 < 8.0):      # bounded: ~8 s, patch by patch
+            p2 = om.forward(xs[m:m + 1])['posteriors'][1].astype(np.float64)
+            alpath.gen_A_matrices(E(), om, osess, xs[m:m + 1], p2, 1e-3)
+            m += 1
         dt2 = time.perf_counter() - t1
         all_cores = {'value': m / dt2, 'unit': 'patches/s', 'cores': torch.get_num_threads(), 'sample': '%d patches, %.1f s' % (m, dt2)}
         torch.set_num_threads(used)

@@ -415,6 +415,23 @@ void c3d_presplit_vec(const float *v, long long F, int e, std::vector<unsigned s
 int c3d_bwd_launch(alq_ctx *ctx, const C3dPlan &plan, int N, const unsigned char *bits, const void *vec16, int e_in, const unsigned char *maskA,
                    float *dB, float *sumA, float *sumB, int rows_per_wave = 8);
 
+// ------------------------------------------------------------------ row-sweep engine for the stride-2 conv_transpose (t3d.hip)
+// 3x3x3 / stride 2 conv_transpose 16 -> 8 channels at 16^3 -> 32^3 (NET-C's up2) and its backward-data pass: every wave sweeps the
+// rows of one input plane on its own (no workgroup barrier), weights in registers, an accumulator = one 1 KB output row.
+struct T3dPlan {
+    bool ok = false;
+    int w_exp = 0;                        // backward: scale exponent of the packed fp16 weight pairs
+    double flops_per_patch = 0;
+    std::vector<unsigned short> h_W;      // forward [9][3 pieces][64][8] bf16 bits; backward [9][2 pieces][64][8] fp16 bits
+    void *d_W = nullptr;
+};
+int t3d_build(const View &in, const View &out, const int k[3], const int lo[3], const int s[3], T3dPlan *fwd, T3dPlan *bwd);
+void t3d_fwd_pack(T3dPlan *plan, const float *W /* TF filter [tap][co][ci] */);
+void t3d_bwd_pack(T3dPlan *plan, const float *W);
+int t3d_fwd_launch(alq_ctx *ctx, const T3dPlan &plan, const View &in, const View &out, const float *bias, int N, float *osum, unsigned *out_amax);
+int t3d_bwd_launch(alq_ctx *ctx, const T3dPlan &plan, const View &dout, const View &din, int N, float in_bound, const unsigned char *mask_bits,
+                   float *dsum);
+
 // ------------------------------------------------------------------ direct first-layer conv (direct.hip)
 struct DirectArgs {
     const float *in;

@@ -89,6 +89,7 @@ struct Layer {
     // plane-sweep engine (c3d.hip) for the conv under the fused two-class head (and its backward): plans on the conv layer,
     // per-(patch, wave) partials of the logit difference / of the head's input sum on the head layer
     C3dPlan c3f, c3b;
+    T3dPlan t3f, t3b;                      // row-sweep engine for the stride-2 conv_transpose (t3d.hip), forward / backward-data
     float *c3_part = nullptr, *c3_asum = nullptr;
     unsigned short *fc_wv16c = nullptr;    // fc_wv as fp16 pairs at their true scale, [voxel][h8 | l8] (c3d_presplit_vec), for c3b
     const unsigned short *dout_vec16c = nullptr;   // set on the conv below for one backward pass, like dout_vec16
@@ -152,6 +153,8 @@ struct alq_model {
     int c3_bwd_rows = 8;           // ALQ_C3D_BWD_ROWS=4 (A/B): the plane-sweep backward kernel in its half-patch form
     bool last_c3 = false;          // the last forward pass ran the head conv on the plane-sweep engine
     bool last_c3_bwd = false;      // ... and the last backward pass its backward
+    int no_t3d = 0;                // ALQ_NO_T3D (A/B): conv_transpose launches on the two-slot engine (igemm4) as in round 4
+    int last_t3f = 0, last_t3b = 0;   // conv_transpose launches of the last forward / backward pass that ran on the row-sweep engine
     bool last_f16_derived = false; // the last forward pass ran a launch on the fp16x2 split with derived input bounds
 
     template <typename T>
@@ -668,6 +671,8 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
                     ALQ_TRY(igemm4_build_plan(gf, NB, &ly.fwd_all));
                 }
             }
+            if (!sp.relu) ALQ_TRY(t3d_build(ly.in, ly.out, sp.k, ly.lo, sp.s, &ly.t3f, &ly.t3b));
+            if (first_param) ly.t3b.ok = false;
             if (!first_param) {
                 ConvDesc b;
                 b.ID = ly.out.D; b.IH = ly.out.H; b.IW = ly.out.W; b.Ci = sp.cout;
@@ -774,6 +779,7 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
     bool c3_head = false;        // ... of the plane-sweep engine: one partial per (patch, wave), the head's input sum likewise
     m->last_head_fused = false;
     m->last_c3 = false;
+    m->last_t3f = 0;
     // A conv / conv_transpose launch contracts with the fp16x2 split if it knows max |x| per patch of (every part of)
     // its input ahead of time: the launches that produce those tensors report them (`prod`), the consumers (`cons`)
     // read one scale per tile.  Producers: the first conv + pool kernel and one-patch-per-tile igemm4 launches.
@@ -841,6 +847,7 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
             if (!l.amax_fwd) ALQ_TRY(m->dalloc(&l.amax_fwd, (size_t)m->max_batch));
             if (l.spec.type == ALQ_CONV && !(p == 0 && use_dcp(0))) need = std::max(need, (size_t)l.fwd[0].p4.a.tpg * 4);
             if (l.spec.type == ALQ_CONVT) need = std::max(need, (size_t)l.fwd_all.a.tpg * (l.fwd_all.multi ? l.fwd_all.a.ngr : 1) * 4);
+            if (l.spec.type == ALQ_CONVT && l.t3f.ok) need = std::max(need, (size_t)16);      // row-sweep engine: one maximum per input plane
         }
         if (need > m->amax_tiles_len) { ALQ_TRY(m->dalloc(&m->amax_tiles, (size_t)m->max_batch * need)); m->amax_tiles_len = need; }
     }
@@ -960,6 +967,18 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                 break;
             }
             case ALQ_CONVT: {
+                // the row-sweep engine (t3d.hip): bf16 triples like the two-slot launch it replaces, nothing but the tensor, its channel
+                // sums and its per-patch maximum to produce (no ReLU behind a conv_transpose of this geometry: no sign field)
+                if (ly.t3f.ok && ly.t3f.d_W && !m->no_t3d && !g_dbg_knobs[3] && !g_dbg_knobs[4] && !g_dbg_knobs[5] && !cons[i] && !ly.spec.relu &&
+                    !(drop && drop->on(i)) && (!with_sums || ly.osum)) {
+                    const bool want_amax = prod[i] != 0;
+                    ALQ_TRY(t3d_fwd_launch(ctx, ly.t3f, in, ly.out, ly.d_bias, N, with_sums ? ly.osum : nullptr, want_amax ? m->amax_tiles : nullptr));
+                    if (want_amax) ALQ_TRY(k_rowmax_u32(ctx, m->amax_tiles, 16, N, ly.amax_fwd));
+                    ly.signs_ready = false;
+                    fused = true;
+                    m->last_t3f += 1;
+                    break;
+                }
                 if (ly.fwd_all.ok && !g_dbg_knobs[4] && !g_dbg_knobs[5]) {
                     const bool want_amax = fuse && prod[i];
                     if (fuse) take_amax(fz, i);
@@ -1063,6 +1082,7 @@ static int run_backward_main(alq_model *m, const float *d_x, int N) {
     ALQ_TRY(k_fill_unit_cotangent(ctx, m->dlogits, N));
     for (Layer &l : m->layers) { l.delta_ready = false; l.dsum_partial = false; l.dout_bits = nullptr; l.dout_vec = nullptr; l.dout_vec16 = nullptr; l.dout_vec16c = nullptr; l.dout_amax = nullptr; }
     m->last_c3_bwd = false;
+    m->last_t3b = 0;
     const bool v4_on = !g_dbg_knobs[4] && !g_dbg_knobs[5];
     {   // bounds on every layer's output cotangent under the unit cotangent (+1, -1): |d out| of the head = 1; a two-class
         // head hands max |W0 - W1| down, a conv / conv_transpose its L1 bound, a pool passes the bound on, a ReLU mask
@@ -1249,6 +1269,16 @@ static int run_backward_main(alq_model *m, const float *d_x, int N) {
                 }
                 const unsigned *mine = ly.dout_amax;
                 ly.dout_amax = nullptr;
+                // the row-sweep engine (t3d.hip) for the backward-data pass of a stride-2 conv_transpose: fp16 pairs under the static
+                // bound like the two-slot launch it replaces; the producer below is a ReLU conv whose sign field masks the result
+                const bool t3 = ly.spec.type == ALQ_CONVT && ly.t3b.ok && ly.t3b.d_W && !m->no_t3d && v4_on && !g_no_f16x2 && !acc && fuse && !hand &&
+                                fz.in_bound > 0.f && !fz.in_amax && fz.split == 0 && fz.store_from == 0 && fz.osumA && !fz.osumB && fz.mask_from == 0 &&
+                                (!fz.mask || fz.mask_bits) && !ly.dout.split && !ly.din.split && prev_param;
+                if (t3) {
+                    ALQ_TRY(t3d_bwd_launch(ctx, ly.t3b, ly.dout, ly.din, N, fz.in_bound, fz.mask ? fz.mask_bits : nullptr, fz.osumA));
+                    fused = true;
+                    m->last_t3b += 1;
+                } else
                 ALQ_TRY(gemm_launch(ctx, ly.bwd, ly.dout, ly.din, nullptr, 0, acc, N, PROF_IGEMM_BWD, fuse, &fused));
                 if (hand) {
                     // two buffers alternate down the chain: this launch may have read the other one
@@ -1539,6 +1569,7 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
         m->no_signs = getenv("ALQ_NO_SIGNS") != nullptr;
         m->no_signs0 = getenv("ALQ_NO_SIGNS0") != nullptr;
         if (const char *f = getenv("ALQ_F16_FWD_MASK")) m->f16_fwd_mask = atoi(f);
+        m->no_t3d = getenv("ALQ_NO_T3D") ? 1 : 0;
         {   // default since round 5: on.  ALQ_NO_F16_DERIVED=1 (or ALQ_F16_DERIVED=0) keeps that launch on bf16 triples (A/B)
             const char *e = getenv("ALQ_F16_DERIVED"), *n = getenv("ALQ_NO_F16_DERIVED");
             m->no_f16_derived = ((e && atoi(e) == 0) || (n && atoi(n) == 1)) ? 1 : 0;
@@ -1726,6 +1757,17 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
             }
         }
         if (ly.fwd_all.ok) ALQ_TRY(set4(m, &ly.fwd_all, Bfull));
+        auto up3 = [&](T3dPlan *pl) -> int {
+            unsigned short *dw = reinterpret_cast<unsigned short *>(pl->d_W);
+            if (!dw) ALQ_TRY(m->dalloc(&dw, pl->h_W.size()));
+            pl->d_W = dw;
+            ALQ_HIP(hipMemcpyAsync(dw, pl->h_W.data(), pl->h_W.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
+            ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
+            std::vector<unsigned short>().swap(pl->h_W);
+            return ALQ_OK;
+        };
+        if (ly.t3f.ok) { t3d_fwd_pack(&ly.t3f, W); ALQ_TRY(up3(&ly.t3f)); }
+        if (ly.t3b.ok && ly.has_bwd && c3d_subnormals_ok(m->ctx)) { t3d_bwd_pack(&ly.t3b, W); ALQ_TRY(up3(&ly.t3b)); }      // (one-accumulator fp16 pairs)
         if (ly.has_bwd) {
             std::vector<float> Bb(W, W + ly.w_elems);   // [(tap, co)][ci] as stored
             ALQ_TRY(gemm_set(m, &ly.bwd, Bb));
@@ -2009,8 +2051,10 @@ int alq_model_debug_copy(alq_model *m, int layer_idx, int what, int N, float *d_
 }
 
 int alq_model_engine_info(alq_model *m, int what) {
-    ALQ_REQUIRE(m && ((what >= 0 && what <= 3) || what == 5 || what == 6), ALQ_EINVAL, "alq_model_engine_info: bad argument");
+    ALQ_REQUIRE(m && ((what >= 0 && what <= 3) || (what >= 5 && what <= 8)), ALQ_EINVAL, "alq_model_engine_info: bad argument");
     if (what == 6) return m->last_f16_derived ? 1 : 0;
+    if (what == 7) return m->last_t3f;        // conv_transpose launches of the last forward pass on the row-sweep engine (t3d.hip)
+    if (what == 8) return m->last_t3b;        // ... of the last backward pass
     ALQ_HIP(hipSetDevice(m->ctx->device));
     if (what == 0) return c3d_subnormals_ok(m->ctx);
     if (what == 1) return m->last_c3 ? 1 : 0;

@@ -970,7 +970,7 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                 // the row-sweep engine (t3d.hip): bf16 triples like the two-slot launch it replaces, nothing but the tensor, its channel
                 // sums and its per-patch maximum to produce (no ReLU behind a conv_transpose of this geometry: no sign field)
                 if (ly.t3f.ok && ly.t3f.d_W && !m->no_t3d && !g_dbg_knobs[3] && !g_dbg_knobs[4] && !g_dbg_knobs[5] && !cons[i] && !ly.spec.relu &&
-                    !(drop && drop->on(i)) && (!with_sums || ly.osum)) {
+                    !(drop && drop->on(i)) && (!with_sums || ly.osum) && !(ly.t3f.kind == 8 && prod[i])) {
                     const bool want_amax = prod[i] != 0;
                     ALQ_TRY(t3d_fwd_launch(ctx, ly.t3f, in, ly.out, ly.d_bias, N, with_sums ? ly.osum : nullptr, want_amax ? m->amax_tiles : nullptr));
                     if (want_amax) ALQ_TRY(k_rowmax_u32(ctx, m->amax_tiles, 16, N, ly.amax_fwd));
@@ -1766,7 +1766,7 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
             std::vector<unsigned short>().swap(pl->h_W);
             return ALQ_OK;
         };
-        if (ly.t3f.ok) { t3d_fwd_pack(&ly.t3f, W); ALQ_TRY(up3(&ly.t3f)); }
+        if (ly.t3f.ok) { if (ly.t3f.kind == 8) t3d8_fwd_pack(&ly.t3f, W); else t3d_fwd_pack(&ly.t3f, W); ALQ_TRY(up3(&ly.t3f)); }
         if (ly.t3b.ok && ly.has_bwd && c3d_subnormals_ok(m->ctx)) { t3d_bwd_pack(&ly.t3b, W); ALQ_TRY(up3(&ly.t3b)); }      // (one-accumulator fp16 pairs)
         if (ly.has_bwd) {
             std::vector<float> Bb(W, W + ly.w_elems);   // [(tap, co)][ci] as stored

@@ -59,6 +59,9 @@ struct T3BwdArgs {
     int N;
 };
 
+#ifndef T3B_PF_N
+#define T3B_PF_N 2
+#endif
 constexpr unsigned T3_OOB = 0xffffff00u;
 #define T3_STR2(x) #x
 #define T3_STR(x) T3_STR2(x)
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void t3d_fwd_kernel(const T3FwdArgs a) {
 // (t_z, t_y) pair; fp16 pairs at their true scale, three products in one accumulator (c3d.hip's one-accumulator form: the
 // matrix cores keep fp16 subnormals, probed by c3d_subnormals_ok).  The sweep runs DOWNWARD (iy = 15 .. 0): a tile fetches the
 // rows t_y = 0, 1 of its three planes and takes t_y = 2 (row 2 iy + 2 = the t_y = 0 row of tile iy + 1) from the tile before it.
-constexpr int T3B_PF = 2;      // tiles of loads in flight per wave (6 KB each)
+constexpr int T3B_PF = T3B_PF_N;      // tiles of loads in flight per wave (6 KB each)
 template <bool MASK, bool SUMS>
 __global__ __launch_bounds__(256, 2) void t3d_bwd_kernel(const T3BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char t3lds[];
@@ -431,6 +434,142 @@ __global__ __launch_bounds__(256, 2) void t3d_bwd_kernel(const T3BwdArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------- forward, 32 -> 16 channels at 8^3
+// NET-C's `up1` (8^3 -> 16^3): 32 input channels are exactly one MFMA K block, so a B fragment (cell n, channels 8 kg .. + 7 of
+// ONE neighbour cell) is two 16-byte global loads of the lane - no LDS transpose; the 64 KB input of a patch sits in L2 (the
+// launch before wrote it), so the 8x re-read of it (once per neighbour role) never reaches HBM.  The 27 x 3 weight fragments
+// (81 KB of bf16 triples) do not fit registers: resident in LDS, one 512-thread workgroup per CU, wave w = input plane w of the
+// patch, tile = 16 cells = rows 2 j, 2 j + 1 of that plane; 8 parity accumulators [16 output channels x 16 cells].
+struct T8FwdArgs {
+    const float *in;             // [N][8][8][8][32] dense
+    float *out;                  // [N][16][16][16][16] dense
+    const unsigned short *W;     // [27 (cz, cy, cx)][3 pieces][64 lanes][8] bf16 bits (t3d8_fwd_pack)
+    const float *bias;           // [16]
+    float *osum;                 // [N][16^3] channel sums of the output, or null
+    int N;
+};
+constexpr int T8_WBYTES = 27 * 3 * 1024;
+
+template <bool SUMS>
+__global__ __launch_bounds__(512, 2) void t3d8_fwd_kernel(const T8FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char t3lds[];
+    {   // the weight fragments into LDS, once
+        const i32x4 *src = reinterpret_cast<const i32x4 *>(a.W);
+        i32x4 *dst = reinterpret_cast<i32x4 *>(t3lds);
+        for (int i = threadIdx.x; i < T8_WBYTES / 16; i += 512) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n = lane & 15, kg = lane >> 4, r = n >> 3, ix = n & 7;
+    f32x4 bias4 = *reinterpret_cast<const f32x4 *>(a.bias + 4 * kg);
+    asm volatile("" : "+v"(bias4));
+    const __amdgpu_buffer_rsrc_t in_rsrc = t3_rsrc(a.in, (unsigned long long)a.N * 8 * 8 * 8 * 32 * 4);
+    const __amdgpu_buffer_rsrc_t out_rsrc = t3_rsrc(a.out, (unsigned long long)a.N * 16 * 16 * 16 * 16 * 4);
+    const __amdgpu_buffer_rsrc_t sum_rsrc = t3_rsrc(a.osum, SUMS ? (unsigned long long)a.N * 16 * 16 * 16 * 4 : 0ull);
+    const int iz = wave;
+    const char *wl = t3lds + lane * 16;
+    const int npw = a.N > (int)blockIdx.x ? (a.N - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;      // patches of this workgroup
+    const int total = npw * 4;
+
+    // per-lane byte offset of (row r of the tile - dy, cell ix - dx, channels 8 kg ..) inside a plane, per (dy, dx); OOB where the
+    // neighbour does not exist for this lane whatever the tile (x < 0); rows < 0 and plane -1 are decided per tile
+    f32x4 X[2][8][2];      // [buffer][neighbour (dz, dy, dx)][16-byte half]
+    auto fetch = [&](int T, f32x4 (*x)[2]) __attribute__((always_inline)) {
+        const bool ok = T < total;
+        const int p = (int)blockIdx.x + (int)gridDim.x * (T >> 2), j = T & 3;
+        const unsigned pb = ((unsigned)p * 8u + (unsigned)iz) * (8u * 8 * 128);      // byte offset of plane (p, iz): 64 voxels x 128 B
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const int dz = d >> 2, dy = (d >> 1) & 1, dx = d & 1;
+            const int y = 2 * j + r - dy, x_ = ix - dx;
+            const bool v = ok && y >= 0 && x_ >= 0 && iz - dz >= 0;
+            const unsigned off = v ? (unsigned)(y * 8 + x_) * 128u + (unsigned)kg * 32u : T3_OOB;
+            const unsigned so = pb - (unsigned)dz * (8u * 8 * 128);
+            x[d][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)off, (int)so, 0));
+            x[d][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)(v ? off + 16u : T3_OOB), (int)so, 0));
+        }
+    };
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int d = 0; d < 8; ++d) { X[b][d][0] = f32x4{0.f, 0.f, 0.f, 0.f}; X[b][d][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    // straight-line body, first pass void (see t3d_fwd_kernel); two tiles per pass: buffer b serves tile T0 + b
+    if (total > 0)
+    for (int T0 = -2; T0 < total; T0 += 2) {
+        const bool live = T0 >= 0;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int T = T0 + b;
+            __builtin_amdgcn_sched_barrier(0);
+            const int Tl = live ? T : 0;
+            const int p = (int)blockIdx.x + (int)gridDim.x * (Tl >> 2), j = Tl & 3;
+            f32x4 acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const int dz = d >> 2, dy = (d >> 1) & 1, dx = d & 1;
+                // the neighbour's 8 channels as bf16 triples
+                f32x4 u0 = X[b][d][0], u1 = X[b][d][1];
+                float e0 = u0.x, e1 = u0.y, e2 = u0.z, e3 = u0.w, e4 = u1.x, e5 = u1.y, e6 = u1.z, e7 = u1.w;
+                i32x4 hi, mi, lo;
+                hi.x = (int)t3_split2(e0, e1); hi.y = (int)t3_split2(e2, e3); hi.z = (int)t3_split2(e4, e5); hi.w = (int)t3_split2(e6, e7);
+                mi.x = (int)t3_split2(e0, e1); mi.y = (int)t3_split2(e2, e3); mi.z = (int)t3_split2(e4, e5); mi.w = (int)t3_split2(e6, e7);
+                lo.x = (int)t3_pack2(e0, e1); lo.y = (int)t3_pack2(e2, e3); lo.z = (int)t3_pack2(e4, e5); lo.w = (int)t3_pack2(e6, e7);
+                const bf16x8 f0 = __builtin_bit_cast(bf16x8, hi), f1 = __builtin_bit_cast(bf16x8, mi), f2 = __builtin_bit_cast(bf16x8, lo);
+                // every output parity this neighbour feeds: per dimension d = 0 -> parities 0 (tap 0: c = 0) and 1 (tap 1: c = 2); d = 1 -> parity 0 (tap 2: c = 1)
+#pragma unroll
+                for (int qz = 0; qz < (dz ? 1 : 2); ++qz)
+#pragma unroll
+                    for (int qy = 0; qy < (dy ? 1 : 2); ++qy)
+#pragma unroll
+                        for (int qx = 0; qx < (dx ? 1 : 2); ++qx) {
+                            const int cz = dz ? 1 : (qz ? 2 : 0), cy = dy ? 1 : (qy ? 2 : 0), cx = dx ? 1 : (qx ? 2 : 0);
+                            const int pz = cz == 2, py = cy == 2, px = cx == 2;
+                            const int combo = (cz * 3 + cy) * 3 + cx;
+                            const bf16x8 w0 = *reinterpret_cast<const bf16x8 *>(wl + (combo * 3 + 0) * 1024);
+                            const bf16x8 w1 = *reinterpret_cast<const bf16x8 *>(wl + (combo * 3 + 1) * 1024);
+                            const bf16x8 w2 = *reinterpret_cast<const bf16x8 *>(wl + (combo * 3 + 2) * 1024);
+                            f32x4 c = acc[(pz * 2 + py) * 2 + px];
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, f0, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, f2, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, f1, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, f0, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, f1, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, f0, c, 0, 0, 0);
+                            acc[(pz * 2 + py) * 2 + px] = c;
+                        }
+            }
+            fetch(T + 2, X[b]);
+            // epilogue: lane = (cell (r, ix), output channels 4 kg .. + 3); output voxel (2 iz + pz, 2 (2 j + r) + py, 2 ix + px), 64 B per voxel
+            const unsigned vb = (((unsigned)p * 16u + (unsigned)(2 * iz)) * 16u + (unsigned)(2 * (2 * j + r))) * 16u + (unsigned)(2 * ix);      // voxel index at parity 0
+            f32x4 vv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                f32x4 v = acc[i];
+                v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+                vv[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int pz = i >> 2, py = (i >> 1) & 1, px = i & 1;
+                const unsigned vox = vb + (unsigned)(pz * 256 + py * 16 + px);
+                const f32x4 v = vv[i];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), out_rsrc, (int)(live ? vox * 64u + (unsigned)kg * 16u : T3_OOB), 0, 0);
+                if constexpr (SUMS) {
+                    float s_ = (v.x + v.y) + (v.z + v.w);
+                    s_ += __shfl_xor(s_, 16, 64);
+                    s_ += __shfl_xor(s_, 32, 64);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, s_), sum_rsrc, (int)((live && kg == 0) ? vox * 4u : T3_OOB), 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 3" :: "v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3]), "v"(vv[4]), "v"(vv[5]), "v"(vv[6]), "v"(vv[7]));      // (store data stays alive: t3d_fwd_kernel)
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------- host
 static bool t3_geometry(const View &in, const View &out, const int k[3], const int lo[3], const int s[3]) {
     return k[0] == 3 && k[1] == 3 && k[2] == 3 && s[0] == 2 && s[1] == 2 && s[2] == 2 && lo[0] == 0 && lo[1] == 0 && lo[2] == 0 &&
@@ -438,9 +577,22 @@ static bool t3_geometry(const View &in, const View &out, const int k[3], const i
            in.split == 0 && out.split == 0 && in.cs == 16 && in.c0 == 0 && out.cs == 8 && out.c0 == 0;
 }
 
+static bool t8_geometry(const View &in, const View &out, const int k[3], const int lo[3], const int s[3]) {
+    return k[0] == 3 && k[1] == 3 && k[2] == 3 && s[0] == 2 && s[1] == 2 && s[2] == 2 && lo[0] == 0 && lo[1] == 0 && lo[2] == 0 &&
+           in.D == 8 && in.H == 8 && in.W == 8 && out.D == 16 && out.H == 16 && out.W == 16 && in.C == 32 && out.C == 16 &&
+           in.split == 0 && out.split == 0 && in.cs == 32 && in.c0 == 0 && out.cs == 16 && out.c0 == 0;
+}
+
 int t3d_build(const View &in, const View &out, const int k[3], const int lo[3], const int s[3], T3dPlan *fwd, T3dPlan *bwd) {
     fwd->ok = bwd->ok = false;
+    fwd->kind = bwd->kind = 0;
     if (getenv("ALQ_NO_T3D")) return ALQ_OK;
+    if (t8_geometry(in, out, k, lo, s) && !getenv("ALQ_NO_T3D8")) {      // 32 -> 16 channels at 8^3: forward only
+        fwd->kind = 8;
+        fwd->flops_per_patch = 2.0 * 27 * 32 * 16 * (double)in.vox();
+        fwd->ok = true;
+        return ALQ_OK;
+    }
     if (!t3_geometry(in, out, k, lo, s)) return ALQ_OK;
     fwd->flops_per_patch = bwd->flops_per_patch = 2.0 * 27 * 16 * 8 * (double)in.vox();
     fwd->ok = bwd->ok = true;
@@ -485,6 +637,29 @@ void t3d_fwd_pack(T3dPlan *plan, const float *W) {
         }
 }
 
+// kind 8 (32 -> 16 channels): W [tap][co (16)][ci (32)]; A fragment of (cz, cy, cx): lane -> row co = lane & 15, k = ci = 8 (lane >> 4) + c;
+// tap per dimension from c: 0 -> tap 0, 1 -> tap 2, 2 -> tap 1.
+void t3d8_fwd_pack(T3dPlan *plan, const float *W) {
+    plan->h_W.assign((size_t)27 * 3 * 64 * 8, 0);
+    auto tap = [](int c) { return c == 0 ? 0 : (c == 1 ? 2 : 1); };
+    for (int cz = 0; cz < 3; ++cz)
+        for (int cy = 0; cy < 3; ++cy)
+            for (int cx = 0; cx < 3; ++cx) {
+                const int combo = (cz * 3 + cy) * 3 + cx, t = (tap(cz) * 3 + tap(cy)) * 3 + tap(cx);
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int co = lane & 15, kg = lane >> 4;
+                    for (int c = 0; c < 8; ++c) {
+                        float w = W[((size_t)t * 16 + co) * 32 + 8 * kg + c];
+                        for (int pc = 0; pc < 3; ++pc) {
+                            const unsigned short h = t3_bf16_rne(w);
+                            plan->h_W[((size_t)(combo * 3 + pc) * 64 + lane) * 8 + c] = h;
+                            w -= t3_bf16_f(h);
+                        }
+                    }
+                }
+            }
+}
+
 // Backward A fragment of (tz, ty): lane -> row ci = lane & 15, k-group = x tap tx = lane >> 4 (3: zero), k = co.  fp16 pairs of
 // w * 2^e_w at their true scale.
 void t3d_bwd_pack(T3dPlan *plan, const float *W) {
@@ -527,6 +702,27 @@ static unsigned t3_grid(alq_ctx *ctx, int N) {
 
 int t3d_fwd_launch(alq_ctx *ctx, const T3dPlan &plan, const View &in, const View &out, const float *bias, int N, float *osum, unsigned *out_amax) {
     ALQ_REQUIRE(plan.ok && plan.d_W, ALQ_EINVAL, "t3d: weights not set");
+    if (plan.kind == 8) {
+        ALQ_REQUIRE(in.cs == 32 && in.c0 == 0 && in.split == 0 && out.cs == 16 && out.c0 == 0 && out.split == 0 && in.D == 8 && in.H == 8 && in.W == 8 &&
+                    out.D == 16 && bias && !out_amax, ALQ_EINVAL, "t3d8: view mismatch");
+        ALQ_REQUIRE(N < 4096, ALQ_EUNSUPPORTED, "t3d: 32-bit byte offsets hold fewer than 4096 patches per pass");
+        if (N <= 0) return ALQ_OK;
+        T8FwdArgs a8;
+        a8.in = in.p; a8.out = out.p; a8.W = reinterpret_cast<const unsigned short *>(plan.d_W); a8.bias = bias; a8.osum = osum; a8.N = N;
+        int cus = 256;
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+        const dim3 grid8((unsigned)std::min(N, cus));
+        ProfScope ps8(ctx, PROF_IGEMM3_FWD, plan.flops_per_patch * N);
+        auto go = [&](auto kfn) -> int {
+            ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, T8_WBYTES));
+            hipLaunchKernelGGL(kfn, grid8, dim3(512), T8_WBYTES, ctx->stream, a8);
+            return ALQ_OK;
+        };
+        ALQ_TRY(osum ? go(t3d8_fwd_kernel<true>) : go(t3d8_fwd_kernel<false>));
+        ALQ_HIP(hipGetLastError());
+        return ALQ_OK;
+    }
     ALQ_REQUIRE(in.cs == 16 && in.c0 == 0 && in.split == 0 && out.cs == 8 && out.c0 == 0 && out.split == 0 && in.D == 16 && out.D == 32 && bias,
                 ALQ_EINVAL, "t3d: view mismatch");
     ALQ_REQUIRE(N < 4096, ALQ_EUNSUPPORTED, "t3d: 32-bit byte offsets hold fewer than 4096 patches per pass");

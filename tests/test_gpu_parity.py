@@ -1183,8 +1183,8 @@ def test_plane_sweep_engine_against_the_two_slot_engine(sess):
 
 
 def test_row_sweep_conv_transpose_against_the_two_slot_engine(sess):
-    """NET-C's `up2` (3x3x3 / stride-2 conv_transpose 16 -> 8, 16^3 -> 32^3; reference call site NN_extended.py:574-587) and its
-    backward-data pass on the row-sweep engine (csrc/t3d.hip, default) against the two-slot engine's launches of round 4
+    """NET-C's `up2` (3x3x3 / stride-2 conv_transpose 16 -> 8, 16^3 -> 32^3; reference call site NN_extended.py:574-587) with its
+    backward-data pass, and `up1` (32 -> 16, 8^3 -> 16^3) forward, on the row-sweep engine (csrc/t3d.hip, default) against the two-slot engine's launches of round 4
     (ALQ_NO_T3D=1): the same arithmetic (bf16 triples forward, fp16 pairs under the static cotangent bound backward) in another
     summation order.  Layer by layer on 40 patches - up2's output, the masked cotangent it hands to dec1 and dec1's channel sums,
     each within 2e-6 of the tensor's maximum - then 300 patches end to end (Fisher pass and forward-only pass): posteriors within
@@ -1196,17 +1196,26 @@ def test_row_sweep_conv_transpose_against_the_two_slot_engine(sess):
     ld, sk, in_shape, pars, (m_new, m_old) = _netc32_models(sess, [{}, {'ALQ_NO_T3D': '1'}], max_batch=n, bias_std=0.05)
     x = sess.empty((n, 32 ** 3), torch.float32)
     check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, 32 ** 3, C.c_void_p(x.data_ptr())))
-    nn_ = 40
+    nn_ = 300      # (all of them: workgroups beyond the first 256 see the patches past 64)
     inner = []
     for m in (m_new, m_old):
         m.fisher_device(x, nn_, None, 1e-3, want=('p1',))
-        inner.append({'up2_out': m.debug_tensor(7, 0, nn_), 'dec1_dout': m.debug_tensor(6, 1, nn_), 'dec1_dsum': m.debug_tensor(6, 3, nn_)})
+        inner.append({'up1_out': m.debug_tensor(5, 0, nn_), 'up2_out': m.debug_tensor(7, 0, nn_), 'dec1_dout': m.debug_tensor(6, 1, nn_),
+                      'dec1_dsum': m.debug_tensor(6, 3, nn_)})
     assert sess.lib.alq_model_engine_info(m_new._m, 7) >= 1 and sess.lib.alq_model_engine_info(m_new._m, 8) >= 1, 'row-sweep engine did not run'
     assert sess.lib.alq_model_engine_info(m_old._m, 7) == 0 and sess.lib.alq_model_engine_info(m_old._m, 8) == 0
-    for k in ('up2_out', 'dec1_dout', 'dec1_dsum'):
+    for k in ('up1_out', 'up2_out', 'dec1_dout', 'dec1_dsum'):
         a, b = inner[0][k], inner[1][k]
         assert a.shape == b.shape and np.isfinite(a).all()
-        assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max(), (k, np.abs(a - b).max(), np.abs(b).max())
+        bad = np.abs(a - b) > 2e-6 * np.abs(b).max()
+        if k.startswith('dec1_d'):
+            # The two engines' forward outputs differ in the last bits, so a pre-activation of dec1 or of the head conv within rounding
+            # of zero may be masked in one model and not in the other: whole elements then differ, around a flipped unit of the head
+            # conv the ~100 cotangent elements its 3x3x3 window reaches.  A few hundred in 20 M (the flips themselves are arbitrated
+            # end to end below); everything else must agree.
+            assert bad.sum() <= 2000, (k, int(bad.sum()))
+        else:
+            assert not bad.any(), (k, np.abs(a - b).max(), np.abs(b).max())
     out = []
     for m in (m_new, m_old):
         r = m.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1', 'A', 'Asum'))

@@ -547,13 +547,12 @@ def cpu_baseline(xs, ld, sk, in_shape, pars):
     if nall > cores:
         used = torch.get_num_threads()
         torch.set_num_threads(nall)
-        alpath.gen_A_matrices(E(), om, osess, xs[:1], p[:1], 1e-3)               # warm-up at the new thread count
+        # ONE patch, no warm-up: at batch 1 with hundreds of threads every op is oversubscribed (measured on the 256-thread GPU box:
+        # ~34 s per patch against 0.12 s at 16 threads) - the number is reported because BASELINE.md names os.cpu_count() threads
         t1 = time.perf_counter()
-        m = 0
-        while m < min(len(xs), 32) and (m < 2 or time.perf_counter() - t1 < 8.0):      # bounded: ~8 s, patch by patch
-            p2 = om.forward(xs[m:m + 1])['posteriors'][1].astype(np.float64)
-            alpath.gen_A_matrices(E(), om, osess, xs[m:m + 1], p2, 1e-3)
-            m += 1
+        m = 1
+        p2 = om.forward(xs[:1])['posteriors'][1].astype(np.float64)
+        alpath.gen_A_matrices(E(), om, osess, xs[:1], p2, 1e-3)
         dt2 = time.perf_counter() - t1
         all_cores = {'value': m / dt2, 'unit': 'patches/s', 'cores': torch.get_num_threads(), 'sample': '%d patches, %.1f s' % (m, dt2)}
         torch.set_num_threads(used)

@@ -473,11 +473,15 @@ struct FcGemmPlan {
     int K = 0, N = 0;
     std::vector<unsigned short> h_W;   // [feature tile][k-step][piece][k-group][feature row][8] bf16 bits
     void *d_W = nullptr;
+    std::vector<unsigned short> h_W16; // the same as fp16 pairs (2 pieces) of w 2^w_exp, for launches with a static input bound
+    void *d_W16 = nullptr;
+    int w_exp = 0;
 };
 int fcgemm_build_plan(int K, int N, FcGemmPlan *plan);
 void fcgemm_pack_weights(FcGemmPlan *plan, const std::vector<float> &Bmat /* [K][N] */);
+void fcgemm_pack_weights_f16(FcGemmPlan *plan, const std::vector<float> &Bmat /* [K][N] */);
 int fcgemm_launch(alq_ctx *ctx, const FcGemmPlan &plan, const View &in, const View &out, const float *bias, int relu,
-                  int M, int prof_cls);
+                  int M, int prof_cls, float in_bound = 0.f);
 
 // one contraction = general plan + (when eligible) pipelined plan / direct first-layer plan
 struct Gemm {
@@ -486,6 +490,7 @@ struct Gemm {
     Igemm3Plan p3;
     Igemm4Plan p4;
     FcGemmPlan pfc;
+    bool pfc_f16 = false;      // also pack the fp16-pair twin of pfc's weights (backward launches)
     DirectPlan pd;
 };
 

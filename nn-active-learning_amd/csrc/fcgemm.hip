@@ -12,8 +12,14 @@
 // ds_read_b128 lane group (8 rows of group q, 8 rows of group q+1) hit 16 different 16-byte bank granules.
 // The weights are the MFMA A operand (rows = features), so a lane ends up with 4 consecutive features of one
 // patch: 16-byte stores.
+// F16 (round 5): backward launches of a Fisher pass know a static bound on their input (the cotangent under the unit cotangent,
+// chained down from the head like the conv launches' - model.hip, run_backward_main): they contract with fp16 PAIRS at their true
+// scale, x 2^e = h + l, three products in one accumulator instead of six (c3d.hip's one-accumulator form; needs fp16 subnormals
+// in the matrix cores: c3d_subnormals_ok), two LDS pieces per operand instead of three.
 #include "alq_internal.h"
 
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 
 namespace alq {
@@ -23,6 +29,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int FC_BM = 128, FC_BN = 64, FC_BK = 32;
 constexpr int FC_XBYTES = 3 * 4 * FC_BM * 16;      // 24 KB
@@ -45,9 +53,13 @@ struct FcGemmArgs {
     float *C;
     const float *bias;
     int M, N, K, lda, ldc, relu;
+    float scale, inv;      // F16: 2^e_in and 2^-(e_in + e_w)
 };
 
+template <bool F16>
 __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
+    constexpr int NP = F16 ? 2 : 3;                     // pieces per operand
+    constexpr int XB = NP * 4 * FC_BM * 16, WB = NP * 4 * FC_BN * 16;
     extern __shared__ __attribute__((aligned(16))) char fc_lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -56,14 +68,14 @@ __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
     const int nt = blockIdx.x, mt = blockIdx.y;
     const int m0 = mt * FC_BM, n0 = nt * FC_BN;
     const int nks = a.K / FC_BK;
-    auto Xbuf = [&](int buf) { return fc_lds + buf * (FC_XBYTES + FC_WBYTES); };
-    auto Wbuf = [&](int buf) { return fc_lds + buf * (FC_XBYTES + FC_WBYTES) + FC_XBYTES; };
+    auto Xbuf = [&](int buf) { return fc_lds + buf * (XB + WB); };
+    auto Wbuf = [&](int buf) { return fc_lds + buf * (XB + WB) + XB; };
 
     // staging roles: activations: 2 tasks per thread, task = (row, k-group): 8 floats; weights: 3 x 16 B per thread
     const int xr0 = tid >> 2, xq = tid & 3;          // rows xr0 and xr0 + 64, k-group xq
-    const char *wsrc = reinterpret_cast<const char *>(a.Bp) + (size_t)nt * nks * FC_WBYTES + tid * 16;
+    const char *wsrc = reinterpret_cast<const char *>(a.Bp) + (size_t)nt * nks * WB + tid * 16;
     f32x4 xa[2][2];
-    i32x4 wr[3];
+    i32x4 wr[NP];
     auto fetch = [&](int ks) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -77,28 +89,42 @@ __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
                 xa[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        const char *ws = wsrc + (size_t)ks * FC_WBYTES;
+        const char *ws = wsrc + (size_t)ks * WB;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) wr[j] = *reinterpret_cast<const i32x4 *>(ws + j * 4096);
+        for (int j = 0; j < NP; ++j) wr[j] = *reinterpret_cast<const i32x4 *>(ws + j * 4096);
     };
     auto stash = [&](int buf) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             float v[8] = {xa[t][0].x, xa[t][0].y, xa[t][0].z, xa[t][0].w, xa[t][1].x, xa[t][1].y, xa[t][1].z, xa[t][1].w};
-            i32x4 pc[3];
+            i32x4 pc[NP];
+            if constexpr (F16) {
+                int hh[4], ll[4];
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                pc[p].x = (int)fc_split2(v[0], v[1]); pc[p].y = (int)fc_split2(v[2], v[3]);
-                pc[p].z = (int)fc_split2(v[4], v[5]); pc[p].w = (int)fc_split2(v[6], v[7]);
+                for (int j = 0; j < 4; ++j) {
+                    const float x0 = v[2 * j] * a.scale, x1 = v[2 * j + 1] * a.scale;
+                    const f16x2 h = __builtin_convertvector(f32x2{x0, x1}, f16x2);
+                    const f16x2 l = __builtin_convertvector(f32x2{x0 - (float)h.x, x1 - (float)h.y}, f16x2);
+                    hh[j] = __builtin_bit_cast(int, h);
+                    ll[j] = __builtin_bit_cast(int, l);
+                }
+                pc[0] = i32x4{hh[0], hh[1], hh[2], hh[3]};
+                pc[1] = i32x4{ll[0], ll[1], ll[2], ll[3]};
+            } else {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    pc[p].x = (int)fc_split2(v[0], v[1]); pc[p].y = (int)fc_split2(v[2], v[3]);
+                    pc[p].z = (int)fc_split2(v[4], v[5]); pc[p].w = (int)fc_split2(v[6], v[7]);
+                }
+                pc[NP - 1].x = (int)fc_pack2(v[0], v[1]); pc[NP - 1].y = (int)fc_pack2(v[2], v[3]);
+                pc[NP - 1].z = (int)fc_pack2(v[4], v[5]); pc[NP - 1].w = (int)fc_pack2(v[6], v[7]);
             }
-            pc[2].x = (int)fc_pack2(v[0], v[1]); pc[2].y = (int)fc_pack2(v[2], v[3]);
-            pc[2].z = (int)fc_pack2(v[4], v[5]); pc[2].w = (int)fc_pack2(v[6], v[7]);
             const int row = xr0 + t * 64;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<i32x4 *>(Xbuf(buf) + ((p * 4 + xq) * FC_BM + row) * 16) = pc[p];
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<i32x4 *>(Xbuf(buf) + ((p * 4 + xq) * FC_BM + row) * 16) = pc[p];
         }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) *reinterpret_cast<i32x4 *>(Wbuf(buf) + tid * 16 + j * 4096) = wr[j];
+        for (int j = 0; j < NP; ++j) *reinterpret_cast<i32x4 *>(Wbuf(buf) + tid * 16 + j * 4096) = wr[j];
     };
 
     // wave tile: 64 patches x 32 features = 4 x 2 MFMA tiles
@@ -110,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
         for (int ni = 0; ni < 2; ++ni) {
             acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int n = n0 + wn + ni * 16 + lq * 4;
-            if (a.bias) acc[mi][ni] = *reinterpret_cast<const f32x4 *>(a.bias + n);
+            if (!F16 && a.bias) acc[mi][ni] = *reinterpret_cast<const f32x4 *>(a.bias + n);      // (F16 launches carry no bias: the host checks)
         }
 
     fetch(0);
@@ -119,28 +145,36 @@ __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
     for (int ks = 0; ks < nks; ++ks) {
         const int buf = ks & 1;
         if (ks + 1 < nks) fetch(ks + 1);
-        bf16x8 Wf[3][2], Xf[3][4];
+        i32x4 Wf[NP][2], Xf[NP][4];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
-                Wf[p][ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4 *>(Wbuf(buf) + ((p * 4 + lq) * FC_BN + wn + ni * 16 + lrow) * 16));
+                Wf[p][ni] = *reinterpret_cast<const i32x4 *>(Wbuf(buf) + ((p * 4 + lq) * FC_BN + wn + ni * 16 + lrow) * 16);
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
-                Xf[p][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4 *>(Xbuf(buf) + ((p * 4 + lq) * FC_BM + wm + mi * 16 + lrow) * 16));
+                Xf[p][mi] = *reinterpret_cast<const i32x4 *>(Xbuf(buf) + ((p * 4 + lq) * FC_BM + wm + mi * 16 + lrow) * 16);
         }
-        // six piece products, smallest first
+        // the piece products, smallest first
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 f32x4 c = acc[mi][ni];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[1][ni], Xf[1][mi], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[2][ni], Xf[0][mi], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[0][ni], Xf[2][mi], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[1][ni], Xf[0][mi], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[0][ni], Xf[1][mi], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[0][ni], Xf[0][mi], c, 0, 0, 0);
+                if constexpr (F16) {
+                    auto H = [](const i32x4 &v) { return __builtin_bit_cast(f16x8, v); };
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(H(Wf[1][ni]), H(Xf[0][mi]), c, 0, 0, 0);      // (l, h) (h, l) (h, h)
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(H(Wf[0][ni]), H(Xf[1][mi]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(H(Wf[0][ni]), H(Xf[0][mi]), c, 0, 0, 0);
+                } else {
+                    auto B = [](const i32x4 &v) { return __builtin_bit_cast(bf16x8, v); };
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B(Wf[1][ni]), B(Xf[1][mi]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B(Wf[NP - 1][ni]), B(Xf[0][mi]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B(Wf[0][ni]), B(Xf[NP - 1][mi]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B(Wf[1][ni]), B(Xf[0][mi]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B(Wf[0][ni]), B(Xf[1][mi]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B(Wf[0][ni]), B(Xf[0][mi]), c, 0, 0, 0);
+                }
                 acc[mi][ni] = c;
             }
         if (ks + 1 < nks) stash(buf ^ 1);
@@ -153,6 +187,7 @@ __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             f32x4 v = acc[mi][ni];
+            if constexpr (F16) { v.x *= a.inv; v.y *= a.inv; v.z *= a.inv; v.w *= a.inv; }
             if (a.relu) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
@@ -204,18 +239,62 @@ void fcgemm_pack_weights(FcGemmPlan *plan, const std::vector<float> &Bmat /* [K]
         }
 }
 
+// fp16 pairs of w 2^e_w at their true scale: [feature tile][k-step][piece (h, l)][k-group q][feature row][8 fp16 along k]
+void fcgemm_pack_weights_f16(FcGemmPlan *plan, const std::vector<float> &Bmat /* [K][N] */) {
+    const int K = plan->K, N = plan->N;
+    const int nks = K / FC_BK, ntl = N / FC_BN;
+    float amax = 0.f;
+    for (float w : Bmat) amax = std::max(amax, std::fabs(w));
+    int ex = 0;
+    if (amax > 0.f) (void)std::frexp(amax, &ex);
+    plan->w_exp = 14 - ex;
+    const size_t blk_elems = (size_t)2 * 4 * FC_BN * 8;
+    plan->h_W16.assign((size_t)K * N * 2, 0);
+    for (int nt = 0; nt < ntl; ++nt)
+        for (int ks = 0; ks < nks; ++ks) {
+            unsigned short *blk = &plan->h_W16[((size_t)nt * nks + ks) * blk_elems];
+            for (int q = 0; q < 4; ++q)
+                for (int r = 0; r < FC_BN; ++r)
+                    for (int j = 0; j < 8; ++j) {
+                        const float ws = std::ldexp(Bmat[(size_t)(ks * FC_BK + q * 8 + j) * N + nt * FC_BN + r], plan->w_exp);
+                        const _Float16 h = (_Float16)ws;
+                        const _Float16 l = (_Float16)(ws - (float)h);
+                        unsigned short hb, lb;
+                        std::memcpy(&hb, &h, 2);
+                        std::memcpy(&lb, &l, 2);
+                        blk[((size_t)(0 * 4 + q) * FC_BN + r) * 8 + j] = hb;
+                        blk[((size_t)(1 * 4 + q) * FC_BN + r) * 8 + j] = lb;
+                    }
+        }
+}
+
 int fcgemm_launch(alq_ctx *ctx, const FcGemmPlan &plan, const View &in, const View &out, const float *bias, int relu,
-                  int M, int prof_cls) {
+                  int M, int prof_cls, float in_bound) {
     ALQ_REQUIRE(plan.d_W && in.C == plan.K && out.C == plan.N && in.c0 == 0 && out.c0 == 0 && in.cs % 4 == 0 && out.cs % 4 == 0 &&
                     in.vox() == 1 && out.vox() == 1,
                 ALQ_EINVAL, "fcgemm: views do not match the plan");
     FcGemmArgs a;
     a.A = in.p; a.Bp = plan.d_W; a.C = out.p; a.bias = bias;
     a.M = M; a.N = plan.N; a.K = plan.K; a.lda = in.cs; a.ldc = out.cs; a.relu = relu;
+    a.scale = 1.f; a.inv = 1.f;
+    const dim3 grid(plan.N / FC_BN, (M + FC_BM - 1) / FC_BM);
+    if (in_bound > 0.f && plan.d_W16 && !bias) {      // fp16 pairs under a static bound on the input (a backward launch of a Fisher pass)
+        int ex = 0;
+        (void)std::frexp(in_bound, &ex);
+        const int e_in = 14 - ex;
+        a.Bp = plan.d_W16;
+        a.scale = std::ldexp(1.f, e_in); a.inv = std::ldexp(1.f, -(e_in + plan.w_exp));
+        const size_t lds16 = 2 * (2 * 4 * FC_BM * 16 + 2 * 4 * FC_BN * 16);
+        ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fcgemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+        ProfScope ps16(ctx, PROF_IGEMM_F16, 2.0 * M * (double)plan.K * plan.N);
+        hipLaunchKernelGGL(fcgemm_kernel<true>, grid, dim3(256), lds16, ctx->stream, a);
+        ALQ_HIP(hipGetLastError());
+        return ALQ_OK;
+    }
     const size_t lds = 2 * (FC_XBYTES + FC_WBYTES);
-    ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fcgemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fcgemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope ps(ctx, prof_cls, 2.0 * M * (double)plan.K * plan.N);
-    hipLaunchKernelGGL(fcgemm_kernel, dim3(plan.N / FC_BN, (M + FC_BM - 1) / FC_BM), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL(fcgemm_kernel<false>, grid, dim3(256), lds, ctx->stream, a);
     ALQ_HIP(hipGetLastError());
     return ALQ_OK;
 }

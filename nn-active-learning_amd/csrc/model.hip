@@ -297,6 +297,15 @@ static int gemm_set(alq_model *m, Gemm *g, const std::vector<float> &Bmat) {
                                m->ctx->stream));
         ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
         std::vector<unsigned short>().swap(g->pfc.h_W);
+        if (g->pfc_f16 && c3d_subnormals_ok(m->ctx)) {      // the fp16-pair twin for launches with a static input bound (backward, Fisher pass)
+            fcgemm_pack_weights_f16(&g->pfc, Bmat);
+            unsigned short *dw16 = reinterpret_cast<unsigned short *>(g->pfc.d_W16);
+            if (!dw16) ALQ_TRY(m->dalloc(&dw16, g->pfc.h_W16.size()));
+            g->pfc.d_W16 = dw16;
+            ALQ_HIP(hipMemcpyAsync(dw16, g->pfc.h_W16.data(), g->pfc.h_W16.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
+            ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
+            std::vector<unsigned short>().swap(g->pfc.h_W16);
+        }
     }
     if (g->pd.ok) {      // direct kernel reads the B matrix [K][Co] as it is
         if (!g->pd.d_W) ALQ_TRY(m->dalloc(&g->pd.d_W, Bmat.size()));
@@ -338,14 +347,15 @@ static int gemm_set(alq_model *m, Gemm *g, const std::vector<float> &Bmat) {
 
 // returns in *fused whether the epilogue fusion request was honoured (only the pipelined kernel can)
 static int gemm_launch(alq_ctx *ctx, const Gemm &g, const View &in, const View &out, const float *bias, int relu,
-                       int accumulate, int N, int cls, const Igemm2Fuse *fuse = nullptr, bool *fused = nullptr) {
+                       int accumulate, int N, int cls, const Igemm2Fuse *fuse = nullptr, bool *fused = nullptr, float fc_in_bound = 0.f) {
     if (g.pd.ok && !accumulate && !(fuse && (fuse->mask || fuse->osumB || fuse->split))) {
         if (fused) *fused = fuse != nullptr;
         return direct_launch(ctx, g.pd, in, out, bias, relu, N, fuse ? fuse->osumA : nullptr, PROF_DIRECT);
     }
     if (g.pfc.ok && !accumulate && !fuse && !g_dbg_knobs[4] && !g_dbg_knobs[5]) {     // wide fc layer: streaming bf16x3 GEMM
         if (fused) *fused = false;
-        return fcgemm_launch(ctx, g.pfc, in, out, bias, relu, N, cls == PROF_IGEMM_BWD ? PROF_IGEMM3_BWD : PROF_IGEMM3_FWD);
+        return fcgemm_launch(ctx, g.pfc, in, out, bias, relu, N, cls == PROF_IGEMM_BWD ? PROF_IGEMM3_BWD : PROF_IGEMM3_FWD,
+                             (g_no_f16x2 || bias || relu) ? 0.f : fc_in_bound);
     }
     const bool split_view = in.split != 0 || out.split != 0;
     ALQ_REQUIRE(!split_view || g.p4.ok, ALQ_EUNSUPPORTED, "split concat view without a two-slot plan");
@@ -731,6 +741,7 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
                     ConvDesc b = d;
                     b.Ci = sp.cout; b.Co = (int)ly.F;
                     ALQ_TRY(gemm_build(b, NB, &ly.bwd));
+                    ly.bwd.pfc_f16 = ly.bwd.pfc.ok && !getenv("ALQ_NO_FC_F16");      // backward launch: fp16 pairs under the static cotangent bound
                     ly.has_bwd = true;
                 }
             }
@@ -1093,7 +1104,8 @@ static int run_backward_main(alq_model *m, const float *d_x, int N) {
         for (int i = nl - 1; i >= 1; --i) {
             const Layer &ly = m->layers[i];
             double inb = ly.dout_bound;
-            if (ly.spec.type == ALQ_FC) inb = (ly.spec.cout == 2 && ly.fc_wv_amax > 0.f && i == nl - 1) ? (double)ly.fc_wv_amax : 0.0;
+            if (ly.spec.type == ALQ_FC)      // the head: max |W0 - W1|; a hidden fc layer: its L1 bound like a conv's (set with the weights)
+                inb = (ly.spec.cout == 2 && ly.fc_wv_amax > 0.f && i == nl - 1) ? (double)ly.fc_wv_amax : (i < nl - 1 ? ly.bwd_l1 * ly.dout_bound : 0.0);
             else if (ly.spec.type != ALQ_POOL) inb = ly.bwd_l1 * ly.dout_bound;
             if (!(inb > 0.0) || ly.dout_bound <= 0.f) inb = 0.0;       // unknown upstream: no bound below either
             auto add = [&](Layer &p) { p.dout_bound = (p.dout_bound < 0.f || inb <= 0.0) ? -1.f : p.dout_bound + (float)(inb * (1.0 + 1e-6)); };
@@ -1187,7 +1199,9 @@ static int run_backward_main(alq_model *m, const float *d_x, int N) {
                                        (can && prev->spec.relu) ? prev->out.p : nullptr, can ? prev->dsum : nullptr,
                                        can ? prev->out.C : 0, &fused));
             } else {
-                ALQ_TRY(gemm_launch(ctx, ly.bwd, ly.dout, flat_view(ly.din), nullptr, 0, 0, N, PROF_IGEMM_BWD));
+                // a wide fc layer's backward GEMM on fp16 pairs under the static bound on its input cotangent (fcgemm.hip, F16)
+                ALQ_TRY(gemm_launch(ctx, ly.bwd, ly.dout, flat_view(ly.din), nullptr, 0, 0, N, PROF_IGEMM_BWD, nullptr, nullptr,
+                                    (ly.dout_bound > 0.f && !m->no_bound16) ? ly.dout_bound : 0.f));
             }
         } else {
             Igemm2Fuse fz;
@@ -1323,7 +1337,9 @@ static int run_backward_general(alq_model *m, int N, const DropSpec *drop) {
                 bool fused = false;
                 ALQ_TRY(k_fc_small_bwd(ctx, ly.dout.p, ly.spec.cout, ly.d_Wp, ly.F, N, ly.din.p, nullptr, nullptr, 0, &fused));
             } else {
-                ALQ_TRY(gemm_launch(ctx, ly.bwd, ly.dout, flat_view(ly.din), nullptr, 0, 0, N, PROF_IGEMM_BWD));
+                // a wide fc layer's backward GEMM on fp16 pairs under the static bound on its input cotangent (fcgemm.hip, F16)
+                ALQ_TRY(gemm_launch(ctx, ly.bwd, ly.dout, flat_view(ly.din), nullptr, 0, 0, N, PROF_IGEMM_BWD, nullptr, nullptr,
+                                    (ly.dout_bound > 0.f && !m->no_bound16) ? ly.dout_bound : 0.f));
             }
         } else {
             ALQ_TRY(gemm_launch(ctx, ly.bwd, ly.dout, ly.din, nullptr, 0, acc, N, PROF_IGEMM_BWD));
@@ -1786,8 +1802,19 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
                         const int64_t ft = (((int64_t)c * Wd + w) * H + h) * D + d;
                         for (int o = 0; o < Co; ++o) Wp[(size_t)o * F + fm] = W[(size_t)o * F + ft];
                     }
+        {   // |cotangent of input f| <= sum_o |W[o][f]| * max |cotangent of the output|: the layer's L1 bound for the chain of static
+            // fp16x2 bounds of the backward pass (like bwd_l1 of a conv)
+            std::vector<double> col((size_t)F, 0.0);
+            for (int o = 0; o < Co; ++o)
+                for (int64_t f = 0; f < F; ++f) col[(size_t)f] += std::fabs((double)W[(size_t)o * F + f]);
+            double best = 0;
+            for (int64_t f = 0; f < F; ++f) best = std::max(best, col[(size_t)f]);
+            ly.bwd_l1 = best;
+        }
         if (ly.dense_fc_small) {
             ly.fc_wv_amax = 0.f;
+            if (Co == 2 && !ly.fc_wv)      // a two-class head that is not fused into a conv: still the bound its input cotangent obeys under the unit cotangent
+                for (int64_t f = 0; f < F; ++f) ly.fc_wv_amax = std::max(ly.fc_wv_amax, std::fabs((0.f + Wp[(size_t)f]) - Wp[(size_t)F + f]));
             if (Co == 2 && ly.fc_wv) {      // the head's input cotangent under the unit cotangent (+1, -1): W0 - W1, set with the weights
                 std::vector<float> wv((size_t)F);
                 for (int64_t f = 0; f < F; ++f) {

@@ -435,11 +435,14 @@ __global__ __launch_bounds__(256, 2) void t3d_bwd_kernel(const T3BwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------- forward, 32 -> 16 channels at 8^3
-// NET-C's `up1` (8^3 -> 16^3): 32 input channels are exactly one MFMA K block, so a B fragment (cell n, channels 8 kg .. + 7 of
-// ONE neighbour cell) is two 16-byte global loads of the lane - no LDS transpose; the 64 KB input of a patch sits in L2 (the
-// launch before wrote it), so the 8x re-read of it (once per neighbour role) never reaches HBM.  The 27 x 3 weight fragments
-// (81 KB of bf16 triples) do not fit registers: resident in LDS, one 512-thread workgroup per CU, wave w = input plane w of the
-// patch, tile = 16 cells = rows 2 j, 2 j + 1 of that plane; 8 parity accumulators [16 output channels x 16 cells].
+// NET-C's `up1` (8^3 -> 16^3).  32 input channels are exactly one MFMA K block: a B fragment is (cell n, channels 8 kg .. + 7 of
+// ONE neighbour cell), so there are 27 (parity, neighbour) MFMA groups per tile and 8 parity accumulators [16 output channels x 16
+// cells]; the 27 x 3 weight fragments (81 KB of bf16 triples) do not fit registers: resident in LDS, ONE 512-thread workgroup per
+// CU, wave w = input plane w of the patch, tile = 16 cells = rows 2 j, 2 j + 1 of that plane (four tiles per plane, unrolled: the
+// ring slots of the rows are compile-time constants).  Rows are split ONCE (bf16 triples) into a wave-private strip of three row
+// slots per plane (rows 2 j - 1, 2 j, 2 j + 1: the first is the previous tile's last); a first version took the B fragments
+// straight from global memory and split every voxel eight times - 640 vector instructions per 162 MFMAs, matrix pipe 33 % busy.
+// x = -1 has no slot (81 KB + 8 strips fill the 160 KB): the d_x = 1 fragments of the lanes ix = 0 are cleared by a select.
 struct T8FwdArgs {
     const float *in;             // [N][8][8][8][32] dense
     float *out;                  // [N][16][16][16][16] dense
@@ -449,6 +452,10 @@ struct T8FwdArgs {
     int N;
 };
 constexpr int T8_WBYTES = 27 * 3 * 1024;
+constexpr int T8_ROWB = 8 * 64 + 32;               // 8 voxels x 32 channels x 2 B, + 32: rows r = 0 / 1 of a fragment read land on disjoint banks
+constexpr int T8_SLOT = 3 * T8_ROWB;               // the three pieces of a row
+constexpr int T8_PLANE = 3 * T8_SLOT;              // three row slots
+constexpr int T8_WAVE = 2 * T8_PLANE;              // planes iz, iz - 1
 
 template <bool SUMS>
 __global__ __launch_bounds__(512, 2) void t3d8_fwd_kernel(const T8FwdArgs a) {
@@ -461,6 +468,7 @@ __global__ __launch_bounds__(512, 2) void t3d8_fwd_kernel(const T8FwdArgs a) {
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n = lane & 15, kg = lane >> 4, r = n >> 3, ix = n & 7;
+    char *strip = t3lds + T8_WBYTES + wave * T8_WAVE;
     f32x4 bias4 = *reinterpret_cast<const f32x4 *>(a.bias + 4 * kg);
     asm volatile("" : "+v"(bias4));
     const __amdgpu_buffer_rsrc_t in_rsrc = t3_rsrc(a.in, (unsigned long long)a.N * 8 * 8 * 8 * 32 * 4);
@@ -469,55 +477,77 @@ __global__ __launch_bounds__(512, 2) void t3d8_fwd_kernel(const T8FwdArgs a) {
     const int iz = wave;
     const char *wl = t3lds + lane * 16;
     const int npw = a.N > (int)blockIdx.x ? (a.N - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;      // patches of this workgroup
-    const int total = npw * 4;
+    // staging: a row = 8 voxels x 32 channels = 1 KB: lane -> voxel lane >> 3, channels 4 (lane & 7) .. + 3
+    const unsigned ld_off = (unsigned)lane * 16u;
+    const int w_off = (lane >> 3) * 64 + (lane & 7) * 8;
+    // fragments: cell (r, ix), neighbour d_x: voxel ix - d_x (ix = 0, d_x = 1: cleared), channels 8 kg .. + 7
+    const int f_off0 = ix * 64 + kg * 16, f_off1 = (ix > 0 ? ix - 1 : 0) * 64 + kg * 16;
+    const int keepx = ix > 0 ? -1 : 0;
 
-    // per-lane byte offset of (row r of the tile - dy, cell ix - dx, channels 8 kg ..) inside a plane, per (dy, dx); OOB where the
-    // neighbour does not exist for this lane whatever the tile (x < 0); rows < 0 and plane -1 are decided per tile
-    f32x4 X[2][8][2];      // [buffer][neighbour (dz, dy, dx)][16-byte half]
-    auto fetch = [&](int T, f32x4 (*x)[2]) __attribute__((always_inline)) {
-        const bool ok = T < total;
-        const int p = (int)blockIdx.x + (int)gridDim.x * (T >> 2), j = T & 3;
-        const unsigned pb = ((unsigned)p * 8u + (unsigned)iz) * (8u * 8 * 128);      // byte offset of plane (p, iz): 64 voxels x 128 B
-#pragma unroll
-        for (int d = 0; d < 8; ++d) {
-            const int dz = d >> 2, dy = (d >> 1) & 1, dx = d & 1;
-            const int y = 2 * j + r - dy, x_ = ix - dx;
-            const bool v = ok && y >= 0 && x_ >= 0 && iz - dz >= 0;
-            const unsigned off = v ? (unsigned)(y * 8 + x_) * 128u + (unsigned)kg * 32u : T3_OOB;
-            const unsigned so = pb - (unsigned)dz * (8u * 8 * 128);
-            x[d][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)off, (int)so, 0));
-            x[d][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)(v ? off + 16u : T3_OOB), (int)so, 0));
-        }
+    f32x4 R[2][4];      // [buffer][plane iz: rows 2 j, 2 j + 1; plane iz - 1: rows 2 j, 2 j + 1]
+    auto fetch = [&](int u, int j, f32x4 *rr) __attribute__((always_inline)) {      // the four rows of tile j of unit u (patch blockIdx + gridDim u)
+        const bool ok = u >= 0 && u < npw;
+        const int p = (int)blockIdx.x + (int)gridDim.x * (ok ? u : 0);
+        const unsigned pb = (((unsigned)p * 8u + (unsigned)iz) * 8u + (unsigned)(2 * j)) * 1024u;      // row (p, iz, 2 j)
+        const unsigned o0 = ok ? ld_off : T3_OOB, o1 = (ok && iz > 0) ? ld_off : T3_OOB;
+        rr[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)o0, (int)pb, 0));
+        rr[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)o0, (int)(pb + 1024u), 0));
+        rr[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)o1, (int)(pb - 8u * 1024u), 0));
+        rr[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)o1, (int)(pb - 8u * 1024u + 1024u), 0));
     };
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int d = 0; d < 8; ++d) { X[b][d][0] = f32x4{0.f, 0.f, 0.f, 0.f}; X[b][d][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int i = 0; i < 4; ++i) R[b][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // straight-line body, first pass void (see t3d_fwd_kernel); two tiles per pass: buffer b serves tile T0 + b
-    if (total > 0)
-    for (int T0 = -2; T0 < total; T0 += 2) {
-        const bool live = T0 >= 0;
+    // one pass of the loop = the four tiles of one plane (unit u = one patch), straight-line; pass u = -1 is void and only fetches
+    // (see t3d_fwd_kernel); tile j uses buffer j & 1 and refills it with tile j + 2 (of the next unit for j = 2, 3)
+    if (npw > 0)
+    for (int u = -1; u < npw; ++u) {
+        const bool live = u >= 0;
+        const int p = (int)blockIdx.x + (int)gridDim.x * (live ? u : 0);
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int T = T0 + b;
+        for (int j = 0; j < 4; ++j) {
             __builtin_amdgcn_sched_barrier(0);
-            const int Tl = live ? T : 0;
-            const int p = (int)blockIdx.x + (int)gridDim.x * (Tl >> 2), j = Tl & 3;
+            const int b = j & 1;
+            // ring: row y of the plane sits in slot (y + 1) % 3, so tile j has its rows 2 j - 1, 2 j, 2 j + 1 in slots s0, s0 + 1, s0 + 2 (mod 3)
+            const int s0 = (2 * j) % 3;
+            if (j == 0) {      // row -1 does not exist: its slot holds zeros for this tile
+                for (int i = lane; i < 2 * 3 * (T8_ROWB / 16); i += 64) {
+                    const int pl = i / (3 * (T8_ROWB / 16)), q = i % (3 * (T8_ROWB / 16));
+                    *reinterpret_cast<i32x4 *>(strip + pl * T8_PLANE + s0 * T8_SLOT + q * 16) = i32x4{0, 0, 0, 0};
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {      // split rows (plane i >> 1, row 2 j + (i & 1)) into slots s0 + 1, s0 + 2
+                const int pl = i >> 1, sl = (s0 + 1 + (i & 1)) % 3;
+                float x = R[b][i].x, y = R[b][i].y, z = R[b][i].z, w = R[b][i].w;
+                const unsigned h0 = t3_split2(x, y), h1 = t3_split2(z, w);
+                const unsigned m0 = t3_split2(x, y), m1 = t3_split2(z, w);
+                char *dst = strip + pl * T8_PLANE + sl * T8_SLOT + w_off;
+                *reinterpret_cast<i32x2 *>(dst) = i32x2{(int)h0, (int)h1};
+                *reinterpret_cast<i32x2 *>(dst + T8_ROWB) = i32x2{(int)m0, (int)m1};
+                *reinterpret_cast<i32x2 *>(dst + 2 * T8_ROWB) = i32x2{(int)t3_pack2(x, y), (int)t3_pack2(z, w)};
+            }
+            fetch(j < 2 ? u : u + 1, (j + 2) & 3, R[b]);
+            // per lane: the slot of row (2 j + r - d_y): d_y = 0 -> s0 + 1 + r, d_y = 1 -> s0 + r (mod 3)
+            const int ro0 = (r ? (s0 + 2) % 3 : (s0 + 1) % 3) * T8_SLOT, ro1 = (r ? (s0 + 1) % 3 : s0 % 3) * T8_SLOT;
             f32x4 acc[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // (tried on the device and dropped, each within +-4 % of this form: requesting the weight fragments of the next one / three
+            // groups ahead of the MFMAs by hand, interleaving the MFMA chains of two groups; without the stores the kernel takes 170 us)
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
                 const int dz = d >> 2, dy = (d >> 1) & 1, dx = d & 1;
-                // the neighbour's 8 channels as bf16 triples
-                f32x4 u0 = X[b][d][0], u1 = X[b][d][1];
-                float e0 = u0.x, e1 = u0.y, e2 = u0.z, e3 = u0.w, e4 = u1.x, e5 = u1.y, e6 = u1.z, e7 = u1.w;
-                i32x4 hi, mi, lo;
-                hi.x = (int)t3_split2(e0, e1); hi.y = (int)t3_split2(e2, e3); hi.z = (int)t3_split2(e4, e5); hi.w = (int)t3_split2(e6, e7);
-                mi.x = (int)t3_split2(e0, e1); mi.y = (int)t3_split2(e2, e3); mi.z = (int)t3_split2(e4, e5); mi.w = (int)t3_split2(e6, e7);
-                lo.x = (int)t3_pack2(e0, e1); lo.y = (int)t3_pack2(e2, e3); lo.z = (int)t3_pack2(e4, e5); lo.w = (int)t3_pack2(e6, e7);
-                const bf16x8 f0 = __builtin_bit_cast(bf16x8, hi), f1 = __builtin_bit_cast(bf16x8, mi), f2 = __builtin_bit_cast(bf16x8, lo);
+                const char *src = strip + dz * T8_PLANE + (dy ? ro1 : ro0) + (dx ? f_off1 : f_off0);
+                i32x4 q0 = *reinterpret_cast<const i32x4 *>(src), q1 = *reinterpret_cast<const i32x4 *>(src + T8_ROWB), q2 = *reinterpret_cast<const i32x4 *>(src + 2 * T8_ROWB);
+                if (dx) {
+                    q0.x &= keepx; q0.y &= keepx; q0.z &= keepx; q0.w &= keepx;
+                    q1.x &= keepx; q1.y &= keepx; q1.z &= keepx; q1.w &= keepx;
+                    q2.x &= keepx; q2.y &= keepx; q2.z &= keepx; q2.w &= keepx;
+                }
+                const bf16x8 f0 = __builtin_bit_cast(bf16x8, q0), f1 = __builtin_bit_cast(bf16x8, q1), f2 = __builtin_bit_cast(bf16x8, q2);
                 // every output parity this neighbour feeds: per dimension d = 0 -> parities 0 (tap 0: c = 0) and 1 (tap 1: c = 2); d = 1 -> parity 0 (tap 2: c = 1)
 #pragma unroll
                 for (int qz = 0; qz < (dz ? 1 : 2); ++qz)
@@ -541,7 +571,6 @@ __global__ __launch_bounds__(512, 2) void t3d8_fwd_kernel(const T8FwdArgs a) {
                             acc[(pz * 2 + py) * 2 + px] = c;
                         }
             }
-            fetch(T + 2, X[b]);
             // epilogue: lane = (cell (r, ix), output channels 4 kg .. + 3); output voxel (2 iz + pz, 2 (2 j + r) + py, 2 ix + px), 64 B per voxel
             const unsigned vb = (((unsigned)p * 16u + (unsigned)(2 * iz)) * 16u + (unsigned)(2 * (2 * j + r))) * 16u + (unsigned)(2 * ix);      // voxel index at parity 0
             f32x4 vv[8];
@@ -555,13 +584,21 @@ __global__ __launch_bounds__(512, 2) void t3d8_fwd_kernel(const T8FwdArgs a) {
             for (int i = 0; i < 8; ++i) {
                 const int pz = i >> 2, py = (i >> 1) & 1, px = i & 1;
                 const unsigned vox = vb + (unsigned)(pz * 256 + py * 16 + px);
-                const f32x4 v = vv[i];
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), out_rsrc, (int)(live ? vox * 64u + (unsigned)kg * 16u : T3_OOB), 0, 0);
-                if constexpr (SUMS) {
-                    float s_ = (v.x + v.y) + (v.z + v.w);
-                    s_ += __shfl_xor(s_, 16, 64);
-                    s_ += __shfl_xor(s_, 32, 64);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, s_), sum_rsrc, (int)((live && kg == 0) ? vox * 4u : T3_OOB), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, vv[i]), out_rsrc, (int)(live ? vox * 64u + (unsigned)kg * 16u : T3_OOB), 0, 0);
+            }
+            if constexpr (SUMS) {      // channel sums: the two cross-lane steps of all eight parities side by side (one LDS round trip each, not sixteen)
+                float s1[8], s2[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s1[i] = (vv[i].x + vv[i].y) + (vv[i].z + vv[i].w);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s2[i] = s1[i] + __shfl_xor(s1[i], 16, 64);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s1[i] = s2[i] + __shfl_xor(s2[i], 32, 64);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int pz = i >> 2, py = (i >> 1) & 1, px = i & 1;
+                    const unsigned vox = vb + (unsigned)(pz * 256 + py * 16 + px);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, s1[i]), sum_rsrc, (int)((live && kg == 0) ? vox * 4u : T3_OOB), 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -715,8 +752,8 @@ int t3d_fwd_launch(alq_ctx *ctx, const T3dPlan &plan, const View &in, const View
         const dim3 grid8((unsigned)std::min(N, cus));
         ProfScope ps8(ctx, PROF_IGEMM3_FWD, plan.flops_per_patch * N);
         auto go = [&](auto kfn) -> int {
-            ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, T8_WBYTES));
-            hipLaunchKernelGGL(kfn, grid8, dim3(512), T8_WBYTES, ctx->stream, a8);
+            ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, T8_WBYTES + 8 * T8_WAVE));
+            hipLaunchKernelGGL(kfn, grid8, dim3(512), T8_WBYTES + 8 * T8_WAVE, ctx->stream, a8);
             return ALQ_OK;
         };
         ALQ_TRY(osum ? go(t3d8_fwd_kernel<true>) : go(t3d8_fwd_kernel<false>));

@@ -434,6 +434,21 @@ int t3d_fwd_launch(alq_ctx *ctx, const T3dPlan &plan, const View &in, const View
 int t3d_bwd_launch(alq_ctx *ctx, const T3dPlan &plan, const View &dout, const View &din, int N, float in_bound, const unsigned char *mask_bits,
                    float *dsum);
 
+// ------------------------------------------------------------------ enc2 backward fused with both pool backward steps (e3d.hip)
+// NET-C in a Fisher pass: [pool2 backward + skip cotangent + ReLU mask + channel sums] -> [3x3x3 conv 16 -> 8 backward-data at
+// 16^3, fp16 pairs under the static bound] -> [pool1 backward into enc1's channel-sum field] in one launch.
+struct E3dPlan {
+    bool ok = false;
+    int w_exp = 0;
+    double flops_per_patch = 0;
+    std::vector<unsigned short> h_Whi, h_Wlo;      // [9 (dz, dy)][2 K steps][64][8] fp16 bits
+    void *d_Whi = nullptr, *d_Wlo = nullptr;
+};
+int e3d_build(const View &in, const View &out, const int k[3], const int lo[3], const int s[3], E3dPlan *plan);
+void e3d_pack(E3dPlan *plan, const float *W /* TF conv filter [tap][ci 8][co 16] */);
+int e3d_bwd_launch(alq_ctx *ctx, const E3dPlan &plan, int N, const float *skip, const float *dpool, const unsigned char *am2, const unsigned char *sg2,
+                   const unsigned char *am1, const unsigned char *sg1, float *dsum2, float *dsum1, float in_bound);
+
 // ------------------------------------------------------------------ direct first-layer conv (direct.hip)
 struct DirectArgs {
     const float *in;

@@ -89,6 +89,7 @@ struct Layer {
     // plane-sweep engine (c3d.hip) for the conv under the fused two-class head (and its backward): plans on the conv layer,
     // per-(patch, wave) partials of the logit difference / of the head's input sum on the head layer
     C3dPlan c3f, c3b;
+    E3dPlan e3b;                           // backward fused with the pool backward steps on either side (e3d.hip; NET-C's enc2)
     T3dPlan t3f, t3b;                      // row-sweep engine for the stride-2 conv_transpose (t3d.hip), forward / backward-data
     float *c3_part = nullptr, *c3_asum = nullptr;
     unsigned short *fc_wv16c = nullptr;    // fc_wv as fp16 pairs at their true scale, [voxel][h8 | l8] (c3d_presplit_vec), for c3b
@@ -153,6 +154,8 @@ struct alq_model {
     int c3_bwd_rows = 8;           // ALQ_C3D_BWD_ROWS=4 (A/B): the plane-sweep backward kernel in its half-patch form
     bool last_c3 = false;          // the last forward pass ran the head conv on the plane-sweep engine
     bool last_c3_bwd = false;      // ... and the last backward pass its backward
+    int no_e3d = 0;                // ALQ_NO_E3D (A/B): pool2 backward, enc2 backward and pool1 backward as three launches as in round 4
+    int last_e3b = 0;              // the last backward pass ran them as one launch (e3d.hip)
     int no_t3d = 0;                // ALQ_NO_T3D (A/B): conv_transpose launches on the two-slot engine (igemm4) as in round 4
     int last_t3f = 0, last_t3b = 0;   // conv_transpose launches of the last forward / backward pass that ran on the row-sweep engine
     bool last_f16_derived = false; // the last forward pass ran a launch on the fp16x2 split with derived input bounds
@@ -614,6 +617,7 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
             if (!first_param && sp.relu) {
                 ALQ_TRY(c3d_fwd_build(ly.in, ly.out, sp.k, ly.lo, sp.s, &ly.c3f));
                 ALQ_TRY(c3d_bwd_build(ly.in, ly.out, sp.k, ly.lo, sp.s, &ly.c3b));
+                ALQ_TRY(e3d_build(ly.in, ly.out, sp.k, ly.lo, sp.s, &ly.e3b));
             }
             if (!first_param) {
                 ConvDesc b;
@@ -1121,9 +1125,31 @@ static int run_backward_main(alq_model *m, const float *d_x, int N) {
                (pl.out.C == 4 || pl.out.C == 8 || pl.out.C == 16) && ((pl.dout.cs | pl.dout.c0 | pl.out.cs | pl.out.c0) & 3) == 0 &&
                src.spec.relu && !g_dbg_knobs[6];
     };
+    int e3_conv = -1;      // the conv whose backward ran fused with the pool backward steps around it (e3d.hip), or -1
+    m->last_e3b = 0;
     for (int i = nl - 1; i >= 0; --i) {
         Layer &ly = m->layers[i];
         const bool prev_is_src = (i > 0 && m->layers[i - 1].out_is_skip_src && ly.spec.skip_src < 0);
+        // [pool (i)] <- [ReLU conv (i - 1), a skip source whose consumer wrote its cotangent] <- [pool (i - 2)] <- [first conv (i - 3)]: one
+        // launch produces both channel-sum fields (e3d.hip); the conv's own box-filter dot product runs as usual when the loop gets there
+        if (ly.spec.type == ALQ_POOL && i >= 3 && !m->no_e3d && v4_on && !g_no_f16x2 && !m->no_bound16 && !m->no_signs && !g_dbg_knobs[2] && !g_dbg_knobs[6]) {
+            Layer &cv = m->layers[i - 1], &p1 = m->layers[i - 2], &c0 = m->layers[i - 3];
+            const bool geo = cv.spec.type == ALQ_CONV && cv.e3b.ok && cv.e3b.d_Whi && cv.spec.relu && cv.signs_ready && cv.out.sg && prev_is_src &&
+                             p1.spec.type == ALQ_POOL && pool_first_ok(p1, c0) && c0.dsum_partial && p1.signs_ready && p1.out.sg && p1.spec.k[0] == 2 &&
+                             ly.spec.k[0] == 2 && ly.spec.k[1] == 2 && ly.spec.k[2] == 2 && ly.lo[0] == 0 && ly.lo[1] == 0 && ly.lo[2] == 0 &&
+                             ly.dout.D == 8 && ly.dout.H == 8 && ly.dout.W == 8 && ly.dout.C == 16 && ly.dout.cs == 16 && ly.dout.c0 == 0 && !ly.dout.split &&
+                             cv.dout.cs == 16 && cv.dout.c0 == 0 && !cv.dout.split && cv.out.cs == 16 && cv.out.c0 == 0 && p1.out.cs == 8 && p1.out.c0 == 0 &&
+                             p1.out.C == 8 && c0.out.D == 32 && cv.dout_bound > 0.f && cv.dsum && c0.dsum;
+            if (geo) {
+                ALQ_TRY(e3d_bwd_launch(ctx, cv.e3b, N, cv.dout.p, ly.dout.p, ly.argmax, cv.out.sg, p1.argmax, p1.out.sg, cv.dsum, c0.dsum, cv.dout_bound));
+                cv.delta_ready = true;
+                c0.delta_ready = true;
+                e3_conv = i - 1;
+                m->last_e3b = 1;
+                continue;
+            }
+        }
+        if (e3_conv >= 0 && i == e3_conv - 1) continue;      // the pool below the fused conv: done
         // Every backward op is the LAST writer of its direct input's cotangent (a skip destination
         // wrote its slice earlier), so it can finish that tensor: ReLU-grad mask + channel sums.
         Layer *prev = i > 0 ? &m->layers[i - 1] : nullptr;
@@ -1170,6 +1196,7 @@ static int run_backward_main(alq_model *m, const float *d_x, int N) {
             }
         }
         if (ly.pidx == 0) break;   // nothing upstream needs a cotangent
+        if (i == e3_conv) continue;      // its backward-data pass ran inside the fused launch
         const int acc = prev_is_src ? 1 : 0;   // the skip destination has already written this slice
         bool fused = false;
         if (isfc) {
@@ -1586,6 +1613,7 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
         m->no_signs0 = getenv("ALQ_NO_SIGNS0") != nullptr;
         if (const char *f = getenv("ALQ_F16_FWD_MASK")) m->f16_fwd_mask = atoi(f);
         m->no_t3d = getenv("ALQ_NO_T3D") ? 1 : 0;
+        m->no_e3d = getenv("ALQ_NO_E3D") ? 1 : 0;
         {   // default since round 5: on.  ALQ_NO_F16_DERIVED=1 (or ALQ_F16_DERIVED=0) keeps that launch on bf16 triples (A/B)
             const char *e = getenv("ALQ_F16_DERIVED"), *n = getenv("ALQ_NO_F16_DERIVED");
             m->no_f16_derived = ((e && atoi(e) == 0) || (n && atoi(n) == 1)) ? 1 : 0;
@@ -1740,6 +1768,15 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
             if (!dw) ALQ_TRY(m->dalloc(&dw, ly.c3b.h_W.size()));
             ly.c3b.d_W = dw;
             ALQ_HIP(hipMemcpyAsync(dw, ly.c3b.h_W.data(), ly.c3b.h_W.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
+            ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
+        }
+        if (ly.e3b.ok && ly.has_bwd && c3d_subnormals_ok(m->ctx)) {      // (fp16 pairs at their true scale: the one-accumulator form)
+            e3d_pack(&ly.e3b, W);
+            unsigned short *dh = reinterpret_cast<unsigned short *>(ly.e3b.d_Whi), *dl = reinterpret_cast<unsigned short *>(ly.e3b.d_Wlo);
+            if (!dh) { ALQ_TRY(m->dalloc(&dh, ly.e3b.h_Whi.size())); ALQ_TRY(m->dalloc(&dl, ly.e3b.h_Wlo.size())); }
+            ly.e3b.d_Whi = dh; ly.e3b.d_Wlo = dl;
+            ALQ_HIP(hipMemcpyAsync(dh, ly.e3b.h_Whi.data(), ly.e3b.h_Whi.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
+            ALQ_HIP(hipMemcpyAsync(dl, ly.e3b.h_Wlo.data(), ly.e3b.h_Wlo.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
             ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
         }
         if (ly.has_bwd) {
@@ -2078,10 +2115,11 @@ int alq_model_debug_copy(alq_model *m, int layer_idx, int what, int N, float *d_
 }
 
 int alq_model_engine_info(alq_model *m, int what) {
-    ALQ_REQUIRE(m && ((what >= 0 && what <= 3) || (what >= 5 && what <= 8)), ALQ_EINVAL, "alq_model_engine_info: bad argument");
+    ALQ_REQUIRE(m && ((what >= 0 && what <= 3) || (what >= 5 && what <= 9)), ALQ_EINVAL, "alq_model_engine_info: bad argument");
     if (what == 6) return m->last_f16_derived ? 1 : 0;
     if (what == 7) return m->last_t3f;        // conv_transpose launches of the last forward pass on the row-sweep engine (t3d.hip)
     if (what == 8) return m->last_t3b;        // ... of the last backward pass
+    if (what == 9) return m->last_e3b;        // the last backward pass ran enc2's backward fused with both pool backward steps (e3d.hip)
     ALQ_HIP(hipSetDevice(m->ctx->device));
     if (what == 0) return c3d_subnormals_ok(m->ctx);
     if (what == 1) return m->last_c3 ? 1 : 0;

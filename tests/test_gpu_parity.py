@@ -1238,6 +1238,42 @@ def test_row_sweep_conv_transpose_against_the_two_slot_engine(sess):
     m_old.close()
 
 
+def test_fused_enc2_backward_against_the_three_launches(sess):
+    """NET-C's pool2 backward -> enc2 backward-data -> pool1 backward as ONE launch (csrc/e3d.hip, default since round 5) against the
+    three launches of round 4 (ALQ_NO_E3D=1: pool_bwd_vec_kernel, the two-slot engine's enc2 launch, pool_bwd_first_kernel).  The
+    forward pass is the same code in both models (posteriors bit-identical), every mask comes from its sign fields, so nothing can
+    flip: the two channel-sum fields the fused launch produces (enc2's and enc1's, all 300 patches) within 2e-6 of the field's
+    maximum, every layer score within 2e-6 + 2e-5 relative, the A matrices likewise."""
+    import ctypes as C
+    from nnal_amd._lib import check
+    torch = sess.torch
+    n = 300
+    ld, sk, in_shape, pars, (m_new, m_old) = _netc32_models(sess, [{}, {'ALQ_NO_E3D': '1'}], max_batch=n, bias_std=0.05)
+    x = sess.empty((n, 32 ** 3), torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, 32 ** 3, C.c_void_p(x.data_ptr())))
+    out = []
+    for m in (m_new, m_old):
+        r = m.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1', 'A', 'Asum'))
+        d = {k: r[k].cpu().numpy() for k in ('p1', 'g0', 'g1', 'A', 'Asum')}
+        d['enc2_dsum'] = m.debug_tensor(2, 3, n)
+        d['enc1_dsum'] = m.debug_tensor(0, 3, n)
+        out.append(d)
+    assert sess.lib.alq_model_engine_info(m_new._m, 9) == 1, 'the fused launch did not run'
+    assert sess.lib.alq_model_engine_info(m_old._m, 9) == 0
+    a, b = out
+    np.testing.assert_array_equal(a['p1'], b['p1'])
+    for k in ('enc2_dsum', 'enc1_dsum'):
+        assert a[k].shape == b[k].shape and np.isfinite(a[k]).all()
+        err = np.abs(a[k] - b[k]).max()
+        assert err <= 2e-6 * np.abs(b[k]).max(), (k, err, np.abs(b[k]).max())
+    for k in ('g0', 'g1'):
+        np.testing.assert_allclose(a[k], b[k], rtol=2e-5, atol=2e-6, err_msg=k)
+    np.testing.assert_allclose(a['A'], b['A'], rtol=2e-5, atol=1e-12 + 2e-6 * np.abs(b['A']).max())
+    np.testing.assert_allclose(a['Asum'], b['Asum'], rtol=2e-5, atol=1e-12 + 2e-6 * np.abs(b['Asum']).max())
+    m_new.close()
+    m_old.close()
+
+
 def test_plane_sweep_backward_half_patch_form_is_bit_identical(sess):
     """The plane-sweep backward kernel in its two forms - a workgroup per patch (default, 8 rows per wave) and per half patch
     (ALQ_C3D_BWD_ROWS=4, halo rows staged twice): every output voxel sees the same MFMAs in the same order, so the layer scores

@@ -1038,8 +1038,10 @@ def test_sign_fields_are_bit_identical(sess):
         # (ALQ_NO_C3D in both arms: the plane-sweep backward kernel of round 4 exists for the sign-field form only - without the
         # fields the launch falls back to the two-slot engine, another summation order; the bit identity is a statement about
         # ONE engine reading its masks from two sources)
-        # (likewise ALQ_NO_T3D: the row-sweep backward kernel of round 5 reads its mask from the sign field only)
-        a, b = run({'ALQ_NO_C3D': '1', 'ALQ_NO_T3D': '1'}), run({'ALQ_NO_SIGNS': '1', 'ALQ_NO_C3D': '1', 'ALQ_NO_T3D': '1'})
+        # (likewise ALQ_NO_T3D and ALQ_NO_E3D: the row-sweep conv_transpose backward and the fused enc2 backward of round 5
+        # read their masks from the sign fields only)
+        pin = {'ALQ_NO_C3D': '1', 'ALQ_NO_T3D': '1', 'ALQ_NO_E3D': '1'}
+        a, b = run(pin), run(dict(pin, ALQ_NO_SIGNS='1'))
         for k in a:
             np.testing.assert_array_equal(a[k], b[k], err_msg='%s %s' % (in_shape, k))
 

@@ -7,6 +7,7 @@ device through `sess.run(getattr(model, var), feed_dict)` (PW_NN.py:466,522).  H
 for device memory, the stream and (in pool_shard.py) torch.distributed.
 """
 import ctypes as C
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -341,9 +342,14 @@ class DeviceModel(object):
             arr[i].skip_src = d['skip_src']
         self._m = C.c_void_p()
         cd = (C.c_int32 * 4)(*dims)
+        self._create_args = (arr, len(self.layers), cd)
         check(self.lib.alq_model_create(sess.ctx, arr, len(self.layers), cd, self.max_batch, C.byref(self._m)))
         _track(self)
         self.max_batch = int(self.lib.alq_model_max_batch(self._m))      # may be below the request: 32-bit tensor offsets (alq.h)
+        # second scoring pipeline (fisher_device): created at the first call that has more than one device pass to run
+        self.lanes = max(1, int(os.environ.get('ALQ_LANES', '1')))
+        self._lane2 = None
+        self._create_env = {k: v for k, v in os.environ.items() if k.startswith('ALQ_')}     # engine switches are read at creation
         self.L = self.lib.alq_model_num_param_layers(self._m)
         self.nclass = self.layers[-1]['cout']
         self.elems_per_patch = int(np.prod(self.in_shape))
@@ -720,18 +726,39 @@ class DeviceModel(object):
         def ptr(tn, off_elems, itemsize):
             return C.c_void_p(tn.data_ptr() + off_elems * itemsize) if tn is not None else None
 
-        for a in range(0, n, self.max_batch):
+        # Device passes of max_batch patches alternate between two PIPELINES (own libalq context = own stream pair, own
+        # workspaces, the same weights): the tail of one pass (the last box-filter dot products, finalisation) and its
+        # small kernels run beside the next pass's first launches instead of leaving the chip idle.  Each pass is the same
+        # launches on the same data whichever pipeline runs it, so every per-patch output is bit-identical to ALQ_LANES=1;
+        # the passes' partial sums of A are added in pass order after the join.
+        starts = list(range(0, n, self.max_batch))
+        lane2 = self._second_lane() if (self.lanes > 1 and len(starts) > 1) else None
+        part = self.sess.empty((max(len(starts), 1), L, L), torch.float64) if asum is not None else None
+        cur = torch.cuda.current_stream(self.sess.device)
+        if lane2 is not None:
+            lane2['stream'].wait_stream(cur)          # inputs, output buffers and the weights are ordered on the caller's stream
+        for k, a in enumerate(starts):
             b = min(n, a + self.max_batch)
             outs = (ptr(p1_in, a, 4), float(diag_load), ptr(out['p1'], a, 4), ptr(out['g0'], a * L, 8),
                     ptr(out['g1'], a * L, 8), ptr(out['A'], a * L * L, 8), ptr(out['trace'], a, 8),
-                    C.c_void_p(part.data_ptr()) if part is not None else None)
-            if rows is None:
-                check(self.lib.alq_fisher(self._m, C.c_void_p(t.data_ptr() + a * self.elems_per_patch * 4), b - a, *outs))
+                    C.c_void_p(part.data_ptr() + k * L * L * 8) if part is not None else None)
+
+            def launch(m):
+                if rows is None:
+                    check(self.lib.alq_fisher(m, C.c_void_p(t.data_ptr() + a * self.elems_per_patch * 4), b - a, *outs))
+                else:
+                    check(self.lib.alq_fisher_rows(m, C.c_void_p(t.data_ptr()), C.c_void_p(rows.data_ptr() + a * 8), b - a, *outs))
+            if lane2 is not None and (k & 1):
+                with torch.cuda.stream(lane2['stream']):
+                    lane2['sess'].bind_stream()
+                    launch(lane2['m'])
             else:
-                check(self.lib.alq_fisher_rows(self._m, C.c_void_p(t.data_ptr()), C.c_void_p(rows.data_ptr() + a * 8),
-                                               b - a, *outs))
-            if asum is not None:
-                asum += part
+                launch(self._m)
+        if lane2 is not None:
+            cur.wait_stream(lane2['stream'])
+        if asum is not None:
+            for k in range(len(starts)):
+                asum += part[k]
         out['Asum'] = asum
         if 'H' in want or 'absdev' in want:
             if out['p1'] is None:
@@ -741,6 +768,52 @@ class DeviceModel(object):
             check(self.lib.alq_score_entropy(self.sess.ctx, C.c_void_p(out['p1'].data_ptr()), n,
                                              ptr(out['absdev'], 0, 8), ptr(out['H'], 0, 4)))
         return out
+
+    def _creation_env(self):
+        """The ALQ_* engine switches are read when a model is created and when its weights are packed: the second pipeline's
+        model is built under the ones the first was created with."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            now = {k: v for k, v in os.environ.items() if k.startswith('ALQ_')}
+            for k in now:
+                del os.environ[k]
+            os.environ.update(self._create_env)
+            try:
+                yield
+            finally:
+                for k in self._create_env:
+                    os.environ.pop(k, None)
+                os.environ.update(now)
+        return cm()
+
+    def _second_lane(self):
+        """The second scoring pipeline of fisher_device: a libalq context on its own torch stream and a model of the same
+        layers on it; its weights follow `set_weights` (the host copies in var_dict are the single state)."""
+        torch = self.sess.torch
+        ln = self._lane2
+        if ln is None:
+            stream = torch.cuda.Stream(self.sess.device)
+            with torch.cuda.stream(stream):
+                sess2 = DeviceSession(self.sess.device.index)
+            m = C.c_void_p()
+            arr, nl, cd = self._create_args
+            with self._creation_env():
+                check(self.lib.alq_model_create(sess2.ctx, arr, nl, cd, self.max_batch, C.byref(m)))
+            if int(self.lib.alq_model_max_batch(m)) != self.max_batch:
+                self.lib.alq_model_destroy(m)
+                raise _lib.AlqError('second pipeline: the library granted another batch size')
+            ln = self._lane2 = dict(sess=sess2, stream=stream, m=m, version=None)
+        if ln['version'] != self._weights_version:
+            if any(v is None for v in self.var_dict.values()):
+                raise RuntimeError('set_weights() has not been called')
+            with self._creation_env():
+                for ti, name in enumerate(self.var_names):
+                    W, b = self.var_dict[name]
+                    check(self.lib.alq_model_set_weights(ln['m'], ti, W.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)))
+            ln['version'] = self._weights_version
+        return ln
 
     def fisher(self, x, p1=None, diag_load=1e-5):
         t, n = self._as_device_batch(x)
@@ -804,6 +877,11 @@ class DeviceModel(object):
         return buf[:e.value].cpu().numpy()
 
     def close(self):
+        ln = getattr(self, '_lane2', None)
+        if ln is not None:
+            self.lib.alq_model_destroy(ln['m'])
+            ln['sess'].close()
+            self._lane2 = None
         if self._m:
             self.lib.alq_model_destroy(self._m)
             self._m = C.c_void_p()

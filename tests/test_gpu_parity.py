@@ -1549,3 +1549,38 @@ def test_fc_backward_on_fp16_pairs_against_bf16_triples(sess):
     for k in ('g0', 'g1'):
         np.testing.assert_allclose(a[k], b[k], rtol=2e-5, atol=2e-6, err_msg=k)
     np.testing.assert_allclose(a['A'], b['A'], rtol=2e-5, atol=1e-12 + 2e-6 * np.abs(b['A']).max())
+
+
+def test_two_scoring_pipelines_are_bit_identical_to_one(sess):
+    """ALQ_LANES=2 (opt-in): `fisher_device` alternates its device passes between two pipelines - a second libalq context on its
+    own stream pair with its own workspaces and a copy of the weights - so that one pass's tail runs beside the next one's first
+    launches.  Every pass is the same launches on the same data whichever pipeline runs it and the passes' partial sums of A are
+    added in pass order: all outputs bit-identical to one pipeline, ragged last pass included; the second pipeline's model is
+    created under the engine switches of the first (here ALQ_NO_E3D, read at creation) and follows `set_weights`."""
+    import ctypes as C
+    from nnal_amd._lib import check
+    torch = sess.torch
+    n = 5 * 48 + 7
+    ld, sk, in_shape, pars, (m,) = _netc32_models(sess, [{'ALQ_NO_E3D': '1'}], max_batch=48, bias_std=0.05)
+    x = sess.empty((n, 32 ** 3), torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, 32 ** 3, C.c_void_p(x.data_ptr())))
+    keys = ('p1', 'H', 'g0', 'g1', 'A', 'trace', 'Asum')
+
+    def run(lanes):
+        m.lanes = lanes
+        r = m.fisher_device(x, n, None, 1e-3, want=keys)
+        return {k: r[k].cpu().numpy() for k in keys}
+    one = run(1)
+    assert m._lane2 is None
+    two = run(2)
+    assert m._lane2 is not None and sess.lib.alq_model_engine_info(m._lane2['m'], 9) == 0, 'second pipeline: other engine switches'
+    for k in keys:
+        np.testing.assert_array_equal(one[k], two[k], err_msg=k)
+    # new weights reach both pipelines
+    pars2 = netspec.he_init(ld, in_shape, seed=15, skips=sk, bias_std=0.05)
+    m.set_weights(pars2)
+    two_b, one_b = run(2), run(1)
+    assert np.abs(one_b['g0'] - one['g0']).max() > 0
+    for k in keys:
+        np.testing.assert_array_equal(one_b[k], two_b[k], err_msg='after set_weights: ' + k)
+    m.close()

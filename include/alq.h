@@ -274,7 +274,10 @@ int alq_debug_set(int key, int value);
  * three piece products in one accumulator, 5: the number of marked 4-channel groups the flip-safe head could NOT re-evaluate
  * exactly since the model was created because a list segment (a quarter of a patch, 128 slots) was full - 0 on every input the
  * tests and the bench use; a dropped group keeps the sign its fp16-pair contraction produced (synchronises the stream).
- * 6: 1 when the last forward pass ran a launch on the fp16-pair split with derived input bounds (opt-in, ALQ_F16_DERIVED=1).
+ * 6: 1 when the last forward pass ran a launch on the fp16-pair split with derived input bounds (default; ALQ_NO_F16_DERIVED=1 off).
+ * 7 / 8: conv_transpose launches of the last forward / backward pass on the row-sweep engine (csrc/t3d.hip), 9: 1 when the last
+ * backward pass ran enc2's backward fused with both pool backward steps (csrc/e3d.hip), 10: 1 when the last forward pass ran
+ * dec1 on the plane-sweep kernel of csrc/d3d.hip.
  * Returns the answer or a negative error code.  */
 int alq_model_engine_info(alq_model *m, int what);
 

@@ -449,6 +449,20 @@ void e3d_pack(E3dPlan *plan, const float *W /* TF conv filter [tap][ci 8][co 16]
 int e3d_bwd_launch(alq_ctx *ctx, const E3dPlan &plan, int N, const float *skip, const float *dpool, const unsigned char *am2, const unsigned char *sg2,
                    const unsigned char *am1, const unsigned char *sg1, float *dsum2, float *dsum1, float in_bound);
 
+// NET-C's dec1 forward (3x3x3 conv 32 -> 16 channels at 16^3 over a split concat, fp16 pairs at per-patch scales): row sweep at one
+// wave per SIMD with all weight fragments in registers (d3d.hip)
+struct D3dPlan {
+    bool ok = false;
+    int w_exp = 0;
+    double flops_per_patch = 0;
+    std::vector<unsigned short> h_Whi, h_Wlo;      // [27 taps][64][8] fp16 bits
+    void *d_Whi = nullptr, *d_Wlo = nullptr;
+};
+int d3d_build(const View &in, const View &out, const int k[3], const int lo[3], const int s[3], D3dPlan *plan);
+void d3d_pack(D3dPlan *plan, const float *W /* TF conv filter [tap][ci 32][co 16] */);
+int d3d_fwd_launch(alq_ctx *ctx, const D3dPlan &plan, int N, const float *inA, const float *inB, const unsigned *amaxA, const unsigned *amaxB,
+                   const float *bias, int relu, float *out, unsigned char *sg, float *osum);
+
 // ------------------------------------------------------------------ direct first-layer conv (direct.hip)
 struct DirectArgs {
     const float *in;

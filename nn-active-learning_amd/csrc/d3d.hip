@@ -1,0 +1,348 @@
+// Forward of NET-C's `dec1` (3x3x3 conv over the concat [up1 output | enc2 skip], 32 -> 16 channels at 16^3, + bias + ReLU;
+// NN_extended.py:416-426) in a Fisher pass: the largest launch the two-slot engine still ran (0.79 ms per 2047 patches at 36 % of
+// the fp16 matrix-core rate).  Plane sweep at ONE wave per SIMD, the scheme of c3d.hip at this layer's shape:
+//   * a workgroup owns a patch and sweeps z; wave w owns output rows 4 w .. 4 w + 3 of every plane.  Step s has input plane s in
+//     LDS (an image of 18 rows x 18 voxel slots, fp16 pairs; y and x halo = zero rows / slots) and contracts it into the THREE
+//     output planes it touches (s + 1, s, s - 1: three accumulator sets in registers, rotating with s, compile-time indices in a
+//     loop unrolled by three), so an activation fragment (input row, dx; hi and lo piece) is read ONCE and feeds up to
+//     3 (dy) x 3 (dz) x 3 products = 27 MFMAs.  A first version swept y with four planes per workgroup: 36 fragment pairs per
+//     162 MFMAs, two void steps in ten, and the same 0.8 ms as the two-slot engine;
+//   * MFMA 16 x 16 x 32 (f16): rows = 16 output channels, columns = the 16 voxels of an x row, K = the 32 input channels of one tap;
+//     all 27 x 2 weight fragments stay in registers (216 of the 512 a lone wave has);
+//   * while plane s is contracted the wave converts its four rows of plane s + 1 (loaded during step s - 1) into the other image,
+//     and finishes output plane s - 1 row by row as its last contributions arrive (row 3 at the start of the next step): bias,
+//     ReLU, 16-byte stores (a lane holds 4 channels of one voxel), the sign byte of those 4 channels, the voxel's channel sum;
+//     one barrier per step; six scheduling blocks (input row) per step, fragments read one block ahead of their MFMAs, one
+//     MFMA then up to two other instructions (c3d_fwd_kernel);
+//   * fp16 pairs x 2^e = h + l 2^-11, lo pieces scaled up, their two products in a second accumulator (the per-patch input bounds
+//     are derived ones - fwd_bounds_kernel - and loose: at their true scale the lo pieces would be fp16 subnormals);
+//   * LDS row = [4 k-groups][18 voxel slots (x = -1 .. 16)][8 channels x 2 B]: the 16 lanes of a k-group read 256 contiguous
+//     bytes (conflict-free), an x shift is +16 B;
+//   * the first and last input plane of a patch also run the MFMAs of the output planes outside the volume (4 % of the work; their
+//     sets are discarded) - no special steps, no control flow inside a patch except the loop of five times three steps.
+#include "alq_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace alq {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+struct D3Args {
+    const float *inA, *inB;       // [N][16^3][16]: channels 0 .. 15 / 16 .. 31 of the concat input (dense)
+    const unsigned *amaxA, *amaxB;      // per patch: bit pattern of a bound on max |x| of each half
+    const unsigned short *Whi;    // [27 taps][64 lanes][8] fp16 bits: hi pieces (d3d_pack)
+    const unsigned short *Wlo;    // the lo pieces (x 2^11), same layout
+    const float *bias;            // [16]
+    float *out;                   // [N][16^3][16]
+    unsigned char *sg;            // sign field of out: byte (voxel * 16 + c) / 4, bit c & 3  (or nullptr)
+    float *osum;                  // [N][16^3] channel sums of out (or nullptr)
+    int e_w;                      // weights were scaled by 2^e_w
+    int relu;
+    int N;
+};
+
+constexpr unsigned D3_OOB = 0xffffff00u;
+constexpr int D3_KG = 18 * 16;                // a k-group block of a row: 18 voxel slots x 8 channels x 2 B
+constexpr int D3_ROWB = 4 * D3_KG;            // one piece of a row: 1152 B
+constexpr int D3_SLOT = 2 * D3_ROWB;          // a row: pieces h, l
+constexpr int D3_PLANE = 18 * D3_SLOT;        // image of a plane: rows y = -1 .. 16: 41,472 B
+constexpr int D3_STRIP = 2 * D3_PLANE;        // the plane being contracted and the one being staged: 82,944 B
+
+__device__ inline __amdgpu_buffer_rsrc_t d3_rsrc(const void *base, unsigned long long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)(unsigned)bytes, 0x00020000);
+}
+__device__ inline int d3_s(unsigned v) { return __builtin_amdgcn_readfirstlane((int)v); }
+
+template <int V> struct D3IC { static constexpr int value = V; };
+// what may fill the gap behind an MFMA: VALU (2), SALU (4), VMEM (0x10), DS (0x80)
+constexpr int D3_FILL_MASK = 0x096;
+
+struct D3Row { f32x4 a, b; };      // what staging one row needs, per lane: 4 channels of one voxel from each half
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void d3d_fwd_kernel(const D3Args a) {
+    extern __shared__ __attribute__((aligned(16))) char d3lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    char *strip = d3lds;
+    // zero fill, once: the images' rows y = -1, 16 and the slots x = -1, 16 of every row are never written again
+    for (int i = threadIdx.x; i < D3_STRIP / 16; i += 256) reinterpret_cast<i32x4 *>(strip)[i] = i32x4{0, 0, 0, 0};
+    __syncthreads();
+    const int n = lane & 15, kg = lane >> 4;
+    f16x8 wh[27], wl[27];
+#pragma unroll
+    for (int c = 0; c < 27; ++c) {
+        wh[c] = *reinterpret_cast<const f16x8 *>(a.Whi + ((size_t)c * 64 + lane) * 8);
+        wl[c] = *reinterpret_cast<const f16x8 *>(a.Wlo + ((size_t)c * 64 + lane) * 8);
+    }
+#pragma unroll
+    for (int c = 0; c < 27; ++c) asm volatile("" : "+a"(wh[c]), "+a"(wl[c]));      // arrived before the loop, and in the accumulator half of the file
+    f32x4 bias4 = *reinterpret_cast<const f32x4 *>(a.bias + 4 * kg);
+    asm volatile("" : "+v"(bias4));
+    const float relu_floor = a.relu ? 0.f : -__builtin_inff();
+
+    typedef const unsigned __attribute__((address_space(4))) *cu32p;
+    const cu32p amaxA_c = (cu32p)(unsigned long long)a.amaxA, amaxB_c = (cu32p)(unsigned long long)a.amaxB;
+    auto patch_exp = [&](int p) __attribute__((always_inline)) {      // max |x| < 2^ex -> scale 2^(14 - ex); all-zero patch: 0  (c3d_fwd_kernel)
+        const unsigned fa = amaxA_c[p], fb = amaxB_c[p];
+        const unsigned fm = fa > fb ? fa : fb;
+        const int ex = (int)((fm >> 23) & 255u) - 126;
+        const int ce = 14 - ex;
+        return fm ? (ce < 96 ? ce : 96) : 0;
+    };
+
+    const __amdgpu_buffer_rsrc_t ia_rsrc = d3_rsrc(a.inA, (unsigned long long)a.N * 4096 * 64);
+    const __amdgpu_buffer_rsrc_t ib_rsrc = d3_rsrc(a.inB, (unsigned long long)a.N * 4096 * 64);
+    const __amdgpu_buffer_rsrc_t o_rsrc = d3_rsrc(a.out, (unsigned long long)a.N * 4096 * 64);
+    const __amdgpu_buffer_rsrc_t s_rsrc = d3_rsrc(a.sg, a.sg ? (unsigned long long)a.N * 4096 * 4 : 0ull);
+    const __amdgpu_buffer_rsrc_t u_rsrc = d3_rsrc(a.osum, a.osum ? (unsigned long long)a.N * 4096 * 4 : 0ull);
+
+    // staging lane roles: voxel x = lane >> 2 of a row, channels 4 cq .. + 3 of each half: k-group 2 h + (cq >> 1), bytes 8 (cq & 1) ..; image row 4 w + 1 + r
+    const int sx = lane >> 2, cq = lane & 3;
+    char *const w_base = strip + (4 * wave + 1) * D3_SLOT + (cq >> 1) * D3_KG + (sx + 1) * 16 + (cq & 1) * 8;      // half A of image 0; half B: + 2 k-group blocks
+    const unsigned ldA = (unsigned)lane * 16u;
+    // fragment lane roles: column n = voxel x (slot n + dx), k-group kg; input row y = 4 w - 1 + r = image row 4 w + r
+    const char *const f_base = strip + 4 * wave * D3_SLOT + kg * D3_KG + n * 16;
+    // epilogue lane roles: voxel x = n of the output row, channels 4 kg .. + 3
+    const unsigned e_out = (unsigned)n * 64u + (unsigned)kg * 16u, e_sg = (unsigned)n * 4u + (unsigned)kg;
+    const unsigned e_sum = kg == 0 ? (unsigned)n * 4u : D3_OOB;
+
+    // patches of this workgroup (XCD-aware as in t3d.hip): workgroup b of XCD b % 8 takes k = b / 8, b / 8 + G / 8, ... of the patches 8 k + b % 8
+    const int G8 = (int)gridDim.x >> 3, xcd = (int)blockIdx.x & 7, jb = (int)blockIdx.x >> 3;
+    const int npx = a.N > xcd ? (a.N - xcd + 7) >> 3 : 0;
+    const int npw = npx > jb ? (npx - jb + G8 - 1) / G8 : 0;
+    auto patch_of = [&](int i) __attribute__((always_inline)) { return 8 * (jb + (i < npw ? i : npw - 1) * G8) + xcd; };
+
+    D3Row RA[4];
+    // loads of this wave's four rows of plane q of the workgroup's sequence (patch q >> 4, plane q & 15)
+    auto fetch = [&](int q) __attribute__((always_inline)) {
+        const unsigned row0 = ((unsigned)patch_of(q >> 4) * 16u + (unsigned)(q & 15)) * 16u + 4u * (unsigned)wave;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            RA[r].a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ia_rsrc, (int)ldA, d3_s((row0 + r) * 1024u), 0));
+            RA[r].b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ib_rsrc, (int)ldA, d3_s((row0 + r) * 1024u), 0));
+        }
+    };
+    // unit u = 2 r + h: half h of row r of RA -> image `img` (scale 2^ce)
+    auto stage_unit = [&](auto U, int img, float sc, float sc11) __attribute__((always_inline)) {
+        constexpr int u = decltype(U)::value, r = u >> 1, h = u & 1;
+        char *dst = w_base + img * D3_PLANE + r * D3_SLOT + h * 2 * D3_KG;
+        const f32x4 g = h ? RA[r].b : RA[r].a;
+        const f16x2 h01 = __builtin_convertvector(f32x2{g.x * sc, g.y * sc}, f16x2), h23 = __builtin_convertvector(f32x2{g.z * sc, g.w * sc}, f16x2);
+        const f16x2 l01 = __builtin_convertvector(f32x2{__builtin_fmaf((float)h01.x, -2048.f, g.x * sc11), __builtin_fmaf((float)h01.y, -2048.f, g.y * sc11)}, f16x2);
+        const f16x2 l23 = __builtin_convertvector(f32x2{__builtin_fmaf((float)h23.x, -2048.f, g.z * sc11), __builtin_fmaf((float)h23.y, -2048.f, g.w * sc11)}, f16x2);
+        *reinterpret_cast<i32x2 *>(dst) = i32x2{__builtin_bit_cast(int, h01), __builtin_bit_cast(int, h23)};
+        *reinterpret_cast<i32x2 *>(dst + D3_ROWB) = i32x2{__builtin_bit_cast(int, l01), __builtin_bit_cast(int, l23)};
+    };
+
+    // three accumulator sets x four rows x (hi products, lo products at 2^11)
+    f32x4 acc[3][4], acx[3][4];
+#pragma unroll
+    for (int st = 0; st < 3; ++st)
+#pragma unroll
+        for (int ry = 0; ry < 4; ++ry) { acc[st][ry] = f32x4{0.f, 0.f, 0.f, 0.f}; acx[st][ry] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    f32x4 okeep[2];
+    okeep[0] = okeep[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // finish row ry of the plane held by set ST: plane zo of patch p (tv: it exists), then clear the set's row
+    auto epi_row = [&](auto ST, auto RY, int p, int zo, bool tv, float inv) __attribute__((always_inline)) {
+        constexpr int st = decltype(ST)::value, ry = decltype(RY)::value;
+        const unsigned vrow = (unsigned)d3_s((((unsigned)p * 16u + (unsigned)(tv ? zo : 0)) * 16u + (unsigned)(4 * wave + ry)) * 16u);      // first voxel of the row
+        const f32x4 c = acc[st][ry], cx = acx[st][ry];
+        acc[st][ry] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acx[st][ry] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float v0 = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(cx.x, 0x1p-11f, c.x), inv, bias4.x), relu_floor);
+        const float v1 = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(cx.y, 0x1p-11f, c.y), inv, bias4.y), relu_floor);
+        const float v2 = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(cx.z, 0x1p-11f, c.z), inv, bias4.z), relu_floor);
+        const float v3 = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(cx.w, 0x1p-11f, c.w), inv, bias4.w), relu_floor);
+        const f32x4 o = f32x4{v0, v1, v2, v3};
+        okeep[ry & 1] = o;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), o_rsrc, (int)(tv ? e_out : D3_OOB), (int)(vrow * 64u), 0);
+        const unsigned bits = (v0 > 0.f ? 1u : 0u) | (v1 > 0.f ? 2u : 0u) | (v2 > 0.f ? 4u : 0u) | (v3 > 0.f ? 8u : 0u);
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bits, s_rsrc, (int)(tv ? e_sg : D3_OOB), (int)(vrow * 4u), 0);
+        float s_ = (v0 + v1) + (v2 + v3);
+        s_ += __shfl_xor(s_, 16, 64);
+        s_ += __shfl_xor(s_, 32, 64);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, s_), u_rsrc, (int)(tv ? e_sum : D3_OOB), (int)(vrow * 4u), 0);
+    };
+
+    // Step s (J = s % 3) of patch i: image q & 1 holds input plane s (q = 16 i + s).  Block r = input row 4 w - 1 + r:
+    //   block 0: row 3 of plane s - 2 (set J + 1, its last contributions came at the end of step s - 1);  blocks 1, 2: the eight staging units of
+    //   plane q + 1 (RA, loaded during step s - 1) into the other image;  block 3: the loads of plane q + 2;  blocks 3, 4, 5: rows 0, 1, 2 of plane
+    //   s - 1 (set J + 2), finished by blocks 2, 3, 4.
+    auto step = [&](auto JJ, int i, int s) __attribute__((always_inline)) {
+        constexpr int J = decltype(JJ)::value;
+        constexpr int S0 = (J + 1) % 3, S1 = J, S2 = (J + 2) % 3;      // sets of the output planes s + 1 (dz = 0), s (dz = 1), s - 1 (dz = 2)
+        __builtin_amdgcn_sched_barrier(0);
+        const int q = 16 * i + s;
+        const int p = patch_of(i);
+        const float inv = __builtin_ldexpf(1.f, -(patch_exp(p) + a.e_w));
+        const int pn = patch_of((q + 1) >> 4);
+        const int cen = patch_exp(pn);
+        const bool nv = ((q + 1) >> 4) < npw;      // (behind the last plane of the workgroup: zeros into the image nobody reads)
+        const float sc = nv ? __builtin_ldexpf(1.f, cen) : 0.f, sc11 = nv ? __builtin_ldexpf(1.f, cen + 11) : 0.f;
+        const int img = q & 1;
+        // every wave's rows of plane q are in image q & 1, and every wave is done reading the image this step overwrites
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const char *fb = f_base + img * D3_PLANE;
+        f16x8 Fh[2][3], Fl[2][3];
+        auto frag = [&](auto R, f16x8 *fh, f16x8 *fl) __attribute__((always_inline)) {
+            constexpr int r = decltype(R)::value;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                fh[dx] = *reinterpret_cast<const f16x8 *>(fb + r * D3_SLOT + dx * 16);
+                fl[dx] = *reinterpret_cast<const f16x8 *>(fb + r * D3_SLOT + dx * 16 + D3_ROWB);
+            }
+        };
+        frag(D3IC<0>{}, Fh[0], Fl[0]);
+        auto block = [&](auto R) __attribute__((always_inline)) {
+            constexpr int r = decltype(R)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (r + 1 < 6) frag(D3IC<r + 1>{}, Fh[(r + 1) % 2], Fl[(r + 1) % 2]);
+            if constexpr (r == 0) epi_row(D3IC<S0>{}, D3IC<3>{}, p, s - 2, s >= 2, inv);
+            if constexpr (r == 1) { stage_unit(D3IC<0>{}, img ^ 1, sc, sc11); stage_unit(D3IC<1>{}, img ^ 1, sc, sc11); stage_unit(D3IC<2>{}, img ^ 1, sc, sc11); stage_unit(D3IC<3>{}, img ^ 1, sc, sc11); }
+            if constexpr (r == 2) { stage_unit(D3IC<4>{}, img ^ 1, sc, sc11); stage_unit(D3IC<5>{}, img ^ 1, sc, sc11); stage_unit(D3IC<6>{}, img ^ 1, sc, sc11); stage_unit(D3IC<7>{}, img ^ 1, sc, sc11); }
+            if constexpr (r == 3) {
+                fetch(q + 2);
+                epi_row(D3IC<S2>{}, D3IC<0>{}, p, s - 1, s >= 1, inv);
+            }
+            if constexpr (r == 4) epi_row(D3IC<S2>{}, D3IC<1>{}, p, s - 1, s >= 1, inv);
+            if constexpr (r == 5) epi_row(D3IC<S2>{}, D3IC<2>{}, p, s - 1, s >= 1, inv);
+            int nm = 0;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const f16x8 xh = Fh[r % 2][dx], xl = Fl[r % 2][dx];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int ry = r - dy;        // output row 4 w + ry takes input row 4 w - 1 + r through tap dy
+                    if (ry < 0 || ry > 3) continue;
+#pragma unroll
+                    for (int dz = 0; dz < 3; ++dz) {
+                        const int st = dz == 0 ? S0 : (dz == 1 ? S1 : S2);
+                        const int tap = (dz * 3 + dy) * 3 + dx;
+                        acx[st][ry] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[tap], xh, acx[st][ry], 0, 0, 0);      // (l, h) + (h, l) at 2^11, (h, h)
+                        acc[st][ry] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[tap], xh, acc[st][ry], 0, 0, 0);
+                        acx[st][ry] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[tap], xl, acx[st][ry], 0, 0, 0);
+                        nm += 3;
+                    }
+                }
+            }
+            (void)nm;
+#pragma unroll
+            for (int m = 0; m < 27 * ((r == 0 || r == 5) ? 1 : ((r == 1 || r == 4) ? 2 : 3)); ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(D3_FILL_MASK, 2, 0);
+            }
+        };
+        block(D3IC<0>{}); block(D3IC<1>{}); block(D3IC<2>{}); block(D3IC<3>{}); block(D3IC<4>{}); block(D3IC<5>{});
+        __builtin_amdgcn_sched_barrier(0);
+        // (16-byte store data is read late by the hardware: the last rows' registers stay theirs until here, t3d_fwd_kernel)
+        const f32x4 k0 = okeep[0], k1 = okeep[1];
+        asm volatile("" :: "v"(k0), "v"(k1));
+    };
+
+    if (npw > 0) {
+        {   // plane 0 of the first patch into image 0, the loads of plane 1
+            fetch(0);
+            const int ce = patch_exp(patch_of(0));
+            const float sc = __builtin_ldexpf(1.f, ce), sc11 = __builtin_ldexpf(1.f, ce + 11);
+            stage_unit(D3IC<0>{}, 0, sc, sc11); stage_unit(D3IC<1>{}, 0, sc, sc11); stage_unit(D3IC<2>{}, 0, sc, sc11); stage_unit(D3IC<3>{}, 0, sc, sc11);
+            stage_unit(D3IC<4>{}, 0, sc, sc11); stage_unit(D3IC<5>{}, 0, sc, sc11); stage_unit(D3IC<6>{}, 0, sc, sc11); stage_unit(D3IC<7>{}, 0, sc, sc11);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(1);
+        }
+        for (int i = 0; i < npw; ++i) {
+            for (int k = 0; k < 5; ++k) {
+                step(D3IC<0>{}, i, 3 * k);
+                step(D3IC<1>{}, i, 3 * k + 1);
+                step(D3IC<2>{}, i, 3 * k + 2);
+            }
+            step(D3IC<0>{}, i, 15);
+            // behind the last input plane: row 3 of plane 14 (set 2), plane 15 (set 0); the set of the plane behind the volume (1) is cleared
+            __builtin_amdgcn_sched_barrier(0);
+            const int p = patch_of(i);
+            const float inv = __builtin_ldexpf(1.f, -(patch_exp(p) + a.e_w));
+            epi_row(D3IC<2>{}, D3IC<3>{}, p, 14, true, inv);
+            epi_row(D3IC<0>{}, D3IC<0>{}, p, 15, true, inv);
+            epi_row(D3IC<0>{}, D3IC<1>{}, p, 15, true, inv);
+            epi_row(D3IC<0>{}, D3IC<2>{}, p, 15, true, inv);
+            epi_row(D3IC<0>{}, D3IC<3>{}, p, 15, true, inv);
+#pragma unroll
+            for (int ry = 0; ry < 4; ++ry) { acc[1][ry] = f32x4{0.f, 0.f, 0.f, 0.f}; acx[1][ry] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 7" :: "v"(okeep[0]), "v"(okeep[1]));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------- host
+int d3d_build(const View &in, const View &out, const int k[3], const int lo[3], const int s[3], D3dPlan *plan) {
+    plan->ok = false;
+    if (getenv("ALQ_NO_D3D")) return ALQ_OK;
+    if (!(k[0] == 3 && k[1] == 3 && k[2] == 3 && s[0] == 1 && s[1] == 1 && s[2] == 1 && lo[0] == 1 && lo[1] == 1 && lo[2] == 1)) return ALQ_OK;
+    if (!(in.D == 16 && in.H == 16 && in.W == 16 && out.D == 16 && out.H == 16 && out.W == 16 && in.C == 32 && in.split == 16 && in.cs == 16 && in.c0 == 0 &&
+          out.C == 16 && out.cs == 16 && out.c0 == 0 && out.split == 0)) return ALQ_OK;
+    plan->flops_per_patch = 2.0 * 27 * 32 * 16 * 4096.0;
+    plan->ok = true;
+    return ALQ_OK;
+}
+
+// W: TF conv filter [tap = (tz * 3 + ty) * 3 + tx][ci (32)][co (16)].  Fragment of a tap: lane -> row co = lane & 15, k-group kg = lane >> 4: ci = 8 kg + c.
+void d3d_pack(D3dPlan *plan, const float *W) {
+    float amax = 0.f;
+    for (size_t i = 0; i < (size_t)27 * 32 * 16; ++i) amax = std::max(amax, std::fabs(W[i]));
+    int ex = 0;
+    if (amax > 0.f) (void)std::frexp(amax, &ex);
+    plan->w_exp = 14 - ex;
+    plan->h_Whi.assign((size_t)27 * 64 * 8, 0);
+    plan->h_Wlo.assign((size_t)27 * 64 * 8, 0);
+    for (int tap = 0; tap < 27; ++tap)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int co = lane & 15, kg = lane >> 4;
+            for (int c = 0; c < 8; ++c) {
+                const float w = W[((size_t)tap * 32 + 8 * kg + c) * 16 + co];
+                const float ws = std::ldexp(w, plan->w_exp);
+                const _Float16 h = (_Float16)ws;
+                const _Float16 l = (_Float16)std::ldexp(ws - (float)h, 11);
+                unsigned short hb, lb;
+                std::memcpy(&hb, &h, 2);
+                std::memcpy(&lb, &l, 2);
+                const size_t o = ((size_t)tap * 64 + lane) * 8 + c;
+                plan->h_Whi[o] = hb;
+                plan->h_Wlo[o] = lb;
+            }
+        }
+}
+
+int d3d_fwd_launch(alq_ctx *ctx, const D3dPlan &plan, int N, const float *inA, const float *inB, const unsigned *amaxA, const unsigned *amaxB,
+                   const float *bias, int relu, float *out, unsigned char *sg, float *osum) {
+    ALQ_REQUIRE(plan.ok && plan.d_Whi && plan.d_Wlo, ALQ_EINVAL, "d3d: weights not set");
+    ALQ_REQUIRE(inA && inB && amaxA && amaxB && bias && out, ALQ_EINVAL, "d3d: missing argument");
+    ALQ_REQUIRE(N < 4096, ALQ_EUNSUPPORTED, "d3d: 32-bit byte offsets hold fewer than 4096 patches per pass");
+    if (N <= 0) return ALQ_OK;
+    D3Args a;
+    a.inA = inA; a.inB = inB; a.amaxA = amaxA; a.amaxB = amaxB;
+    a.Whi = reinterpret_cast<const unsigned short *>(plan.d_Whi); a.Wlo = reinterpret_cast<const unsigned short *>(plan.d_Wlo);
+    a.bias = bias; a.out = out; a.sg = sg; a.osum = osum; a.e_w = plan.w_exp; a.relu = relu; a.N = N;
+    int cus = 256;
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+    long long g = std::min<long long>((long long)cus, (long long)N);
+    g = std::max<long long>(8, (g + 7) / 8 * 8);
+    const size_t lds = D3_STRIP;
+    ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(d3d_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope ps(ctx, PROF_IGEMM_F16, plan.flops_per_patch * N);
+    hipLaunchKernelGGL(d3d_fwd_kernel, dim3((unsigned)g), dim3(256), lds, ctx->stream, a);
+    ALQ_HIP(hipGetLastError());
+    return ALQ_OK;
+}
+
+}  // namespace alq

@@ -89,6 +89,7 @@ struct Layer {
     // plane-sweep engine (c3d.hip) for the conv under the fused two-class head (and its backward): plans on the conv layer,
     // per-(patch, wave) partials of the logit difference / of the head's input sum on the head layer
     C3dPlan c3f, c3b;
+    D3dPlan d3f;                           // forward on the row-sweep engine of d3d.hip (NET-C's dec1)
     E3dPlan e3b;                           // backward fused with the pool backward steps on either side (e3d.hip; NET-C's enc2)
     T3dPlan t3f, t3b;                      // row-sweep engine for the stride-2 conv_transpose (t3d.hip), forward / backward-data
     float *c3_part = nullptr, *c3_asum = nullptr;
@@ -156,6 +157,8 @@ struct alq_model {
     bool last_c3_bwd = false;      // ... and the last backward pass its backward
     int no_e3d = 0;                // ALQ_NO_E3D (A/B): pool2 backward, enc2 backward and pool1 backward as three launches as in round 4
     int last_e3b = 0;              // the last backward pass ran them as one launch (e3d.hip)
+    int no_d3d = 0;                // ALQ_NO_D3D (A/B): dec1's forward on the two-slot engine as in round 4
+    int last_d3f = 0;              // the last forward pass ran it on the row-sweep engine (d3d.hip)
     int no_t3d = 0;                // ALQ_NO_T3D (A/B): conv_transpose launches on the two-slot engine (igemm4) as in round 4
     int last_t3f = 0, last_t3b = 0;   // conv_transpose launches of the last forward / backward pass that ran on the row-sweep engine
     bool last_f16_derived = false; // the last forward pass ran a launch on the fp16x2 split with derived input bounds
@@ -618,6 +621,7 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
                 ALQ_TRY(c3d_fwd_build(ly.in, ly.out, sp.k, ly.lo, sp.s, &ly.c3f));
                 ALQ_TRY(c3d_bwd_build(ly.in, ly.out, sp.k, ly.lo, sp.s, &ly.c3b));
                 ALQ_TRY(e3d_build(ly.in, ly.out, sp.k, ly.lo, sp.s, &ly.e3b));
+                ALQ_TRY(d3d_build(ly.in, ly.out, sp.k, ly.lo, sp.s, &ly.d3f));
             }
             if (!first_param) {
                 ConvDesc b;
@@ -795,6 +799,7 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
     m->last_head_fused = false;
     m->last_c3 = false;
     m->last_t3f = 0;
+    m->last_d3f = 0;
     // A conv / conv_transpose launch contracts with the fp16x2 split if it knows max |x| per patch of (every part of)
     // its input ahead of time: the launches that produce those tensors report them (`prod`), the consumers (`cons`)
     // read one scale per tile.  Producers: the first conv + pool kernel and one-patch-per-tile igemm4 launches.
@@ -973,6 +978,18 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                     break;
                 }
                 if (fuse) take_amax(fz, i);
+                // the row-sweep engine (d3d.hip) where its geometry applies, both per-patch input bounds are known and nothing but the tensor,
+                // its channel sums and its sign field is wanted
+                if (fuse && ly.d3f.ok && ly.d3f.d_Whi && !m->no_d3d && fz.in_amax && fz.in_amax2 && !prod[i] && !g_no_f16x2 && !g_dbg_knobs[4] && !g_dbg_knobs[5] &&
+                    with_sums && fz.osumA && in.split == 16 && !(drop && drop->on(i))) {
+                    const bool sgd = !m->no_signs && ly.spec.relu && ly.out.sg;
+                    ALQ_TRY(d3d_fwd_launch(ctx, ly.d3f, N, in.p, in.p + in.delta, fz.in_amax, fz.in_amax2, ly.d_bias, ly.spec.relu ? 1 : 0, ly.out.p,
+                                           sgd ? ly.out.sg : nullptr, fz.osumA));
+                    ly.signs_ready = sgd;
+                    fused = true;
+                    m->last_d3f = 1;
+                    break;
+                }
                 if (fuse && prod[i]) fz.out_amax = m->amax_tiles;
                 const bool sg_here = with_sums && fuse && !m->no_signs && ly.spec.relu && ly.out.sg && v4_fwd(ly.fwd[0], in, ly.out);
                 if (sg_here) fz.sign_out = ly.out.sg;
@@ -1614,6 +1631,7 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
         if (const char *f = getenv("ALQ_F16_FWD_MASK")) m->f16_fwd_mask = atoi(f);
         m->no_t3d = getenv("ALQ_NO_T3D") ? 1 : 0;
         m->no_e3d = getenv("ALQ_NO_E3D") ? 1 : 0;
+        m->no_d3d = getenv("ALQ_NO_D3D") ? 1 : 0;
         {   // default since round 5: on.  ALQ_NO_F16_DERIVED=1 (or ALQ_F16_DERIVED=0) keeps that launch on bf16 triples (A/B)
             const char *e = getenv("ALQ_F16_DERIVED"), *n = getenv("ALQ_NO_F16_DERIVED");
             m->no_f16_derived = ((e && atoi(e) == 0) || (n && atoi(n) == 1)) ? 1 : 0;
@@ -1777,6 +1795,15 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
             ly.e3b.d_Whi = dh; ly.e3b.d_Wlo = dl;
             ALQ_HIP(hipMemcpyAsync(dh, ly.e3b.h_Whi.data(), ly.e3b.h_Whi.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
             ALQ_HIP(hipMemcpyAsync(dl, ly.e3b.h_Wlo.data(), ly.e3b.h_Wlo.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
+            ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
+        }
+        if (ly.d3f.ok) {
+            d3d_pack(&ly.d3f, W);
+            unsigned short *dh = reinterpret_cast<unsigned short *>(ly.d3f.d_Whi), *dl = reinterpret_cast<unsigned short *>(ly.d3f.d_Wlo);
+            if (!dh) { ALQ_TRY(m->dalloc(&dh, ly.d3f.h_Whi.size())); ALQ_TRY(m->dalloc(&dl, ly.d3f.h_Wlo.size())); }
+            ly.d3f.d_Whi = dh; ly.d3f.d_Wlo = dl;
+            ALQ_HIP(hipMemcpyAsync(dh, ly.d3f.h_Whi.data(), ly.d3f.h_Whi.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
+            ALQ_HIP(hipMemcpyAsync(dl, ly.d3f.h_Wlo.data(), ly.d3f.h_Wlo.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
             ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
         }
         if (ly.has_bwd) {
@@ -2115,10 +2142,11 @@ int alq_model_debug_copy(alq_model *m, int layer_idx, int what, int N, float *d_
 }
 
 int alq_model_engine_info(alq_model *m, int what) {
-    ALQ_REQUIRE(m && ((what >= 0 && what <= 3) || (what >= 5 && what <= 9)), ALQ_EINVAL, "alq_model_engine_info: bad argument");
+    ALQ_REQUIRE(m && ((what >= 0 && what <= 3) || (what >= 5 && what <= 10)), ALQ_EINVAL, "alq_model_engine_info: bad argument");
     if (what == 6) return m->last_f16_derived ? 1 : 0;
     if (what == 7) return m->last_t3f;        // conv_transpose launches of the last forward pass on the row-sweep engine (t3d.hip)
     if (what == 8) return m->last_t3b;        // ... of the last backward pass
+    if (what == 10) return m->last_d3f;       // the last forward pass ran dec1 on the row-sweep engine (d3d.hip)
     if (what == 9) return m->last_e3b;        // the last backward pass ran enc2's backward fused with both pool backward steps (e3d.hip)
     ALQ_HIP(hipSetDevice(m->ctx->device));
     if (what == 0) return c3d_subnormals_ok(m->ctx);

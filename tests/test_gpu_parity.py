@@ -1584,3 +1584,44 @@ def test_two_scoring_pipelines_are_bit_identical_to_one(sess):
     for k in keys:
         np.testing.assert_array_equal(one_b[k], two_b[k], err_msg='after set_weights: ' + k)
     m.close()
+
+
+def test_plane_sweep_dec1_forward_against_the_two_slot_engine(sess):
+    """NET-C's `dec1` forward (3x3x3 conv over the concat [up1 | enc2], 32 -> 16 channels at 16^3 + bias + ReLU; reference call site
+    NN_extended.py:416-426) on the plane-sweep kernel of csrc/d3d.hip (default since round 5) against the two-slot engine's launch
+    (ALQ_NO_D3D=1): the same arithmetic - fp16 pairs at per-patch scales from the derived input bounds - in another summation
+    order.  300 patches (every workgroup sees several): the layer's output within 2e-6 of its maximum, up2's input channel sums
+    (the field the kernel's epilogue adds up) through up2's score, posteriors within 2e-6, layer scores within 2e-6 + 2e-5
+    relative or the patch goes to the fp64 arbiter; an all-zero patch and a ragged last workgroup (n = 300 is not a multiple of
+    8) ride along."""
+    import ctypes as C
+    from nnal_amd._lib import check
+    torch = sess.torch
+    n = 300
+    ld, sk, in_shape, pars, (m_new, m_old) = _netc32_models(sess, [{}, {'ALQ_NO_D3D': '1'}], max_batch=n, bias_std=0.05)
+    x = sess.empty((n, 32 ** 3), torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, 32 ** 3, C.c_void_p(x.data_ptr())))
+    x[17].zero_()
+    out = []
+    for m in (m_new, m_old):
+        r = m.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1', 'A', 'Asum'))
+        d = {k: r[k].cpu().numpy() for k in ('p1', 'g0', 'g1', 'A', 'Asum')}
+        d['dec1_out'] = m.debug_tensor(6, 0, n)
+        out.append(d)
+    assert sess.lib.alq_model_engine_info(m_new._m, 10) == 1, 'the plane-sweep kernel did not run'
+    assert sess.lib.alq_model_engine_info(m_old._m, 10) == 0
+    a, b = out
+    assert a['dec1_out'].shape == b['dec1_out'].shape and np.isfinite(a['dec1_out']).all()
+    err = np.abs(a['dec1_out'] - b['dec1_out']).max()
+    assert err <= 2e-6 * np.abs(b['dec1_out']).max(), (err, np.abs(b['dec1_out']).max())
+    np.testing.assert_allclose(a['p1'], b['p1'], rtol=0, atol=2e-6)
+    bad = set()
+    for k in ('g0', 'g1'):
+        e = np.abs(a[k] - b[k])
+        bad |= set(np.nonzero((e > 2e-6 + 2e-5 * np.abs(b[k])).any(axis=1))[0].tolist())
+    flips = _fp64_arbitrate(ld, sk, in_shape, pars, x.cpu().numpy(), sorted(bad), [a, b], ['plane sweep', 'two-slot'])
+    assert flips <= 8, flips
+    good = np.array(sorted(set(range(n)) - bad))
+    np.testing.assert_allclose(a['A'][good], b['A'][good], rtol=2e-5, atol=1e-12 + 2e-6 * np.abs(b['A']).max())
+    m_new.close()
+    m_old.close()

@@ -457,7 +457,11 @@ struct D3dPlan {
     double flops_per_patch = 0;
     std::vector<unsigned short> h_Whi, h_Wlo;      // [27 taps][64][8] fp16 bits
     void *d_Whi = nullptr, *d_Wlo = nullptr;
+    std::vector<unsigned short> h_Bhi, h_Blo;      // backward: [2 row blocks][3 dz][5 K steps][64][8]
+    void *d_Bhi = nullptr, *d_Blo = nullptr;
 };
+void d3d_bwd_pack(D3dPlan *plan, const float *W);      // (after d3d_pack: the same weight scale)
+int d3d_bwd_launch(alq_ctx *ctx, const D3dPlan &plan, int N, const float *dout, float in_bound, float *dinA, float *dinB, float *sumB);
 int d3d_build(const View &in, const View &out, const int k[3], const int lo[3], const int s[3], D3dPlan *plan);
 void d3d_pack(D3dPlan *plan, const float *W /* TF conv filter [tap][ci 32][co 16] */);
 int d3d_fwd_launch(alq_ctx *ctx, const D3dPlan &plan, int N, const float *inA, const float *inB, const unsigned *amaxA, const unsigned *amaxB,

@@ -16,6 +16,7 @@ for f in igemm igemm2 igemm3 igemm4 c3d t3d e3d d3d fcgemm direct kernels topk m
   X=""; if [ "$f" = igemm4 ]; then X="-fno-slp-vectorize --save-temps=obj ${ALQ_G4_FLAGS:-}"; fi
   # c3d: the same choice (its staging / epilogue arithmetic runs between the wave's own MFMAs)
   if [ "$f" = c3d ]; then X="-fno-slp-vectorize ${ALQ_C3_FLAGS:-}"; fi
+  if [ "$f" = d3d ]; then X="-fno-slp-vectorize ${ALQ_D3_FLAGS:-}"; fi      # (d3d: like c3d; same-box 523 -> 490 / 710 -> 675 us)
   ( hipcc $FLAGS $X -c "$HERE/$f.hip" -o "$BUILD/$f.o" ${ALQ_EXTRA_FLAGS:-} ) &
   pids+=($!)
 done

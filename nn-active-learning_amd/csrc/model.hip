@@ -159,6 +159,7 @@ struct alq_model {
     int last_e3b = 0;              // the last backward pass ran them as one launch (e3d.hip)
     int no_d3d = 0;                // ALQ_NO_D3D (A/B): dec1's forward on the two-slot engine as in round 4
     int last_d3f = 0;              // the last forward pass ran it on the row-sweep engine (d3d.hip)
+    int no_d3b = 0, last_d3b = 0;  // ALQ_NO_D3D_BWD (A/B): only the backward launch on the two-slot engine; the last backward pass ran it on d3d.hip
     int no_t3d = 0;                // ALQ_NO_T3D (A/B): conv_transpose launches on the two-slot engine (igemm4) as in round 4
     int last_t3f = 0, last_t3b = 0;   // conv_transpose launches of the last forward / backward pass that ran on the row-sweep engine
     bool last_f16_derived = false; // the last forward pass ran a launch on the fp16x2 split with derived input bounds
@@ -1144,6 +1145,7 @@ static int run_backward_main(alq_model *m, const float *d_x, int N) {
     };
     int e3_conv = -1;      // the conv whose backward ran fused with the pool backward steps around it (e3d.hip), or -1
     m->last_e3b = 0;
+    m->last_d3b = 0;
     for (int i = nl - 1; i >= 0; --i) {
         Layer &ly = m->layers[i];
         const bool prev_is_src = (i > 0 && m->layers[i - 1].out_is_skip_src && ly.spec.skip_src < 0);
@@ -1332,10 +1334,19 @@ static int run_backward_main(alq_model *m, const float *d_x, int N) {
                 const bool t3 = ly.spec.type == ALQ_CONVT && ly.t3b.ok && ly.t3b.d_W && !m->no_t3d && v4_on && !g_no_f16x2 && !acc && fuse && !hand &&
                                 fz.in_bound > 0.f && !fz.in_amax && fz.split == 0 && fz.store_from == 0 && fz.osumA && !fz.osumB && fz.mask_from == 0 &&
                                 (!fz.mask || fz.mask_bits) && !ly.dout.split && !ly.din.split && prev_param;
+                // the plane-sweep kernel of d3d.hip for the backward-data pass of the conv over a split concat (NET-C's dec1): fp16 pairs under the static
+                // bound like the two-slot launch it replaces; channels [0, 16) = the skip source's cotangent (stored), [16, 32) = the producer's (stored + summed)
+                const bool d3 = ly.spec.type == ALQ_CONV && ly.d3f.ok && ly.d3f.d_Bhi && !m->no_d3d && !m->no_d3b && v4_on && !g_no_f16x2 && !acc && fuse && !hand &&
+                                fz.in_bound > 0.f && !fz.in_amax && fz.split == 16 && fz.store_from == 0 && !fz.mask && !fz.osumA && fz.osumB &&
+                                !ly.dout.split && ly.dout.cs == 16 && ly.dout.c0 == 0 && ly.din.split == 16 && ly.din.cs == 16 && ly.din.c0 == 0 && ly.din.C == 32;
                 if (t3) {
                     ALQ_TRY(t3d_bwd_launch(ctx, ly.t3b, ly.dout, ly.din, N, fz.in_bound, fz.mask ? fz.mask_bits : nullptr, fz.osumA));
                     fused = true;
                     m->last_t3b += 1;
+                } else if (d3) {
+                    ALQ_TRY(d3d_bwd_launch(ctx, ly.d3f, N, ly.dout.p, fz.in_bound, ly.din.p, ly.din.p + ly.din.delta, fz.osumB));
+                    fused = true;
+                    m->last_d3b = 1;
                 } else
                 ALQ_TRY(gemm_launch(ctx, ly.bwd, ly.dout, ly.din, nullptr, 0, acc, N, PROF_IGEMM_BWD, fuse, &fused));
                 if (hand) {
@@ -1632,6 +1643,7 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
         m->no_t3d = getenv("ALQ_NO_T3D") ? 1 : 0;
         m->no_e3d = getenv("ALQ_NO_E3D") ? 1 : 0;
         m->no_d3d = getenv("ALQ_NO_D3D") ? 1 : 0;
+        m->no_d3b = getenv("ALQ_NO_D3D_BWD") ? 1 : 0;
         {   // default since round 5: on.  ALQ_NO_F16_DERIVED=1 (or ALQ_F16_DERIVED=0) keeps that launch on bf16 triples (A/B)
             const char *e = getenv("ALQ_F16_DERIVED"), *n = getenv("ALQ_NO_F16_DERIVED");
             m->no_f16_derived = ((e && atoi(e) == 0) || (n && atoi(n) == 1)) ? 1 : 0;
@@ -1804,6 +1816,14 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
             ly.d3f.d_Whi = dh; ly.d3f.d_Wlo = dl;
             ALQ_HIP(hipMemcpyAsync(dh, ly.d3f.h_Whi.data(), ly.d3f.h_Whi.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
             ALQ_HIP(hipMemcpyAsync(dl, ly.d3f.h_Wlo.data(), ly.d3f.h_Wlo.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
+            if (ly.has_bwd) {
+                d3d_bwd_pack(&ly.d3f, W);
+                unsigned short *bh = reinterpret_cast<unsigned short *>(ly.d3f.d_Bhi), *bl = reinterpret_cast<unsigned short *>(ly.d3f.d_Blo);
+                if (!bh) { ALQ_TRY(m->dalloc(&bh, ly.d3f.h_Bhi.size())); ALQ_TRY(m->dalloc(&bl, ly.d3f.h_Blo.size())); }
+                ly.d3f.d_Bhi = bh; ly.d3f.d_Blo = bl;
+                ALQ_HIP(hipMemcpyAsync(bh, ly.d3f.h_Bhi.data(), ly.d3f.h_Bhi.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
+                ALQ_HIP(hipMemcpyAsync(bl, ly.d3f.h_Blo.data(), ly.d3f.h_Blo.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
+            }
             ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
         }
         if (ly.has_bwd) {
@@ -2142,10 +2162,11 @@ int alq_model_debug_copy(alq_model *m, int layer_idx, int what, int N, float *d_
 }
 
 int alq_model_engine_info(alq_model *m, int what) {
-    ALQ_REQUIRE(m && ((what >= 0 && what <= 3) || (what >= 5 && what <= 10)), ALQ_EINVAL, "alq_model_engine_info: bad argument");
+    ALQ_REQUIRE(m && ((what >= 0 && what <= 3) || (what >= 5 && what <= 11)), ALQ_EINVAL, "alq_model_engine_info: bad argument");
     if (what == 6) return m->last_f16_derived ? 1 : 0;
     if (what == 7) return m->last_t3f;        // conv_transpose launches of the last forward pass on the row-sweep engine (t3d.hip)
     if (what == 8) return m->last_t3b;        // ... of the last backward pass
+    if (what == 11) return m->last_d3b;       // the last backward pass ran dec1's backward-data launch on the plane-sweep kernel (d3d.hip)
     if (what == 10) return m->last_d3f;       // the last forward pass ran dec1 on the row-sweep engine (d3d.hip)
     if (what == 9) return m->last_e3b;        // the last backward pass ran enc2's backward fused with both pool backward steps (e3d.hip)
     ALQ_HIP(hipSetDevice(m->ctx->device));

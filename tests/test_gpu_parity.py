@@ -1040,7 +1040,7 @@ def test_sign_fields_are_bit_identical(sess):
         # ONE engine reading its masks from two sources)
         # (likewise ALQ_NO_T3D and ALQ_NO_E3D: the row-sweep conv_transpose backward and the fused enc2 backward of round 5
         # read their masks from the sign fields only)
-        pin = {'ALQ_NO_C3D': '1', 'ALQ_NO_T3D': '1', 'ALQ_NO_E3D': '1'}
+        pin = {'ALQ_NO_C3D': '1', 'ALQ_NO_T3D': '1', 'ALQ_NO_E3D': '1'}      # (d3d.hip's launches take no masks: the same in both arms)
         a, b = run(pin), run(dict(pin, ALQ_NO_SIGNS='1'))
         for k in a:
             np.testing.assert_array_equal(a[k], b[k], err_msg='%s %s' % (in_shape, k))
@@ -1623,5 +1623,43 @@ def test_plane_sweep_dec1_forward_against_the_two_slot_engine(sess):
     assert flips <= 8, flips
     good = np.array(sorted(set(range(n)) - bad))
     np.testing.assert_allclose(a['A'][good], b['A'][good], rtol=2e-5, atol=1e-12 + 2e-6 * np.abs(b['A']).max())
+    m_new.close()
+    m_old.close()
+
+
+def test_plane_sweep_dec1_backward_against_the_two_slot_engine(sess):
+    """NET-C's `dec1` backward-data launch (16 -> 32 channels at 16^3: both halves of the concat cotangent + up1's channel sums) on the
+    plane-sweep kernel of csrc/d3d.hip (default since round 5) against the two-slot engine's launch (ALQ_NO_D3D_BWD=1).  Same
+    arithmetic (fp16 pairs under the static cotangent bound), same forward pass and masks (nothing can flip), another summation
+    order: up1's cotangent and channel sums and enc2's channel sums (ALQ_NO_E3D in both arms so that they are stored; they hold
+    the other half of the concat cotangent) within 2e-6 of their maxima on 300 patches, posteriors bit-identical, every layer score
+    within 2e-6 + 2e-5 relative."""
+    import ctypes as C
+    from nnal_amd._lib import check
+    torch = sess.torch
+    n = 300
+    ld, sk, in_shape, pars, (m_new, m_old) = _netc32_models(sess, [{'ALQ_NO_E3D': '1'}, {'ALQ_NO_E3D': '1', 'ALQ_NO_D3D_BWD': '1'}], max_batch=n, bias_std=0.05)
+    x = sess.empty((n, 32 ** 3), torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, 32 ** 3, C.c_void_p(x.data_ptr())))
+    x[17].zero_()
+    out = []
+    for m in (m_new, m_old):
+        r = m.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1', 'A', 'Asum'))
+        d = {k: r[k].cpu().numpy() for k in ('p1', 'g0', 'g1', 'A', 'Asum')}
+        d['up1_dout'] = m.debug_tensor(5, 1, n)
+        d['up1_dsum'] = m.debug_tensor(5, 3, n)
+        d['enc2_dsum'] = m.debug_tensor(2, 3, n)
+        out.append(d)
+    assert sess.lib.alq_model_engine_info(m_new._m, 11) == 1, 'the plane-sweep kernel did not run'
+    assert sess.lib.alq_model_engine_info(m_old._m, 11) == 0
+    a, b = out
+    np.testing.assert_array_equal(a['p1'], b['p1'])
+    for k in ('up1_dout', 'up1_dsum', 'enc2_dsum'):
+        assert a[k].shape == b[k].shape and np.isfinite(a[k]).all()
+        err = np.abs(a[k] - b[k]).max()
+        assert err <= 2e-6 * np.abs(b[k]).max(), (k, err, np.abs(b[k]).max())
+    for k in ('g0', 'g1'):
+        np.testing.assert_allclose(a[k], b[k], rtol=2e-5, atol=2e-6, err_msg=k)
+    np.testing.assert_allclose(a['A'], b['A'], rtol=2e-5, atol=1e-12 + 2e-6 * np.abs(b['A']).max())
     m_new.close()
     m_old.close()

@@ -420,7 +420,7 @@ int c3d_bwd_launch(alq_ctx *ctx, const C3dPlan &plan, int N, const unsigned char
 // rows of one input plane on its own (no workgroup barrier), weights in registers, an accumulator = one 1 KB output row.
 struct T3dPlan {
     bool ok = false;
-    int kind = 0;                         // 0: 16 -> 8 channels at 16^3 (up2); 8: 32 -> 16 channels at 8^3 (up1, forward only)
+    int kind = 0;                         // 0: 16 -> 8 channels at 16^3 (up2); 8: 32 -> 16 channels at 8^3 (up1; backward: t3d8b.hip)
     int w_exp = 0;                        // backward: scale exponent of the packed fp16 weight pairs
     double flops_per_patch = 0;
     std::vector<unsigned short> h_W;      // forward [9][3 pieces][64][8] bf16 bits; backward [9][2 pieces][64][8] fp16 bits
@@ -430,6 +430,8 @@ int t3d_build(const View &in, const View &out, const int k[3], const int lo[3], 
 void t3d_fwd_pack(T3dPlan *plan, const float *W /* TF filter [tap][co][ci] */);
 void t3d_bwd_pack(T3dPlan *plan, const float *W);
 void t3d8_fwd_pack(T3dPlan *plan, const float *W /* [tap][16][32] */);
+void t3d8_bwd_pack(T3dPlan *plan, const float *W /* [tap][16][32] */);      // (t3d8b.hip)
+int t3d8_bwd_launch(alq_ctx *ctx, const T3dPlan &plan, const View &dout, const View &din, int N, float in_bound, const unsigned char *mask_bits, float *dsum);
 int t3d_fwd_launch(alq_ctx *ctx, const T3dPlan &plan, const View &in, const View &out, const float *bias, int N, float *osum, unsigned *out_amax);
 int t3d_bwd_launch(alq_ctx *ctx, const T3dPlan &plan, const View &dout, const View &din, int N, float in_bound, const unsigned char *mask_bits,
                    float *dsum);

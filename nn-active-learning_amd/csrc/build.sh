@@ -9,7 +9,7 @@ FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -I$HERE -Wall 
 BUILD="$HERE/build${ALQ_BUILD_TAG:-}"
 mkdir -p "$BUILD"
 pids=()
-for f in igemm igemm2 igemm3 igemm4 c3d t3d e3d d3d fcgemm direct kernels topk model comm train sim; do
+for f in igemm igemm2 igemm3 igemm4 c3d t3d t3d8b e3d d3d fcgemm direct kernels topk model comm train sim; do
   # igemm4: no SLP vectorisation (a performance choice) - it turns neighbouring scalar f32 multiplies / adds of the staging and epilogue code into
   # v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, which issue slower than the scalar pairs next to another wave's MFMAs on
   # the same SIMD (same-box A/B: 155.4 k -> 156.6 k patches/s); conversions still pack (v_cvt_pk_f16_f32 / _bf16_f32)
@@ -37,5 +37,5 @@ else
   # another ROCm version may name the --save-temps files differently: the check is a tuning aid, not a build requirement
   echo "build.sh: warning: device assembly of igemm4 not found ($ASM); packed-fp32 check skipped" >&2
 fi
-hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT" "$BUILD"/{igemm,igemm2,igemm3,igemm4,c3d,t3d,e3d,d3d,fcgemm,direct,kernels,topk,model,comm,train,sim}.o -ldl
+hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT" "$BUILD"/{igemm,igemm2,igemm3,igemm4,c3d,t3d,t3d8b,e3d,d3d,fcgemm,direct,kernels,topk,model,comm,train,sim}.o -ldl
 echo "built $OUT"

@@ -1867,7 +1867,8 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
             return ALQ_OK;
         };
         if (ly.t3f.ok) { if (ly.t3f.kind == 8) t3d8_fwd_pack(&ly.t3f, W); else t3d_fwd_pack(&ly.t3f, W); ALQ_TRY(up3(&ly.t3f)); }
-        if (ly.t3b.ok && ly.has_bwd && c3d_subnormals_ok(m->ctx)) { t3d_bwd_pack(&ly.t3b, W); ALQ_TRY(up3(&ly.t3b)); }      // (one-accumulator fp16 pairs)
+        if (ly.t3b.ok && ly.has_bwd && ly.t3b.kind == 8) { t3d8_bwd_pack(&ly.t3b, W); ALQ_TRY(up3(&ly.t3b)); }      // (two accumulators)
+        else if (ly.t3b.ok && ly.has_bwd && c3d_subnormals_ok(m->ctx)) { t3d_bwd_pack(&ly.t3b, W); ALQ_TRY(up3(&ly.t3b)); }      // (one-accumulator fp16 pairs)
         if (ly.has_bwd) {
             std::vector<float> Bb(W, W + ly.w_elems);   // [(tap, co)][ci] as stored
             ALQ_TRY(gemm_set(m, &ly.bwd, Bb));

@@ -624,10 +624,11 @@ int t3d_build(const View &in, const View &out, const int k[3], const int lo[3], 
     fwd->ok = bwd->ok = false;
     fwd->kind = bwd->kind = 0;
     if (getenv("ALQ_NO_T3D")) return ALQ_OK;
-    if (t8_geometry(in, out, k, lo, s) && !getenv("ALQ_NO_T3D8")) {      // 32 -> 16 channels at 8^3: forward only
-        fwd->kind = 8;
-        fwd->flops_per_patch = 2.0 * 27 * 32 * 16 * (double)in.vox();
+    if (t8_geometry(in, out, k, lo, s) && !getenv("ALQ_NO_T3D8")) {      // 32 -> 16 channels at 8^3: forward here, backward in t3d8b.hip
+        fwd->kind = bwd->kind = 8;
+        fwd->flops_per_patch = bwd->flops_per_patch = 2.0 * 27 * 32 * 16 * (double)in.vox();
         fwd->ok = true;
+        bwd->ok = !getenv("ALQ_NO_T3D8B");
         return ALQ_OK;
     }
     if (!t3_geometry(in, out, k, lo, s)) return ALQ_OK;
@@ -779,6 +780,7 @@ int t3d_fwd_launch(alq_ctx *ctx, const T3dPlan &plan, const View &in, const View
 
 int t3d_bwd_launch(alq_ctx *ctx, const T3dPlan &plan, const View &dout, const View &din, int N, float in_bound, const unsigned char *mask_bits, float *dsum) {
     ALQ_REQUIRE(plan.ok && plan.d_W, ALQ_EINVAL, "t3d: weights not set");
+    if (plan.kind == 8) return t3d8_bwd_launch(ctx, plan, dout, din, N, in_bound, mask_bits, dsum);
     ALQ_REQUIRE(dout.cs == 8 && dout.c0 == 0 && dout.split == 0 && din.cs == 16 && din.c0 == 0 && din.split == 0 && din.D == 16 && dout.D == 32 && in_bound > 0.f,
                 ALQ_EINVAL, "t3d: view mismatch");
     ALQ_REQUIRE(N < 4096, ALQ_EUNSUPPORTED, "t3d: 32-bit byte offsets hold fewer than 4096 patches per pass");

@@ -1663,3 +1663,39 @@ def test_plane_sweep_dec1_backward_against_the_two_slot_engine(sess):
     np.testing.assert_allclose(a['A'], b['A'], rtol=2e-5, atol=1e-12 + 2e-6 * np.abs(b['A']).max())
     m_new.close()
     m_old.close()
+
+
+def test_up1_backward_kernel_against_the_two_slot_engine(sess):
+    """NET-C's `up1` backward-data launch (stride-2 conv of the 16-channel cotangent at 16^3 into 32 channels at 8^3, masked by bott's
+    sign field, + channel sums; reference call site NN_extended.py:574-587) on the kernel of csrc/t3d8b.hip (default since round 5)
+    against the two-slot engine's launch (ALQ_NO_T3D8B=1).  Same arithmetic (fp16 pairs under the static cotangent bound), same
+    forward pass and masks: bott's cotangent and channel sums within 2e-6 of their maxima on 300 patches (an all-zero patch and a
+    ragged last workgroup among them), posteriors bit-identical, every layer score within 2e-6 + 2e-5 relative."""
+    import ctypes as C
+    from nnal_amd._lib import check
+    torch = sess.torch
+    n = 300
+    ld, sk, in_shape, pars, (m_new, m_old) = _netc32_models(sess, [{}, {'ALQ_NO_T3D8B': '1'}], max_batch=n, bias_std=0.05)
+    x = sess.empty((n, 32 ** 3), torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, 32 ** 3, C.c_void_p(x.data_ptr())))
+    x[17].zero_()
+    out = []
+    for m in (m_new, m_old):
+        r = m.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1', 'A', 'Asum'))
+        d = {k: r[k].cpu().numpy() for k in ('p1', 'g0', 'g1', 'A', 'Asum')}
+        d['bott_dout'] = m.debug_tensor(4, 1, n)
+        d['bott_dsum'] = m.debug_tensor(4, 3, n)
+        out.append(d)
+    assert sess.lib.alq_model_engine_info(m_new._m, 8) == 2, 'up1 backward did not run on the row-sweep engine'
+    assert sess.lib.alq_model_engine_info(m_old._m, 8) == 1
+    a, b = out
+    np.testing.assert_array_equal(a['p1'], b['p1'])
+    for k in ('bott_dout', 'bott_dsum'):
+        assert a[k].shape == b[k].shape and np.isfinite(a[k]).all()
+        err = np.abs(a[k] - b[k]).max()
+        assert err <= 2e-6 * np.abs(b[k]).max(), (k, err, np.abs(b[k]).max())
+    for k in ('g0', 'g1'):
+        np.testing.assert_allclose(a[k], b[k], rtol=2e-5, atol=2e-6, err_msg=k)
+    np.testing.assert_allclose(a['A'], b['A'], rtol=2e-5, atol=1e-12 + 2e-6 * np.abs(b['A']).max())
+    m_new.close()
+    m_old.close()

@@ -89,7 +89,7 @@ def main():
             e['hbm_read_MB_per_launch'] = round(rd_b / 1e6, 1)
             e['hbm_write_MB_per_launch'] = round(wr_b / 1e6, 1)
             e['hbm_GBps'] = round((rd_b + wr_b) / (st['avg_us'] * 1e-6) / 1e9, 0)
-            if name.startswith(('igemm4_kernel', 'c3d_fwd_kernel', 'c3d_bwd_kernel', 't3d_fwd_kernel', 't3d_bwd_kernel', 't3d8_fwd_kernel', 'e3d_bwd_kernel')):      # the twelve contraction launches of a pass
+            if name.startswith(('igemm4_kernel', 'c3d_fwd_kernel', 'c3d_bwd_kernel', 't3d_fwd_kernel', 't3d_bwd_kernel', 't3d8_fwd_kernel', 'e3d_bwd_kernel', 'd3d_fwd_kernel', 'd3d_bwd_kernel', 't3d8_bwd_kernel')):      # the twelve contraction launches of a pass
                 ig['ms'] += st['avg_us'] * st['calls'] / 1e3
                 ig['n'] += st['calls']
                 ig['rd'] += rd_b * st['calls']
@@ -102,7 +102,7 @@ def main():
                                  hbm_bytes_per_launch=(ig['rd'] + ig['wr']) / ig['n'])
     if ig['n'] and len(sys.argv) > 3:      # the traffic file bench.py reads (profiles/pmc_traffic.json)
         batch = int(sys.argv[4]) if len(sys.argv) > 4 else 2000
-        tj = dict(kernel='the 12 contraction launches of a pass (igemm4_kernel variants + c3d_fwd / c3d_bwd + t3d_fwd / t3d_bwd / t3d8_fwd), bench.py --pool 8188 '
+        tj = dict(kernel='the 12 contraction launches of a pass (igemm4_kernel variants + c3d_fwd / c3d_bwd + t3d_fwd / t3d_bwd / t3d8_fwd + d3d_fwd / d3d_bwd + e3d_bwd), bench.py --pool 8188 '
                          '--batch %d --steps 1 --warmup 1' % batch,
                   launches=ig['n'], read_bytes_per_launch=ig['rd'] / ig['n'], write_bytes_per_launch=ig['wr'] / ig['n'],
                   hbm_bytes_per_launch=(ig['rd'] + ig['wr']) / ig['n'],

@@ -7,7 +7,7 @@ Definitions (the same ones bench.py prints):
   * dominant kernel = the twelve contraction launches of a pass: every instantiation of `alq::igemm4_kernel` (conv /
     conv_transpose forward + backward-data) and, since round 4, `alq::c3d_fwd_kernel` / `alq::c3d_bwd_kernel` (the conv under
     the head on the plane-sweep engine), since round 5 `alq::t3d_fwd_kernel` / `t3d_bwd_kernel` / `t3d8_fwd_kernel` (the
-    conv_transpose layers on the row-sweep engine) and `e3d_bwd_kernel` (enc2's backward fused with both pool backwards) - the keys of the output keep the historical `igemm4_` prefix;
+    conv_transpose layers on the row-sweep engine) `e3d_bwd_kernel` (enc2's backward fused with both pool backwards) and `d3d_fwd_kernel` / `d3d_bwd_kernel` (dec1's pair) - the keys of the output keep the historical `igemm4_` prefix;
   * executed 16-bit MFMA flops of a pass = the launches' ALGORITHMIC fp32 flops (2 x MACs of the real taps / channels,
     the library's own count, `roofline.igemm4_alg_flops_per_patch` of the bench line) x the 16-bit products issued per
     fp32-accurate MAC: 6 for the bf16x3 launches, 3 for the fp16x2 ones;
@@ -36,7 +36,7 @@ def main():
     variants = []
     for r in csv.DictReader(open(stats_csv)):
         total_ns += float(r['TotalDurationNs'])
-        kname = next((k for k in ('igemm4_kernel', 'c3d_fwd_kernel', 'c3d_bwd_kernel', 't3d8_fwd_kernel', 't3d_fwd_kernel', 't3d_bwd_kernel', 'e3d_bwd_kernel') if k in r['Name']), None)
+        kname = next((k for k in ('igemm4_kernel', 'c3d_fwd_kernel', 'c3d_bwd_kernel', 't3d8_fwd_kernel', 't3d_fwd_kernel', 't3d_bwd_kernel', 'e3d_bwd_kernel', 'd3d_fwd_kernel', 'd3d_bwd_kernel', 't3d8_bwd_kernel') if k in r['Name']), None)
         if kname:
             ig_ns += float(r['TotalDurationNs'])
             ig_calls += int(r['Calls'])

@@ -469,6 +469,19 @@ void d3d_pack(D3dPlan *plan, const float *W /* TF conv filter [tap][ci 32][co 16
 int d3d_fwd_launch(alq_ctx *ctx, const D3dPlan &plan, int N, const float *inA, const float *inB, const unsigned *amaxA, const unsigned *amaxB,
                    const float *bias, int relu, float *out, unsigned char *sg, float *osum);
 
+// NET-C's enc2 forward (3x3x3 conv 8 -> 16 channels at 16^3, fp16 pairs at per-patch scales) + the 2x2x2 max-pool behind it in one launch (f3d.hip)
+struct F3dPlan {
+    bool ok = false;
+    int w_exp = 0;
+    double flops_per_patch = 0;
+    std::vector<unsigned short> h_Whi, h_Wlo;      // [9 (dz, dy)][64][8] fp16 bits
+    void *d_Whi = nullptr, *d_Wlo = nullptr;
+};
+int f3d_build(const View &in, const View &out, const int k[3], const int lo[3], const int s[3], F3dPlan *plan);
+void f3d_pack(F3dPlan *plan, const float *W /* TF conv filter [tap][ci 8][co 16] */);
+int f3d_fwd_launch(alq_ctx *ctx, const F3dPlan &plan, int N, const float *in, const unsigned *amax, const float *bias, float *out, unsigned char *sg,
+                   float *osum, float *pout, unsigned char *parg, float *posum);
+
 // ------------------------------------------------------------------ direct first-layer conv (direct.hip)
 struct DirectArgs {
     const float *in;

@@ -9,14 +9,14 @@ FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -I$HERE -Wall 
 BUILD="$HERE/build${ALQ_BUILD_TAG:-}"
 mkdir -p "$BUILD"
 pids=()
-for f in igemm igemm2 igemm3 igemm4 c3d t3d t3d8b e3d d3d fcgemm direct kernels topk model comm train sim; do
+for f in igemm igemm2 igemm3 igemm4 c3d t3d t3d8b e3d d3d f3d fcgemm direct kernels topk model comm train sim; do
   # igemm4: no SLP vectorisation (a performance choice) - it turns neighbouring scalar f32 multiplies / adds of the staging and epilogue code into
   # v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, which issue slower than the scalar pairs next to another wave's MFMAs on
   # the same SIMD (same-box A/B: 155.4 k -> 156.6 k patches/s); conversions still pack (v_cvt_pk_f16_f32 / _bf16_f32)
   X=""; if [ "$f" = igemm4 ]; then X="-fno-slp-vectorize --save-temps=obj ${ALQ_G4_FLAGS:-}"; fi
   # c3d: the same choice (its staging / epilogue arithmetic runs between the wave's own MFMAs)
   if [ "$f" = c3d ]; then X="-fno-slp-vectorize ${ALQ_C3_FLAGS:-}"; fi
-  if [ "$f" = d3d ]; then X="-fno-slp-vectorize ${ALQ_D3_FLAGS:-}"; fi      # (d3d: like c3d; same-box 523 -> 490 / 710 -> 675 us)
+  if [ "$f" = d3d ] || [ "$f" = f3d ]; then X="-fno-slp-vectorize ${ALQ_D3_FLAGS:-}"; fi      # (d3d: like c3d; same-box 523 -> 490 / 710 -> 675 us)
   ( hipcc $FLAGS $X -c "$HERE/$f.hip" -o "$BUILD/$f.o" ${ALQ_EXTRA_FLAGS:-} ) &
   pids+=($!)
 done
@@ -37,5 +37,5 @@ else
   # another ROCm version may name the --save-temps files differently: the check is a tuning aid, not a build requirement
   echo "build.sh: warning: device assembly of igemm4 not found ($ASM); packed-fp32 check skipped" >&2
 fi
-hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT" "$BUILD"/{igemm,igemm2,igemm3,igemm4,c3d,t3d,t3d8b,e3d,d3d,fcgemm,direct,kernels,topk,model,comm,train,sim}.o -ldl
+hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT" "$BUILD"/{igemm,igemm2,igemm3,igemm4,c3d,t3d,t3d8b,e3d,d3d,f3d,fcgemm,direct,kernels,topk,model,comm,train,sim}.o -ldl
 echo "built $OUT"

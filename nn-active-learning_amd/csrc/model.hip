@@ -90,6 +90,7 @@ struct Layer {
     // per-(patch, wave) partials of the logit difference / of the head's input sum on the head layer
     C3dPlan c3f, c3b;
     D3dPlan d3f;                           // forward on the row-sweep engine of d3d.hip (NET-C's dec1)
+    F3dPlan f3f;                           // forward fused with the max-pool behind it (f3d.hip; NET-C's enc2)
     E3dPlan e3b;                           // backward fused with the pool backward steps on either side (e3d.hip; NET-C's enc2)
     T3dPlan t3f, t3b;                      // row-sweep engine for the stride-2 conv_transpose (t3d.hip), forward / backward-data
     float *c3_part = nullptr, *c3_asum = nullptr;
@@ -159,6 +160,7 @@ struct alq_model {
     int last_e3b = 0;              // the last backward pass ran them as one launch (e3d.hip)
     int no_d3d = 0;                // ALQ_NO_D3D (A/B): dec1's forward on the two-slot engine as in round 4
     int last_d3f = 0;              // the last forward pass ran it on the row-sweep engine (d3d.hip)
+    int no_f3d = 0, last_f3f = 0;  // ALQ_NO_F3D (A/B): enc2's forward on the two-slot engine + the pool as its own launch; the last forward pass ran them fused (f3d.hip)
     int no_d3b = 0, last_d3b = 0;  // ALQ_NO_D3D_BWD (A/B): only the backward launch on the two-slot engine; the last backward pass ran it on d3d.hip
     int no_t3d = 0;                // ALQ_NO_T3D (A/B): conv_transpose launches on the two-slot engine (igemm4) as in round 4
     int last_t3f = 0, last_t3b = 0;   // conv_transpose launches of the last forward / backward pass that ran on the row-sweep engine
@@ -623,6 +625,7 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
                 ALQ_TRY(c3d_bwd_build(ly.in, ly.out, sp.k, ly.lo, sp.s, &ly.c3b));
                 ALQ_TRY(e3d_build(ly.in, ly.out, sp.k, ly.lo, sp.s, &ly.e3b));
                 ALQ_TRY(d3d_build(ly.in, ly.out, sp.k, ly.lo, sp.s, &ly.d3f));
+                ALQ_TRY(f3d_build(ly.in, ly.out, sp.k, ly.lo, sp.s, &ly.f3f));
             }
             if (!first_param) {
                 ConvDesc b;
@@ -801,6 +804,7 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
     m->last_c3 = false;
     m->last_t3f = 0;
     m->last_d3f = 0;
+    m->last_f3f = 0;
     // A conv / conv_transpose launch contracts with the fp16x2 split if it knows max |x| per patch of (every part of)
     // its input ahead of time: the launches that produce those tensors report them (`prod`), the consumers (`cons`)
     // read one scale per tile.  Producers: the first conv + pool kernel and one-patch-per-tile igemm4 launches.
@@ -989,6 +993,20 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                     ly.signs_ready = sgd;
                     fused = true;
                     m->last_d3f = 1;
+                    break;
+                }
+                // enc2 + the pool behind it in one launch (f3d.hip): fp16 pairs under the first layer's measured maximum
+                if (fuse && ly.f3f.ok && ly.f3f.d_Whi && !m->no_f3d && cons[i] == 2 && fz.in_amax && !fz.in_amax2 && !prod[i] && !g_no_f16x2 && !g_dbg_knobs[4] && !g_dbg_knobs[5] &&
+                    with_sums && fz.osumA && sp.relu && in.split == 0 && !(drop && (drop->on(i) || drop->on(i + 1))) && nx && nx->spec.type == ALQ_POOL &&
+                    nx->spec.k[0] == 2 && nx->spec.k[1] == 2 && nx->spec.k[2] == 2 && nx->lo[0] == 0 && nx->lo[1] == 0 && nx->lo[2] == 0 && nx->out.D == 8 && nx->out.H == 8 &&
+                    nx->out.W == 8 && nx->out.C == 16 && nx->out.cs == 16 && nx->out.c0 == 0 && !nx->out.split && nx->argmax && !prod[i + 1]) {
+                    const bool sgd = !m->no_signs && ly.out.sg;
+                    ALQ_TRY(f3d_fwd_launch(ctx, ly.f3f, N, in.p, fz.in_amax, ly.d_bias, ly.out.p, sgd ? ly.out.sg : nullptr, fz.osumA, nx->out.p, nx->argmax, nx->osum));
+                    ly.signs_ready = sgd;
+                    nx->signs_ready = false;
+                    fused = true;
+                    skip_next = true;
+                    m->last_f3f = 1;
                     break;
                 }
                 if (fuse && prod[i]) fz.out_amax = m->amax_tiles;
@@ -1643,6 +1661,7 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
         m->no_t3d = getenv("ALQ_NO_T3D") ? 1 : 0;
         m->no_e3d = getenv("ALQ_NO_E3D") ? 1 : 0;
         m->no_d3d = getenv("ALQ_NO_D3D") ? 1 : 0;
+        m->no_f3d = getenv("ALQ_NO_F3D") ? 1 : 0;
         m->no_d3b = getenv("ALQ_NO_D3D_BWD") ? 1 : 0;
         {   // default since round 5: on.  ALQ_NO_F16_DERIVED=1 (or ALQ_F16_DERIVED=0) keeps that launch on bf16 triples (A/B)
             const char *e = getenv("ALQ_F16_DERIVED"), *n = getenv("ALQ_NO_F16_DERIVED");
@@ -1692,6 +1711,9 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
             m->layers[nl - 3].spec.type == ALQ_CONVT && !m->layers[nl - 3].spec.relu && m->layers[nl - 4].spec.type == ALQ_CONV &&
             m->layers[nl - 4].spec.relu)
             m->f16_fwd_derived = 1 << (nl - 4);
+        for (int i = 1; i + 1 < nl; ++i)      // enc2 of NET-C: its fused kernel (f3d.hip) contracts fp16 pairs under the first layer's measured maximum
+            if (m->layers[i].f3f.ok && m->f16_fwd_derived) m->f16_fwd_derived |= 1 << i;
+        if (const char *e = getenv("ALQ_F16_DERIVED_MASK")) m->f16_fwd_derived = atoi(e);      // (study: other forward launches on fp16 pairs, by layer bit)
     }
     *out = m;
     return ALQ_OK;
@@ -1807,6 +1829,15 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
             ly.e3b.d_Whi = dh; ly.e3b.d_Wlo = dl;
             ALQ_HIP(hipMemcpyAsync(dh, ly.e3b.h_Whi.data(), ly.e3b.h_Whi.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
             ALQ_HIP(hipMemcpyAsync(dl, ly.e3b.h_Wlo.data(), ly.e3b.h_Wlo.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
+            ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
+        }
+        if (ly.f3f.ok) {
+            f3d_pack(&ly.f3f, W);
+            unsigned short *dh = reinterpret_cast<unsigned short *>(ly.f3f.d_Whi), *dl = reinterpret_cast<unsigned short *>(ly.f3f.d_Wlo);
+            if (!dh) { ALQ_TRY(m->dalloc(&dh, ly.f3f.h_Whi.size())); ALQ_TRY(m->dalloc(&dl, ly.f3f.h_Wlo.size())); }
+            ly.f3f.d_Whi = dh; ly.f3f.d_Wlo = dl;
+            ALQ_HIP(hipMemcpyAsync(dh, ly.f3f.h_Whi.data(), ly.f3f.h_Whi.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
+            ALQ_HIP(hipMemcpyAsync(dl, ly.f3f.h_Wlo.data(), ly.f3f.h_Wlo.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
             ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
         }
         if (ly.d3f.ok) {
@@ -2163,10 +2194,11 @@ int alq_model_debug_copy(alq_model *m, int layer_idx, int what, int N, float *d_
 }
 
 int alq_model_engine_info(alq_model *m, int what) {
-    ALQ_REQUIRE(m && ((what >= 0 && what <= 3) || (what >= 5 && what <= 11)), ALQ_EINVAL, "alq_model_engine_info: bad argument");
+    ALQ_REQUIRE(m && ((what >= 0 && what <= 3) || (what >= 5 && what <= 12)), ALQ_EINVAL, "alq_model_engine_info: bad argument");
     if (what == 6) return m->last_f16_derived ? 1 : 0;
     if (what == 7) return m->last_t3f;        // conv_transpose launches of the last forward pass on the row-sweep engine (t3d.hip)
     if (what == 8) return m->last_t3b;        // ... of the last backward pass
+    if (what == 12) return m->last_f3f;       // the last forward pass ran enc2 + pool2 as one launch (f3d.hip)
     if (what == 11) return m->last_d3b;       // the last backward pass ran dec1's backward-data launch on the plane-sweep kernel (d3d.hip)
     if (what == 10) return m->last_d3f;       // the last forward pass ran dec1 on the row-sweep engine (d3d.hip)
     if (what == 9) return m->last_e3b;        // the last backward pass ran enc2's backward fused with both pool backward steps (e3d.hip)

@@ -466,7 +466,16 @@ def test_config3_netc_properties(sess):
     om64 = OracleModel(ld, in_shape, pars64, skips=sk, dtype=sess.torch.float64)
     p64, S64, sizes = factored_ref.factored_unit_scores(om64, xsn.astype(np.float64))
     g64, h64, _ = factored_ref.fisher_from_unit(p64[1], S64, sizes, 1e-3)
-    for gd, gr in ((g0[:nchk], g64), (g1[:nchk], h64)):
+    # (round 5: enc2's forward contracts fp16 pairs - 22 bits - too, so one of these six may hold a ReLU input that fp64 and the device
+    # put on different sides of zero; such a patch must be explained by the fp64 arbiter like everywhere else, the others stay within 2e-6)
+    flagged = sorted(set(np.nonzero(np.maximum(np.abs(g0[:nchk] - g64), np.abs(g1[:nchk] - h64)).max(axis=1) > 2e-6)[0].tolist()))
+    assert len(flagged) <= 2, flagged
+    for i in flagged:
+        found = factored_ref.relu_flip_explains(om64, xsn[i].astype(np.float64), [(g0[i], g1[i])], 1e-3)
+        assert found[0] is not None, 'patch %d differs from fp64 and no near-zero ReLU input explains it' % i
+        assert max(np.abs(g0[i] - g64[i]).max(), np.abs(g1[i] - h64[i]).max()) <= 1e-3
+    ok = np.array([i for i in range(nchk) if i not in flagged])
+    for gd, gr in ((g0[:nchk][ok], g64[ok]), (g1[:nchk][ok], h64[ok])):
         err = np.abs(gd - gr)
         assert err.max() <= 2e-6, 'max abs error %.3e vs fp64' % err.max()
         big = np.abs(gr) > 1e-5
@@ -1697,5 +1706,48 @@ def test_up1_backward_kernel_against_the_two_slot_engine(sess):
     for k in ('g0', 'g1'):
         np.testing.assert_allclose(a[k], b[k], rtol=2e-5, atol=2e-6, err_msg=k)
     np.testing.assert_allclose(a['A'], b['A'], rtol=2e-5, atol=1e-12 + 2e-6 * np.abs(b['A']).max())
+    m_new.close()
+    m_old.close()
+
+
+def test_fused_enc2_forward_and_pool_against_the_two_launches(sess):
+    """NET-C's `enc2` forward (3x3x3 conv 8 -> 16 at 16^3 + bias + ReLU; NN_extended.py:416-426) and the 2x2x2 max-pool behind it as ONE
+    launch (csrc/f3d.hip, default since round 5: fp16 pairs under the first layer's measured maximum) against the two-slot engine's
+    launch on the same split + the pool kernel (ALQ_NO_F3D=1, ALQ_F16_DERIVED_MASK=68).  300 patches (an all-zero one among them):
+    enc2's output and the pooled tensor within 2e-6 of their maximum; the pooled tensor EXACTLY the window maximum of the kernel's
+    own output; posteriors within 2e-6; layer scores (they run through the arg-max bytes, both sign fields and all three channel-sum
+    fields the kernel writes) within 2e-6 + 2e-5 relative or the patch goes to the fp64 arbiter."""
+    import ctypes as C
+    from nnal_amd._lib import check
+    torch = sess.torch
+    n = 300
+    ld, sk, in_shape, pars, (m_new, m_old) = _netc32_models(sess, [{}, {'ALQ_NO_F3D': '1', 'ALQ_F16_DERIVED_MASK': '68'}], max_batch=n, bias_std=0.05)
+    x = sess.empty((n, 32 ** 3), torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, 32 ** 3, C.c_void_p(x.data_ptr())))
+    x[17].zero_()
+    out = []
+    for m in (m_new, m_old):
+        r = m.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1', 'A', 'Asum'))
+        d = {k: r[k].cpu().numpy() for k in ('p1', 'g0', 'g1', 'A', 'Asum')}
+        d['enc2_out'] = m.debug_tensor(2, 0, n).reshape(n, 16, 16, 16, 16)
+        d['pool2_out'] = m.debug_tensor(3, 0, n).reshape(n, 8, 8, 8, 16)
+        out.append(d)
+    assert sess.lib.alq_model_engine_info(m_new._m, 12) == 1, 'the fused launch did not run'
+    assert sess.lib.alq_model_engine_info(m_old._m, 12) == 0
+    a, b = out
+    for k in ('enc2_out', 'pool2_out'):
+        assert np.isfinite(a[k]).all()
+        err = np.abs(a[k] - b[k]).max()
+        assert err <= 2e-6 * np.abs(b[k]).max(), (k, err, np.abs(b[k]).max())
+    np.testing.assert_array_equal(a['enc2_out'].reshape(n, 8, 2, 8, 2, 8, 2, 16).max(axis=(2, 4, 6)), a['pool2_out'])
+    np.testing.assert_allclose(a['p1'], b['p1'], rtol=0, atol=2e-6)
+    bad = set()
+    for k in ('g0', 'g1'):
+        e = np.abs(a[k] - b[k])
+        bad |= set(np.nonzero((e > 2e-6 + 2e-5 * np.abs(b[k])).any(axis=1))[0].tolist())
+    flips = _fp64_arbitrate(ld, sk, in_shape, pars, x.cpu().numpy(), sorted(bad), [a, b], ['fused', 'two launches'])
+    assert flips <= 8, flips
+    good = np.array(sorted(set(range(n)) - bad))
+    np.testing.assert_allclose(a['A'][good], b['A'][good], rtol=2e-5, atol=1e-12 + 2e-6 * np.abs(b['A']).max())
     m_new.close()
     m_old.close()

@@ -16,6 +16,6 @@ else
   for i in 0 $(seq 1 $N); do
     L=libalq_v$i.so; [ $i = 0 ] && L=libalq.so
     ( cd /tmp && ALQ_LIB=$L rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/d3v$i -o s --output-format csv -- python3 $ROOT/tools/gpu_d3d_time.py > /dev/null 2>&1 )
-    echo "variant $i: $(grep -E 'd3d_(fwd|bwd)' gpurun_out/d3v$i/s_kernel_stats.csv | awk -F, '{printf "%s %.1f us   ", substr($1,7,14), $4/1000}')"
+    echo "variant $i: $(grep -E '(d3d_fwd|d3d_bwd|f3d_fwd)' gpurun_out/d3v$i/s_kernel_stats.csv | awk -F, '{printf "%s %.1f us   ", substr($1,7,14), $4/1000}')"
   done
 fi

@@ -30,9 +30,11 @@ pars = netspec.he_init(ld, in_shape, seed=14, skips=sk)
 x = sess.empty((n, 32 ** 3), torch.float32)
 check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, 32 ** 3, C.c_void_p(x.data_ptr())))
 ARMS = (('default', {}, None), ('no_f16_derived', {'ALQ_NO_F16_DERIVED': '1'}, None), ('bf16x3', {'ALQ_NO_F16X2': '1'}, None), ('fp32', {}, (4, 1)))
+if os.environ.get('ACC_EXTRA_MASK'):      # study arm: more forward launches on fp16 pairs (ALQ_F16_DERIVED_MASK, layer bits)
+    ARMS = ARMS[:1] + (('extra_mask_' + os.environ['ACC_EXTRA_MASK'], {'ALQ_F16_DERIVED_MASK': os.environ['ACC_EXTRA_MASK']}, None),) + ARMS[1:]
 res = {}
 for name, env, knob in ARMS:
-    for k in ('ALQ_NO_F16_DERIVED', 'ALQ_NO_F16X2'):
+    for k in ('ALQ_NO_F16_DERIVED', 'ALQ_NO_F16X2', 'ALQ_F16_DERIVED_MASK'):
         os.environ.pop(k, None)
     os.environ.update(env)
     m = device.DeviceModel(sess, ld, in_shape, sk, max_batch=n)
@@ -47,7 +49,7 @@ for name, env, knob in ARMS:
     m.close()
 out = {'patches': n}
 ref = res['fp32']
-for name in ('default', 'no_f16_derived', 'bf16x3'):
+for name in [a_[0] for a_ in ARMS if a_[0] != 'fp32']:
     a = res[name]
     d = np.maximum(np.abs(a['g0'] - ref['g0']), np.abs(a['g1'] - ref['g1'])).max(axis=1)
     out[name] = {'over_2e-6': int((d > 2e-6).sum()), 'over_1e-5': int((d > 1e-5).sum()), 'over_1e-4': int((d > 1e-4).sum()),

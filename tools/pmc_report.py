@@ -89,7 +89,7 @@ def main():
             e['hbm_read_MB_per_launch'] = round(rd_b / 1e6, 1)
             e['hbm_write_MB_per_launch'] = round(wr_b / 1e6, 1)
             e['hbm_GBps'] = round((rd_b + wr_b) / (st['avg_us'] * 1e-6) / 1e9, 0)
-            if name.startswith(('igemm4_kernel', 'c3d_fwd_kernel', 'c3d_bwd_kernel', 't3d_fwd_kernel', 't3d_bwd_kernel', 't3d8_fwd_kernel', 'e3d_bwd_kernel', 'd3d_fwd_kernel', 'd3d_bwd_kernel', 't3d8_bwd_kernel')):      # the twelve contraction launches of a pass
+            if name.startswith(('igemm4_kernel', 'c3d_fwd_kernel', 'c3d_bwd_kernel', 't3d_fwd_kernel', 't3d_bwd_kernel', 't3d8_fwd_kernel', 'e3d_bwd_kernel', 'd3d_fwd_kernel', 'd3d_bwd_kernel', 't3d8_bwd_kernel', 'f3d_fwd_kernel')):      # the twelve contraction launches of a pass
                 ig['ms'] += st['avg_us'] * st['calls'] / 1e3
                 ig['n'] += st['calls']
                 ig['rd'] += rd_b * st['calls']

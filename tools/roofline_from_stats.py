@@ -36,7 +36,7 @@ def main():
     variants = []
     for r in csv.DictReader(open(stats_csv)):
         total_ns += float(r['TotalDurationNs'])
-        kname = next((k for k in ('igemm4_kernel', 'c3d_fwd_kernel', 'c3d_bwd_kernel', 't3d8_fwd_kernel', 't3d_fwd_kernel', 't3d_bwd_kernel', 'e3d_bwd_kernel', 'd3d_fwd_kernel', 'd3d_bwd_kernel', 't3d8_bwd_kernel') if k in r['Name']), None)
+        kname = next((k for k in ('igemm4_kernel', 'c3d_fwd_kernel', 'c3d_bwd_kernel', 't3d8_fwd_kernel', 't3d_fwd_kernel', 't3d_bwd_kernel', 'e3d_bwd_kernel', 'd3d_fwd_kernel', 'd3d_bwd_kernel', 't3d8_bwd_kernel', 'f3d_fwd_kernel') if k in r['Name']), None)
         if kname:
             ig_ns += float(r['TotalDurationNs'])
             ig_calls += int(r['Calls'])

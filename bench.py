@@ -235,9 +235,9 @@ def main():
                                                    'products): what a launch would reach at most if every one ran the 3-product fp16-pair split'
                                                    % PEAK_BF16_MFMA_TFLOPS,
                          'kernel': 'the 12 contraction launches of a pass: c3d_fwd_kernel / c3d_bwd_kernel (the conv under the head: 53 % of the '
-                                   'flops, fp16 pairs), d3d_fwd / d3d_bwd (dec1), t3d_fwd / t3d_bwd (up2), t3d8_fwd / t3d8_bwd (up1), e3d_bwd '
-                                   '(enc2 backward + both pool backwards) and three igemm4_kernel launches (enc2 forward, bott forward / '
-                                   'backward); fp16 pairs in the backward launches and dec1 forward, bf16 triples in the other forward ones',
+                                   'flops, fp16 pairs), d3d_fwd / d3d_bwd (dec1), t3d_fwd / t3d_bwd (up2), t3d8_fwd / t3d8_bwd (up1), f3d_fwd (enc2 forward + '
+                                   'pool2), e3d_bwd (enc2 backward + both pool backwards) and two igemm4_kernel launches (bott forward / backward); '
+                                   'fp16 pairs in the backward launches and in the dec1 / enc2 forward launches, bf16 triples in the other forward ones',
                          'peak_note': 'algorithmic fp32 flops; peak = flop-weighted harmonic mean of %.0f dense 16-bit MFMA / %d '
                                       'products (bf16x3 launches, %.0f %% of the flops) and / 3 (the fp16x2 launches)'
                                       % (PEAK_BF16_MFMA_TFLOPS, SPLIT_PRODUCTS, 100.0 * bf_fl / max(ig_fl, 1.0)),
@@ -260,15 +260,17 @@ def main():
                                             'BESIDE the igemm launches (their spans overlap those, they do not add up to the step)'},
         }
         note('GPU: %.1f patches/s' % value)
+        # what the LAST pass of the timed region ran on (asked before the accuracy passes below, one of which is the exact-fp32 engine)
+        info = sess.lib.alq_model_engine_info
+        line['config']['head_conv_engine']['dec1_forward_fp16_pairs'] = int(info(model._m, 6))
+        line['config']['engines'] = {'dec1_forward_plane_sweep': int(info(model._m, 10)), 'dec1_backward_plane_sweep': int(info(model._m, 11)),
+                                     'enc2_forward_fused_with_pool': int(info(model._m, 12)),
+                                     'conv_transpose_forward_row_sweep_launches': int(info(model._m, 7)),
+                                     'conv_transpose_backward_row_sweep_launches': int(info(model._m, 8)),
+                                     'enc2_backward_fused_with_pool_backwards': int(info(model._m, 9)),
+                                     'scoring_pipelines': int(model.lanes)}
         if ws == 1:
             line['accuracy'] = accuracy_vs_exact_fp32(sess, model, x, min(args.batch, n_local))
-            line['config']['head_conv_engine']['dec1_forward_fp16_pairs'] = int(sess.lib.alq_model_engine_info(model._m, 6))
-            info = sess.lib.alq_model_engine_info
-            line['config']['engines'] = {'dec1_forward_plane_sweep': int(info(model._m, 10)), 'dec1_backward_plane_sweep': int(info(model._m, 11)),
-                                         'conv_transpose_forward_row_sweep_launches': int(info(model._m, 7)),
-                                         'conv_transpose_backward_row_sweep_launches': int(info(model._m, 8)),
-                                         'enc2_backward_fused_with_pool_backwards': int(info(model._m, 9)),
-                                         'scoring_pipelines': int(model.lanes)}
         if ws == 1 and args.netb_pool > 0:
             line['netb'] = netb_rate(sess, args.netb_pool, x)
         if not args.no_cpu_baseline and ws == 1:      # reported at N = 1 only (the other ranks would sit in the barrier)

@@ -277,7 +277,8 @@ int alq_debug_set(int key, int value);
  * 6: 1 when the last forward pass ran a launch on the fp16-pair split with derived input bounds (default; ALQ_NO_F16_DERIVED=1 off).
  * 7 / 8: conv_transpose launches of the last forward / backward pass on the row-sweep engine (csrc/t3d.hip), 9: 1 when the last
  * backward pass ran enc2's backward fused with both pool backward steps (csrc/e3d.hip), 10: 1 when the last forward pass ran
- * dec1 on the plane-sweep kernel of csrc/d3d.hip.
+ * dec1 on the plane-sweep kernel of csrc/d3d.hip, 11: the same for its backward-data launch, 12: 1 when the last forward pass
+ * ran enc2 and the max-pool behind it as one launch (csrc/f3d.hip).
  * Returns the answer or a negative error code.  */
 int alq_model_engine_info(alq_model *m, int what);
 

@@ -1751,3 +1751,39 @@ def test_fused_enc2_forward_and_pool_against_the_two_launches(sess):
     np.testing.assert_allclose(a['A'][good], b['A'][good], rtol=2e-5, atol=1e-12 + 2e-6 * np.abs(b['A']).max())
     m_new.close()
     m_old.close()
+
+
+def test_round5_kernels_off_together_match_the_default(sess):
+    """Every layer-specific kernel of round 5 has its own A/B test against the launch it replaces; this one switches them ALL off at
+    once (ALQ_NO_T3D, ALQ_NO_E3D, ALQ_NO_D3D, ALQ_NO_F3D: the round-4 configuration with the fp16-pair dec1 forward) - the
+    combination a maintainer gets on a device where none of them applies must still be the same function: 300 patches, posteriors
+    within 2e-6, layer scores within 2e-6 + 2e-5 relative or explained by the fp64 arbiter, and the engine reports agree with the
+    switches."""
+    import ctypes as C
+    from nnal_amd._lib import check
+    torch = sess.torch
+    n = 300
+    off = {'ALQ_NO_T3D': '1', 'ALQ_NO_E3D': '1', 'ALQ_NO_D3D': '1', 'ALQ_NO_F3D': '1'}
+    ld, sk, in_shape, pars, (m_new, m_old) = _netc32_models(sess, [{}, off], max_batch=n, bias_std=0.05)
+    x = sess.empty((n, 32 ** 3), torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, 32 ** 3, C.c_void_p(x.data_ptr())))
+    out = []
+    for m in (m_new, m_old):
+        r = m.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1', 'A', 'Asum'))
+        out.append({k: r[k].cpu().numpy() for k in ('p1', 'g0', 'g1', 'A', 'Asum')})
+    info = sess.lib.alq_model_engine_info
+    assert [info(m_new._m, k) for k in (7, 8, 9, 10, 11, 12)] == [2, 2, 1, 1, 1, 1]
+    assert [info(m_old._m, k) for k in (7, 8, 9, 10, 11, 12)] == [0, 0, 0, 0, 0, 0]
+    assert info(m_old._m, 1) == 1 and info(m_old._m, 2) == 1, 'the plane-sweep head conv stays on in the round-4 configuration'
+    a, b = out
+    np.testing.assert_allclose(a['p1'], b['p1'], rtol=0, atol=2e-6)
+    bad = set()
+    for k in ('g0', 'g1'):
+        e = np.abs(a[k] - b[k])
+        bad |= set(np.nonzero((e > 2e-6 + 2e-5 * np.abs(b[k])).any(axis=1))[0].tolist())
+    flips = _fp64_arbitrate(ld, sk, in_shape, pars, x.cpu().numpy(), sorted(bad), [a, b], ['round 5', 'round 4'])
+    assert flips <= 10, flips
+    good = np.array(sorted(set(range(n)) - bad))
+    np.testing.assert_allclose(a['A'][good], b['A'][good], rtol=2e-5, atol=1e-12 + 2e-6 * np.abs(b['A']).max())
+    m_new.close()
+    m_old.close()

@@ -74,6 +74,7 @@ struct ProfSlot {
 
 struct alq_ctx {
     int device = 0;
+    int num_cus = 256;         // compute units of the device (alq_ctx_create): what the persistent-grid launches size themselves by
     hipStream_t stream = nullptr;
     bool prof_on = false;
     int prof_every = 1;        // time the launches of every prof_every-th alq_fisher pass (event pairs cost ~6 % when on every launch)

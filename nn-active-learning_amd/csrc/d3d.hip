@@ -579,9 +579,7 @@ int d3d_bwd_launch(alq_ctx *ctx, const D3dPlan &plan, int N, const float *dout, 
     a.dout = dout; a.Whi = reinterpret_cast<const unsigned short *>(plan.d_Bhi); a.Wlo = reinterpret_cast<const unsigned short *>(plan.d_Blo);
     a.dinA = dinA; a.dinB = dinB; a.sumB = sumB;
     a.scale = std::ldexp(1.f, e_in); a.scale11 = std::ldexp(1.f, e_in + 11); a.inv = std::ldexp(1.f, -(e_in + plan.w_exp)); a.N = N;
-    int cus = 256;
-    hipDeviceProp_t pr;
-    if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+    const int cus = ctx->num_cus;
     long long g = std::min<long long>((long long)cus, (long long)N);
     g = std::max<long long>(8, (g + 7) / 8 * 8);
     const size_t lds = DB_STRIP;
@@ -602,9 +600,7 @@ int d3d_fwd_launch(alq_ctx *ctx, const D3dPlan &plan, int N, const float *inA, c
     a.inA = inA; a.inB = inB; a.amaxA = amaxA; a.amaxB = amaxB;
     a.Whi = reinterpret_cast<const unsigned short *>(plan.d_Whi); a.Wlo = reinterpret_cast<const unsigned short *>(plan.d_Wlo);
     a.bias = bias; a.out = out; a.sg = sg; a.osum = osum; a.e_w = plan.w_exp; a.relu = relu; a.N = N;
-    int cus = 256;
-    hipDeviceProp_t pr;
-    if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+    const int cus = ctx->num_cus;
     long long g = std::min<long long>((long long)cus, (long long)N);
     g = std::max<long long>(8, (g + 7) / 8 * 8);
     const size_t lds = D3_STRIP;

@@ -353,9 +353,7 @@ int e3d_bwd_launch(alq_ctx *ctx, const E3dPlan &plan, int N, const float *skip, 
     a.skip = skip; a.dpool = dpool; a.am2 = am2; a.sg2 = sg2; a.Whi = reinterpret_cast<const unsigned short *>(plan.d_Whi);
     a.Wlo = reinterpret_cast<const unsigned short *>(plan.d_Wlo); a.am1 = am1; a.sg1 = sg1; a.dsum2 = dsum2; a.dsum1 = dsum1;
     a.scale = std::ldexp(1.f, e_in); a.inv = std::ldexp(1.f, -(e_in + plan.w_exp)); a.N = N;
-    int cus = 256;
-    hipDeviceProp_t pr;
-    if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+    const int cus = ctx->num_cus;
     long long g = std::min<long long>(2LL * cus, (long long)N * 4);
     g = std::max<long long>(8, (g + 7) / 8 * 8);
     const size_t lds = E3_WLO + E3_STRIP;

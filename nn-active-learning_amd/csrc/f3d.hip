@@ -354,9 +354,7 @@ int f3d_fwd_launch(alq_ctx *ctx, const F3dPlan &plan, int N, const float *in, co
     F3Args a;
     a.in = in; a.amax = amax; a.Whi = reinterpret_cast<const unsigned short *>(plan.d_Whi); a.Wlo = reinterpret_cast<const unsigned short *>(plan.d_Wlo);
     a.bias = bias; a.out = out; a.sg = sg; a.osum = osum; a.pout = pout; a.parg = parg; a.posum = posum; a.e_w = plan.w_exp; a.N = N;
-    int cus = 256;
-    hipDeviceProp_t pr;
-    if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+    const int cus = ctx->num_cus;
     long long g = std::min<long long>((long long)F3_WGS * cus, (long long)N);
     g = std::max<long long>(8, (g + 7) / 8 * 8);
     ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(f3d_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F3_STRIP));

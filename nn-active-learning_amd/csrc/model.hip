@@ -1573,6 +1573,7 @@ int alq_ctx_create(int device, void *stream, alq_ctx **out) {
                 "libalq is built for gfx950 (MI355X) only, device %d is %s", device, prop.gcnArchName);
     alq_ctx *c = new alq_ctx();
     c->device = device;
+    if (prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
     c->stream = reinterpret_cast<hipStream_t>(stream);
     if (hipMalloc(&c->param_block, ALQ_PARAM_BLOCK_BYTES) != hipSuccess) {
         delete c;

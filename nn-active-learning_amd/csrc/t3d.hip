@@ -59,12 +59,7 @@ struct T3BwdArgs {
     int N;
 };
 
-#ifndef T3B_PF_N
-#define T3B_PF_N 2
-#endif
 constexpr unsigned T3_OOB = 0xffffff00u;
-#define T3_STR2(x) #x
-#define T3_STR(x) T3_STR2(x)
 // forward LDS strip of a wave: [row 0: plane iz, row 1: plane iz - 1][3 pieces][17 voxel slots (slot 0 = x -1: zero)][16 ch x 2 B]
 constexpr int T3F_ROWB = 17 * 32, T3F_WAVE = 2 * 3 * T3F_ROWB;
 // backward: [6 rows][2 pieces][34 voxel slots (32, 33: zero)][8 ch x 2 B]
@@ -178,9 +173,6 @@ __global__ __launch_bounds__(256, 2) void t3d_fwd_kernel(const T3FwdArgs a) {
             // (nothing moves across a tile boundary: left alone the scheduler starts the next tile's split early - and with it the
             // wait for loads that were meant to stay in flight for another tile)
             __builtin_amdgcn_sched_barrier(0);
-#ifdef T3_DRAIN
-            asm volatile("s_waitcnt vmcnt(" T3_STR(T3_DRAIN) ")" ::: "memory");
-#endif
             const T3Cur cur = t3_tile(live ? T : 0, total, wave);
             const int p = cur.p, iz = cur.iz, iy = cur.s;
             // split the two rows of this tile into bf16 triples, into the strip
@@ -290,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void t3d_fwd_kernel(const T3FwdArgs a) {
 // (t_z, t_y) pair; fp16 pairs at their true scale, three products in one accumulator (c3d.hip's one-accumulator form: the
 // matrix cores keep fp16 subnormals, probed by c3d_subnormals_ok).  The sweep runs DOWNWARD (iy = 15 .. 0): a tile fetches the
 // rows t_y = 0, 1 of its three planes and takes t_y = 2 (row 2 iy + 2 = the t_y = 0 row of tile iy + 1) from the tile before it.
-constexpr int T3B_PF = T3B_PF_N;      // tiles of loads in flight per wave (6 KB each)
+constexpr int T3B_PF = 2;      // tiles of loads in flight per wave (6 KB each)
 template <bool MASK, bool SUMS>
 __global__ __launch_bounds__(256, 2) void t3d_bwd_kernel(const T3BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char t3lds[];
@@ -727,9 +719,7 @@ void t3d_bwd_pack(T3dPlan *plan, const float *W) {
 
 static unsigned t3_grid(alq_ctx *ctx, int N) {
     // two workgroups per CU; units = 4 per patch, dealt per XCD (t3_unit): a multiple of 8 workgroups
-    int cus = 256;
-    hipDeviceProp_t pr;
-    if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+    const int cus = ctx->num_cus;
     const long long units = (long long)N * 4;
     int per_cu = 2;
     if (const char *e = getenv("ALQ_T3D_WGS")) per_cu = std::max(1, std::min(2, atoi(e)));      // (tuning / diagnostics)
@@ -747,9 +737,7 @@ int t3d_fwd_launch(alq_ctx *ctx, const T3dPlan &plan, const View &in, const View
         if (N <= 0) return ALQ_OK;
         T8FwdArgs a8;
         a8.in = in.p; a8.out = out.p; a8.W = reinterpret_cast<const unsigned short *>(plan.d_W); a8.bias = bias; a8.osum = osum; a8.N = N;
-        int cus = 256;
-        hipDeviceProp_t pr;
-        if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+        const int cus = ctx->num_cus;
         const dim3 grid8((unsigned)std::min(N, cus));
         ProfScope ps8(ctx, PROF_IGEMM3_FWD, plan.flops_per_patch * N);
         auto go = [&](auto kfn) -> int {
@@ -769,11 +757,10 @@ int t3d_fwd_launch(alq_ctx *ctx, const T3dPlan &plan, const View &in, const View
     a.in = in.p; a.out = out.p; a.W = reinterpret_cast<const unsigned short *>(plan.d_W); a.bias = bias; a.osum = osum; a.out_amax = out_amax; a.N = N;
     ProfScope ps(ctx, PROF_IGEMM3_FWD, plan.flops_per_patch * N);
     const dim3 grid(t3_grid(ctx, N));
-    const unsigned pad = getenv("ALQ_T3D_LDSPAD") ? 60000u : 0u;      // (diagnostics: one workgroup per CU at an unchanged grid)
-    if (osum && out_amax) hipLaunchKernelGGL((t3d_fwd_kernel<true, true>), grid, dim3(256), 4 * T3F_WAVE + pad, ctx->stream, a);
-    else if (osum) hipLaunchKernelGGL((t3d_fwd_kernel<true, false>), grid, dim3(256), 4 * T3F_WAVE + pad, ctx->stream, a);
-    else if (out_amax) hipLaunchKernelGGL((t3d_fwd_kernel<false, true>), grid, dim3(256), 4 * T3F_WAVE + pad, ctx->stream, a);
-    else hipLaunchKernelGGL((t3d_fwd_kernel<false, false>), grid, dim3(256), 4 * T3F_WAVE + pad, ctx->stream, a);
+    if (osum && out_amax) hipLaunchKernelGGL((t3d_fwd_kernel<true, true>), grid, dim3(256), 4 * T3F_WAVE, ctx->stream, a);
+    else if (osum) hipLaunchKernelGGL((t3d_fwd_kernel<true, false>), grid, dim3(256), 4 * T3F_WAVE, ctx->stream, a);
+    else if (out_amax) hipLaunchKernelGGL((t3d_fwd_kernel<false, true>), grid, dim3(256), 4 * T3F_WAVE, ctx->stream, a);
+    else hipLaunchKernelGGL((t3d_fwd_kernel<false, false>), grid, dim3(256), 4 * T3F_WAVE, ctx->stream, a);
     ALQ_HIP(hipGetLastError());
     return ALQ_OK;
 }

@@ -261,9 +261,7 @@ int t3d8_bwd_launch(alq_ctx *ctx, const T3dPlan &plan, const View &dout, const V
     T8BwdArgs a;
     a.dout = dout.p; a.din = din.p; a.W = reinterpret_cast<const unsigned short *>(plan.d_W); a.mask_bits = mask_bits; a.dsum = dsum;
     a.scale = std::ldexp(1.f, e_in); a.scale11 = std::ldexp(1.f, e_in + 11); a.inv = std::ldexp(1.f, -(e_in + plan.w_exp)); a.N = N;
-    int cus = 256;
-    hipDeviceProp_t pr;
-    if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+    const int cus = ctx->num_cus;
     long long g = std::min<long long>(2LL * cus, (long long)N);
     g = std::max<long long>(8, (g + 7) / 8 * 8);
     ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(t3d8_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T8B_LDS));

@@ -2,7 +2,8 @@
 // 2x2x2 max-pool behind it (`pool2`, NN_extended.py:428-441) in the same launch.  On the two-slot engine the conv took 0.32 ms per 2047
 // patches whether it multiplied bf16 triples or fp16 pairs (its tiles at 16^3 are prologue-bound), the pool another 0.17 ms
 // to read the tensor back.  The plane sweep of d3d.hip at this layer's shape:
-//   * fp16 pairs under the MEASURED per-patch maximum of the first layer (the pool in between cannot raise it): the round-5 accuracy
+//   * fp16 pairs at their true scale in ONE accumulator (the input bound is the MEASURED per-patch maximum of the first layer - the pool in
+//     between cannot raise it - so the lo pieces of typical values are normal fp16 numbers; the matrix cores keep the subnormal rest): the round-5 accuracy
 //     study (tools/gpu_accuracy_stats.py, ACC_EXTRA_MASK=68) counts 120 / 113 / 56 patches beyond 2e-6 / 1e-5 / 1e-4 of the exact-fp32
 //     engine with this launch on the pair split against 122 / 116 / 58 without and 118 / 112 / 56 for bf16 triples everywhere;
 //   * a workgroup sweeps the 16 planes of a patch, wave w owns output rows 4 w .. 4 w + 3; K = 32 = three x offsets x 8 input
@@ -59,10 +60,14 @@ template <int V> struct F3IC { static constexpr int value = V; };
 #ifndef F3_PIPE
 #define F3_PIPE 2
 #endif
+#ifndef F3_ONEACC
+#define F3_ONEACC 1      // 1: lo pieces at their true scale, all three products in one accumulator (needs fp16 subnormals in the matrix cores: c3d_subnormals_ok)
+#endif
 constexpr int F3_FILL_MASK = 0x096;       // what may fill the gap behind an MFMA: VALU, SALU, VMEM, DS
 
 #ifndef F3_WGS
-#define F3_WGS 1
+#define F3_WGS 2      // workgroups per CU: with one accumulator per output the kernel fits 224 registers, and a second workgroup issues MFMAs while the first one's
+                      // wave is in its epilogue / pool arithmetic: 292 -> 222 us per 2047 patches (two accumulators: 256 registers + spills, 378 us)
 #endif
 #if F3_WGS == 1
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void f3d_fwd_kernel(const F3Args a) {
@@ -135,8 +140,13 @@ __global__ __launch_bounds__(256, 2) void f3d_fwd_kernel(const F3Args a) {
         char *dst = w_base + img * F3_PLANE + 2 * u * F3_SLOT;
         const f32x4 g = RA[u];
         const f16x2 h01 = __builtin_convertvector(f32x2{g.x * sc, g.y * sc}, f16x2), h23 = __builtin_convertvector(f32x2{g.z * sc, g.w * sc}, f16x2);
+#if F3_ONEACC
+        const f16x2 l01 = __builtin_convertvector(f32x2{__builtin_fmaf(g.x, sc, -(float)h01.x), __builtin_fmaf(g.y, sc, -(float)h01.y)}, f16x2);
+        const f16x2 l23 = __builtin_convertvector(f32x2{__builtin_fmaf(g.z, sc, -(float)h23.x), __builtin_fmaf(g.w, sc, -(float)h23.y)}, f16x2);
+#else
         const f16x2 l01 = __builtin_convertvector(f32x2{__builtin_fmaf((float)h01.x, -2048.f, g.x * sc11), __builtin_fmaf((float)h01.y, -2048.f, g.y * sc11)}, f16x2);
         const f16x2 l23 = __builtin_convertvector(f32x2{__builtin_fmaf((float)h23.x, -2048.f, g.z * sc11), __builtin_fmaf((float)h23.y, -2048.f, g.w * sc11)}, f16x2);
+#endif
         *reinterpret_cast<i32x2 *>(dst) = i32x2{__builtin_bit_cast(int, h01), __builtin_bit_cast(int, h23)};
         *reinterpret_cast<i32x2 *>(dst + F3_ROWB) = i32x2{__builtin_bit_cast(int, l01), __builtin_bit_cast(int, l23)};
     };
@@ -152,6 +162,8 @@ __global__ __launch_bounds__(256, 2) void f3d_fwd_kernel(const F3Args a) {
     for (int ry = 0; ry < 4; ++ry) keep[ry] = f32x4{0.f, 0.f, 0.f, 0.f};
     hold = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 pkeep = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 okeep[2];
+    okeep[0] = okeep[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // one channel of a pooled voxel: the window in order (dz, dy, dx); the first maximum wins (strict >, as pool_fwd_vox_kernel).  Returns the maximum, idx = its position
     auto pool1 = [&](float e00, float e01, float e10, float e11, float o00, float o01, float o10, float o11, unsigned *idx) __attribute__((always_inline)) {
@@ -180,6 +192,7 @@ __global__ __launch_bounds__(256, 2) void f3d_fwd_kernel(const F3Args a) {
         const unsigned pv = (unsigned)f3_s((((unsigned)p * 8u + (unsigned)(tv ? (zo >> 1) : 0)) * 8u + (unsigned)prow) * 8u);      // first pooled voxel of the row
         const f32x4 o = f32x4{m0, m1, m2, m3};
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), po_rsrc, (int)(tv ? p_out : F3_OOB), (int)(pv * 64u), 0);
+        asm volatile("s_nop 1" :: "v"(o));      // (a 16-byte store with a scalar offset reads its data late: nothing may write these registers in the next cycles, t3d_fwd_kernel)
         __builtin_amdgcn_raw_buffer_store_b32((int)(i0 | (i1 << 8) | (i2 << 16) | (i3 << 24)), pa_rsrc, (int)(tv ? p_arg : F3_OOB), (int)(pv * 16u), 0);
         float s_ = (m0 + m1) + (m2 + m3);
         s_ += __shfl_xor(s_, 16, 64);
@@ -193,13 +206,18 @@ __global__ __launch_bounds__(256, 2) void f3d_fwd_kernel(const F3Args a) {
         constexpr int st = decltype(ST)::value, ry = decltype(RY)::value;
         constexpr bool odd = decltype(ODD)::value != 0;
         const unsigned vrow = (unsigned)f3_s((((unsigned)p * 16u + (unsigned)(tv ? zo : 0)) * 16u + (unsigned)(4 * wave + ry)) * 16u);      // first voxel of the row
+#if F3_ONEACC
+        const f32x4 c = acc[st][ry], cx = f32x4{0.f, 0.f, 0.f, 0.f};
+#else
         const f32x4 c = acc[st][ry], cx = acx[st][ry];      // (not cleared: the first MFMA of the set's next plane starts from zero)
+#endif
         const float v0 = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(cx.x, 0x1p-11f, c.x), inv, bias4.x), 0.f);
         const float v1 = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(cx.y, 0x1p-11f, c.y), inv, bias4.y), 0.f);
         const float v2 = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(cx.z, 0x1p-11f, c.z), inv, bias4.z), 0.f);
         const float v3 = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(cx.w, 0x1p-11f, c.w), inv, bias4.w), 0.f);
         const f32x4 o = f32x4{v0, v1, v2, v3};
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), o_rsrc, (int)(tv ? e_out : F3_OOB), (int)(vrow * 64u), 0);
+        asm volatile("s_nop 1" :: "v"(o));
         const unsigned bits = (v0 > 0.f ? 1u : 0u) | (v1 > 0.f ? 2u : 0u) | (v2 > 0.f ? 4u : 0u) | (v3 > 0.f ? 8u : 0u);
         __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bits, s_rsrc, (int)(tv ? e_sg : F3_OOB), (int)(vrow * 4u), 0);
         float s_ = (v0 + v1) + (v2 + v3);
@@ -212,6 +230,7 @@ __global__ __launch_bounds__(256, 2) void f3d_fwd_kernel(const F3Args a) {
             hold = o;
         } else {
             pool_rows(keep[ry - 1], keep[ry], hold, o, p, zo, 2 * wave + (ry >> 1), tv);
+            okeep[ry >> 1] = o;      // (its 16-byte store reads the registers late - with a second wave on the SIMD later than the pool's arithmetic lasts)
         }
     };
 
@@ -258,9 +277,15 @@ __global__ __launch_bounds__(256, 2) void f3d_fwd_kernel(const F3Args a) {
                     const int kk = dz * 3 + dy;
                     const bool first = dz == 0 && dy == 0;      // the first contribution to row ry of plane s + 1 starts its accumulators
                     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+#if F3_ONEACC
+                    f32x4 c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[kk], xh, first ? zero : acc[st][ry], 0, 0, 0);      // the small products first
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[kk], xl, c1, 0, 0, 0);
+                    acc[st][ry] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[kk], xh, c1, 0, 0, 0);
+#else
                     acx[st][ry] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[kk], xh, first ? zero : acx[st][ry], 0, 0, 0);      // (l, h) + (h, l) at 2^11, (h, h)
                     acc[st][ry] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[kk], xh, first ? zero : acc[st][ry], 0, 0, 0);
                     acx[st][ry] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[kk], xl, acx[st][ry], 0, 0, 0);
+#endif
                 }
             }
 #pragma unroll
@@ -271,8 +296,8 @@ __global__ __launch_bounds__(256, 2) void f3d_fwd_kernel(const F3Args a) {
         };
         block(F3IC<0>{}); block(F3IC<1>{}); block(F3IC<2>{}); block(F3IC<3>{}); block(F3IC<4>{}); block(F3IC<5>{});
         __builtin_amdgcn_sched_barrier(0);
-        const f32x4 k0 = pkeep;
-        asm volatile("" :: "v"(k0));
+        const f32x4 k0 = pkeep, k1 = okeep[0], k2 = okeep[1];
+        asm volatile("" :: "v"(k0), "v"(k1), "v"(k2));
     };
 
     if (npw > 0) {
@@ -302,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void f3d_fwd_kernel(const F3Args a) {
 #pragma unroll
             for (int ry = 0; ry < 4; ++ry) { acc[0][ry] = f32x4{0.f, 0.f, 0.f, 0.f}; acx[0][ry] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 7" :: "v"(pkeep));
+            asm volatile("s_nop 7" :: "v"(pkeep), "v"(okeep[0]), "v"(okeep[1]));
         }
     }
 }
@@ -335,7 +360,7 @@ void f3d_pack(F3dPlan *plan, const float *W) {
                 const float w = tx < 3 ? W[((size_t)(kk * 3 + tx) * 8 + c) * 16 + co] : 0.f;
                 const float ws = std::ldexp(w, plan->w_exp);
                 const _Float16 h = (_Float16)ws;
-                const _Float16 l = (_Float16)std::ldexp(ws - (float)h, 11);
+                const _Float16 l = (_Float16)std::ldexp(ws - (float)h, F3_ONEACC ? 0 : 11);
                 unsigned short hb, lb;
                 std::memcpy(&hb, &h, 2);
                 std::memcpy(&lb, &l, 2);

@@ -1832,6 +1832,7 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
             ALQ_HIP(hipMemcpyAsync(dl, ly.e3b.h_Wlo.data(), ly.e3b.h_Wlo.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
             ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
         }
+        if (ly.f3f.ok && !c3d_subnormals_ok(m->ctx)) ly.f3f.ok = false;      // (one-accumulator fp16 pairs)
         if (ly.f3f.ok) {
             f3d_pack(&ly.f3f, W);
             unsigned short *dh = reinterpret_cast<unsigned short *>(ly.f3f.d_Whi), *dl = reinterpret_cast<unsigned short *>(ly.f3f.d_Wlo);

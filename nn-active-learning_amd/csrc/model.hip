@@ -1410,9 +1410,9 @@ static int run_backward_general(alq_model *m, int N, const DropSpec *drop) {
                 bool fused = false;
                 ALQ_TRY(k_fc_small_bwd(ctx, ly.dout.p, ly.spec.cout, ly.d_Wp, ly.F, N, ly.din.p, nullptr, nullptr, 0, &fused));
             } else {
-                // a wide fc layer's backward GEMM on fp16 pairs under the static bound on its input cotangent (fcgemm.hip, F16)
-                ALQ_TRY(gemm_launch(ctx, ly.bwd, ly.dout, flat_view(ly.din), nullptr, 0, 0, N, PROF_IGEMM_BWD, nullptr, nullptr,
-                                    (ly.dout_bound > 0.f && !m->no_bound16) ? ly.dout_bound : 0.f));
+                // no bound: ly.dout_bound belongs to the unit cotangent of a Fisher pass (run_backward_main), this
+                // cotangent is arbitrary (loss scale, dropout factors) - the bf16-triple path, whatever ran before
+                ALQ_TRY(gemm_launch(ctx, ly.bwd, ly.dout, flat_view(ly.din), nullptr, 0, 0, N, PROF_IGEMM_BWD, nullptr, nullptr, 0.f));
             }
         } else {
             ALQ_TRY(gemm_launch(ctx, ly.bwd, ly.dout, ly.din, nullptr, 0, acc, N, PROF_IGEMM_BWD));

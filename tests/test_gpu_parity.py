@@ -1560,6 +1560,52 @@ def test_fc_backward_on_fp16_pairs_against_bf16_triples(sess):
     np.testing.assert_allclose(a['A'], b['A'], rtol=2e-5, atol=1e-12 + 2e-6 * np.abs(b['A']).max())
 
 
+def test_param_grads_do_not_depend_on_an_earlier_fisher_pass(sess):
+    """alq_param_grads (NN.get_gradients / the training gradient, NN.py:621-645) runs the general backward pass on an ARBITRARY
+    cotangent (loss scale, mode 1, dropout factors): the static cotangent bound a Fisher pass leaves in the layers belongs to the
+    unit cotangent and must not select or scale the wide fc layers' backward split.  NET-B gradients on a fresh model == after a
+    Fisher pass == on a model created under ALQ_NO_FC_F16, bit for bit, for a tiny and for a large loss scale (values far below /
+    above the Fisher bound)."""
+    torch = sess.torch
+    ld = netspec.net_b_small(width=512)      # fc 6144 -> 512 -> 512 -> 2: both hidden fc backward launches are wide (fcgemm)
+    in_shape = (32, 32, 32)
+    pars = netspec.he_init(ld, in_shape, seed=17)
+    n = 24
+    rs = np.random.RandomState(6)
+    x = sess.to_device(rs.randn(n, int(np.prod(in_shape))).astype(np.float32), torch.float32)
+    labels = rs.randint(0, 2, n).astype(np.int32)
+
+    def grads(m):
+        out = []
+        for scale in (1. / 4096, 300.):
+            g, _, _ = m.param_grads_device(x, n, 1, labels=labels, loss_scale=scale, per_sample=False)
+            out.append(g.cpu().numpy())
+        g, _, _ = m.param_grads_device(x, n, 0, cls=1)
+        out.append(g.cpu().numpy())
+        return out
+
+    fresh = _device_model(sess, ld, in_shape, (), pars, max_batch=n)
+    ref = grads(fresh)
+    fresh.close()
+    after = _device_model(sess, ld, in_shape, (), pars, max_batch=n)
+    after.fisher_device(x, n, None, 1e-3, want=('g0', 'g1'))
+    got = grads(after)
+    after.close()
+    old = os.environ.get('ALQ_NO_FC_F16')
+    os.environ['ALQ_NO_FC_F16'] = '1'
+    try:
+        plain = _device_model(sess, ld, in_shape, (), pars, max_batch=n)
+    finally:
+        os.environ.pop('ALQ_NO_FC_F16', None) if old is None else os.environ.__setitem__('ALQ_NO_FC_F16', old)
+    plain.fisher_device(x, n, None, 1e-3, want=('g0', 'g1'))
+    triples = grads(plain)
+    plain.close()
+    for a, b, c in zip(ref, got, triples):
+        assert np.isfinite(a).all()
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(a, c)
+
+
 def test_two_scoring_pipelines_are_bit_identical_to_one(sess):
     """ALQ_LANES=2 (opt-in): `fisher_device` alternates its device passes between two pipelines - a second libalq context on its
     own stream pair with its own workspaces and a copy of the weights - so that one pass's tail runs beside the next one's first

@@ -60,8 +60,17 @@ def main():
     ap.add_argument('--same-gpu', action='store_true',
                     help='functional rehearsal on a one-GPU box: every rank computes on cuda:0 (use with --backend gloo; RCCL '
                          'refuses two ranks on one device); throughput numbers of such a run mean nothing')
-    ap.add_argument('--prof-every', type=int, default=8, help='HIP-event timing on every k-th pass of the timed region')
+    ap.add_argument('--prof-every', type=int, default=8, help='--lanes 1 only: HIP-event timing on every k-th pass of the timed region')
+    ap.add_argument('--lanes', type=int, default=2,
+                    help='scoring pipelines of the timed region (device.DeviceModel.lanes): 2 = device passes alternate between two libalq '
+                         'contexts so that one pass\'s tail runs beside the next one\'s first launches (outputs bit-identical to 1, '
+                         'test_two_scoring_pipelines_are_bit_identical_to_one).  Per-launch durations then include co-residency, so the '
+                         'roofline object always comes from a SEPARATE single-pipeline pass with HIP events on every launch')
+    ap.add_argument('--roofline-passes', type=int, default=8, help='device passes of the separate single-pipeline roofline pass')
     ap.add_argument('--cpu-sample', type=int, default=128, help='patches the CPU baseline scores (~15 s on 16 cores)')
+    ap.add_argument('--cpu-all-cores', action='store_true',
+                    help='also time ONE patch of the CPU baseline with os.cpu_count() threads (BASELINE.md 3 names that thread count; at '
+                         'batch 1 it oversubscribes every op: 0.03 patches/s on the 256-thread box, ~35 s)')
     ap.add_argument('--config', type=int, default=2, choices=(0, 1, 2, 3, 4),
                     help='BASELINE.json configs[i]: 0 NET-A entropy query over 1,000 patches, 1 NET-A Fisher scoring of 10,000, 2 NET-C Fisher '
                          'scoring of 100,000 per GPU (the metric\'s config, default), 3 ONE pool of 1,000,000 over the GPUs (= --pool-global '
@@ -117,6 +126,7 @@ def main():
     model = device.DeviceModel(sess, ld, in_shape, sk, max_batch=args.batch)
     model.set_weights(pars)
     args.batch = model.max_batch          # what the library granted (alq_model_max_batch)
+    model.lanes = max(1, args.lanes)
 
     strong = args.pool_global > 0
     n_global = args.pool_global if strong else args.pool * ws
@@ -151,9 +161,11 @@ def main():
         step()
     note('timing %d step(s)' % args.steps)
     sess.prof_reset()
-    # HIP events on our stream around the launches of every 8th pass of the timed region (on every launch the
-    # event pairs themselves cost ~6 % of the step)
-    sess.prof_enable(0 if os.environ.get('ALQ_BENCH_NO_EVENTS') else args.prof_every)
+    # one pipeline: HIP events on our stream around the launches of every 8th pass of the timed region (on every launch the
+    # event pairs themselves cost ~6 % of the step); two pipelines: none - a launch's event span would include whatever the
+    # other pipeline runs beside it - and the roofline pass below instead
+    in_region = model.lanes == 1 and not os.environ.get('ALQ_BENCH_NO_EVENTS')
+    sess.prof_enable(args.prof_every if in_region else 0)
     pool_shard.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -165,6 +177,20 @@ def main():
     sess.prof_enable(False)
     prof = sess.prof_read()
     dt = pool_shard.max_over_ranks(dt)
+    lanes_timed = int(model.lanes)
+    prof_patches = None
+    if not in_region and not os.environ.get('ALQ_BENCH_NO_EVENTS'):
+        # the roofline pass: the same launches on the first passes of the pool, ONE pipeline, HIP events on every launch
+        # (outside the timed region; what rocprofv3 --kernel-trace shows for `--lanes 1`)
+        model.lanes = 1
+        prof_patches = min(n_local, args.roofline_passes * args.batch)
+        sess.prof_reset()
+        sess.prof_enable(1)
+        model.fisher_device(x, prof_patches, None, 1e-3, want=('p1', 'H', 'g0', 'g1', 'A', 'trace', 'Asum'))
+        torch.cuda.synchronize()
+        sess.prof_enable(False)
+        prof = sess.prof_read()
+        model.lanes = lanes_timed
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
@@ -184,7 +210,8 @@ def main():
         # at the default sizes; a ragged last pass would be counted at full size, so derive the count from the passes)
         passes_per_step = -(-n_local // args.batch)
         sampled_passes = ig_n / 12.0
-        prof_patches = sampled_passes * (n_local / float(passes_per_step))
+        if prof_patches is None:
+            prof_patches = sampled_passes * (n_local / float(passes_per_step))
         achieved = ig_fl / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
         peak_bf, peak_f16 = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS, PEAK_BF16_MFMA_TFLOPS / 3
         peak = ig_fl / (bf_fl / peak_bf + f16['flops'] / peak_f16) if ig_fl > 0 else peak_bf
@@ -250,7 +277,10 @@ def main():
                          'hbm_frac': (traffic * ig_n / (ig_ms * 1e-3) / (PEAK_HBM_TBPS * 1e12)) if traffic and ig_ms > 0 else None,
                          'f16x2_launches': {'tflops': f16['flops'] / (f16['ms'] * 1e-3) / 1e12 if f16['ms'] > 0 else 0.0,
                                           'avg_launch_ms': f16['ms'] / max(f16['launches'], 1), 'bound_tflops': peak_f16},
-                         'launches': ig_n, 'avg_launch_ms': ig_ms / max(ig_n, 1), 'timed_every_kth_pass': args.prof_every,
+                         'launches': ig_n, 'avg_launch_ms': ig_ms / max(ig_n, 1),
+                         'timed': ('HIP events on every k-th pass of the timed region, k = %d' % args.prof_every) if in_region else
+                                  ('a separate single-pipeline pass over the first %d pool patches behind the timed region, HIP events on '
+                                   'every launch (the timed region ran %d pipelines: its launches overlap each other)' % (prof_patches, lanes_timed)),
                          'all_conv_engines_tflops': conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
                          'flops_per_patch_executed': F_EXEC, 'flops_per_patch_survey': F_SURVEY,
                          'whole_step_tflops_executed': F_EXEC * value / ws / 1e12,
@@ -268,14 +298,14 @@ def main():
                                      'conv_transpose_forward_row_sweep_launches': int(info(model._m, 7)),
                                      'conv_transpose_backward_row_sweep_launches': int(info(model._m, 8)),
                                      'enc2_backward_fused_with_pool_backwards': int(info(model._m, 9)),
-                                     'scoring_pipelines': int(model.lanes)}
+                                     'scoring_pipelines': lanes_timed}
         if ws == 1:
             line['accuracy'] = accuracy_vs_exact_fp32(sess, model, x, min(args.batch, n_local))
         if ws == 1 and args.netb_pool > 0:
             line['netb'] = netb_rate(sess, args.netb_pool, x)
         if not args.no_cpu_baseline and ws == 1:      # reported at N = 1 only (the other ranks would sit in the barrier)
             note('timing the CPU baseline')
-            line['cpu_baseline'] = cpu_baseline(x[:args.cpu_sample].cpu().numpy(), ld, sk, in_shape, pars)
+            line['cpu_baseline'] = cpu_baseline(x[:args.cpu_sample].cpu().numpy(), ld, sk, in_shape, pars, args.cpu_all_cores)
         print(json.dumps(line))
     if ws > 1:
         dist.barrier()
@@ -283,17 +313,26 @@ def main():
 
 
 def _conv_roofline(prof, note):
-    """Roofline object from the HIP-event classes of the contraction engines (whatever ran: the small nets of configs[0..1] use
-    the first-layer kernel, the bf16x3 engines and the fp32 fallback)."""
-    keys = ('igemm_fwd', 'igemm_bwd', 'igemm3_fwd', 'igemm3_bwd', 'direct_conv', 'igemm_f16x2')
-    ms = sum(prof[k]['ms'] for k in keys if k in prof)
-    fl = sum(prof[k]['flops'] for k in keys if k in prof)
-    n = sum(prof[k]['launches'] for k in keys if k in prof)
-    peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
+    """Roofline object from the HIP-event classes of the contraction engines, against the split that RAN: launches of the
+    fp16-pair class execute 3 products per MAC (ceiling 2500 / 3), the bf16-triple engines (and the first-layer / fp32 fallback
+    kernels, counted with them) 6 (ceiling 2500 / 6); `peak` = their flop-weighted harmonic mean, `useful_frac` = algorithmic
+    flops against 2500 / 3 as in the main line."""
+    bf_keys = ('igemm_fwd', 'igemm_bwd', 'igemm3_fwd', 'igemm3_bwd', 'direct_conv')
+    f16 = prof.get('igemm_f16x2', {'ms': 0.0, 'flops': 0.0, 'launches': 0})
+    bf_fl = sum(prof[k]['flops'] for k in bf_keys if k in prof)
+    ms = sum(prof[k]['ms'] for k in bf_keys if k in prof) + f16['ms']
+    fl = bf_fl + f16['flops']
+    n = sum(prof[k]['launches'] for k in bf_keys if k in prof) + f16['launches']
+    peak_bf, peak_f16 = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS, PEAK_BF16_MFMA_TFLOPS / 3
+    peak = fl / (bf_fl / peak_bf + f16['flops'] / peak_f16) if fl > 0 else peak_bf
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    return {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
-            'kernel': 'all contraction launches (first-layer kernel, igemm3 / igemm4 bf16x3, fp32 fallback engine)', 'launches': n,
-            'avg_launch_ms': ms / max(n, 1), 'peak_note': 'dense 16-bit MFMA %.0f TFLOP/s / 6 products of the bf16x3 split' % PEAK_BF16_MFMA_TFLOPS,
+    return {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'useful_frac': ach / peak_f16, 'traffic': None,
+            'kernel': 'all contraction launches (first-layer kernel, bf16x3 engines, fp16-pair launches, fp32 fallback engine)', 'launches': n,
+            'avg_launch_ms': ms / max(n, 1),
+            'peak_note': 'algorithmic fp32 flops; peak = flop-weighted harmonic mean of %.0f dense 16-bit MFMA / 6 products (bf16x3 and first-layer '
+                         'launches, %.0f %% of the flops) and / 3 (fp16-pair launches); useful_frac = achieved / (%.0f / 3)'
+                         % (PEAK_BF16_MFMA_TFLOPS, 100.0 * bf_fl / max(fl, 1.0), PEAK_BF16_MFMA_TFLOPS),
+            'alg_flops': {'bf16x3': bf_fl, 'f16x2': f16['flops']},
             'note': note, 'time_share_ms_sampled': {k: v['ms'] for k, v in prof.items()}}
 
 
@@ -390,6 +429,8 @@ def loop_config(args, sess, rank, ws):
     model = device.DeviceModel(sess, ld, in_shape, sk, max_batch=args.batch)
     model.set_weights(pars)
     model.get_optimizer(1e-4, [], 'SGD')
+    if not os.environ.get('ALQ_BENCH_NO_EVENTS'):
+        model.lanes = 1       # the loop's launches are event-timed in place: one pipeline, so that a span is one launch
     a, b = pool_shard.shard_bounds(n, ws, rank)
     pool = sess.empty((b - a, 32 ** 3), torch.float32)
     check(sess.lib.alq_synth_patches(sess.ctx, 1005, a, b - a, 32 ** 3, C.c_void_p(pool.data_ptr())))
@@ -517,7 +558,7 @@ def accuracy_vs_exact_fp32(sess, model, x, n):
                        'ReLU / max-pool decisions that fp32 rounding puts on either side (each engine has its own set against fp64)'}
 
 
-def cpu_baseline(xs, ld, sk, in_shape, pars):
+def cpu_baseline(xs, ld, sk, in_shape, pars, all_cores_too=False):
     """The oracle (CPU port with the reference's structure: batch 1, one backward per class per
     sample, full gradients materialised, NumPy shrink, PW_NNAL.py:757-814) on this box's host
     cores, on a bounded sample of the same patches."""
@@ -553,7 +594,7 @@ def cpu_baseline(xs, ld, sk, in_shape, pars):
     # reference's structure is batch 1, so beyond ~16 threads a sample gains little (the per-op work is one patch)
     all_cores = None
     nall = max(1, min(affinity or (os.cpu_count() or 1), os.cpu_count() or 1))
-    if nall > cores:
+    if nall > cores and all_cores_too:
         used = torch.get_num_threads()
         torch.set_num_threads(nall)
         # ONE patch, no warm-up: at batch 1 with hundreds of threads every op is oversubscribed (measured on the 256-thread GPU box:
@@ -568,7 +609,9 @@ def cpu_baseline(xs, ld, sk, in_shape, pars):
     return {'value': len(xs) / dt, 'unit': 'patches/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'host_cores': os.cpu_count(), 'affinity_cores': affinity, 'all_cores': all_cores,
             'sample': '%d of the pool\'s patches (NET-C 32^3), forward + per-sample gen_A_matrices, %.1f s; %d threads '
-                      '(the box reports %s cores, %s in this process\'s affinity mask; capped at 16)'
+                      '(the box reports %s cores, %s in this process\'s affinity mask).  BASELINE.md 3 names os.cpu_count() threads: '
+                      'the reference structure is batch 1, every op is then oversubscribed (0.03 patches/s at 256 threads, rounds 4-5; '
+                      '--cpu-all-cores re-measures it into `all_cores`), so the baseline stated here is the FASTER 16-thread one'
                       % (len(xs), dt, torch.get_num_threads(), os.cpu_count(), affinity)}
 
 

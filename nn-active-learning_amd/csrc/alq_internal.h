@@ -70,6 +70,19 @@ struct ProfSlot {
 
 }  // namespace alq
 
+// ---- the 16-byte-store data hazard (device code) -------------------------------------------------------------------------
+// A `buffer_store_dwordx3/x4` reads its data registers AFTER it has issued.  The compiler's hazard recogniser knows the case
+// (GCNHazardRecognizer::createsVALUHazard, "VMEM store of more than 64 bits followed by a VALU write of its vdata": 2 wait
+// states on gfx940+), but only for stores WITHOUT a register soffset; for a store whose scalar offset is an SGPR - every
+// plane / row-sweep store of d3d / f3d / t3d / t3d8b / c3d - it inserts nothing.  Round 5 saw exactly that case corrupt
+// outputs once a second wave shared the SIMD (the rows held a later vector result; HISTORY.md 13).  ALQ_STORE_HOLD(data),
+// placed right behind such a store, keeps the data registers the store's for ALQ_STORE_HOLD_STATES wait states (the table
+// entry's figure for its sibling): they are inputs of the statement, so nothing may be allocated into them before it, and
+// the "memory" clobber keeps the store in front of it.  tools/isa_store_hazard.py checks the RESULT in the device assembly
+// of every build (csrc/build.sh): no such store may have a writer of its data registers within fewer wait states.
+#define ALQ_STORE_HOLD_STATES 2
+#define ALQ_STORE_HOLD(...) asm volatile("s_nop 1" ::__VA_ARGS__ : "memory")
+
 #define ALQ_PARAM_BLOCK_BYTES 512
 
 struct alq_ctx {

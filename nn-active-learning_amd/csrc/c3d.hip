@@ -742,6 +742,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         val.w = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v3) & k3);
         const unsigned vox = E.pv + E.row_v + (unsigned)i * 32u + (unsigned)hx * 16u;      // first voxel of this half row
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, val), dB_rsrc, (int)E.off_dB, (int)(vox * 32u), 2 /* nt */);
+#ifndef C3_NO_HOLD
+        ALQ_STORE_HOLD("v"(val));      // (16-byte store with a register soffset: alq_internal.h)
+#endif
         const float t = (val.x + val.y) + (val.z + val.w);
         // lanes (j, q) and (j, q ^ 1) hold the two 4-channel groups of one voxel.  v_permlane16_swap(a, b) returns
         // ([a.row0, b.row0, a.row2, b.row2], [a.row1, b.row1, a.row3, b.row3]) (rows of 16 lanes; probed on the device,

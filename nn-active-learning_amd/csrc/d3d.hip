@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const f32x4 o = f32x4{v0, v1, v2, v3};
         okeep[ry & 1] = o;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), o_rsrc, (int)(tv ? e_out : D3_OOB), (int)(vrow * 64u), 0);
-        asm volatile("s_nop 1" :: "v"(o));      // (a 16-byte store with a scalar offset reads its data late: nothing may write these registers in the next cycles, t3d_fwd_kernel)
+        ALQ_STORE_HOLD("v"(o));      // (a 16-byte store with a scalar offset reads its data late: nothing may write these registers in the next cycles, t3d_fwd_kernel)
         const unsigned bits = (v0 > 0.f ? 1u : 0u) | (v1 > 0.f ? 2u : 0u) | (v2 > 0.f ? 4u : 0u) | (v3 > 0.f ? 8u : 0u);
         __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bits, s_rsrc, (int)(tv ? e_sg : D3_OOB), (int)(vrow * 4u), 0);
         float s_ = (v0 + v1) + (v2 + v3);
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int ry = 0; ry < 4; ++ry) { acc[0][ry] = f32x4{0.f, 0.f, 0.f, 0.f}; acx[0][ry] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 7" :: "v"(okeep[0]), "v"(okeep[1]));
+            asm volatile("s_nop 7" :: "v"(okeep[0]), "v"(okeep[1]) : "memory");
         }
     }
 }
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const f32x4 o = f32x4{v0, v1, v2, v3};
         okeep[ry & 1] = o;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), o_rsrc, (int)(tv ? e_out : D3_OOB), (int)(vrow * 64u), 0);
-        asm volatile("s_nop 1" :: "v"(o));      // (a 16-byte store with a scalar offset reads its data late: nothing may write these registers in the next cycles, t3d_fwd_kernel)
+        ALQ_STORE_HOLD("v"(o));      // (a 16-byte store with a scalar offset reads its data late: nothing may write these registers in the next cycles, t3d_fwd_kernel)
         float s_ = (v0 + v1) + (v2 + v3);
         s_ += __shfl_xor(s_, 16, 64);
         s_ += __shfl_xor(s_, 32, 64);
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int ry = 0; ry < 8; ++ry) { acc[0][ry] = f32x4{0.f, 0.f, 0.f, 0.f}; acx[0][ry] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 7" :: "v"(okeep[0]), "v"(okeep[1]));
+            asm volatile("s_nop 7" :: "v"(okeep[0]), "v"(okeep[1]) : "memory");
         }
     }
 }

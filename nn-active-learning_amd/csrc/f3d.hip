@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void f3d_fwd_kernel(const F3Args a) {
         const unsigned pv = (unsigned)f3_s((((unsigned)p * 8u + (unsigned)(tv ? (zo >> 1) : 0)) * 8u + (unsigned)prow) * 8u);      // first pooled voxel of the row
         const f32x4 o = f32x4{m0, m1, m2, m3};
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), po_rsrc, (int)(tv ? p_out : F3_OOB), (int)(pv * 64u), 0);
-        asm volatile("s_nop 1" :: "v"(o));      // (a 16-byte store with a scalar offset reads its data late: nothing may write these registers in the next cycles, t3d_fwd_kernel)
+        ALQ_STORE_HOLD("v"(o));      // (a 16-byte store with a scalar offset reads its data late: nothing may write these registers in the next cycles, t3d_fwd_kernel)
         __builtin_amdgcn_raw_buffer_store_b32((int)(i0 | (i1 << 8) | (i2 << 16) | (i3 << 24)), pa_rsrc, (int)(tv ? p_arg : F3_OOB), (int)(pv * 16u), 0);
         float s_ = (m0 + m1) + (m2 + m3);
         s_ += __shfl_xor(s_, 16, 64);
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void f3d_fwd_kernel(const F3Args a) {
         const float v3 = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(cx.w, 0x1p-11f, c.w), inv, bias4.w), 0.f);
         const f32x4 o = f32x4{v0, v1, v2, v3};
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), o_rsrc, (int)(tv ? e_out : F3_OOB), (int)(vrow * 64u), 0);
-        asm volatile("s_nop 1" :: "v"(o));
+        ALQ_STORE_HOLD("v"(o));
         const unsigned bits = (v0 > 0.f ? 1u : 0u) | (v1 > 0.f ? 2u : 0u) | (v2 > 0.f ? 4u : 0u) | (v3 > 0.f ? 8u : 0u);
         __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bits, s_rsrc, (int)(tv ? e_sg : F3_OOB), (int)(vrow * 4u), 0);
         float s_ = (v0 + v1) + (v2 + v3);
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void f3d_fwd_kernel(const F3Args a) {
 #pragma unroll
             for (int ry = 0; ry < 4; ++ry) { acc[0][ry] = f32x4{0.f, 0.f, 0.f, 0.f}; acx[0][ry] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 7" :: "v"(pkeep), "v"(okeep[0]), "v"(okeep[1]));
+            asm volatile("s_nop 7" :: "v"(pkeep), "v"(okeep[0]), "v"(okeep[1]) : "memory");
         }
     }
 }

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void t3d_fwd_kernel(const T3FwdArgs a) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 3" :: "v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3]));
+            asm volatile("s_nop 3" :: "v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3]) : "memory");
         }
     }
 }
@@ -412,6 +412,9 @@ __global__ __launch_bounds__(256, 2) void t3d_bwd_kernel(const T3BwdArgs a) {
                 v.x = (nb & 1u) ? v.x : 0.f; v.y = (nb & 2u) ? v.y : 0.f;
                 v.z = (nb & 4u) ? v.z : 0.f; v.w = (nb & 8u) ? v.w : 0.f;
             }
+            // (opaque: in the peeled void first pass v is a constant, and the compiler would otherwise materialise one copy for the
+            // store and another for the hold below - the hold must name the registers the store reads, tools/isa_store_hazard.py)
+            asm volatile("" : "+v"(v));
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), out_rsrc, (int)st_o, (int)(crow * 1024u), 0);
             if constexpr (SUMS) {
                 float s = (v.x + v.y) + (v.z + v.w);
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void t3d_bwd_kernel(const T3BwdArgs a) {
             }
             // (the store's data registers stay alive for a while: see the forward kernel's epilogue)
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 3" :: "v"(v));
+            asm volatile("s_nop 3" :: "v"(v) : "memory");
         }
     }
 }
@@ -594,7 +597,7 @@ __global__ __launch_bounds__(512, 2) void t3d8_fwd_kernel(const T8FwdArgs a) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 3" :: "v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3]), "v"(vv[4]), "v"(vv[5]), "v"(vv[6]), "v"(vv[7]));      // (store data stays alive: t3d_fwd_kernel)
+            asm volatile("s_nop 3" :: "v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3]), "v"(vv[4]), "v"(vv[5]), "v"(vv[6]), "v"(vv[7]) : "memory");      // (store data stays alive: t3d_fwd_kernel)
         }
     }
 }

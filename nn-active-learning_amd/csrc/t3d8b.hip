@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void t3d8_bwd_kernel(const T8BwdArgs a) {
             s_ += __shfl_xor(s_, 32, 64);
             part[j] = s_;
             if (cb == 1 && kg == 0) xch[(tp + 2 * j) * 16 + n] = s_;
-            asm volatile("s_nop 3" :: "v"(o));      // (16-byte store data is read late by the hardware: t3d_fwd_kernel)
+            asm volatile("s_nop 3" :: "v"(o) : "memory");      // (16-byte store data is read late by the hardware: t3d_fwd_kernel)
         }
         __syncthreads();      // the partner's partial sums are there; everyone is done reading the ring planes the next step overwrites
         if (cb == 0 && a.dsum) {

@@ -346,8 +346,10 @@ class DeviceModel(object):
         check(self.lib.alq_model_create(sess.ctx, arr, len(self.layers), cd, self.max_batch, C.byref(self._m)))
         _track(self)
         self.max_batch = int(self.lib.alq_model_max_batch(self._m))      # may be below the request: 32-bit tensor offsets (alq.h)
-        # second scoring pipeline (fisher_device): created at the first call that has more than one device pass to run
-        self.lanes = max(1, int(os.environ.get('ALQ_LANES', '1')))
+        # second scoring pipeline (fisher_device): created at the first call that has more than one device pass to run.
+        # Default since round 6 (ALQ_LANES=1: one pipeline): outputs are bit-identical, +2.5 % on the 100k-patch pool
+        # (profiles/r05_lanes_ab.txt); it costs a second set of workspaces once a call spans more than one pass
+        self.lanes = max(1, int(os.environ.get('ALQ_LANES', '2')))
         self._lane2 = None
         self._create_env = {k: v for k, v in os.environ.items() if k.startswith('ALQ_')}     # engine switches are read at creation
         self.L = self.lib.alq_model_num_param_layers(self._m)

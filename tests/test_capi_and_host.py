@@ -313,3 +313,38 @@ def test_run_method_bookkeeping_against_the_reference_run(golden_dir, tmp_path, 
                 blocks = [mine[j * k:(j + 1) * k] for j in range(it + 1)]
                 mine = np.concatenate([blocks[j] for j in g['resume_listdir_order']] + blocks[3:])
             np.testing.assert_array_equal(mine, g['train_seen_%d_%d' % (it, s_)])
+
+
+def test_store_hazard_gate_flags_an_early_rewrite_of_store_data(tmp_path):
+    """csrc/build.sh runs tools/isa_store_hazard.py over the sweep kernels' device assembly: a 16-byte buffer store with a
+    REGISTER soffset (the compiler inserts no wait states for it, alq_internal.h ALQ_STORE_HOLD) must keep its data registers
+    untouched for 2 wait states.  The gate itself, on hand-written assembly: an early VALU rewrite fails, the same code with
+    the hold passes, a store with an immediate soffset is the compiler's business, a rewrite on the taken arm of a branch is
+    found, a load into the data registers (written on return, much later) is not counted."""
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'isa_store_hazard.py')
+
+    def run(body):
+        f = tmp_path / 'k.s'
+        f.write_text('\t.text\nkern:\n' + body + '\ts_endpgm\n')
+        return subprocess.run([sys.executable, tool, '--min', '2', str(f)], capture_output=True, text=True)
+
+    bad = '\tbuffer_store_dwordx4 v[4:7], v0, s[8:11], s3 offen\n\tv_add_f32_e32 v5, v1, v2\n'
+    r = run(bad)
+    assert r.returncode == 1 and 'HAZARD (0 wait states' in r.stderr
+    r = run('\tbuffer_store_dwordx4 v[4:7], v0, s[8:11], s3 offen\n\ts_nop 1\n\tv_add_f32_e32 v5, v1, v2\n')
+    assert r.returncode == 0, r.stderr
+    r = run('\tbuffer_store_dwordx4 v[4:7], v0, s[8:11], s3 offen\n\ts_mov_b32 s0, 0\n\tv_mfma_f32_16x16x32_f16 v[4:7], v[10:13], v[14:17], v[4:7]\n')
+    assert r.returncode == 1 and 'HAZARD (1 wait states' in r.stderr
+    assert run('\tbuffer_store_dwordx4 v[4:7], v0, s[8:11], 0 offen\n\tv_add_f32_e32 v5, v1, v2\n').returncode == 0
+    assert run('\tbuffer_store_dwordx4 v[4:7], v0, s[8:11], s3 offen\n\tbuffer_load_dwordx4 v[4:7], v0, s[8:11], s3 offen\n'
+               '\ts_nop 0\n\tv_add_f32_e32 v9, v1, v2\n').returncode == 0
+    r = run('\tbuffer_store_dwordx4 v[4:7], v0, s[8:11], s3 offen\n\ts_cbranch_scc1 .LBB0_2\n\ts_nop 3\n\tv_mov_b32_e32 v4, 0\n'
+            '.LBB0_2:\n\tv_mov_b32_e32 v6, 0\n')
+    assert r.returncode == 1 and 'HAZARD (1 wait states' in r.stderr
+    # the product build's own report: every sweep-kernel store held for at least 2 wait states
+    rep = os.path.join(os.path.dirname(_lib.LIB_PATH), 'csrc', 'build', 'store_hazard_report.txt')
+    if os.path.exists(rep):
+        for ln in open(rep):
+            m = re.search(r'(\d+) 12/16-byte stores.*rewritten: (\w+)', ln)
+            assert m and (int(m.group(1)) == 0 or int(m.group(2)) >= 2), ln

@@ -71,10 +71,12 @@ def main():
     ap.add_argument('--cpu-all-cores', action='store_true',
                     help='also time ONE patch of the CPU baseline with os.cpu_count() threads (BASELINE.md 3 names that thread count; at '
                          'batch 1 it oversubscribes every op: 0.03 patches/s on the 256-thread box, ~35 s)')
-    ap.add_argument('--config', type=int, default=2, choices=(0, 1, 2, 3, 4),
+    ap.add_argument('--config', type=int, default=2, choices=(0, 1, 2, 3, 4, 5),
                     help='BASELINE.json configs[i]: 0 NET-A entropy query over 1,000 patches, 1 NET-A Fisher scoring of 10,000, 2 NET-C Fisher '
                          'scoring of 100,000 per GPU (the metric\'s config, default), 3 ONE pool of 1,000,000 over the GPUs (= --pool-global '
-                         '1000000), 4 the active-learning loop, 5 rounds over 200,000 patches')
+                         '1000000), 4 the active-learning loop, 5 rounds over 200,000 patches; 5 (not a BASELINE.json config) the VOLUME-level `fi` query the '
+                         'reference times (PW_AL.py:848-855): query_multimg over synthetic padded subjects through alq_gather_normalize, '
+                         'the reference\'s own (25,25,1) x 2-modality NET-B')
     args = ap.parse_args()
     if args.config == 3 and args.pool_global == 0:
         args.pool_global = 1000000
@@ -112,8 +114,8 @@ def main():
     from nnal_amd import netspec   # network definition + seeded weight draw (product copy; not timed)
 
     sess = device.DeviceSession(local_rank)
-    if args.config in (0, 1, 4):
-        line = small_config(args, sess, rank, ws) if args.config < 4 else loop_config(args, sess, rank, ws)
+    if args.config in (0, 1, 4, 5):
+        line = small_config(args, sess, rank, ws) if args.config < 4 else (loop_config(args, sess, rank, ws) if args.config == 4 else volume_config(args, sess, rank, ws))
         if rank == 0:
             print(json.dumps(line))
         if ws > 1:
@@ -482,6 +484,118 @@ def loop_config(args, sess, rank, ws):
     return line
 
 
+def volume_config(args, sess, rank, ws):
+    """--config 5: the query the reference actually times (PW_AL.Experiment_MultiImg.run_method, PW_AL.py:848-855):
+    PW_NNAL.query_multimg(expr, model, sess, all_padded_imgs, pool_inds, labeled_inds, 'fi') (PW_NNAL.py:547-627) over padded
+    VOLUMES - uncertainty filter over every pool voxel (get_patches gather -> channel normalisation -> NET-B forward), Fisher
+    matrices of the B = 4096 most uncertain (gather with the slab statistics -> alq_fisher), SDP, k draws.  Synthetic subjects of
+    the reference's shape: patch (25, 25, 1) x 2 modalities (run_on_subjects.py:18), NET-B = NN.create_PW1 (NN.py:1328-1336).
+    value = pool voxels scored per second of the whole query; roofline = the gather kernel (HBM-bound: algorithmic bytes = the
+    float64 voxels a patch reads + the float32 patch it writes) from a separate pass with HIP events around the gather calls."""
+    import torch
+    from nnal_amd import device, netspec, patch_utils, PW_NNAL
+    S, m = 4, 2
+    dims = (192, 192, 24)
+    patch_shape = (25, 25, 1)
+    rad = (12, 12, 0)
+    rs = np.random.RandomState(1006)
+    all_padded, pool_inds, stats = [], [], []
+    for i in range(S):
+        vols = [rs.randn(*dims) * (1. + .2 * j) + .3 * i for j in range(m)]                # float64, like nrrd.read + np.pad
+        mask = (rs.rand(*dims) < .5).astype(np.int64)
+        all_padded.append([np.pad(v, [(r, r) for r in rad], 'constant') for v in vols] + [mask])
+        # grid of spacing 3 in plane, every slice (PW_AL.gen_multimg_inds, PW_AL.py:921-975): ~98k voxels per subject
+        g = np.zeros(dims, bool)
+        g[::3, ::3, :] = True
+        pool_inds.append(np.nonzero(g.ravel())[0].astype(np.int64))
+        stats.append([v for vol in vols for v in (float(vol.mean()), float(vol.std()))])
+    n_pool = int(sum(len(p) for p in pool_inds))
+
+    class Expr(object):
+        pars = {'patch_shape': patch_shape, 'ntb': 8192, 'k': 100, 'B': args.topB, 'lambda_': .01, 'SDP_solver': 'CVXOPT'}
+        nclass = 2
+        train_stats = np.asarray(stats)
+    expr = Expr()
+    ld = netspec.net_b()
+    in_shape = (25, 25, 2)
+    pars = netspec.he_init(ld, in_shape, seed=16)
+    model = device.DeviceModel(sess, ld, in_shape, (), max_batch=8192)
+    model.set_weights(pars)
+    np.random.seed(5)
+    steps = max(1, args.steps)
+
+    def step():
+        return PW_NNAL.query_multimg(expr, model, sess, all_padded, pool_inds, [[] for _ in range(S)], 'fi')
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        q = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # stage times of one more query (events / host clocks; not in `value`)
+    t1 = time.perf_counter()
+    dv = {}
+    sel_inds, sel_posts = PW_NNAL.bin_uncertainty_filter_multimg(expr, model, sess, all_padded, pool_inds, expr.pars['B'], _vols=dv)
+    torch.cuda.synchronize()
+    t_filter = time.perf_counter() - t1
+    # the gather alone: every pool voxel of every subject, chunks of 8192 as batch_eval cuts them, device events around the calls
+    ev = []
+    for i in range(S):
+        for a in range(0, len(pool_inds[i]), 8192):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            t = dv[i].gather(pool_inds[i][a:a + 8192], patch_shape, expr.train_stats[i], quirk=1)
+            e1.record()
+            ev.append((e0, e1, int(t.shape[0])))
+    torch.cuda.synchronize()
+    g_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in ev)
+    g_n = sum(c for _, _, c in ev)
+    per_patch = 25 * 25 * m * (8 + 4)            # float64 voxels read + float32 patch written
+    sess.prof_reset()
+    sess.prof_enable(1)
+    model.forward_device(t, int(t.shape[0]))
+    torch.cuda.synchronize()
+    sess.prof_enable(False)
+    prof = sess.prof_read()
+    ach = per_patch * g_n / (g_ms * 1e-3) / 1e9
+    line = {'metric': 'pool voxels/sec scored by the volume-level fi query (25x25x1 x 2 modalities, 2-class)', 'value': n_pool * steps / dt, 'unit': 'patches/s',
+            'n_gpus': 1, 'steps': steps, 'warmup': max(args.warmup, 1), 'ms_per_step': 1e3 * dt / steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64 gather + normalisation rounded once to f32; f32 network (16-bit operand splits on the MFMA, fp32 accumulate)',
+            'data': 'synthetic',
+            'config': {'workload': 'query_multimg(..., \'fi\') (PW_NNAL.py:547-627, timed by the reference at PW_AL.py:848-855) over %d synthetic subjects of %r '
+                                   'voxels x %d modalities (float64, zero-padded by the patch radii), pool = in-plane grid of spacing 3 = %d voxels, patch %r, '
+                                   'NET-B = NN.create_PW1 at [N, 25, 25, 2], B = %d, k = 100, SDP by NNAL_tools (cvxopt absent)' % (S, dims, m, n_pool, patch_shape, args.topB),
+                       'pool_global': n_pool, 'batch': model.max_batch, 'queries_per_subject': [int(len(v)) for v in q],
+                       'stage_seconds': {'uncertainty_filter_over_the_pool': t_filter, 'whole_query': dt / steps}},
+            'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_TBPS * 1e3, 'unit': 'GB/s', 'frac': ach / (PEAK_HBM_TBPS * 1e3), 'traffic': None,
+                         'kernel': 'gather_norm_kernel<double, float> (alq_gather_normalize = patch_utils.get_patches + the normalisation of PW_NN.batch_eval, '
+                                   'patch_utils.py:1087-1173, PW_NN.py:503-506)',
+                         'algorithmic_bytes_per_patch': per_patch, 'patches': g_n, 'launches': len(ev), 'avg_launch_ms': g_ms / max(len(ev), 1),
+                         'note': 'torch events around DeviceVolumes.gather (index upload + one kernel) for every chunk of the pool; the windows of neighbouring '
+                                 'grid voxels overlap, so most volume reads are L2 hits: the kernel is bound by its 5 KB of output per patch and by the '
+                                 'per-chunk index upload, not by HBM reads',
+                         'forward_pass_of_one_chunk_ms': {k: v['ms'] for k, v in prof.items() if v['ms'] > 0}}}
+    if not args.no_cpu_baseline:
+        from oracle import alpath
+        from oracle.model import OracleModel, OracleSession
+        torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
+        om = OracleModel(ld, in_shape, pars)
+        osess = OracleSession(om)
+        nb = 2048
+        st0 = [[expr.train_stats[0, 2 * j], expr.train_stats[0, 2 * j + 1]] for j in range(m)]
+        alpath.batch_eval(om, osess, all_padded[0][:-1], pool_inds[0][:64], patch_shape, 64, st0, 'posteriors')
+        t0 = time.perf_counter()
+        alpath.batch_eval(om, osess, all_padded[0][:-1], pool_inds[0][:nb], patch_shape, 256, st0, 'posteriors')
+        dtc = time.perf_counter() - t0
+        line['cpu_baseline'] = {'value': nb / dtc, 'unit': 'patches/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                                'sample': 'the oracle\'s batch_eval (Python gather loop of get_patches + normalisation + batched forward, the filter '
+                                          'stage that dominates the query) over %d pool voxels of subject 0, %.1f s' % (nb, dtc)}
+    model.close()
+    return line
+
+
 NETB_BATCH = 2048      # same-box sweep over 8192 patches: 186 k patches/s at 256, 278 k at 512, 330 k at 1024, 350 k at 2048
 
 
@@ -533,13 +647,17 @@ def netb_rate(sess, n, x):
                          'time_share_ms': {k: v['ms'] for k, v in prof.items()}}}
 
 
-def accuracy_vs_exact_fp32(sess, model, x, n):
-    """One batch of the pool (outside the timed region): the shipped engines against the exact-fp32 MFMA engine on the device
+def accuracy_vs_exact_fp32(sess, model, x, n, n64=512):
+    """Outside the timed region.  (1) One batch of the pool: the shipped engines against the exact-fp32 MFMA engine on the device
     (alq_debug_set(4, 1): fp32 fma chains, no operand split).  north_star's bar is 'scores within 1e-4': the scores are not
     continuous in the rounding noise (a ReLU input within rounding of zero switches a backward path), so what can be stated is how
-    MANY patches differ by more than that between two fp32-level engines; tests/test_gpu_parity.py sends every such patch of a
-    2000-patch batch to the fp64 arbiter."""
+    MANY patches differ by more than that between two fp32-level engines.  (2) `vs_fp64`: BOTH engines against the fp64 evaluation
+    on the device (csrc/ref64.hip) on the first n64 patches: patches beyond 2e-6 / 1e-4, the largest difference, and how many
+    fragile decisions (|pre-activation| <= eps x the layer's rms, pool near-ties) the fp64 evaluation has to invert to reproduce
+    each engine's scores (0 / 1 / 2 / 3 / unexplained) - the evidence that the 16-bit splits are no further from the exact
+    arithmetic than an fp32 engine is (tests/test_gpu_ref64.py asserts shipped <= 1.25 x exact-fp32 + 4)."""
     import torch
+    from nnal_amd import ref64
     from nnal_amd._lib import check
     keys = ('p1', 'g0', 'g1')
     r = model.fisher_device(x, n, None, 1e-3, want=keys)
@@ -552,10 +670,25 @@ def accuracy_vs_exact_fp32(sess, model, x, n):
         check(sess.lib.alq_debug_set(4, 0))
     torch.cuda.synchronize()
     d = np.maximum(np.abs(a['g0'] - b['g0']), np.abs(a['g1'] - b['g1'])).max(axis=1)
-    return {'patches': int(n), 'over_2e-6': int((d > 2e-6).sum()), 'over_1e-4': int((d > 1e-4).sum()), 'max_abs_dg': float(d.max()),
-            'max_abs_dp': float(np.abs(a['p1'] - b['p1']).max()),
-            'against': 'the exact-fp32 MFMA engine on the device (alq_debug_set(4, 1)), first batch of the pool; differences beyond 2e-6 are '
-                       'ReLU / max-pool decisions that fp32 rounding puts on either side (each engine has its own set against fp64)'}
+    out = {'patches': int(n), 'over_2e-6': int((d > 2e-6).sum()), 'over_1e-4': int((d > 1e-4).sum()), 'max_abs_dg': float(d.max()),
+           'max_abs_dp': float(np.abs(a['p1'] - b['p1']).max()),
+           'against': 'the exact-fp32 MFMA engine on the device (alq_debug_set(4, 1)), first batch of the pool; differences beyond 2e-6 are '
+                      'ReLU / max-pool decisions that fp32 rounding puts on either side (each engine has its own set against fp64: vs_fp64)'}
+    n64 = min(n64, n)
+    if n64 > 0:
+        t0 = time.perf_counter()
+        r64 = ref64.Ref64(model, max_samples=128)
+        rep, base, _ = r64.engine_report(x, np.arange(n64), {'shipped': (a['g0'][:n64], a['g1'][:n64]), 'exact_fp32': (b['g0'][:n64], b['g1'][:n64])},
+                                         eps=ref64.DEFAULT_EPS)
+        for k in ('shipped', 'exact_fp32'):
+            rep[k]['max_abs_dp'] = float(np.abs((a if k == 'shipped' else b)['p1'][:n64] - base['p1']).max())
+        out['vs_fp64'] = {'patches': int(n64), 'shipped': rep['shipped'], 'exact_fp32': rep['exact_fp32'], 'fragility': rep['_fragility'],
+                          'seconds': time.perf_counter() - t0,
+                          'how': 'fp64 forward + unit-cotangent backward + factored layer sums on the device (alq_ref64_scores); a patch whose '
+                                 'scores are not within 2e-6 + 2e-5 relative of the plain fp64 value is re-evaluated with every set of <= 3 of '
+                                 'its 10 most fragile decisions inverted (fragile: within eps x rms of the decision boundary); flips_needed = '
+                                 'the fewest that reproduce the engine\'s scores'}
+    return out
 
 
 def cpu_baseline(xs, ld, sk, in_shape, pars, all_cores_too=False):

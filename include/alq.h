@@ -237,6 +237,36 @@ int alq_colsum_max(alq_ctx *ctx, const double *d_S, int64_t n, int b, const doub
 int alq_take_colmax(alq_ctx *ctx, const double *d_S, int64_t n, int b, int j, int first, double *d_v);
 int alq_fold_rowmax(alq_ctx *ctx, const double *d_S, int t, int64_t n, double *d_v);
 
+/* ---- fp64 accuracy reference on the device (csrc/ref64.hip; bench.py `accuracy`, tests) ------------------------------- */
+/* One inverted decision of an fp64 evaluation.  layer = model layer index of a ReLU'd conv / conv_transpose / fc layer: the
+ * ReLU decision of element `idx` of that layer's pre-activation of ONE sample ([vox, C] flattened; fc: the unit) is
+ * inverted (passes although <= 0, cut although > 0); layer = index of a max-pool layer: element `idx` of the pool's INPUT is
+ * lifted by `delta` before the window maximum is taken (a near-tie decided the other way).  layer < 0: unused slot.
+ * In candidate lists `pad` is 0 for a ReLU unit, 1 for a pool window.                                                   */
+typedef struct {
+    int32_t layer;
+    int32_t pad;
+    int64_t idx;
+    double delta;
+} alq_flip_t;
+/* fp64 evaluation of the scored path for N samples (rows d_rows of the fp32 pool d_x, or its first N rows when d_rows is
+ * NULL): the reference's graph (conv / conv_transpose / max-pool / fc, 'con' skips; NN.py:258-340, NN_extended.py:366-601)
+ * in double precision, one backward pass with the unit cotangent (+1, -1) on the two logits, and the per-layer sums
+ * S[n][t] = sum of all entries of d(z0 - z1)/d(theta_t) - what NNAL_tools.shrink_gradient(., 'sum') (NNAL_tools.py:784-796)
+ * divides by the layer's size.  h_dW / h_db: host arrays of DEVICE pointers to the fp64 weights / biases of the parameterised
+ * layers, TF layouts as alq_model_set_weights EXCEPT fc: [out][in] with `in` in ACTIVATION-MEMORY order ([D, H, W, C]
+ * flattened) of the layer's input.  d_flips: [N][flips_per_sample] decisions to invert per sample, or NULL.
+ * cand_cap > 0: d_cand / d_cand_key / d_cand_count [N][cand_cap] / [N] receive every FRAGILE decision of a sample - a ReLU
+ * input with |pre-activation| <= eps * (rms pre-activation of that layer and sample), key = that ratio; a pool window whose two
+ * largest inputs lie within eps * (rms of the pool's input) of each other with a positive maximum, key = gap / rms, idx = the
+ * runner-up, delta = the lift that makes it win - in no particular order; d_cand_count may exceed cand_cap (list truncated).
+ * d_logits [N][2], d_S [N][L], d_rms [n_layers][N] (rms pre-activation / pool input per layer and sample; may be NULL).
+ * Allocates its workspace per call and synchronises the stream: an accuracy tool, never on the scoring path.             */
+int alq_ref64_scores(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, const int32_t in_dims[4],
+                     const double *const *h_dW, const double *const *h_db, const float *d_x, const int64_t *d_rows, int N,
+                     const alq_flip_t *d_flips, int flips_per_sample, double eps, int cand_cap,
+                     double *d_logits, double *d_S, double *d_rms, alq_flip_t *d_cand, double *d_cand_key, int32_t *d_cand_count);
+
 /* ---- measurement hooks (bench.py only) -------------------------------------------------- */
 /* Per-kernel-class HIP-event timing on the context's stream.  alq_prof_enable(ctx, 1) makes
  * every launch of an instrumented kernel class record start/stop events; on = k > 1 samples the

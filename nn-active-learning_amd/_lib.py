@@ -74,6 +74,7 @@ _SIGNATURES = {
     'alq_debug_set_stamp_buffer': (C.c_int, [_P]),
     'alq_debug_set': (C.c_int, [C.c_int, C.c_int]),
     'alq_model_engine_info': (C.c_int, [_P, C.c_int]),
+    'alq_ref64_scores': (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, C.c_int, _P, C.c_int, C.c_double, C.c_int, _P, _P, _P, _P, _P, _P]),
     'alq_synth_patches': (C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, _P]),
 }
 

@@ -10,7 +10,7 @@ BUILD="$HERE/build${ALQ_BUILD_TAG:-}"
 mkdir -p "$BUILD"
 HAZARD_FILES="c3d d3d f3d t3d t3d8b e3d"
 pids=()
-for f in igemm igemm2 igemm3 igemm4 c3d t3d t3d8b e3d d3d f3d fcgemm direct kernels topk model comm train sim; do
+for f in igemm igemm2 igemm3 igemm4 c3d t3d t3d8b e3d d3d f3d fcgemm direct kernels topk model comm train sim ref64; do
   # igemm4: no SLP vectorisation (a performance choice) - it turns neighbouring scalar f32 multiplies / adds of the staging and epilogue code into
   # v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, which issue slower than the scalar pairs next to another wave's MFMAs on
   # the same SIMD (same-box A/B: 155.4 k -> 156.6 k patches/s); conversions still pack (v_cvt_pk_f16_f32 / _bf16_f32)
@@ -51,5 +51,5 @@ for f in $HAZARD_FILES; do
 done
 python3 "$ROOT/tools/isa_store_hazard.py" --min 2 "${HZ[@]}" > "$BUILD/store_hazard_report.txt" || { cat "$BUILD/store_hazard_report.txt" >&2; echo "build.sh: store-hazard gate failed" >&2; exit 1; }
 for f in $HAZARD_FILES; do rm -f "$BUILD"/$f-hip-*.bc "$BUILD"/$f-hip-*.hipi "$BUILD"/$f-hip-*.s "$BUILD"/$f-hip-*.o "$BUILD"/$f-hip-*.out "$BUILD"/$f-hip-*.hipfb "$BUILD"/$f-host-*.bc "$BUILD"/$f-host-*.hipi "$BUILD"/$f-host-*.s; done
-hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT" "$BUILD"/{igemm,igemm2,igemm3,igemm4,c3d,t3d,t3d8b,e3d,d3d,f3d,fcgemm,direct,kernels,topk,model,comm,train,sim}.o -ldl
+hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT" "$BUILD"/{igemm,igemm2,igemm3,igemm4,c3d,t3d,t3d8b,e3d,d3d,f3d,fcgemm,direct,kernels,topk,model,comm,train,sim,ref64}.o -ldl
 echo "built $OUT"

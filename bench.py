@@ -512,7 +512,7 @@ def volume_config(args, sess, rank, ws):
     n_pool = int(sum(len(p) for p in pool_inds))
 
     class Expr(object):
-        pars = {'patch_shape': patch_shape, 'ntb': 8192, 'k': 100, 'B': args.topB, 'lambda_': .01, 'SDP_solver': 'CVXOPT'}
+        pars = {'patch_shape': patch_shape, 'ntb': 8192, 'k': 100, 'B': args.topB, 'lambda_': 0., 'SDP_solver': 'CVXOPT'}
         nclass = 2
         train_stats = np.asarray(stats)
     expr = Expr()

@@ -182,7 +182,7 @@ def fisher_from_unit(p1, S, sizes, diag_load):
     return g0, g1, A
 
 
-def relu_flip_explains(model64, x1, targets, diag_load, atol=2e-6, rtol=2e-5, eps=2e-5, max_units=10, max_flips=3):
+def relu_flip_explains(model64, x1, targets, diag_load, atol=2e-6, rtol=2e-5, eps=4e-6, max_units=10, max_flips=3):
     """fp64 arbiter for a disagreement between fp32-level implementations on ONE patch.
 
     `targets`: list of (g0 [L], g1 [L]) score vectors of that patch (e.g. two device engines).  Each must lie within
@@ -191,7 +191,8 @@ def relu_flip_explains(model64, x1, targets, diag_load, atol=2e-6, rtol=2e-5, ep
     rms pre-activation, i.e. one that fp32 rounding can legitimately put on either side of zero - or (round 4) a max-pool window
     (window = stride, even extents) whose two largest inputs lie within eps x the layer's rms of each other with a positive
     maximum: which of them is the arg-max decides where the window's whole cotangent goes.  At most `max_units` most fragile
-    units are considered, at most `max_flips` of them inverted together.
+    units are considered, at most `max_flips` of them inverted together.  eps = 4e-6 = 5.4 x the largest key the device arbiter
+    (nnal_amd/ref64.py, same rule) measured over the decisions that explain the engines' disagreements on the bench patches.
     Returns a list, per target, of the tuple of inverted units ((layer name, flat index), ...; a pool window as
     ('pool:<name>', flat index of the lifted input)) - () = the plain fp64 value - or None when no such evaluation matches (the
     disagreement is NOT such a flip)."""

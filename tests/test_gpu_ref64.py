@@ -145,7 +145,7 @@ def test_shipped_engines_are_no_further_from_fp64_than_the_exact_fp32_engine(ses
         assert a[k] <= 1.25 * b[k] + 4, (k, a, b)
     assert a['flips_needed']['unexplained'] == 0 and b['flips_needed']['unexplained'] == 0, rep
     assert rep['_fragility']['candidate_lists_truncated'] == 0
-    assert rep['_fragility']['max_key'] <= ref64.DEFAULT_EPS
+    assert rep['_fragility']['max_key'] <= ref64.DEFAULT_EPS / 2, rep['_fragility']      # the window is not the binding constraint
     # the negative control: scores scaled by 1 + 1e-3 are NOT explained by any inversion
     bad = {'scaled': (eng['shipped'][0][:16] * 1.001, eng['shipped'][1][:16] * 1.001)}
     rep2, _, _ = r64.engine_report(x, np.arange(16), bad, eps=ref64.DEFAULT_EPS)

@@ -300,9 +300,10 @@ def main():
                                      'conv_transpose_forward_row_sweep_launches': int(info(model._m, 7)),
                                      'conv_transpose_backward_row_sweep_launches': int(info(model._m, 8)),
                                      'enc2_backward_fused_with_pool_backwards': int(info(model._m, 9)),
+                                     'head_conv_backward_k_steps': {7: 7, 8: 9, 4: 9}.get(int(info(model._m, 13)), 0),
                                      'scoring_pipelines': lanes_timed}
         if ws == 1:
-            line['accuracy'] = accuracy_vs_exact_fp32(sess, model, x, min(args.batch, n_local))
+            line['accuracy'] = accuracy_vs_exact_fp32(sess, model, x, min(args.batch, n_local), n64=min(args.batch, n_local))
         if ws == 1 and args.netb_pool > 0:
             line['netb'] = netb_rate(sess, args.netb_pool, x)
         if not args.no_cpu_baseline and ws == 1:      # reported at N = 1 only (the other ranks would sit in the barrier)
@@ -583,7 +584,7 @@ def volume_config(args, sess, rank, ws):
         torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
         om = OracleModel(ld, in_shape, pars)
         osess = OracleSession(om)
-        nb = 2048
+        nb = int(len(pool_inds[0]))          # ~12 s of the CPU port
         st0 = [[expr.train_stats[0, 2 * j], expr.train_stats[0, 2 * j + 1]] for j in range(m)]
         alpath.batch_eval(om, osess, all_padded[0][:-1], pool_inds[0][:64], patch_shape, 64, st0, 'posteriors')
         t0 = time.perf_counter()

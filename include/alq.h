@@ -301,14 +301,15 @@ int alq_debug_set(int key, int value);
  * keep fp16 subnormal operands (probed once; the one-accumulator form of the plane-sweep engine needs it), 1: 1 when the last
  * forward pass ran the conv under the two-class head on the plane-sweep engine (csrc/c3d.hip; replaces the tf.nn.conv3d call
  * site NN_extended.py:416-426 for that layer), 2: the same for the last backward pass, 3: 1 when that engine accumulates the
- * three piece products in one accumulator, 5: the number of marked 4-channel groups the flip-safe head could NOT re-evaluate
- * exactly since the model was created because a list segment (a quarter of a patch, 128 slots) was full - 0 on every input the
- * tests and the bench use; a dropped group keeps the sign its fp16-pair contraction produced (synchronises the stream).
+ * three piece products in one accumulator, 5: the number of marked 4-channel groups that did not fit their list segment (a quarter of a patch,
+ * 128 slots) since the model was created - 0 on every input the tests and the bench use; none is dropped: an overflowing
+ * segment is drained by the sweep path of the fix-up kernel (synchronises the stream).
  * 6: 1 when the last forward pass ran a launch on the fp16-pair split with derived input bounds (default; ALQ_NO_F16_DERIVED=1 off).
  * 7 / 8: conv_transpose launches of the last forward / backward pass on the row-sweep engine (csrc/t3d.hip), 9: 1 when the last
  * backward pass ran enc2's backward fused with both pool backward steps (csrc/e3d.hip), 10: 1 when the last forward pass ran
  * dec1 on the plane-sweep kernel of csrc/d3d.hip, 11: the same for its backward-data launch, 12: 1 when the last forward pass
- * ran enc2 and the max-pool behind it as one launch (csrc/f3d.hip).
+ * ran enc2 and the max-pool behind it as one launch (csrc/f3d.hip), 13: which form of the head conv's backward kernel the last backward
+ * pass ran (csrc/c3d.hip): 7 = the 27 taps packed into 7 k-steps (default), 8 / 4 = the 9-k-step kernel (ALQ_C3D_BWD_ROWS), 0 = none.
  * Returns the answer or a negative error code.  */
 int alq_model_engine_info(alq_model *m, int what);
 

@@ -415,7 +415,10 @@ struct C3dPlan {
     double flops_per_patch = 0;
     std::vector<unsigned short> h_W;      // [k-step][piece][lane][8] fp16 bits
     void *d_W = nullptr;
+    std::vector<unsigned short> h_W7;     // backward, 7-k-step form: [A0 A1 A2 B0 B1 B2 S][piece][lane][8] (c3d_bwd7_pack)
+    void *d_W7 = nullptr;
 };
+void c3d_bwd7_pack(C3dPlan *plan, const std::vector<float> &Bmat);      // after c3d_bwd_pack (same scale exponent)
 int c3d_subnormals_ok(alq_ctx *ctx);      // 1: the matrix cores keep fp16 subnormal operands (needed by the one-accumulator form)
 int c3d_fwd_build(const View &in, const View &out, const int k[3], const int lo[3], const int s[3], C3dPlan *plan);
 void c3d_fwd_pack(C3dPlan *plan, const std::vector<float> &Bmat /* [(tap, ci)][co] */);

@@ -81,6 +81,13 @@ static_assert(C3_WD >= 1 && C3_WD <= 8, "weight-difference slices are fetched 1.
 #ifndef C3_BPIPE
 #define C3_BPIPE 2
 #endif
+// the 7-k-step backward kernel: non-MFMA instructions behind each MFMA of the sweep's pattern, weights pinned to accumulation registers
+#ifndef C3_B7PIPE
+#define C3_B7PIPE 2
+#endif
+#ifndef C3_B7PINW
+#define C3_B7PINW 0
+#endif
 
 // LDS image of one input plane (bytes).  Slot = 8 fp16 channels of one tensor at one voxel, one piece (h or l).
 constexpr int C3_TEN = 34 * 16;          // slots x = -1 .. 32 of one (row, piece, tensor); the two outer ones stay zero
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // epilogue constants of a finished plane (patch ordinal pe, plane zo); !valid: inv = 0, zero bias and lane offsets past the
     // arrays turn the epilogue of a step without a finished plane into a no-op
     // tau_u: the marking threshold as an integer key, (bits(tau) - 1) >> 1, 0 when nothing is to be marked (epi_row)
-    struct Epi { float inv; f32x4 b4; float tau; unsigned tau_u; unsigned off_w, off_b, row_f, bits_s; };
+    struct Epi { float inv; f32x4 b4; float tau; unsigned tau_u; unsigned zadj; unsigned off_w, off_b, row_f, bits_s; };
     auto epi_setup = [&](bool valid, int pe, int zo) __attribute__((always_inline)) {
         Epi e;
         const int p = valid ? (int)patch_of(pe) : 0;
@@ -255,6 +262,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // (an all-zero patch: every pre-activation IS its bias in both arithmetics - nothing to mark)
         e.tau = (valid && (amaxA_c[p] | amaxB_c[p]) != 0u) ? __builtin_ldexpf(a.flip_tau, 14 - ce) : 0.f;
         e.tau_u = e.tau > 0.f ? (__builtin_bit_cast(unsigned, e.tau) - 1u) >> 1 : 0u;
+        // a pre-activation that is EXACTLY +0 needs no second look only when this lane's four biases are zero (then it is an
+        // all-zero window, +0 in the exact evaluation too); under a non-zero bias +0 can be acc * inv == -bias, or inputs flushed by
+        // the fp16 split, with a tiny positive exact value: those are marked (key 0 instead of 0x7fffffff)
+        e.zadj = (bias4.x == 0.f && bias4.y == 0.f && bias4.z == 0.f && bias4.w == 0.f) ? 1u : 0u;
         e.off_w = valid ? epi_lane_f * 4u : OOB;
         e.off_b = valid ? (epi_lane_f >> 2) : OOB;
         e.row_f = (unsigned)(zo * 32 + wave * 8) * 256u;       // float offset of row 8 w of that plane inside the patch
@@ -299,11 +310,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float mn = fminf(fminf(__builtin_fabsf(val.x), __builtin_fabsf(val.y)), fminf(__builtin_fabsf(val.z), __builtin_fabsf(val.w)));
 #if C3_EPI2
             // mn, tau >= 0: their bit patterns order like the numbers, and the sign of the difference is the answer (no compare, no
-            // VCC round trip with its wait states).  A pre-activation that is EXACTLY +0 is not marked: under this arithmetic that
-            // is an all-zero window under a zero bias (the reference's initial weights on a zero-padded volume), +0 in the exact
-            // evaluation too - marking those filled the list segments of padded patches with groups that need no second look.
-            // The key (bits - 1) >> 1 sends +0 to 0x7fffffff (above every threshold) and keeps the order of everything else.
-            unsure = (((__builtin_bit_cast(unsigned, mn) - 1u) >> 1) - E.tau_u) >> 31;
+            // VCC round trip with its wait states).  A pre-activation that is EXACTLY +0 under ZERO biases is not marked: that is an
+            // all-zero window (the reference's initial weights on a zero-padded volume), +0 in the exact evaluation too - marking
+            // those filled the list segments of padded patches with groups that need no second look.  The key (bits - zadj) >> 1
+            // sends +0 to 0x7fffffff (above every threshold) when zadj = 1 (zero biases) and to 0 (marked) otherwise, and keeps
+            // the order of everything else.
+            unsure = (((__builtin_bit_cast(unsigned, mn) - E.zadj) >> 1) - E.tau_u) >> 31;
 #else
             unsure = (mn < E.tau && mn > 0.f) ? 16u : 0u;
 #endif
@@ -917,6 +929,345 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (np > 0) light(IC<1>{}, np - 1, D - 1);
 }
 
+// ======================================================================================================================
+// The same backward launch with the 27 taps PACKED INTO 7 K-STEPS instead of 9 (round 6).  The kernel above spends one k-step per
+// (dz, dy) on the three x offsets and a ZERO fourth k-group: a quarter of its MFMAs multiply zeros.  Here a k-group is a TAP
+// addressed per lane, and the nine in-plane taps of an output voxel, taken in row-major order p = 3 dy + dx, are cut into
+//   A = p 0..3: row y - 1 at x - 1, x, x + 1 and row y at x - 1        (one k-step)
+//   B = p 4..7: row y at x, x + 1 and row y + 1 at x - 1, x            (one k-step)
+//   p = 8:      row y + 1 at x + 1 - the leftover tap of each of the three planes: ONE k-step S whose k-groups are the PLANES
+//               zo - 1, zo, zo + 1 of the output plane zo.
+// A and B stay input-stationary in z exactly like the kernel above (a fragment of input plane z feeds the three rotating
+// accumulator sets of the output planes z + 1, z, z - 1): 2 fragments x 3 planes x 3 products = 18 MFMAs per half row and step;
+// S is output-stationary: at step z it completes output plane z - 1 from the images of planes z - 2, z - 1, z, which a RING OF FOUR
+// plane images keeps resident (three + the one being staged): 3 MFMAs.  21 MFMAs per half row and step instead of 27, six
+// 16-byte fragment reads per 21 MFMAs.  LDS image: piece-major (h rows, then l rows) so that the row pitch is 34 slots = 2 mod 16 -
+// the two k-groups of a 16-lane read group that straddle a row (A: (y - 1, x + 1) | (y, x - 1)) land on disjoint banks - and a
+// plane pitch of 0 mod 16 slots for the S fragment's lanes.  The z halo has no image: the S weights of the k-group whose plane
+// does not exist (plane -1 at z = 1, plane D in the light step) are zeroed for that step.
+namespace {
+constexpr int P7_ROW = 34 * 16;               // one piece of one image row: slots x = -1 .. 32
+constexpr int P7_PIECE = 34 * P7_ROW;         // rows y = -1 .. 32
+constexpr int P7_PLANE = 2 * P7_PIECE + 128;  // h image | l image | pad: 2320 slots
+constexpr int P7_LDS = 4 * P7_PLANE;          // 148,480 of the 163,840 bytes
+static_assert((P7_ROW / 16) % 16 == 2 && (P7_PLANE / 16) % 16 == 0 && P7_LDS <= 160 * 1024, "bank-conflict-free pitches (see above)");
+}  // namespace
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void c3d_bwd7_kernel(const C3BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int RW = 8, NU = 4;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    const int D = a.D;
+    const unsigned plane_v = 32u * 32u;
+    const unsigned patch_v = (unsigned)D * plane_v;
+
+    for (int i = tid * 16; i < P7_LDS; i += 256 * 16) *reinterpret_cast<i32x4 *>(lds + i) = i32x4{0, 0, 0, 0};
+
+    // weights: [A0 A1 A2 B0 B1 B2 S] x [h, l] x [64 lanes] x [8] fp16 (c3d_bwd7_pack)
+    f16x8 Wa[3][2], Wb[3][2], Ws[2];
+    {
+        const i32x4 *Wg = reinterpret_cast<const i32x4 *>(a.W);
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {
+                Wa[dz][pc] = __builtin_bit_cast(f16x8, Wg[((0 + dz) * 2 + pc) * 64 + lane]);
+                Wb[dz][pc] = __builtin_bit_cast(f16x8, Wg[((3 + dz) * 2 + pc) * 64 + lane]);
+            }
+        Ws[0] = __builtin_bit_cast(f16x8, Wg[(6 * 2 + 0) * 64 + lane]);
+        Ws[1] = __builtin_bit_cast(f16x8, Wg[(6 * 2 + 1) * 64 + lane]);
+#if C3_B7PINW
+        // 192 accumulators + the 48 registers of A and B fit the accumulation half (240 of 256): started there, they leave the
+        // architectural half to the fragments, the staging and the epilogue (the S weights are masked per step: they stay vector)
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {
+                i32x4 x = __builtin_bit_cast(i32x4, Wa[dz][pc]), y = __builtin_bit_cast(i32x4, Wb[dz][pc]);
+                asm volatile("" : "+a"(x), "+a"(y));
+                Wa[dz][pc] = __builtin_bit_cast(f16x8, x); Wb[dz][pc] = __builtin_bit_cast(f16x8, y);
+            }
+#endif
+    }
+    // fragment reads, lane (column j = voxel 16 hx + j, k-group q): byte offsets inside a plane image, + i rows, + hx * 256
+    const int offA = wave * RW * P7_ROW + (lq < 3 ? (lj + lq) * 16 : P7_ROW + lj * 16);
+    const int offB = (wave * RW + 1) * P7_ROW + (lq < 2 ? (lj + 1 + lq) * 16 : P7_ROW + (lj + lq - 2) * 16);
+    const int offS = (wave * RW + 2) * P7_ROW + (lj + 2) * 16;
+    const int ringS = lq < 2 ? lq + 2 : 0;       // ring slot of the lane's plane relative to the current one: z - 2, z - 1, z, (z)
+    // staging: a unit = two rows of the wave's strip, lane = (row lane >> 5, x = lane & 31); image row = y + 1
+    const int st_lane = (wave * RW + 1 + (lane >> 5)) * P7_ROW + ((lane & 31) + 1) * 16;
+    const float inv = __builtin_ldexpf(1.f, -(a.e_in + a.e_w));
+
+    const int G = gridDim.x, b0 = blockIdx.x;
+    const int np = b0 < a.N ? (a.N - b0 + G - 1) / G : 0;
+
+    f32x4 acc[3][RW][2];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int i = 0; i < RW; ++i) { acc[s][i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[s][i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    auto rsrc_of = [&](const void *base, unsigned long long bytes) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)(unsigned)bytes, 0x00020000);
+    };
+    const unsigned OOB = 0xffffff00u;
+    const __amdgpu_buffer_rsrc_t vec_rsrc = rsrc_of(a.vec, (unsigned long long)patch_v * 32u);
+    const __amdgpu_buffer_rsrc_t bits_rsrc = rsrc_of(a.bits, (unsigned long long)a.N * patch_v * 2u);
+    const __amdgpu_buffer_rsrc_t mask_rsrc = rsrc_of(a.maskA, a.maskA ? (unsigned long long)a.N * patch_v * 2u : 0ull);
+    const __amdgpu_buffer_rsrc_t dB_rsrc = rsrc_of(a.dB, (unsigned long long)a.N * patch_v * 32u);
+    const __amdgpu_buffer_rsrc_t sA_rsrc = rsrc_of(a.sumA, (unsigned long long)a.N * patch_v * 4u);
+    const __amdgpu_buffer_rsrc_t sB_rsrc = rsrc_of(a.sumB, (unsigned long long)a.N * patch_v * 4u);
+    auto item_patch = [&](int pi) __attribute__((always_inline)) { return (unsigned)(b0 + pi * G); };
+
+    // ---- staging of a plane: units u = 0 .. 3 (rows 8 w + 2 u, + 1): as in the kernel above ------------------------------------
+    i32x4 Vh[2], Vl[2];
+    unsigned Sb[2];
+    struct Src { unsigned voff, vvox, soff; };
+    auto src_of = [&](int pi) __attribute__((always_inline)) {
+        Src c;
+        const bool ok = pi < np;
+        const int y = wave * RW + (lane >> 5);
+        c.vvox = (unsigned)(y * 32 + (lane & 31));
+        c.voff = ok ? c.vvox * 2u : OOB;
+        c.soff = ok ? item_patch(pi) * patch_v * 2u : 0u;
+        return c;
+    };
+    auto mask8 = [&](int b, i32x4 h, i32x4 l, i32x4 *oh, i32x4 *ol) __attribute__((always_inline)) {
+        const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe(b, 0, 1), m1 = (unsigned)__builtin_amdgcn_sbfe(b, 1, 1);
+        const unsigned m2 = (unsigned)__builtin_amdgcn_sbfe(b, 2, 1), m3 = (unsigned)__builtin_amdgcn_sbfe(b, 3, 1);
+        const unsigned m4 = (unsigned)__builtin_amdgcn_sbfe(b, 8, 1), m5 = (unsigned)__builtin_amdgcn_sbfe(b, 9, 1);
+        const unsigned m6 = (unsigned)__builtin_amdgcn_sbfe(b, 10, 1), m7 = (unsigned)__builtin_amdgcn_sbfe(b, 11, 1);
+        const unsigned k0 = (m0 & 0xffffu) | (m1 & 0xffff0000u), k1 = (m2 & 0xffffu) | (m3 & 0xffff0000u);
+        const unsigned k2 = (m4 & 0xffffu) | (m5 & 0xffff0000u), k3 = (m6 & 0xffffu) | (m7 & 0xffff0000u);
+        *oh = i32x4{(int)((unsigned)h.x & k0), (int)((unsigned)h.y & k1), (int)((unsigned)h.z & k2), (int)((unsigned)h.w & k3)};
+        *ol = i32x4{(int)((unsigned)l.x & k0), (int)((unsigned)l.y & k1), (int)((unsigned)l.z & k2), (int)((unsigned)l.w & k3)};
+    };
+    auto load_unit = [&](const Src &c, unsigned z, auto U) __attribute__((always_inline)) {
+        constexpr int u = decltype(U)::value;
+        const unsigned so = (z * plane_v + (unsigned)u * 64u);
+        Vh[u & 1] = __builtin_amdgcn_raw_buffer_load_b128(vec_rsrc, (int)(c.vvox * 32u), (int)(so * 32u), 0);
+        Vl[u & 1] = __builtin_amdgcn_raw_buffer_load_b128(vec_rsrc, (int)(c.vvox * 32u + 16u), (int)(so * 32u), 0);
+        Sb[u & 1] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(bits_rsrc, (int)c.voff, (int)(c.soff + so * 2u), 0);
+    };
+    auto stage_unit = [&](int wbase, auto U) __attribute__((always_inline)) {
+        constexpr int u = decltype(U)::value;
+        i32x4 oh, ol;
+        mask8((int)Sb[u & 1], Vh[u & 1], Vl[u & 1], &oh, &ol);
+        char *dst = lds + wbase + (2 * u) * P7_ROW;
+        *reinterpret_cast<i32x4 *>(dst) = oh;
+        *reinterpret_cast<i32x4 *>(dst + P7_PIECE) = ol;
+    };
+
+    int c1_pi = 0, c1_z = 0, c2_pi = 0, c2_z = 0;
+    auto advance = [&](int &pi, int &z) __attribute__((always_inline)) { if (++z == D) { z = 0; ++pi; } };
+
+    // ---- epilogue of one finished x row: as in the kernel above ---------------------------------------------------------------
+    unsigned mkq[2][2] = {{0u, 0u}, {0u, 0u}};
+    struct Epi { unsigned pv; unsigned row_v; float inv; unsigned off_mask, off_dB, off_sum; };
+    auto epi_setup = [&](bool valid, int pe, int zo) __attribute__((always_inline)) {
+        Epi e;
+        e.pv = valid ? item_patch(pe) * patch_v : 0u;
+        e.row_v = (unsigned)(zo * 32 + wave * RW) * 32u;
+        e.inv = valid ? inv : 0.f;
+        e.off_mask = (valid && lq < 2) ? (unsigned)(lj * 2 + lq) : OOB;
+        e.off_dB = (valid && lq >= 2) ? (unsigned)lj * 32u + (unsigned)(lq - 2) * 16u : OOB;
+        e.off_sum = valid ? (unsigned)((lq & 1) * 16 + lj) * 4u : OOB;
+        return e;
+    };
+    auto mask_load = [&](const Epi &E, auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx)
+            mkq[i & 1][hx] = (unsigned char)__builtin_amdgcn_raw_buffer_load_b8(mask_rsrc, (int)E.off_mask,
+                                                                               (int)((E.pv + E.row_v + (unsigned)i * 32u + (unsigned)hx * 16u) * 2u), 0);
+    };
+    const bool has_mask = a.maskA != nullptr;
+    float t_keep = 0.f;
+    auto epi_half = [&](auto S, auto I, auto HX, const Epi &E) __attribute__((always_inline)) {
+        constexpr int s = decltype(S)::value, i = decltype(I)::value, hx = decltype(HX)::value;
+        const unsigned mk = mkq[i & 1][hx];
+        if constexpr (hx == 1 && i + 2 < RW) mask_load(E, IC<i + 2>{});
+        const f32x4 c = acc[s][i][hx];
+        const int nib = (lq < 2 && has_mask) ? (int)mk : 15;
+        const float v0 = c.x * E.inv, v1 = c.y * E.inv, v2 = c.z * E.inv, v3 = c.w * E.inv;
+        f32x4 val;
+        unsigned k0 = (unsigned)__builtin_amdgcn_sbfe(nib, 0, 1), k1 = (unsigned)__builtin_amdgcn_sbfe(nib, 1, 1);
+        unsigned k2 = (unsigned)__builtin_amdgcn_sbfe(nib, 2, 1), k3 = (unsigned)__builtin_amdgcn_sbfe(nib, 3, 1);
+        asm("" : "+v"(k0), "+v"(k1), "+v"(k2), "+v"(k3));
+        val.x = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v0) & k0);
+        val.y = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v1) & k1);
+        val.z = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v2) & k2);
+        val.w = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v3) & k3);
+        const unsigned vox = E.pv + E.row_v + (unsigned)i * 32u + (unsigned)hx * 16u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, val), dB_rsrc, (int)E.off_dB, (int)(vox * 32u), 2 /* nt */);
+        ALQ_STORE_HOLD("v"(val));      // (16-byte store with a register soffset: alq_internal.h)
+        const float t = (val.x + val.y) + (val.z + val.w);
+        const unsigned tu = __builtin_bit_cast(unsigned, t);
+        const auto sw = hx == 0 ? __builtin_amdgcn_permlane16_swap(tu, 0u, false, false) : __builtin_amdgcn_permlane16_swap(0u, tu, false, false);
+        const unsigned s0 = sw[0], s1 = sw[1];
+        const float t2 = __builtin_bit_cast(float, s0) + __builtin_bit_cast(float, s1);
+        if constexpr (hx == 0) {
+            t_keep = t2;
+        } else {
+            const float ts = t_keep + t2;
+            const unsigned rowv = E.pv + E.row_v + (unsigned)i * 32u;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ts), sA_rsrc, (int)(lq < 2 ? E.off_sum : OOB), (int)(rowv * 4u), 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ts), sB_rsrc, (int)(lq >= 2 ? E.off_sum : OOB), (int)(rowv * 4u), 0);
+        }
+    };
+    auto epi_row = [&](auto S, auto I, const Epi &E) __attribute__((always_inline)) {
+        epi_half(S, I, IC<0>{}, E);
+        epi_half(S, I, IC<1>{}, E);
+    };
+    // the S weights with the k-group of a plane that does not exist zeroed (kill: that k-group, or -1)
+    auto s_weights = [&](int kill, f16x8 &sh, f16x8 &sl) __attribute__((always_inline)) {
+        const int km = lq == kill ? 0 : -1;
+        i32x4 h = __builtin_bit_cast(i32x4, Ws[0]), l = __builtin_bit_cast(i32x4, Ws[1]);
+        h.x &= km; h.y &= km; h.z &= km; h.w &= km;
+        l.x &= km; l.y &= km; l.z &= km; l.w &= km;
+        sh = __builtin_bit_cast(f16x8, h); sl = __builtin_bit_cast(f16x8, l);
+    };
+    // three products of one k-step into one accumulator, the small ones first
+    auto mac3 = [&](f32x4 c, const f16x8 &wh, const f16x8 &wl, const f16x8 &bh, const f16x8 &bl) __attribute__((always_inline)) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh, c, 0, 0, 0);
+        return c;
+    };
+
+    auto step = [&](auto RR, int pi, int z, long long n) __attribute__((always_inline)) {
+        constexpr int R = decltype(RR)::value;
+        constexpr int S_lo = (R + 2) % 3, S_mid = R, S_hi = (R + 1) % 3;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int cur = (int)(n & 3) * P7_PLANE;
+        const int baseA = offA + cur, baseB = offB + cur;
+        const int baseS = offS + (int)((unsigned)((int)(n & 3) + ringS) & 3u) * P7_PLANE;
+        const int wbase = st_lane + (int)((n + 1) & 3) * P7_PLANE;
+        const Src C1 = src_of(c1_pi), C2 = src_of(c2_pi);
+        const unsigned z1 = (unsigned)c1_z, z2 = (unsigned)c2_z;
+        const bool ev = z >= 2 || (z == 0 && pi > 0);
+        const Epi E = epi_setup(ev, z >= 2 ? pi : pi - 1, z >= 2 ? z - 2 : D - 1);
+        f16x8 sh, sl;
+        s_weights(z == 1 ? 0 : -1, sh, sl);       // output plane 0 (completed at z = 1): its plane -1 is the z halo
+
+        struct Frag { f16x8 ah, al, bh, bl, sh, sl; };
+        auto frag = [&](int i, int hx, Frag &f) __attribute__((always_inline)) {
+            const int o = i * P7_ROW + hx * 256;
+            f.ah = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(lds + baseA + o));
+            f.al = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(lds + baseA + o + P7_PIECE));
+            f.bh = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(lds + baseB + o));
+            f.bl = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(lds + baseB + o + P7_PIECE));
+            f.sh = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(lds + baseS + o));
+            f.sl = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(lds + baseS + o + P7_PIECE));
+        };
+        Frag fc, fn;
+        frag(0, 0, fc);
+        auto row = [&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            epi_row(IC<S_hi>{}, I, E);          // row i of the plane finished two steps ago, then its accumulators restart below
+            if constexpr ((i & 1) == 0) {
+                stage_unit(wbase, IC<i / 2>{});
+                if constexpr (i / 2 + 2 < NU) load_unit(C1, z1, IC<i / 2 + 2>{}); else load_unit(C2, z2, IC<i / 2 + 2 - NU>{});
+            }
+#pragma unroll
+            for (int hx = 0; hx < 2; ++hx) {
+                if (hx == 0) frag(i, 1, fn);
+                else if (i < RW - 1) frag(i + 1, 0, fn);
+                // output planes z + 1 (first contribution: starts at zero), z, z - 1
+                f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = acc[S_mid][i][hx], c2 = acc[S_lo][i][hx];
+                c0 = mac3(c0, Wa[0][0], Wa[0][1], fc.ah, fc.al);
+                c1 = mac3(c1, Wa[1][0], Wa[1][1], fc.ah, fc.al);
+                c2 = mac3(c2, Wa[2][0], Wa[2][1], fc.ah, fc.al);
+                c0 = mac3(c0, Wb[0][0], Wb[0][1], fc.bh, fc.bl);
+                c1 = mac3(c1, Wb[1][0], Wb[1][1], fc.bh, fc.bl);
+                c2 = mac3(c2, Wb[2][0], Wb[2][1], fc.bh, fc.bl);
+                c2 = mac3(c2, sh, sl, fc.sh, fc.sl);
+                acc[S_hi][i][hx] = c0; acc[S_mid][i][hx] = c1; acc[S_lo][i][hx] = c2;
+                fc = fn;
+            }
+#if C3_B7PIPE
+#pragma unroll
+            for (int m = 0; m < 42; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(C3_FILL_MASK, C3_B7PIPE, 0);
+            }
+#endif
+        };
+        row(IC<0>{}); row(IC<1>{}); row(IC<2>{}); row(IC<3>{}); row(IC<4>{}); row(IC<5>{}); row(IC<6>{}); row(IC<7>{});
+        {
+            const Epi En = epi_setup(z + 1 < D ? z >= 1 : true, pi, z + 1 < D ? z - 1 : D - 2);
+            mask_load(En, IC<0>{});
+            mask_load(En, IC<1>{});
+        }
+        c1_pi = c2_pi; c1_z = c2_z;
+        advance(c2_pi, c2_z);
+    };
+    // a step without an input plane: the epilogue of the finished plane held by set S, which is then cleared.  LAST = the light step
+    // behind plane D - 1 of a patch's sweep (finished plane D - 2): plane D - 1, held by set (S + 1) % 3, still lacks its S k-step
+    // (planes D - 2, D - 1 and the z halo), which n - the count of planes staged so far - locates in the ring
+    auto light = [&](auto S, auto LAST, int pe, int zo, long long n) __attribute__((always_inline)) {
+        constexpr int s = decltype(S)::value;
+        constexpr bool last = decltype(LAST)::value != 0;
+        const Epi E = epi_setup(true, pe, zo);
+        auto rows = [&](auto I) __attribute__((always_inline)) { epi_row(S, I, E); };
+        rows(IC<0>{}); rows(IC<1>{}); rows(IC<2>{}); rows(IC<3>{}); rows(IC<4>{}); rows(IC<5>{}); rows(IC<6>{}); rows(IC<7>{});
+#pragma unroll
+        for (int i = 0; i < RW; ++i) { acc[s][i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[s][i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if constexpr (last) {
+            constexpr int sp = (s + 1) % 3;
+            f16x8 sh, sl;
+            s_weights(2, sh, sl);
+            const int baseS = offS + (int)((unsigned)((int)(n & 3) + ringS) & 3u) * P7_PLANE;
+#pragma unroll
+            for (int i = 0; i < RW; ++i)
+#pragma unroll
+                for (int hx = 0; hx < 2; ++hx) {
+                    const int o = i * P7_ROW + hx * 256;
+                    const f16x8 bh = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(lds + baseS + o));
+                    const f16x8 bl = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(lds + baseS + o + P7_PIECE));
+                    acc[sp][i][hx] = mac3(acc[sp][i][hx], sh, sl, bh, bl);
+                }
+        }
+        {
+            const Epi En = epi_setup(zo == D - 2, pe, D - 1);
+            mask_load(En, IC<0>{});
+            mask_load(En, IC<1>{});
+        }
+    };
+
+    __syncthreads();
+    if (np > 0) {
+        const Src C0 = src_of(0);
+        const int wb = st_lane;       // ring slot 0
+        load_unit(C0, 0u, IC<0>{}); load_unit(C0, 0u, IC<1>{});
+        stage_unit(wb, IC<0>{}); stage_unit(wb, IC<1>{});
+        load_unit(C0, 0u, IC<2>{}); load_unit(C0, 0u, IC<3>{});
+        stage_unit(wb, IC<2>{}); stage_unit(wb, IC<3>{});
+        c1_pi = 0; c1_z = 0;
+        advance(c1_pi, c1_z);
+        c2_pi = c1_pi; c2_z = c1_z;
+        advance(c2_pi, c2_z);
+        const Src C1 = src_of(c1_pi);
+        load_unit(C1, (unsigned)c1_z, IC<0>{}); load_unit(C1, (unsigned)c1_z, IC<1>{});
+    }
+    long long n = 0;
+    for (int pi = 0; pi < np; ++pi) {
+        for (int zz = 0; zz < 10; ++zz) {
+            step(IC<0>{}, pi, 3 * zz, n); ++n;
+            step(IC<1>{}, pi, 3 * zz + 1, n); ++n;
+            step(IC<2>{}, pi, 3 * zz + 2, n); ++n;
+        }
+        step(IC<0>{}, pi, 30, n); ++n;
+        step(IC<1>{}, pi, 31, n); ++n;
+        light(IC<0>{}, IC<1>{}, pi, D - 2, n);
+    }
+    if (np > 0) light(IC<1>{}, IC<0>{}, np - 1, D - 1, n);
+}
+
 // One MFMA on fp16 SUBNORMAL operands: 32 products 2^-20 * 2^10 per element -> 2^-5 when the matrix core keeps subnormal
 // inputs (gfx950 does), 0 when it flushes them.  The one-accumulator form relies on it for the low pieces of small values.
 __global__ void c3d_subnormal_probe(float *out) {
@@ -1055,6 +1406,34 @@ void c3d_bwd_pack(C3dPlan *plan, const std::vector<float> &Bmat) {
             }
 }
 
+// The 7-k-step form (c3d_bwd7_kernel): fragments [A0 A1 A2 B0 B1 B2 S] x [h, l]; lane (ci = lane & 15, k-group q = lane >> 4) of
+// fragment f holds the weights of ONE tap (dz, dy, dx) - offsets (dz - 1, dy - 1, dx - 1) of the cotangent voxel relative to the
+// output voxel; the forward tap that links them is (2 - dz, 2 - dy, 2 - dx) - or zeros:
+//   A_dz: q < 3 -> (dz, 0, q), q = 3 -> (dz, 1, 0);   B_dz: (dz, 1, 1), (dz, 1, 2), (dz, 2, 0), (dz, 2, 1);   S: q < 3 -> (q, 2, 2).
+void c3d_bwd7_pack(C3dPlan *plan, const std::vector<float> &Bmat) {
+    plan->h_W7.assign((size_t)7 * 2 * 64 * 8, 0);
+    for (int f = 0; f < 7; ++f)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int ci = lane & 15, q = lane >> 4;
+            int dz = -1, dy = 0, dx = 0;
+            if (f < 3) { dz = f; if (q < 3) { dy = 0; dx = q; } else { dy = 1; dx = 0; } }
+            else if (f < 6) { dz = f - 3; const int p = 4 + q; dy = p / 3; dx = p % 3; }
+            else if (q < 3) { dz = q; dy = 2; dx = 2; }
+            for (int c = 0; c < 8; ++c) {
+                float w = 0.f;
+                if (dz >= 0) w = Bmat[((size_t)(((2 - dz) * 3 + (2 - dy)) * 3 + (2 - dx)) * 16 + ci) * 8 + c];
+                const float ws = std::ldexp(w, plan->w_exp);
+                const _Float16 h = (_Float16)ws;
+                const _Float16 l = (_Float16)(ws - (float)h);
+                unsigned short hb, lb;
+                std::memcpy(&hb, &h, 2);
+                std::memcpy(&lb, &l, 2);
+                plan->h_W7[((size_t)(f * 2 + 0) * 64 + lane) * 8 + c] = hb;
+                plan->h_W7[((size_t)(f * 2 + 1) * 64 + lane) * 8 + c] = lb;
+            }
+        }
+}
+
 // the head's weight difference as fp16 pairs at their true scale: per voxel (8 channels) [h8 | l8], x 2^e = h + l
 void c3d_presplit_vec(const float *v, long long F, int e, std::vector<unsigned short> *out) {
     out->assign((size_t)F * 2, 0);
@@ -1085,7 +1464,12 @@ int c3d_bwd_launch(alq_ctx *ctx, const C3dPlan &plan, int N, const unsigned char
     // unless the model was created under ALQ_C3D_BWD_ROWS=4: the half-patch form (4 rows per wave, 128 registers per lane left to
     // co-resident kernels)
     const int rows8 = rows_per_wave == 4 ? 0 : 1;
-    if (rows8) {
+    if (rows_per_wave == 7 && plan.d_W7) {      // the 27 taps in 7 k-steps (default since round 6; ALQ_C3D_BWD_ROWS=8: the 9-k-step kernel)
+        a.W = plan.d_W7;
+        auto kfn = c3d_bwd7_kernel;
+        ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, P7_LDS));
+        hipLaunchKernelGGL(kfn, dim3((unsigned)std::min(N, 256)), dim3(256), P7_LDS, ctx->stream, a);
+    } else if (rows8) {
         auto kfn = c3d_bwd_kernel<true, 8>;
         const int ldsb = 2 * (32 + 2) * B3_ROW + 2 * B3_ROW;
         ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));

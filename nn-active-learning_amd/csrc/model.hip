@@ -1655,7 +1655,8 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
         m->no_flipfix = getenv("ALQ_NO_FLIPFIX") != nullptr;
         m->no_presplit = getenv("ALQ_NO_PRESPLIT") != nullptr;
         m->no_c3d = getenv("ALQ_NO_C3D") != nullptr;
-        { const char *e = getenv("ALQ_C3D_BWD_ROWS"); m->c3_bwd_rows = (e && atoi(e) == 4) ? 4 : 8; }
+        // 7 (default): the 27 taps packed into 7 k-steps (c3d_bwd7_kernel); 8: the 9-k-step kernel of round 4; 4: its half-patch form
+        { const char *e = getenv("ALQ_C3D_BWD_ROWS"); m->c3_bwd_rows = (e && atoi(e) == 4) ? 4 : ((e && atoi(e) == 8) ? 8 : 7); }
         m->no_signs = getenv("ALQ_NO_SIGNS") != nullptr;
         m->no_signs0 = getenv("ALQ_NO_SIGNS0") != nullptr;
         if (const char *f = getenv("ALQ_F16_FWD_MASK")) m->f16_fwd_mask = atoi(f);
@@ -1821,6 +1822,11 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
             if (!dw) ALQ_TRY(m->dalloc(&dw, ly.c3b.h_W.size()));
             ly.c3b.d_W = dw;
             ALQ_HIP(hipMemcpyAsync(dw, ly.c3b.h_W.data(), ly.c3b.h_W.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
+            c3d_bwd7_pack(&ly.c3b, B);          // the 7-k-step form of the same weights (c3d_bwd7_kernel)
+            unsigned short *dw7 = reinterpret_cast<unsigned short *>(ly.c3b.d_W7);
+            if (!dw7) ALQ_TRY(m->dalloc(&dw7, ly.c3b.h_W7.size()));
+            ly.c3b.d_W7 = dw7;
+            ALQ_HIP(hipMemcpyAsync(dw7, ly.c3b.h_W7.data(), ly.c3b.h_W7.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
             ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
         }
         if (ly.e3b.ok && ly.has_bwd && c3d_subnormals_ok(m->ctx)) {      // (fp16 pairs at their true scale: the one-accumulator form)
@@ -2196,7 +2202,8 @@ int alq_model_debug_copy(alq_model *m, int layer_idx, int what, int N, float *d_
 }
 
 int alq_model_engine_info(alq_model *m, int what) {
-    ALQ_REQUIRE(m && ((what >= 0 && what <= 3) || (what >= 5 && what <= 12)), ALQ_EINVAL, "alq_model_engine_info: bad argument");
+    ALQ_REQUIRE(m && ((what >= 0 && what <= 3) || (what >= 5 && what <= 13)), ALQ_EINVAL, "alq_model_engine_info: bad argument");
+    if (what == 13) return m->last_c3_bwd ? m->c3_bwd_rows : 0;      // form of the head conv's backward kernel: 7 = 27 taps in 7 k-steps, 8 / 4 = the 9-k-step kernel
     if (what == 6) return m->last_f16_derived ? 1 : 0;
     if (what == 7) return m->last_t3f;        // conv_transpose launches of the last forward pass on the row-sweep engine (t3d.hip)
     if (what == 8) return m->last_t3b;        // ... of the last backward pass

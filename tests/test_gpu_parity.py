@@ -1286,14 +1286,14 @@ def test_fused_enc2_backward_against_the_three_launches(sess):
 
 
 def test_plane_sweep_backward_half_patch_form_is_bit_identical(sess):
-    """The plane-sweep backward kernel in its two forms - a workgroup per patch (default, 8 rows per wave) and per half patch
+    """The 9-k-step plane-sweep backward kernel in its two forms - a workgroup per patch (ALQ_C3D_BWD_ROWS=8, 8 rows per wave) and per half patch
     (ALQ_C3D_BWD_ROWS=4, halo rows staged twice): every output voxel sees the same MFMAs in the same order, so the layer scores
     must be identical bit for bit.  257 patches: the last workgroups of both grids hold one work item fewer."""
     import ctypes as C
     from nnal_amd._lib import check
     torch = sess.torch
     n = 257
-    ld, sk, in_shape, pars, (m8, m4) = _netc32_models(sess, [{}, {'ALQ_C3D_BWD_ROWS': '4'}], max_batch=n, bias_std=0.05)
+    ld, sk, in_shape, pars, (m8, m4) = _netc32_models(sess, [{'ALQ_C3D_BWD_ROWS': '8'}, {'ALQ_C3D_BWD_ROWS': '4'}], max_batch=n, bias_std=0.05)
     x = sess.empty((n, 32 ** 3), torch.float32)
     check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, 32 ** 3, C.c_void_p(x.data_ptr())))
     keys = ('p1', 'g0', 'g1', 'A')
@@ -1306,6 +1306,47 @@ def test_plane_sweep_backward_half_patch_form_is_bit_identical(sess):
         np.testing.assert_array_equal(out[0][k], out[1][k], err_msg=k)
     m8.close()
     m4.close()
+
+
+def test_head_conv_backward_in_seven_k_steps_against_the_nine_k_step_kernel(sess):
+    """The backward of the conv under the two-class head (tf.gradients through NN_extended.py:416-426: 8 -> 16 channels at 32^3 from
+    sign bytes x (W0 - W1)) with its 27 taps packed into 7 k-steps (csrc/c3d.hip c3d_bwd7_kernel, default since round 6: lane-addressed
+    taps, the leftover tap of the three planes as one output-stationary k-step over a ring of four plane images) against the 9-k-step
+    kernel it replaces (ALQ_C3D_BWD_ROWS=8: a quarter of its MFMAs multiply a zero k-group).  Same fp16-pair products, same forward
+    pass and masks (nothing can flip), another summation order: up2's cotangent (the stored half) and channel sums and enc1's
+    channel sums within 2e-6 of their maxima on 300 patches (an all-zero patch, workgroups with one and two patches: the z halo at
+    the patch seams of the ring), posteriors bit-identical, every layer score within 2e-6 + 2e-5 relative; 2047 patches: scores."""
+    import ctypes as C
+    from nnal_amd._lib import check
+    torch = sess.torch
+    n = 300
+    ld, sk, in_shape, pars, (m_new, m_old) = _netc32_models(sess, [{}, {'ALQ_C3D_BWD_ROWS': '8'}], max_batch=2047, bias_std=0.05)
+    x = sess.empty((2047, 32 ** 3), torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, 2047, 32 ** 3, C.c_void_p(x.data_ptr())))
+    x[17].zero_()
+    out = []
+    for m in (m_new, m_old):
+        r = m.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1', 'A', 'Asum'))
+        d = {k: r[k].cpu().numpy() for k in ('p1', 'g0', 'g1', 'A', 'Asum')}
+        d['up2_dout'] = m.debug_tensor(7, 1, n)
+        d['up2_dsum'] = m.debug_tensor(7, 3, n)
+        d['enc1_dsum'] = m.debug_tensor(0, 3, n)
+        r = m.fisher_device(x, 2047, None, 1e-3, want=('g0', 'g1'))
+        d['g0_full'], d['g1_full'] = r['g0'].cpu().numpy(), r['g1'].cpu().numpy()
+        out.append(d)
+    assert sess.lib.alq_model_engine_info(m_new._m, 13) == 7, 'the 7-k-step kernel did not run'
+    assert sess.lib.alq_model_engine_info(m_old._m, 13) == 8
+    a, b = out
+    np.testing.assert_array_equal(a['p1'], b['p1'])
+    for k in ('up2_dout', 'up2_dsum', 'enc1_dsum'):
+        assert a[k].shape == b[k].shape and np.isfinite(a[k]).all()
+        err = np.abs(a[k] - b[k]).max()
+        assert err <= 2e-6 * np.abs(b[k]).max(), (k, err, np.abs(b[k]).max())
+    for k in ('g0', 'g1', 'g0_full', 'g1_full'):
+        np.testing.assert_allclose(a[k], b[k], rtol=2e-5, atol=2e-6, err_msg=k)
+    np.testing.assert_allclose(a['A'], b['A'], rtol=2e-5, atol=1e-12 + 2e-6 * np.abs(b['A']).max())
+    m_new.close()
+    m_old.close()
 
 
 def test_fp16_forward_with_derived_bounds_against_bf16_triples(sess):

@@ -545,8 +545,10 @@ struct FcGemmPlan {
 int fcgemm_build_plan(int K, int N, FcGemmPlan *plan);
 void fcgemm_pack_weights(FcGemmPlan *plan, const std::vector<float> &Bmat /* [K][N] */);
 void fcgemm_pack_weights_f16(FcGemmPlan *plan, const std::vector<float> &Bmat /* [K][N] */);
+// in_bound > 0 (no bias): fp16 pairs under that static bound; row_amax (device, [M], scratch): fp16 pairs under the per-row maxima the
+// launch measures into it first; neither: bf16 triples
 int fcgemm_launch(alq_ctx *ctx, const FcGemmPlan &plan, const View &in, const View &out, const float *bias, int relu,
-                  int M, int prof_cls, float in_bound = 0.f);
+                  int M, int prof_cls, float in_bound = 0.f, unsigned *row_amax = nullptr);
 
 // one contraction = general plan + (when eligible) pipelined plan / direct first-layer plan
 struct Gemm {
@@ -555,7 +557,8 @@ struct Gemm {
     Igemm3Plan p3;
     Igemm4Plan p4;
     FcGemmPlan pfc;
-    bool pfc_f16 = false;      // also pack the fp16-pair twin of pfc's weights (backward launches)
+    bool pfc_f16 = false;      // also pack the fp16-pair twin of pfc's weights (backward launches; forward launches of wide fc layers)
+    unsigned *fc_row_amax = nullptr;   // forward launch of a wide fc layer on fp16 pairs: [max_batch] measured input maxima (scratch)
     DirectPlan pd;
 };
 

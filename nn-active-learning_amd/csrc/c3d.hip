@@ -83,7 +83,7 @@ static_assert(C3_WD >= 1 && C3_WD <= 8, "weight-difference slices are fetched 1.
 #endif
 // the 7-k-step backward kernel: non-MFMA instructions behind each MFMA of the sweep's pattern, weights pinned to accumulation registers
 #ifndef C3_B7PIPE
-#define C3_B7PIPE 2
+#define C3_B7PIPE 4
 #endif
 #ifndef C3_B7PINW
 #define C3_B7PINW 0

@@ -12,6 +12,8 @@
 // ds_read_b128 lane group (8 rows of group q, 8 rows of group q+1) hit 16 different 16-byte bank granules.
 // The weights are the MFMA A operand (rows = features), so a lane ends up with 4 consecutive features of one
 // patch: 16-byte stores.
+// F16 forward (round 6): fc1 / fc2 of a pass measure the per-patch maximum of their input (fc_rowmax_kernel: one read of [M x K]) and
+// contract with fp16 pairs scaled per patch; bias and ReLU ride in the epilogue.  ALQ_NO_FC_F16_FWD=1 at model creation: bf16 triples.
 // F16 (round 5): backward launches of a Fisher pass know a static bound on their input (the cotangent under the unit cotangent,
 // chained down from the head like the conv launches' - model.hip, run_backward_main): they contract with fp16 PAIRS at their true
 // scale, x 2^e = h + l, three products in one accumulator instead of six (c3d.hip's one-accumulator form; needs fp16 subnormals
@@ -54,7 +56,33 @@ struct FcGemmArgs {
     const float *bias;
     int M, N, K, lda, ldc, relu;
     float scale, inv;      // F16: 2^e_in and 2^-(e_in + e_w)
+    // F16 forward launches (round 6): per-row (patch) maxima |A| (float bits, fc_rowmax_kernel) instead of one static bound: row m is
+    // scaled by 2^(14 - ex_m), its results by the inverse; e_w = the weights' exponent
+    const unsigned *row_amax;
+    int e_w;
 };
+
+// max |A[m][:]| per row as float bits (one wave per row; rows beyond M are not written)
+__global__ __launch_bounds__(256) void fc_rowmax_kernel(const float *A, int M, int K, int lda, unsigned *out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float *p = A + (size_t)row * lda;
+    float m = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(p + k);
+        m = fmaxf(fmaxf(m, fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y))), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) out[row] = __builtin_bit_cast(unsigned, m);
+}
+
+// scale exponent of a row with maximum bits fm: max |x| < 2^ex -> 2^(14 - ex) (c3d.hip's rule; an all-zero row: 0)
+__device__ inline int fc_row_exp(unsigned fm) {
+    const int ex = (int)((fm >> 23) & 255u) - 126;
+    const int ce = 14 - ex;
+    return fm ? (ce < 96 ? ce : 96) : 0;
+}
 
 template <bool F16>
 __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
@@ -76,6 +104,16 @@ __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
     const char *wsrc = reinterpret_cast<const char *>(a.Bp) + (size_t)nt * nks * WB + tid * 16;
     f32x4 xa[2][2];
     i32x4 wr[NP];
+    float rsc[2] = {a.scale, a.scale};          // F16: scale of this thread's two staging rows
+    if constexpr (F16) {
+        if (a.row_amax) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int row = m0 + xr0 + t * 64;
+                rsc[t] = __builtin_ldexpf(1.f, fc_row_exp(row < a.M ? a.row_amax[row] : 0u));
+            }
+        }
+    }
     auto fetch = [&](int ks) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -102,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
                 int hh[4], ll[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float x0 = v[2 * j] * a.scale, x1 = v[2 * j + 1] * a.scale;
+                    const float x0 = v[2 * j] * rsc[t], x1 = v[2 * j + 1] * rsc[t];
                     const f16x2 h = __builtin_convertvector(f32x2{x0, x1}, f16x2);
                     const f16x2 l = __builtin_convertvector(f32x2{x0 - (float)h.x, x1 - (float)h.y}, f16x2);
                     hh[j] = __builtin_bit_cast(int, h);
@@ -187,7 +225,14 @@ __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             f32x4 v = acc[mi][ni];
-            if constexpr (F16) { v.x *= a.inv; v.y *= a.inv; v.z *= a.inv; v.w *= a.inv; }
+            if constexpr (F16) {
+                const float iv = a.row_amax ? __builtin_ldexpf(1.f, -(fc_row_exp(a.row_amax[m]) + a.e_w)) : a.inv;
+                v.x *= iv; v.y *= iv; v.z *= iv; v.w *= iv;
+                if (a.bias) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bias + n0 + wn + ni * 16 + lq * 4);
+                    v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+                }
+            }
             if (a.relu) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
@@ -269,15 +314,26 @@ void fcgemm_pack_weights_f16(FcGemmPlan *plan, const std::vector<float> &Bmat /*
 }
 
 int fcgemm_launch(alq_ctx *ctx, const FcGemmPlan &plan, const View &in, const View &out, const float *bias, int relu,
-                  int M, int prof_cls, float in_bound) {
+                  int M, int prof_cls, float in_bound, unsigned *row_amax) {
     ALQ_REQUIRE(plan.d_W && in.C == plan.K && out.C == plan.N && in.c0 == 0 && out.c0 == 0 && in.cs % 4 == 0 && out.cs % 4 == 0 &&
                     in.vox() == 1 && out.vox() == 1,
                 ALQ_EINVAL, "fcgemm: views do not match the plan");
     FcGemmArgs a;
     a.A = in.p; a.Bp = plan.d_W; a.C = out.p; a.bias = bias;
     a.M = M; a.N = plan.N; a.K = plan.K; a.lda = in.cs; a.ldc = out.cs; a.relu = relu;
-    a.scale = 1.f; a.inv = 1.f;
+    a.scale = 1.f; a.inv = 1.f; a.row_amax = nullptr; a.e_w = plan.w_exp;
     const dim3 grid(plan.N / FC_BN, (M + FC_BM - 1) / FC_BM);
+    if (row_amax && plan.d_W16) {      // fp16 pairs under the MEASURED per-patch maximum of the input (a forward launch; bias + ReLU in the epilogue)
+        hipLaunchKernelGGL(fc_rowmax_kernel, dim3((M + 3) / 4), dim3(256), 0, ctx->stream, in.p, M, plan.K, in.cs, row_amax);
+        a.Bp = plan.d_W16;
+        a.row_amax = row_amax;
+        const size_t lds16 = 2 * (2 * 4 * FC_BM * 16 + 2 * 4 * FC_BN * 16);
+        ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fcgemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+        ProfScope ps16(ctx, PROF_IGEMM_F16, 2.0 * M * (double)plan.K * plan.N);
+        hipLaunchKernelGGL(fcgemm_kernel<true>, grid, dim3(256), lds16, ctx->stream, a);
+        ALQ_HIP(hipGetLastError());
+        return ALQ_OK;
+    }
     if (in_bound > 0.f && plan.d_W16 && !bias) {      // fp16 pairs under a static bound on the input (a backward launch of a Fisher pass)
         int ex = 0;
         (void)std::frexp(in_bound, &ex);

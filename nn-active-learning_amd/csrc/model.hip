@@ -363,8 +363,10 @@ static int gemm_launch(alq_ctx *ctx, const Gemm &g, const View &in, const View &
     }
     if (g.pfc.ok && !accumulate && !fuse && !g_dbg_knobs[4] && !g_dbg_knobs[5]) {     // wide fc layer: streaming bf16x3 GEMM
         if (fused) *fused = false;
+        // forward launches of wide fc layers: fp16 pairs under the per-patch maxima the launch measures (fcgemm.hip, round 6)
         return fcgemm_launch(ctx, g.pfc, in, out, bias, relu, N, cls == PROF_IGEMM_BWD ? PROF_IGEMM3_BWD : PROF_IGEMM3_FWD,
-                             (g_no_f16x2 || bias || relu) ? 0.f : fc_in_bound);
+                             (g_no_f16x2 || bias || relu) ? 0.f : fc_in_bound,
+                             (cls == PROF_IGEMM_FWD && !g_no_f16x2) ? g.fc_row_amax : nullptr);
     }
     const bool split_view = in.split != 0 || out.split != 0;
     ALQ_REQUIRE(!split_view || g.p4.ok, ALQ_EUNSUPPORTED, "split concat view without a two-slot plan");
@@ -749,6 +751,10 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
                 d.tz = {0}; d.ty = {0}; d.tx = {0};
                 ly.fwd.resize(1);
                 ALQ_TRY(gemm_build(d, NB, &ly.fwd[0]));
+                if (ly.fwd[0].pfc.ok && !getenv("ALQ_NO_FC_F16_FWD")) {      // forward launch of a wide fc layer on fp16 pairs (measured per-patch maxima)
+                    ly.fwd[0].pfc_f16 = true;
+                    ALQ_TRY(m->dalloc(&ly.fwd[0].fc_row_amax, (size_t)m->max_batch));
+                }
                 if (!first_param) {
                     ConvDesc b = d;
                     b.Ci = sp.cout; b.Co = (int)ly.F;

@@ -151,3 +151,57 @@ def test_shipped_engines_are_no_further_from_fp64_than_the_exact_fp32_engine(ses
     rep2, _, _ = r64.engine_report(x, np.arange(16), bad, eps=ref64.DEFAULT_EPS)
     assert rep2['scaled']['flips_needed']['unexplained'] >= 14, rep2
     m.close()
+
+
+def test_netb_wide_fc_forward_on_fp16_pairs(sess):
+    """NET-B (NN.create_PW1, NN.py:1328-1336) with its wide fc layers' FORWARD launches on fp16 pairs under the per-patch maxima the
+    launch measures (csrc/fcgemm.hip, round 6; 3 products per MAC instead of 6) against bf16 triples (ALQ_NO_FC_F16_FWD=1) and
+    against the exact-fp32 engine, all three judged by the fp64 evaluation on the device: posteriors within 2e-6 of each other,
+    the fp16-pair build disagrees with fp64 on no more patches than 1.25 x the exact-fp32 engine + 4, nothing unexplained."""
+    import os
+    from nnal_amd import device, ref64
+    from nnal_amd._lib import check
+    torch = sess.torch
+    n = 256
+    ld = netspec.net_b_small(width=512)          # fc 6144 -> 512 -> 512 -> 2: both hidden layers run on fcgemm
+    in_shape = (32, 32, 32)
+    pars = netspec.he_init(ld, in_shape, seed=13)
+    x = sess.to_device(np.random.RandomState(21).randn(n, 32 ** 3).astype(np.float32), torch.float32)
+    eng, post, f16 = {}, {}, {}
+    for name, env in (('fp16_pairs', {}), ('bf16_triples', {'ALQ_NO_FC_F16_FWD': '1'})):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            m = device.DeviceModel(sess, ld, in_shape, (), max_batch=n)
+            m.set_weights(pars)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        sess.prof_reset()
+        sess.prof_enable(1)
+        r = m.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1'))
+        torch.cuda.synchronize()
+        sess.prof_enable(False)
+        f16[name] = sess.prof_read()['igemm_f16x2']['launches']
+        eng[name] = (r['g0'].cpu().numpy(), r['g1'].cpu().numpy())
+        post[name] = r['p1'].cpu().numpy()
+        if name == 'fp16_pairs':
+            check(sess.lib.alq_debug_set(4, 1))
+            try:
+                r = m.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1'))
+                eng['exact_fp32'] = (r['g0'].cpu().numpy(), r['g1'].cpu().numpy())
+            finally:
+                check(sess.lib.alq_debug_set(4, 0))
+            r64 = ref64.Ref64(m, max_samples=64)
+            keep = m
+        else:
+            m.close()
+    assert f16['fp16_pairs'] >= f16['bf16_triples'] + 2, f16          # both wide fc forward launches took the split
+    np.testing.assert_allclose(post['fp16_pairs'], post['bf16_triples'], rtol=0, atol=2e-6)
+    rep, base, found = r64.engine_report(x, np.arange(n), eng, eps=ref64.DEFAULT_EPS)
+    print(rep)
+    for k in ('over_2e-6', 'over_1e-4'):
+        assert rep['fp16_pairs'][k] <= 1.25 * rep['exact_fp32'][k] + 4, (k, rep)
+    for k in eng:
+        assert rep[k]['flips_needed']['unexplained'] == 0, (k, rep[k])
+    keep.close()

@@ -282,7 +282,7 @@ def main():
                          'launches': ig_n, 'avg_launch_ms': ig_ms / max(ig_n, 1),
                          'timed': ('HIP events on every k-th pass of the timed region, k = %d' % args.prof_every) if in_region else
                                   ('a separate single-pipeline pass over the first %d pool patches behind the timed region, HIP events on '
-                                   'every launch (the timed region ran %d pipelines: its launches overlap each other)' % (prof_patches, lanes_timed)),
+                                   'every launch (the timed region ran %d pipelines: its launches overlap each other)' % (int(prof_patches or 0), lanes_timed)),
                          'all_conv_engines_tflops': conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
                          'flops_per_patch_executed': F_EXEC, 'flops_per_patch_survey': F_SURVEY,
                          'whole_step_tflops_executed': F_EXEC * value / ws / 1e12,
@@ -635,13 +635,23 @@ def netb_rate(sess, n, x):
     peak_bf, peak_f16 = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS, PEAK_BF16_MFMA_TFLOPS / 3
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     peak = fl / (bf_fl / peak_bf + f16['flops'] / peak_f16) if fl > 0 else peak_bf
+    traffic, traffic_note = None, None          # PMC passes are separate runs (PMC_ARGS="tools/gpu_netb.py 2048" tools/run_pmc.sh)
+    tp = os.path.join(ROOT, 'profiles', 'netb_pmc_traffic.json')
+    if os.path.exists(tp):
+        try:
+            tj = json.load(open(tp))
+            traffic = tj['hbm_bytes_per_launch'] * NETB_BATCH / float(tj.get('batch', NETB_BATCH))
+            traffic_note = 'PMC 2*FETCH_SIZE + WRITE_SIZE per contraction launch of a NET-B pass (profiles/netb_pmc_traffic.json)'
+        except Exception:
+            traffic = None
     return {'value': n / dt, 'unit': 'patches/s', 'net': 'NET-B = NN.create_PW1 (NN.py:1328-1336), input [N,32,32,32], 7 parameterised layers',
             'patches': n, 'batch': NETB_BATCH, 'flops_per_patch_executed': 190.9e6 + 151.5e6,
             'tflops_executed': (190.9e6 + 151.5e6) * n / dt / 1e12,
             'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak if peak > 0 else 0.0,
-                         'useful_frac': ach / peak_f16, 'traffic': None, 'launches': nl, 'avg_launch_ms': ms / max(nl, 1),
-                         'kernel': 'the contraction launches of a NET-B pass (4 conv forward + 3 conv backward-data on the two-slot engine, '
-                                   '3 fc forward + 2 fc backward on fcgemm), HIP events on every launch of a separate pass',
+                         'useful_frac': ach / peak_f16, 'traffic': traffic, 'traffic_note': traffic_note, 'launches': nl, 'avg_launch_ms': ms / max(nl, 1),
+                         'kernel': 'the contraction launches of a NET-B pass (4 conv forward + 3 conv backward-data on the two-slot / bf16x3 / fp32 engines, '
+                                   '2 wide fc forward (fp16 pairs under measured per-patch maxima since round 6) + 2 wide fc backward on fcgemm), HIP events '
+                                   'on every launch of a separate pass',
                          'peak_note': 'algorithmic fp32 flops; peak = flop-weighted harmonic mean of %.0f / 6 (bf16x3 launches, %.0f %% of the '
                                       'flops) and %.0f / 3 (fp16-pair launches)' % (PEAK_BF16_MFMA_TFLOPS, 100.0 * bf_fl / max(fl, 1.0), PEAK_BF16_MFMA_TFLOPS),
                          'alg_flops_per_patch': {'bf16x3': bf_fl / max(n, 1), 'f16x2': f16['flops'] / max(n, 1)},

@@ -88,6 +88,11 @@ static_assert(C3_WD >= 1 && C3_WD <= 8, "weight-difference slices are fetched 1.
 #ifndef C3_B7PINW
 #define C3_B7PINW 0
 #endif
+// timing experiments only (results wrong): 1 no epilogue in the sweep steps, 2 no staging (loads + LDS writes), 4 no S k-step,
+// 8 no hold behind the 16-byte stores
+#ifndef C3_B7ABL
+#define C3_B7ABL 0
+#endif
 
 // LDS image of one input plane (bytes).  Slot = 8 fp16 channels of one tensor at one voxel, one piece (h or l).
 constexpr int C3_TEN = 34 * 16;          // slots x = -1 .. 32 of one (row, piece, tensor); the two outer ones stay zero
@@ -1103,7 +1108,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         val.w = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v3) & k3);
         const unsigned vox = E.pv + E.row_v + (unsigned)i * 32u + (unsigned)hx * 16u;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, val), dB_rsrc, (int)E.off_dB, (int)(vox * 32u), 2 /* nt */);
-        ALQ_STORE_HOLD("v"(val));      // (16-byte store with a register soffset: alq_internal.h)
+        if constexpr (!(C3_B7ABL & 8)) ALQ_STORE_HOLD("v"(val));      // (16-byte store with a register soffset: alq_internal.h)
         const float t = (val.x + val.y) + (val.z + val.w);
         const unsigned tu = __builtin_bit_cast(unsigned, t);
         const auto sw = hx == 0 ? __builtin_amdgcn_permlane16_swap(tu, 0u, false, false) : __builtin_amdgcn_permlane16_swap(0u, tu, false, false);
@@ -1168,8 +1173,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         auto row = [&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
             __builtin_amdgcn_sched_barrier(0);
-            epi_row(IC<S_hi>{}, I, E);          // row i of the plane finished two steps ago, then its accumulators restart below
-            if constexpr ((i & 1) == 0) {
+            if constexpr (!(C3_B7ABL & 1)) epi_row(IC<S_hi>{}, I, E);          // row i of the plane finished two steps ago, then its accumulators restart below
+            else { const f32x4 k0 = acc[S_hi][i][0], k1 = acc[S_hi][i][1]; asm volatile("" :: "v"(k0), "v"(k1)); }      // (timing build: the MFMAs stay alive)
+            if constexpr ((i & 1) == 0 && !(C3_B7ABL & 2)) {
                 stage_unit(wbase, IC<i / 2>{});
                 if constexpr (i / 2 + 2 < NU) load_unit(C1, z1, IC<i / 2 + 2>{}); else load_unit(C2, z2, IC<i / 2 + 2 - NU>{});
             }
@@ -1185,7 +1191,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 c0 = mac3(c0, Wb[0][0], Wb[0][1], fc.bh, fc.bl);
                 c1 = mac3(c1, Wb[1][0], Wb[1][1], fc.bh, fc.bl);
                 c2 = mac3(c2, Wb[2][0], Wb[2][1], fc.bh, fc.bl);
-                c2 = mac3(c2, sh, sl, fc.sh, fc.sl);
+                if constexpr (!(C3_B7ABL & 4)) c2 = mac3(c2, sh, sl, fc.sh, fc.sl);
                 acc[S_hi][i][hx] = c0; acc[S_mid][i][hx] = c1; acc[S_lo][i][hx] = c2;
                 fc = fn;
             }

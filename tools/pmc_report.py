@@ -35,6 +35,12 @@ def per_kernel_counters(path):
     return out
 
 
+# the twelve contraction launches of a NET-C pass; PMC_KERNELS="a,b,..." overrides (NET-B: igemm4_kernel,igemm3_kernel,igemm_kernel,fcgemm_kernel)
+CONTRACTION = tuple(os.environ['PMC_KERNELS'].split(',')) if os.environ.get('PMC_KERNELS') else (
+    'igemm4_kernel', 'c3d_fwd_kernel', 'c3d_bwd7_kernel', 'c3d_bwd_kernel', 't3d_fwd_kernel', 't3d_bwd_kernel', 't3d8_fwd_kernel', 'e3d_bwd_kernel',
+    'd3d_fwd_kernel', 'd3d_bwd_kernel', 't3d8_bwd_kernel', 'f3d_fwd_kernel')
+
+
 def mean(v):
     return sum(v) / len(v) if v else 0.0
 
@@ -89,7 +95,7 @@ def main():
             e['hbm_read_MB_per_launch'] = round(rd_b / 1e6, 1)
             e['hbm_write_MB_per_launch'] = round(wr_b / 1e6, 1)
             e['hbm_GBps'] = round((rd_b + wr_b) / (st['avg_us'] * 1e-6) / 1e9, 0)
-            if name.startswith(('igemm4_kernel', 'c3d_fwd_kernel', 'c3d_bwd_kernel', 't3d_fwd_kernel', 't3d_bwd_kernel', 't3d8_fwd_kernel', 'e3d_bwd_kernel', 'd3d_fwd_kernel', 'd3d_bwd_kernel', 't3d8_bwd_kernel', 'f3d_fwd_kernel')):      # the twelve contraction launches of a pass
+            if name.startswith(CONTRACTION):      # the contraction launches of a pass
                 ig['ms'] += st['avg_us'] * st['calls'] / 1e3
                 ig['n'] += st['calls']
                 ig['rd'] += rd_b * st['calls']
@@ -102,12 +108,12 @@ def main():
                                  hbm_bytes_per_launch=(ig['rd'] + ig['wr']) / ig['n'])
     if ig['n'] and len(sys.argv) > 3:      # the traffic file bench.py reads (profiles/pmc_traffic.json)
         batch = int(sys.argv[4]) if len(sys.argv) > 4 else 2000
-        tj = dict(kernel='the 12 contraction launches of a pass (igemm4_kernel variants + c3d_fwd / c3d_bwd + t3d_fwd / t3d_bwd / t3d8_fwd + d3d_fwd / d3d_bwd + e3d_bwd), bench.py --pool 8188 '
-                         '--batch %d --steps 1 --warmup 1' % batch,
+        tj = dict(kernel=os.environ.get('PMC_KERNEL_NOTE', 'the 12 contraction launches of a pass (c3d_fwd / c3d_bwd7 + t3d_fwd / t3d_bwd + t3d8_fwd / t3d8_bwd + d3d_fwd / d3d_bwd + f3d_fwd + e3d_bwd + two igemm4_kernel launches), '
+                         'bench.py --lanes 1 --pool 8188 --batch %d --steps 1 --warmup 1' % batch),
                   launches=ig['n'], read_bytes_per_launch=ig['rd'] / ig['n'], write_bytes_per_launch=ig['wr'] / ig['n'],
                   hbm_bytes_per_launch=(ig['rd'] + ig['wr']) / ig['n'],
                   corrections='KiB -> bytes; FETCH_SIZE x2 (gfx950 wide reads); source %s (tools/run_pmc.sh)' % dst, batch=batch,
-                  hbm_bytes_per_patch_all_contraction_launches=(ig['rd'] + ig['wr']) / ig['n'] * 12.0 / batch)
+                  hbm_bytes_per_patch_all_contraction_launches=(ig['rd'] + ig['wr']) / ig['n'] * float(os.environ.get('PMC_LAUNCHES_PER_PASS', '12')) / batch)
         json.dump(tj, open(sys.argv[3], 'w'), indent=1)
     json.dump(out, open(dst, 'w'), indent=1)
     print(json.dumps(out.get('igemm4_all', {}), indent=1))

@@ -36,7 +36,7 @@ def main():
     variants = []
     for r in csv.DictReader(open(stats_csv)):
         total_ns += float(r['TotalDurationNs'])
-        kname = next((k for k in ('igemm4_kernel', 'c3d_fwd_kernel', 'c3d_bwd_kernel', 't3d8_fwd_kernel', 't3d_fwd_kernel', 't3d_bwd_kernel', 'e3d_bwd_kernel', 'd3d_fwd_kernel', 'd3d_bwd_kernel', 't3d8_bwd_kernel', 'f3d_fwd_kernel') if k in r['Name']), None)
+        kname = next((k for k in ('igemm4_kernel', 'c3d_fwd_kernel', 'c3d_bwd7_kernel', 'c3d_bwd_kernel', 't3d8_fwd_kernel', 't3d_fwd_kernel', 't3d_bwd_kernel', 'e3d_bwd_kernel', 'd3d_fwd_kernel', 'd3d_bwd_kernel', 't3d8_bwd_kernel', 'f3d_fwd_kernel') if k in r['Name']), None)
         if kname:
             ig_ns += float(r['TotalDurationNs'])
             ig_calls += int(r['Calls'])
@@ -54,7 +54,7 @@ def main():
         'algorithmic_tflops': alg / secs / 1e12, 'executed_16bit_tflops': executed / secs / 1e12,
         'frac': executed / secs / 1e12 / PEAK_16BIT_TFLOPS,
         'bench_line': {'frac': rf['frac'], 'avg_launch_ms': rf['avg_launch_ms'], 'executed_16bit_tflops': rf['executed_16bit_tflops'],
-                       'value': line['value'], 'note': 'HIP events of every %d-th pass inside the SAME run' % rf['timed_every_kth_pass']},
+                       'value': line['value'], 'note': rf.get('timed', 'HIP events of every %s-th pass inside the SAME run' % rf.get('timed_every_kth_pass'))},
         'igemm4_share_of_all_kernel_time': ig_ns / total_ns,
         'variants': sorted(variants, key=lambda v: -v['total_ms']),
     }

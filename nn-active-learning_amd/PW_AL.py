@@ -271,11 +271,12 @@ class Experiment(object):
             self.load_parameters()
 
     def save_parameters(self, pars):
-        import copy
         plain = _plain(pars)          # (an unsupported value fails before the file is touched)
         with open(os.path.join(self.root_dir, 'parameters.txt'), 'w') as f:
-            self.pars = copy.deepcopy(pars)
             _yaml_dump(plain, f)
+        # every rank - the writer included - holds what the FILE holds (arrays as lists): rank 0 keeping the caller's
+        # numpy arrays while the others load plain lists made `pars['stats']`-style values differ in type across ranks
+        self.load_parameters()
 
     def load_parameters(self):
         with open(os.path.join(self.root_dir, 'parameters.txt'), 'r') as f:

@@ -9,7 +9,7 @@ export TMPDIR=/tmp ALQ_BENCH_NO_EVENTS=1
 cd "$ROOT"
 for r in $(seq 1 "$R"); do
   for L in "$@"; do
-    ALQ_LIB="$L" rocprofv3 --kernel-trace --stats -d "$OUT/${L}_$r" -o s --output-format csv -- python3 bench.py --lanes 1 --pool 16376 --steps 2 --warmup 1 --no-cpu-baseline --netb-pool 0 > "$OUT/${L}_$r.json" 2> "$OUT/${L}_$r.err"
+    ALQ_LIB="$L" rocprofv3 --kernel-trace --stats -d "$OUT/${L}_$r" -o s --output-format csv -- python3 bench.py --lanes 1 --pool 16376 --steps 2 --warmup 1 --no-cpu-baseline --no-accuracy --netb-pool 0 > "$OUT/${L}_$r.json" 2> "$OUT/${L}_$r.err"
     echo "done $L round $r"
   done
 done

@@ -64,7 +64,7 @@ def main():
     kern = collections.OrderedDict()
     ig = dict(ms=0.0, n=0, rd=0.0, wr=0.0)
     for name, st in stats.items():
-        if st['pct'] < 0.3:
+        if st['pct'] < 0.1:
             continue
         e = collections.OrderedDict(calls=st['calls'], avg_us=round(st['avg_us'], 1), pct_of_gpu_time=st['pct'])
         m = mf.get(name, {})

@@ -14,7 +14,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd "$ROOT"
 # PMC_ARGS overrides the profiled program + arguments (e.g. PMC_ARGS="tools/gpu_netb.py 2048" for the NET-B passes)
-ARGS="${PMC_ARGS:-bench.py --lanes 1 --pool $POOL --steps 1 --warmup 1 --no-cpu-baseline --netb-pool 0}"
+ARGS="${PMC_ARGS:-bench.py --lanes 1 --pool $POOL --steps 1 --warmup 1 --no-cpu-baseline --no-accuracy --netb-pool 0}"
 export ALQ_BENCH_NO_EVENTS=1
 run() {   # name, extra rocprofv3 flags...
   local name="$1"; shift

@@ -27,11 +27,11 @@ class FlipT(C.Structure):
 
 
 # Width of the fragility window (|pre-activation| / rms of the layer's pre-activations, pool: gap / rms of its input).  MEASURED,
-# not assumed: over the bench patches the decisions whose inversion reproduces an engine's scores (shipped 16-bit splits and
-# the exact-fp32 engine alike) have keys up to 7.4e-7 (512 patches, 49 decisions, profiles/r06_accuracy_vs_fp64.json; bench.py
-# reports the figure of every run as accuracy.vs_fp64.fragility.max_key) - a few fp32 roundings (2^-24 = 6e-8) of a 432-term
-# pre-activation.  eps = 4e-6 is 5.4 x that maximum (round 5 used 2e-5, 27 x): wide enough that no explanation is missed, narrow
-# enough that an engine noticeably worse than fp32 would be left UNEXPLAINED; the tests assert max_key <= eps / 2.
+# not assumed: over the first 2047 bench patches the decisions whose inversion reproduces an engine's scores (shipped 16-bit splits
+# and the exact-fp32 engine alike) have keys up to 1.17e-6 (211 decisions, profiles/r06_accuracy_vs_fp64.json; bench.py reports the
+# figure of every run as accuracy.vs_fp64.fragility.max_key) - a few fp32 roundings (2^-24 = 6e-8) of a 432-term pre-activation.
+# eps = 4e-6 is 3.4 x that maximum (round 5 used 2e-5, 17 x): wide enough that no explanation is missed, narrow enough that an
+# engine noticeably worse than fp32 would be left UNEXPLAINED; the tests assert max_key <= eps / 2 on their 512 patches.
 DEFAULT_EPS = 4e-6
 
 FLIP_DTYPE = np.dtype([('layer', np.int32), ('pad', np.int32), ('idx', np.int64), ('delta', np.float64)])

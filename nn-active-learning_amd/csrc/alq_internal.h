@@ -81,7 +81,11 @@ struct ProfSlot {
 // the "memory" clobber keeps the store in front of it.  tools/isa_store_hazard.py checks the RESULT in the device assembly
 // of every build (csrc/build.sh): no such store may have a writer of its data registers within fewer wait states.
 #define ALQ_STORE_HOLD_STATES 2
+#ifdef ALQ_HOLD_NOMEM      // (timing experiment: what the "memory" clobber costs the schedule)
+#define ALQ_STORE_HOLD(...) asm volatile("s_nop 1" ::__VA_ARGS__)
+#else
 #define ALQ_STORE_HOLD(...) asm volatile("s_nop 1" ::__VA_ARGS__ : "memory")
+#endif
 
 #define ALQ_PARAM_BLOCK_BYTES 512
 

@@ -152,6 +152,7 @@ struct alq_model {
     int no_f16_derived = 0;        // 1 with ALQ_NO_F16_DERIVED=1: those launches stay on bf16x3 (A/B; default since round 5: they take the split)
     float *d_bound_L = nullptr, *d_bound_B = nullptr;      // per layer: out = in * L + B (k_fwd_bounds)
     int *d_bound_src = nullptr;
+    int no_light_kernels = 0;      // ALQ_NO_LIGHT_KERNELS (A/B): forward-only passes keep dec1 / enc2 + pool2 on the two-slot engine as until round 5
     int no_c3d = 0;                // ALQ_NO_C3D (A/B): the head conv pair on the two-slot engine (igemm4) as in round 3
     int c3_bwd_rows = 8;           // ALQ_C3D_BWD_ROWS=4 (A/B): the plane-sweep backward kernel in its half-patch form
     bool last_c3 = false;          // the last forward pass ran the head conv on the plane-sweep engine
@@ -991,9 +992,10 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                 if (fuse) take_amax(fz, i);
                 // the row-sweep engine (d3d.hip) where its geometry applies, both per-patch input bounds are known and nothing but the tensor,
                 // its channel sums and its sign field is wanted
+                // (round 6: forward-only passes too - the entropy filter over a pool is most of a query round - without sums / sign field)
                 if (fuse && ly.d3f.ok && ly.d3f.d_Whi && !m->no_d3d && fz.in_amax && fz.in_amax2 && !prod[i] && !g_no_f16x2 && !g_dbg_knobs[4] && !g_dbg_knobs[5] &&
-                    with_sums && fz.osumA && in.split == 16 && !(drop && drop->on(i))) {
-                    const bool sgd = !m->no_signs && ly.spec.relu && ly.out.sg;
+                    ((with_sums && fz.osumA) || (light && !m->no_light_kernels)) && in.split == 16 && !(drop && drop->on(i))) {
+                    const bool sgd = with_sums && !m->no_signs && ly.spec.relu && ly.out.sg;
                     ALQ_TRY(d3d_fwd_launch(ctx, ly.d3f, N, in.p, in.p + in.delta, fz.in_amax, fz.in_amax2, ly.d_bias, ly.spec.relu ? 1 : 0, ly.out.p,
                                            sgd ? ly.out.sg : nullptr, fz.osumA));
                     ly.signs_ready = sgd;
@@ -1003,11 +1005,12 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                 }
                 // enc2 + the pool behind it in one launch (f3d.hip): fp16 pairs under the first layer's measured maximum
                 if (fuse && ly.f3f.ok && ly.f3f.d_Whi && !m->no_f3d && cons[i] == 2 && fz.in_amax && !fz.in_amax2 && !prod[i] && !g_no_f16x2 && !g_dbg_knobs[4] && !g_dbg_knobs[5] &&
-                    with_sums && fz.osumA && sp.relu && in.split == 0 && !(drop && (drop->on(i) || drop->on(i + 1))) && nx && nx->spec.type == ALQ_POOL &&
+                    ((with_sums && fz.osumA) || (light && !m->no_light_kernels)) && sp.relu && in.split == 0 && !(drop && (drop->on(i) || drop->on(i + 1))) && nx && nx->spec.type == ALQ_POOL &&
                     nx->spec.k[0] == 2 && nx->spec.k[1] == 2 && nx->spec.k[2] == 2 && nx->lo[0] == 0 && nx->lo[1] == 0 && nx->lo[2] == 0 && nx->out.D == 8 && nx->out.H == 8 &&
                     nx->out.W == 8 && nx->out.C == 16 && nx->out.cs == 16 && nx->out.c0 == 0 && !nx->out.split && nx->argmax && !prod[i + 1]) {
-                    const bool sgd = !m->no_signs && ly.out.sg;
-                    ALQ_TRY(f3d_fwd_launch(ctx, ly.f3f, N, in.p, fz.in_amax, ly.d_bias, ly.out.p, sgd ? ly.out.sg : nullptr, fz.osumA, nx->out.p, nx->argmax, nx->osum));
+                    const bool sgd = with_sums && !m->no_signs && ly.out.sg;
+                    ALQ_TRY(f3d_fwd_launch(ctx, ly.f3f, N, in.p, fz.in_amax, ly.d_bias, ly.out.p, sgd ? ly.out.sg : nullptr, fz.osumA, nx->out.p, nx->argmax,
+                                           with_sums ? nx->osum : nullptr));
                     ly.signs_ready = sgd;
                     nx->signs_ready = false;
                     fused = true;
@@ -1662,6 +1665,7 @@ int alq_model_create(alq_ctx *ctx, const alq_layer_t *layers, int n_layers, cons
         m->no_presplit = getenv("ALQ_NO_PRESPLIT") != nullptr;
         m->no_c3d = getenv("ALQ_NO_C3D") != nullptr;
         // 7 (default): the 27 taps packed into 7 k-steps (c3d_bwd7_kernel); 8: the 9-k-step kernel of round 4; 4: its half-patch form
+        m->no_light_kernels = getenv("ALQ_NO_LIGHT_KERNELS") != nullptr;
         { const char *e = getenv("ALQ_C3D_BWD_ROWS"); m->c3_bwd_rows = (e && atoi(e) == 4) ? 4 : ((e && atoi(e) == 8) ? 8 : 7); }
         m->no_signs = getenv("ALQ_NO_SIGNS") != nullptr;
         m->no_signs0 = getenv("ALQ_NO_SIGNS0") != nullptr;

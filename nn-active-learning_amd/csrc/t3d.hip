@@ -21,6 +21,9 @@
 //     no d_x = 1 tap; backward: the 4th x tap slot) - irrelevant under the HBM bound.
 // Two 256-thread workgroups per CU (two waves per SIMD): one wave's loads / stores / split run beside the other's MFMAs.
 #include "alq_internal.h"
+#ifndef T3_CLOBBER
+#define T3_CLOBBER : "memory"
+#endif
 
 #include <algorithm>
 #include <cmath>
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void t3d_fwd_kernel(const T3FwdArgs a) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 3" :: "v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3]) : "memory");
+            asm volatile("s_nop 3" :: "v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3]) T3_CLOBBER);
         }
     }
 }
@@ -414,7 +417,9 @@ __global__ __launch_bounds__(256, 2) void t3d_bwd_kernel(const T3BwdArgs a) {
             }
             // (opaque: in the peeled void first pass v is a constant, and the compiler would otherwise materialise one copy for the
             // store and another for the hold below - the hold must name the registers the store reads, tools/isa_store_hazard.py)
+#ifndef T3_NO_OPAQUE
             asm volatile("" : "+v"(v));
+#endif
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), out_rsrc, (int)st_o, (int)(crow * 1024u), 0);
             if constexpr (SUMS) {
                 float s = (v.x + v.y) + (v.z + v.w);
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void t3d_bwd_kernel(const T3BwdArgs a) {
             }
             // (the store's data registers stay alive for a while: see the forward kernel's epilogue)
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 3" :: "v"(v) : "memory");
+            asm volatile("s_nop 3" :: "v"(v) T3_CLOBBER);
         }
     }
 }
@@ -597,7 +602,7 @@ __global__ __launch_bounds__(512, 2) void t3d8_fwd_kernel(const T8FwdArgs a) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 3" :: "v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3]), "v"(vv[4]), "v"(vv[5]), "v"(vv[6]), "v"(vv[7]) : "memory");      // (store data stays alive: t3d_fwd_kernel)
+            asm volatile("s_nop 3" :: "v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3]), "v"(vv[4]), "v"(vv[5]), "v"(vv[6]), "v"(vv[7]) T3_CLOBBER);      // (store data stays alive: t3d_fwd_kernel)
         }
     }
 }

@@ -1349,6 +1349,36 @@ def test_head_conv_backward_in_seven_k_steps_against_the_nine_k_step_kernel(sess
     m_old.close()
 
 
+def test_forward_only_passes_on_the_layer_kernels(sess):
+    """The entropy filter's pass (alq_forward: PW_NN.batch_eval 'posteriors', PW_NN.py:514-529) is most of a query round.  Since round 6
+    it runs NET-C's dec1 and enc2 + pool2 on the layer kernels of the Fisher pass (csrc/d3d.hip, f3d.hip: fp16 pairs under derived /
+    measured bounds, no sums, no sign field) instead of the two-slot engine (ALQ_NO_LIGHT_KERNELS=1): posteriors within 2e-6 of the
+    old path on 300 patches (an all-zero patch among them), predictions identical where |p - .5| > 1e-5, and the forward-only
+    posteriors EQUAL the Fisher pass's p1 bit for bit (same kernels, same arithmetic: what the filter ranks is what the scores use)."""
+    import ctypes as C
+    from nnal_amd._lib import check
+    torch = sess.torch
+    n = 300
+    ld, sk, in_shape, pars, (m_new, m_old) = _netc32_models(sess, [{}, {'ALQ_NO_LIGHT_KERNELS': '1'}], max_batch=n, bias_std=0.05)
+    x = sess.empty((n, 32 ** 3), torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, 32 ** 3, C.c_void_p(x.data_ptr())))
+    x[17].zero_()
+    post, pred = [], []
+    for m in (m_new, m_old):
+        po, pr, _ = m.forward_device(x, n, want_pred=True)
+        post.append(po.cpu().numpy())
+        pred.append(pr.cpu().numpy())
+        info = (sess.lib.alq_model_engine_info(m._m, 10), sess.lib.alq_model_engine_info(m._m, 12))
+        assert info == ((1, 1) if m is m_new else (0, 0)), info
+    np.testing.assert_allclose(post[0], post[1], rtol=0, atol=2e-6)
+    sure = np.abs(post[1][1] - .5) > 1e-5
+    np.testing.assert_array_equal(pred[0][sure], pred[1][sure])
+    p1 = m_new.fisher_device(x, n, None, 1e-3, want=('p1',))['p1'].cpu().numpy()
+    np.testing.assert_array_equal(post[0][1], p1)
+    m_new.close()
+    m_old.close()
+
+
 def test_fp16_forward_with_derived_bounds_against_bf16_triples(sess):
     """Default since round 5 (ALQ_NO_F16_DERIVED=1 is the other arm): NET-C's `dec1` forward launch on the fp16-pair split, its per-patch input maxima DERIVED from the first
     layer's measured maximum through the layers' L1 norms (csrc/kernels.hip, fwd_bounds_kernel) instead of measured.  Against the

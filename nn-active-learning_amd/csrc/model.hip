@@ -50,6 +50,11 @@ struct Layer {
     float *d_bias = nullptr;
     float *d_Wp = nullptr;     // skinny fc: [nout][F] in activation-memory order
     std::vector<Gemm> fwd;        // 1 contraction (conv / fc) or one per output parity class (convT)
+    // conv whose output is too wide for the matrix-core engines (NET-B's 96-channel conv: igemm2 / igemm3 hold <= 48, the two-slot
+    // engine <= 32 output channels) and would run on the fp32 engine: the same contraction as launches of fwd_co_w output channels
+    // each, writing channel slices of the output (round 6)
+    std::vector<Gemm> fwd_co;
+    int fwd_co_w = 0;
     Igemm4Plan fwd_all;           // convT: every output class from one staged block (igemm4.hip), when eligible
     Gemm bwd;
     bool has_bwd = false;
@@ -623,6 +628,22 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
             g4.OD = ly.out.D; g4.OH = ly.out.H; g4.OW = ly.out.W; g4.Co = sp.cout;
             for (int q = 0; q < 3; ++q) { g4.k[q] = sp.k[q]; g4.s[q] = sp.s[q]; g4.lo[q] = ly.lo[q]; }
             ALQ_TRY(gemm_build(d, NB, &ly.fwd[0], &g4));
+            if (!ly.fwd[0].p4.ok && !ly.fwd[0].p3.ok && !ly.fwd[0].pd.ok && sp.cout > 32 && !getenv("ALQ_NO_CO_SPLIT")) {
+                for (int w : {32, 48, 16}) {
+                    if (sp.cout % w || sp.cout <= w) continue;
+                    std::vector<Gemm> parts(sp.cout / w);
+                    bool ok = true;
+                    for (size_t j = 0; j < parts.size() && ok; ++j) {
+                        ConvDesc dj = d;
+                        dj.Co = w;
+                        G4Geom gj = g4;
+                        gj.Co = w;
+                        ALQ_TRY(gemm_build(dj, NB, &parts[j], &gj));
+                        ok = parts[j].p4.ok || parts[j].p3.ok;
+                    }
+                    if (ok) { ly.fwd_co = std::move(parts); ly.fwd_co_w = w; break; }
+                }
+            }
             if (!first_param && sp.relu) {
                 ALQ_TRY(c3d_fwd_build(ly.in, ly.out, sp.k, ly.lo, sp.s, &ly.c3f));
                 ALQ_TRY(c3d_bwd_build(ly.in, ly.out, sp.k, ly.lo, sp.s, &ly.c3b));
@@ -1019,6 +1040,19 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                     break;
                 }
                 if (fuse && prod[i]) fz.out_amax = m->amax_tiles;
+                if (!ly.fwd_co.empty() && !prod[i] && !cons[i] && !g_dbg_knobs[4] && !g_dbg_knobs[5]) {
+                    // a wide conv as launches over slices of its output channels (no epilogue fusion: channel sums and ReLU masks the plain way)
+                    for (size_t j = 0; j < ly.fwd_co.size(); ++j) {
+                        View oj = ly.out;
+                        oj.c0 = ly.out.c0 + (int)j * ly.fwd_co_w;
+                        oj.C = ly.fwd_co_w;
+                        bool f1 = false;
+                        ALQ_TRY(gemm_launch(ctx, ly.fwd_co[j], in, oj, ly.d_bias + j * ly.fwd_co_w, ly.spec.relu, 0, N, PROF_IGEMM_FWD, nullptr, &f1));
+                    }
+                    fused = false;
+                    ly.signs_ready = false;
+                    break;
+                }
                 const bool sg_here = with_sums && fuse && !m->no_signs && ly.spec.relu && ly.out.sg && v4_fwd(ly.fwd[0], in, ly.out);
                 if (sg_here) fz.sign_out = ly.out.sg;
                 ALQ_TRY(gemm_launch(ctx, ly.fwd[0], in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM_FWD, fuse, &fused));
@@ -1816,6 +1850,13 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
         // TF [tap][ci][co] is already the fwd B matrix [(tap, ci)][co]
         std::vector<float> B(W, W + ly.w_elems);
         ALQ_TRY(gemm_set(m, &ly.fwd[0], B));
+        for (size_t j = 0; j < ly.fwd_co.size(); ++j) {      // the output-channel slices of a wide conv: columns [j w, (j + 1) w) of B
+            const int w = ly.fwd_co_w, K = ntaps * Ci;
+            std::vector<float> Bj((size_t)K * w);
+            for (int k = 0; k < K; ++k)
+                for (int c = 0; c < w; ++c) Bj[(size_t)k * w + c] = B[(size_t)k * Co + j * w + c];
+            ALQ_TRY(gemm_set(m, &ly.fwd_co[j], Bj));
+        }
         if (ly.c3f.ok) {
             // one accumulator (pieces at their true scale) only where the matrix cores honour fp16 subnormals
             if (ly.c3f.oneacc && !c3d_subnormals_ok(m->ctx)) ly.c3f.oneacc = 0;

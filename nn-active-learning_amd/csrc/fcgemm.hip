@@ -84,26 +84,32 @@ __device__ inline int fc_row_exp(unsigned fm) {
     return fm ? (ce < 96 ? ce : 96) : 0;
 }
 
-template <bool F16>
+// BN = features per workgroup tile: 64 (the packed weight tile), or 128 = two packed tiles side by side (fp16 pairs only, round 6):
+// a wave then owns 64 x 64 = 4 x 4 MFMA tiles - 16 fragment reads per 48 MFMAs instead of 12 per 24 (the 64-wide kernel is
+// LDS-read bound: 56 % LDS active at 28 % MFMA busy) - and the activation tile is staged and split for half as many workgroups.
+template <bool F16, int BN>
 __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
+    static_assert(BN == FC_BN || (F16 && BN == 2 * FC_BN), "128-wide tiles for the fp16-pair form only");
     constexpr int NP = F16 ? 2 : 3;                     // pieces per operand
-    constexpr int XB = NP * 4 * FC_BM * 16, WB = NP * 4 * FC_BN * 16;
+    constexpr int NC = BN / FC_BN;                      // packed 64-feature weight tiles per workgroup
+    constexpr int NI = BN / 32;                         // MFMA column tiles per wave
+    constexpr int XB = NP * 4 * FC_BM * 16, WB = NP * 4 * BN * 16, WB64 = NP * 4 * FC_BN * 16;
     extern __shared__ __attribute__((aligned(16))) char fc_lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & 15, lq = lane >> 4;
     const int nt = blockIdx.x, mt = blockIdx.y;
-    const int m0 = mt * FC_BM, n0 = nt * FC_BN;
+    const int m0 = mt * FC_BM, n0 = nt * BN;
     const int nks = a.K / FC_BK;
     auto Xbuf = [&](int buf) { return fc_lds + buf * (XB + WB); };
     auto Wbuf = [&](int buf) { return fc_lds + buf * (XB + WB) + XB; };
 
     // staging roles: activations: 2 tasks per thread, task = (row, k-group): 8 floats; weights: 3 x 16 B per thread
     const int xr0 = tid >> 2, xq = tid & 3;          // rows xr0 and xr0 + 64, k-group xq
-    const char *wsrc = reinterpret_cast<const char *>(a.Bp) + (size_t)nt * nks * WB + tid * 16;
+    const char *wsrc = reinterpret_cast<const char *>(a.Bp) + (size_t)(nt * NC) * nks * WB64 + tid * 16;
     f32x4 xa[2][2];
-    i32x4 wr[NP];
+    i32x4 wr[NC][NP];
     float rsc[2] = {a.scale, a.scale};          // F16: scale of this thread's two staging rows
     if constexpr (F16) {
         if (a.row_amax) {
@@ -127,9 +133,12 @@ __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
                 xa[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        const char *ws = wsrc + (size_t)ks * WB;
 #pragma unroll
-        for (int j = 0; j < NP; ++j) wr[j] = *reinterpret_cast<const i32x4 *>(ws + j * 4096);
+        for (int c = 0; c < NC; ++c) {
+            const char *ws = wsrc + ((size_t)c * nks + ks) * WB64;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) wr[c][j] = *reinterpret_cast<const i32x4 *>(ws + j * 4096);
+        }
     };
     auto stash = [&](int buf) {
 #pragma unroll
@@ -161,17 +170,21 @@ __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) *reinterpret_cast<i32x4 *>(Xbuf(buf) + ((p * 4 + xq) * FC_BM + row) * 16) = pc[p];
         }
+        // LDS weights: [piece][k-group q][BN feature rows] x 16 bytes; thread = (q = tid >> 6, row = tid & 63) of its 64-feature tile
 #pragma unroll
-        for (int j = 0; j < NP; ++j) *reinterpret_cast<i32x4 *>(Wbuf(buf) + tid * 16 + j * 4096) = wr[j];
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int j = 0; j < NP; ++j)
+                *reinterpret_cast<i32x4 *>(Wbuf(buf) + ((j * 4 + (tid >> 6)) * BN + c * FC_BN + (tid & 63)) * 16) = wr[c][j];
     };
 
-    // wave tile: 64 patches x 32 features = 4 x 2 MFMA tiles
-    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 32;
-    f32x4 acc[4][2];
+    // wave tile: 64 patches x BN / 2 features = 4 x NI MFMA tiles
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * (BN / 2);
+    f32x4 acc[4][NI];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
             acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int n = n0 + wn + ni * 16 + lq * 4;
             if (!F16 && a.bias) acc[mi][ni] = *reinterpret_cast<const f32x4 *>(a.bias + n);      // (F16 launches carry no bias: the host checks)
@@ -183,12 +196,12 @@ __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
     for (int ks = 0; ks < nks; ++ks) {
         const int buf = ks & 1;
         if (ks + 1 < nks) fetch(ks + 1);
-        i32x4 Wf[NP][2], Xf[NP][4];
+        i32x4 Wf[NP][NI], Xf[NP][4];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-                Wf[p][ni] = *reinterpret_cast<const i32x4 *>(Wbuf(buf) + ((p * 4 + lq) * FC_BN + wn + ni * 16 + lrow) * 16);
+            for (int ni = 0; ni < NI; ++ni)
+                Wf[p][ni] = *reinterpret_cast<const i32x4 *>(Wbuf(buf) + ((p * 4 + lq) * BN + wn + ni * 16 + lrow) * 16);
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
                 Xf[p][mi] = *reinterpret_cast<const i32x4 *>(Xbuf(buf) + ((p * 4 + lq) * FC_BM + wm + mi * 16 + lrow) * 16);
@@ -197,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
+            for (int ni = 0; ni < NI; ++ni) {
                 f32x4 c = acc[mi][ni];
                 if constexpr (F16) {
                     auto H = [](const i32x4 &v) { return __builtin_bit_cast(f16x8, v); };
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
         const int m = m0 + wm + mi * 16 + lrow;
         if (m >= a.M) continue;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
             f32x4 v = acc[mi][ni];
             if constexpr (F16) {
                 const float iv = a.row_amax ? __builtin_ldexpf(1.f, -(fc_row_exp(a.row_amax[m]) + a.e_w)) : a.inv;
@@ -313,6 +326,23 @@ void fcgemm_pack_weights_f16(FcGemmPlan *plan, const std::vector<float> &Bmat /*
         }
 }
 
+// the fp16-pair launch: 128-feature tiles where the layer's width allows (ALQ_FC_BN64=1: the 64-wide kernel, A/B)
+static int fc16_go(alq_ctx *ctx, const FcGemmPlan &plan, const FcGemmArgs &a, int M) {
+    static const bool bn64 = getenv("ALQ_FC_BN64") != nullptr;
+    ProfScope ps16(ctx, PROF_IGEMM_F16, 2.0 * M * (double)plan.K * plan.N);
+    if (plan.N % (2 * FC_BN) == 0 && !bn64) {
+        const size_t lds = 2 * (2 * 4 * FC_BM * 16 + 2 * 4 * (2 * FC_BN) * 16);
+        ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fcgemm_kernel<true, 2 * FC_BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((fcgemm_kernel<true, 2 * FC_BN>), dim3(plan.N / (2 * FC_BN), (M + FC_BM - 1) / FC_BM), dim3(256), lds, ctx->stream, a);
+    } else {
+        const size_t lds = 2 * (2 * 4 * FC_BM * 16 + 2 * 4 * FC_BN * 16);
+        ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fcgemm_kernel<true, FC_BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((fcgemm_kernel<true, FC_BN>), dim3(plan.N / FC_BN, (M + FC_BM - 1) / FC_BM), dim3(256), lds, ctx->stream, a);
+    }
+    ALQ_HIP(hipGetLastError());
+    return ALQ_OK;
+}
+
 int fcgemm_launch(alq_ctx *ctx, const FcGemmPlan &plan, const View &in, const View &out, const float *bias, int relu,
                   int M, int prof_cls, float in_bound, unsigned *row_amax) {
     ALQ_REQUIRE(plan.d_W && in.C == plan.K && out.C == plan.N && in.c0 == 0 && out.c0 == 0 && in.cs % 4 == 0 && out.cs % 4 == 0 &&
@@ -327,11 +357,7 @@ int fcgemm_launch(alq_ctx *ctx, const FcGemmPlan &plan, const View &in, const Vi
         hipLaunchKernelGGL(fc_rowmax_kernel, dim3((M + 3) / 4), dim3(256), 0, ctx->stream, in.p, M, plan.K, in.cs, row_amax);
         a.Bp = plan.d_W16;
         a.row_amax = row_amax;
-        const size_t lds16 = 2 * (2 * 4 * FC_BM * 16 + 2 * 4 * FC_BN * 16);
-        ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fcgemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
-        ProfScope ps16(ctx, PROF_IGEMM_F16, 2.0 * M * (double)plan.K * plan.N);
-        hipLaunchKernelGGL(fcgemm_kernel<true>, grid, dim3(256), lds16, ctx->stream, a);
-        ALQ_HIP(hipGetLastError());
+        ALQ_TRY(fc16_go(ctx, plan, a, M));
         return ALQ_OK;
     }
     if (in_bound > 0.f && plan.d_W16 && !bias) {      // fp16 pairs under a static bound on the input (a backward launch of a Fisher pass)
@@ -340,17 +366,13 @@ int fcgemm_launch(alq_ctx *ctx, const FcGemmPlan &plan, const View &in, const Vi
         const int e_in = 14 - ex;
         a.Bp = plan.d_W16;
         a.scale = std::ldexp(1.f, e_in); a.inv = std::ldexp(1.f, -(e_in + plan.w_exp));
-        const size_t lds16 = 2 * (2 * 4 * FC_BM * 16 + 2 * 4 * FC_BN * 16);
-        ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fcgemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
-        ProfScope ps16(ctx, PROF_IGEMM_F16, 2.0 * M * (double)plan.K * plan.N);
-        hipLaunchKernelGGL(fcgemm_kernel<true>, grid, dim3(256), lds16, ctx->stream, a);
-        ALQ_HIP(hipGetLastError());
+        ALQ_TRY(fc16_go(ctx, plan, a, M));
         return ALQ_OK;
     }
     const size_t lds = 2 * (FC_XBYTES + FC_WBYTES);
-    ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fcgemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fcgemm_kernel<false, FC_BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope ps(ctx, prof_cls, 2.0 * M * (double)plan.K * plan.N);
-    hipLaunchKernelGGL(fcgemm_kernel<false>, grid, dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL((fcgemm_kernel<false, FC_BN>), grid, dim3(256), lds, ctx->stream, a);
     ALQ_HIP(hipGetLastError());
     return ALQ_OK;
 }

@@ -90,10 +90,14 @@ __device__ inline int fc_row_exp(unsigned fm) {
 template <bool F16, int BN>
 __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
     static_assert(BN == FC_BN || (F16 && BN == 2 * FC_BN), "128-wide tiles for the fp16-pair form only");
+    // WD: the weight fragments come straight from global memory (the packed layout IS the MFMA lane layout: 256 contiguous bytes per
+    // 16 lanes), one k-step ahead in registers, instead of through LDS: the 64-wide kernel's LDS was 56 % active - 32 KB of writes
+    // at ~80 B/clk and 64 KB of fragment reads per k-step - of which the weights were half
+    constexpr bool WD = BN == 2 * FC_BN;
     constexpr int NP = F16 ? 2 : 3;                     // pieces per operand
     constexpr int NC = BN / FC_BN;                      // packed 64-feature weight tiles per workgroup
     constexpr int NI = BN / 32;                         // MFMA column tiles per wave
-    constexpr int XB = NP * 4 * FC_BM * 16, WB = NP * 4 * BN * 16, WB64 = NP * 4 * FC_BN * 16;
+    constexpr int XB = NP * 4 * FC_BM * 16, WB = WD ? 0 : NP * 4 * BN * 16, WB64 = NP * 4 * FC_BN * 16;
     extern __shared__ __attribute__((aligned(16))) char fc_lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -110,6 +114,15 @@ __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
     const char *wsrc = reinterpret_cast<const char *>(a.Bp) + (size_t)(nt * NC) * nks * WB64 + tid * 16;
     f32x4 xa[2][2];
     i32x4 wr[NC][NP];
+    // WD: this lane's fragment of MFMA column tile ni = feature row wn + 16 ni + lrow, k-group lq, of packed tile (row >> 6)
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * (BN / 2);
+    i32x4 Wn[NP][NI];
+    const char *wfrag[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int rowf = wn + ni * 16 + lrow;
+        wfrag[ni] = reinterpret_cast<const char *>(a.Bp) + (size_t)(nt * NC + (rowf >> 6)) * nks * WB64 + (lq * FC_BN + (rowf & 63)) * 16;
+    }
     float rsc[2] = {a.scale, a.scale};          // F16: scale of this thread's two staging rows
     if constexpr (F16) {
         if (a.row_amax) {
@@ -133,11 +146,18 @@ __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
                 xa[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
+        if constexpr (WD) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const char *ws = wsrc + ((size_t)c * nks + ks) * WB64;
+            for (int p = 0; p < NP; ++p)
 #pragma unroll
-            for (int j = 0; j < NP; ++j) wr[c][j] = *reinterpret_cast<const i32x4 *>(ws + j * 4096);
+                for (int ni = 0; ni < NI; ++ni) Wn[p][ni] = *reinterpret_cast<const i32x4 *>(wfrag[ni] + (size_t)ks * WB64 + p * 4096);
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const char *ws = wsrc + ((size_t)c * nks + ks) * WB64;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) wr[c][j] = *reinterpret_cast<const i32x4 *>(ws + j * 4096);
+            }
         }
     };
     auto stash = [&](int buf) {
@@ -171,15 +191,16 @@ __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
             for (int p = 0; p < NP; ++p) *reinterpret_cast<i32x4 *>(Xbuf(buf) + ((p * 4 + xq) * FC_BM + row) * 16) = pc[p];
         }
         // LDS weights: [piece][k-group q][BN feature rows] x 16 bytes; thread = (q = tid >> 6, row = tid & 63) of its 64-feature tile
+        if constexpr (!WD) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
+            for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int j = 0; j < NP; ++j)
-                *reinterpret_cast<i32x4 *>(Wbuf(buf) + ((j * 4 + (tid >> 6)) * BN + c * FC_BN + (tid & 63)) * 16) = wr[c][j];
+                for (int j = 0; j < NP; ++j)
+                    *reinterpret_cast<i32x4 *>(Wbuf(buf) + ((j * 4 + (tid >> 6)) * BN + c * FC_BN + (tid & 63)) * 16) = wr[c][j];
+        }
     };
 
     // wave tile: 64 patches x BN / 2 features = 4 x NI MFMA tiles
-    const int wm = (wave & 1) * 64, wn = (wave >> 1) * (BN / 2);
     f32x4 acc[4][NI];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -195,13 +216,19 @@ __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
     __syncthreads();
     for (int ks = 0; ks < nks; ++ks) {
         const int buf = ks & 1;
-        if (ks + 1 < nks) fetch(ks + 1);
         i32x4 Wf[NP][NI], Xf[NP][4];
+        if constexpr (WD) {      // the fragments fetched one k-step ago (fetch(0) in front of the loop)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) Wf[p][ni] = Wn[p][ni];
+        }
+        if (ks + 1 < nks) fetch(ks + 1);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-                Wf[p][ni] = *reinterpret_cast<const i32x4 *>(Wbuf(buf) + ((p * 4 + lq) * BN + wn + ni * 16 + lrow) * 16);
+                if constexpr (!WD) Wf[p][ni] = *reinterpret_cast<const i32x4 *>(Wbuf(buf) + ((p * 4 + lq) * BN + wn + ni * 16 + lrow) * 16);
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
                 Xf[p][mi] = *reinterpret_cast<const i32x4 *>(Xbuf(buf) + ((p * 4 + lq) * FC_BM + wm + mi * 16 + lrow) * 16);
@@ -331,7 +358,7 @@ static int fc16_go(alq_ctx *ctx, const FcGemmPlan &plan, const FcGemmArgs &a, in
     static const bool bn64 = getenv("ALQ_FC_BN64") != nullptr;
     ProfScope ps16(ctx, PROF_IGEMM_F16, 2.0 * M * (double)plan.K * plan.N);
     if (plan.N % (2 * FC_BN) == 0 && !bn64) {
-        const size_t lds = 2 * (2 * 4 * FC_BM * 16 + 2 * 4 * (2 * FC_BN) * 16);
+        const size_t lds = 2 * (2 * 4 * FC_BM * 16);          // activations only: the weight fragments come from global memory
         ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fcgemm_kernel<true, 2 * FC_BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((fcgemm_kernel<true, 2 * FC_BN>), dim3(plan.N / (2 * FC_BN), (M + FC_BM - 1) / FC_BM), dim3(256), lds, ctx->stream, a);
     } else {

@@ -1803,6 +1803,11 @@ int alq_model_set_weights(alq_model *m, int t, const float *W, const float *b) {
     ALQ_REQUIRE(lyp != nullptr, ALQ_EINVAL, "no parameterised layer %d", t);
     Layer &ly = *lyp;
     const alq_layer_t &sp = ly.spec;
+    // Which kernels get their weights packed below depends on whether the matrix cores keep fp16 subnormals: the answer is a
+    // property of the device, probed once per context.  A probe that could not RUN must not select engines (it used to read as
+    // "flushes subnormals" for this call only: the plans of one layer then differed from the others' for good): retry, then fail.
+    for (int tries = 0; tries < 3 && m->ctx->f16_subnormal_mfma < 0; ++tries) (void)c3d_subnormals_ok(m->ctx);
+    ALQ_REQUIRE(m->ctx->f16_subnormal_mfma >= 0, ALQ_EHIP, "alq_model_set_weights: the fp16-subnormal probe of the matrix cores could not run (device error)");
     ALQ_HIP(hipMemcpyAsync(ly.d_bias, b, ly.b_elems * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
     const int Ci = ly.in.C, Co = sp.cout;
     const int ntaps = sp.k[0] * sp.k[1] * sp.k[2];

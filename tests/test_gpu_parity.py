@@ -1081,7 +1081,7 @@ def test_default_engines_against_fp64_flip_safe_head(sess, n=64):
     g0, g1 = r['g0'].cpu().numpy(), r['g1'].cpu().numpy()
     off = np.nonzero((np.maximum(np.abs(g0 - g64), np.abs(g1 - h64)) > 2e-6).any(axis=1))[0]
     # The head conv's own decisions are exact given its inputs; what remains (round 4, 64 patches instead of 16: ~6 % of the
-    # patches hold such a unit, tools/gpu_fullbatch_dbg.py) is a pre-activation within rounding of zero whose INPUTS - the
+    # patches hold such a unit, profiles/r04_fullbatch_engine_disagreements.txt) is a pre-activation within rounding of zero whose INPUTS - the
     # outputs of fp32-level launches upstream - put it on the other side than the fp64 network has it.  A ReLU derivative is a
     # step, so the scores jump by up to ~1e-3; every fp32 implementation has these patches (the exact-fp32 engine: others).
     # Each one must be explained by the fp64 arbiter, and there must be few.

@@ -348,3 +348,34 @@ def test_store_hazard_gate_flags_an_early_rewrite_of_store_data(tmp_path):
         for ln in open(rep):
             m = re.search(r'(\d+) 12/16-byte stores.*rewritten: (\w+)', ln)
             assert m and (int(m.group(1)) == 0 or int(m.group(2)) >= 2), ln
+
+
+def test_ref64_host_side_scores_and_flip_records():
+    """nnal_amd/ref64.py, the host half of the fp64 device reference: `scores` forms p1, g0, g1, A from logits and layer sums exactly as
+    gen_A_matrices does (tests/factored_ref.fisher_from_unit restates PW_NNAL.py:770-814), saturation branches included, and the
+    flip record is the 24-byte alq_flip_t of include/alq.h."""
+    from nnal_amd import ref64
+    from tests import factored_ref
+    assert ref64.FLIP_DTYPE.itemsize == 24 and ref64.FLIP_DTYPE.names == ('layer', 'pad', 'idx', 'delta')
+    hdr = open(os.path.join(os.path.dirname(_lib.LIB_PATH), '..', 'include', 'alq.h')).read()
+    assert re.search(r'int32_t layer;\s*int32_t pad;\s*int64_t idx;\s*double delta;\s*}\s*alq_flip_t;', hdr)
+    r = ref64.Ref64.__new__(ref64.Ref64)
+    r.L = 5
+    r.sizes = np.array([10., 2000., 33., 7., 4098.])
+    rs = np.random.RandomState(3)
+    z = rs.randn(40, 2) * 4
+    z[0] = (-30., 30.)          # p1 > 1 - 1e-6
+    z[1] = (30., -30.)          # p1 < 1e-6
+    S = rs.randn(40, 5) * 100
+    out = r.scores(z, S, diag_load=1e-3)
+    p = np.exp(z - z.max(1, keepdims=True))
+    p1 = p[:, 1] / p.sum(1)
+    g0, g1, A = factored_ref.fisher_from_unit(p1, S, r.sizes, 1e-3)
+    g0[1 - p1 < 1e-6] = 0.          # (fisher_from_unit zeroes the skipped class inside A only)
+    g1[p1 < 1e-6] = 0.
+    np.testing.assert_allclose(out['p1'], p1, rtol=1e-14)
+    np.testing.assert_allclose(out['g0'], g0, rtol=1e-13, atol=0)
+    np.testing.assert_allclose(out['g1'], g1, rtol=1e-13, atol=0)
+    np.testing.assert_allclose(out['A'], A, rtol=1e-12, atol=1e-18)
+    assert ref64.Ref64.close(np.array([1.0, 2.0]), np.array([1.0 + 1e-6, 2.0]))
+    assert not ref64.Ref64.close(np.array([1.0, 2.0]), np.array([1.001, 2.0]))

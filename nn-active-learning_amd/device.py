@@ -733,14 +733,23 @@ class DeviceModel(object):
         # small kernels run beside the next pass's first launches instead of leaving the chip idle.  Each pass is the same
         # launches on the same data whichever pipeline runs it, so every per-patch output is bit-identical to ALQ_LANES=1;
         # the passes' partial sums of A are added in pass order after the join.
-        starts = list(range(0, n, self.max_batch))
+        # Pass sizes: an EVEN number of equal passes, so that two pipelines get the same work (100,000 patches at 2047 per pass are
+        # 49 passes - one pipeline runs 25 of them and the other idles through the last one: 268.0 against 272.7 k patches/s
+        # same-box, three rounds).  Per-patch results do not depend on the cut (tests: any batch cut is bit-identical); the cut itself
+        # does not depend on the number of pipelines, so the pass-ordered sum of A is the same bits with one pipeline or two
+        step = self.max_batch
+        if n > self.max_batch and not os.environ.get('ALQ_NO_PASS_BALANCE'):
+            P = -(-n // self.max_batch)
+            P += P & 1
+            step = -(-n // P)
+        starts = list(range(0, n, step))
         lane2 = self._second_lane() if (self.lanes > 1 and len(starts) > 1) else None
         part = self.sess.empty((max(len(starts), 1), L, L), torch.float64) if asum is not None else None
         cur = torch.cuda.current_stream(self.sess.device)
         if lane2 is not None:
             lane2['stream'].wait_stream(cur)          # inputs, output buffers and the weights are ordered on the caller's stream
         for k, a in enumerate(starts):
-            b = min(n, a + self.max_batch)
+            b = min(n, a + step)
             outs = (ptr(p1_in, a, 4), float(diag_load), ptr(out['p1'], a, 4), ptr(out['g0'], a * L, 8),
                     ptr(out['g1'], a * L, 8), ptr(out['A'], a * L * L, 8), ptr(out['trace'], a, 8),
                     C.c_void_p(part.data_ptr() + k * L * L * 8) if part is not None else None)

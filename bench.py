@@ -50,9 +50,10 @@ def main():
     ap.add_argument('--pool-global', type=int, default=0, help='strong scaling: one pool of this many patches over all GPUs')
     ap.add_argument('--netb-pool', type=int, default=16384, help='patches of the NET-B side measurement at N = 1 (0 = skip)')
     ap.add_argument('--batch', type=int, default=2047,
-                    help='patches per device pass.  2047 = the most the engines\' unsigned 32-bit tensor offsets address for 32^3 NET-C '
-                         '(the library clamps a larger request to it), and all but one of the 256 plane-sweep workgroups then hold '
-                         'exactly 8 patches (batch 2000: 208 hold 8, 48 hold 7; same-box A/B +1.2 %%, profiles/r04af_batch_sweep.txt)')
+                    help='most patches per device pass.  2047 = the most the engines\' unsigned 32-bit tensor offsets address for 32^3 NET-C '
+                         '(the library clamps a larger request to it).  fisher_device cuts a pool into an EVEN number of equal passes of at '
+                         'most this size, so that the two scoring pipelines get the same work (100,000 patches: 50 passes of 2000; '
+                         '+1.75 %% same-box against 48 x 2047 + 1744)')
     ap.add_argument('--topB', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-accuracy', action='store_true', help='skip the accuracy passes behind the timed region (PMC / sweep runs: their fp64 kernels would dominate a short trace)')

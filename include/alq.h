@@ -58,6 +58,11 @@ int alq_ctx_destroy(alq_ctx *ctx);
 /* Moves the context to another stream; the new stream first waits (event) for everything the library enqueued on the old
  * one, so back-to-back calls on two streams need no host synchronisation.                                           */
 int alq_ctx_set_stream(alq_ctx *ctx, void *stream);
+/* on = 0: the per-layer statistics kernels of later alq_fisher calls stay on the caller's stream instead of the context's side
+ * stream (on = 1, the default, restores it).  For a caller that overlaps WHOLE passes on two contexts (device.DeviceModel's two
+ * scoring pipelines): the other pipeline's launches already fill the gaps, and four streams competing cost 1.2 % (round 6).
+ * Results do not depend on it (same kernels, same order per context).                                                      */
+int alq_ctx_use_side_stream(alq_ctx *ctx, int on);
 int alq_ctx_synchronize(alq_ctx *ctx);
 
 /* ---- model ------------------------------------------------------------------------------ */

@@ -27,6 +27,7 @@ _SIGNATURES = {
     'alq_version': (C.c_int, []),
     'alq_ctx_create': (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
     'alq_ctx_destroy': (C.c_int, [_P]),
+    'alq_ctx_use_side_stream': (C.c_int, [_P, C.c_int]),
     'alq_ctx_set_stream': (C.c_int, [_P, _P]),
     'alq_ctx_synchronize': (C.c_int, [_P]),
     'alq_model_create': (C.c_int, [_P, C.POINTER(LayerT), C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(_P)]),

@@ -103,6 +103,7 @@ struct alq_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool side_used = false;
+    bool side_off = false;     // alq_ctx_use_side_stream(ctx, 0): statistics kernels stay on the main stream (a caller that overlaps whole passes on two contexts)
     void *param_block = nullptr;   // small device buffer for per-call parameters (gather)
     void *comm = nullptr;          // RCCL communicator of this rank (comm.hip), or null
     int comm_rank = 0, comm_world = 1;

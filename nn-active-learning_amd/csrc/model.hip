@@ -1139,7 +1139,7 @@ struct SideStream {
     hipStream_t main;
     bool on = false;
     explicit SideStream(alq_ctx *ctx) : c(ctx), main(ctx->stream) {
-        if (!c->side) return;
+        if (!c->side || c->side_off) return;
         if (hipEventRecord(c->ev_fork, main) != hipSuccess || hipStreamWaitEvent(c->side, c->ev_fork, 0) != hipSuccess) {
             (void)hipGetLastError();
             return;
@@ -1653,6 +1653,12 @@ int alq_ctx_destroy(alq_ctx *ctx) {
     }
     (void)hipFree(ctx->param_block);
     delete ctx;
+    return ALQ_OK;
+}
+
+int alq_ctx_use_side_stream(alq_ctx *ctx, int on) {
+    ALQ_REQUIRE(ctx != nullptr, ALQ_EINVAL, "null ctx");
+    ctx->side_off = on == 0;
     return ALQ_OK;
 }
 

@@ -746,7 +746,13 @@ class DeviceModel(object):
         lane2 = self._second_lane() if (self.lanes > 1 and len(starts) > 1) else None
         part = self.sess.empty((max(len(starts), 1), L, L), torch.float64) if asum is not None else None
         cur = torch.cuda.current_stream(self.sess.device)
+        # with two pipelines whole passes overlap: the per-context side streams (the statistics kernels of a layer beside its
+        # contraction) then only add two more streams competing for the same gaps (274.4 -> 277.8 k patches/s without them, same
+        # box, three rounds); a single pipeline keeps its side stream (+3.4 %, round 4).  Same kernels, same results either way.
+        side_on = 0 if (lane2 is not None and not os.environ.get('ALQ_LANES_SIDE_STREAM')) else 1
+        check(self.lib.alq_ctx_use_side_stream(self.sess.ctx, side_on))
         if lane2 is not None:
+            check(self.lib.alq_ctx_use_side_stream(lane2['sess'].ctx, side_on))
             lane2['stream'].wait_stream(cur)          # inputs, output buffers and the weights are ordered on the caller's stream
         for k, a in enumerate(starts):
             b = min(n, a + step)
@@ -767,6 +773,8 @@ class DeviceModel(object):
                 launch(self._m)
         if lane2 is not None:
             cur.wait_stream(lane2['stream'])
+        if not side_on:
+            check(self.lib.alq_ctx_use_side_stream(self.sess.ctx, 1))
         if asum is not None:
             for k in range(len(starts)):
                 asum += part[k]

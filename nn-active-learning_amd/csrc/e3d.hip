@@ -65,6 +65,7 @@ constexpr int E3_RING = 6;                    // row slots per plane
 constexpr int E3_PLANE = E3_RING * E3_SLOT;
 constexpr int E3_STRIP = 6 * E3_PLANE;        // planes 4 q - 1 .. 4 q + 4
 constexpr int E3_WLO = 9 * 2 * 1024;          // lo weight fragments
+constexpr int E3_SINK = E3_SLOT;              // behind the ring: where the void steps' rows go (see the staging)
 
 __device__ inline __amdgpu_buffer_rsrc_t e3_rsrc(const void *base, unsigned long long bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)(unsigned)bytes, 0x00020000);
@@ -237,7 +238,9 @@ __global__ __launch_bounds__(256, 2) void e3d_bwd_kernel(const E3Args a) {
                 const float sc11 = scr * 2048.f;
                 const f16x2 l01 = __builtin_convertvector(f32x2{__builtin_fmaf((float)h01.x, -2048.f, g0 * sc11), __builtin_fmaf((float)h01.y, -2048.f, g1 * sc11)}, f16x2);
                 const f16x2 l23 = __builtin_convertvector(f32x2{__builtin_fmaf((float)h23.x, -2048.f, g2 * sc11), __builtin_fmaf((float)h23.y, -2048.f, g3 * sc11)}, f16x2);
-                char *dst = strip + pi * E3_PLANE + ((yy + 6) % 6) * E3_SLOT + w_off;
+                // a void step stages into the sink behind the ring, never into the ring: the step that replays the stream's last one has
+                // that step's slots, which slower waves of the workgroup may still be contracting (no barrier separates them)
+                char *dst = strip + (live ? pi * E3_PLANE + ((yy + 6) % 6) * E3_SLOT : E3_STRIP) + w_off;
                 *reinterpret_cast<i32x2 *>(dst) = i32x2{__builtin_bit_cast(int, h01), __builtin_bit_cast(int, h23)};
                 *reinterpret_cast<i32x2 *>(dst + E3_ROWB) = i32x2{__builtin_bit_cast(int, l01), __builtin_bit_cast(int, l23)};
             }
@@ -356,7 +359,7 @@ int e3d_bwd_launch(alq_ctx *ctx, const E3dPlan &plan, int N, const float *skip, 
     const int cus = ctx->num_cus;
     long long g = std::min<long long>(2LL * cus, (long long)N * 4);
     g = std::max<long long>(8, (g + 7) / 8 * 8);
-    const size_t lds = E3_WLO + E3_STRIP;
+    const size_t lds = E3_WLO + E3_STRIP + E3_SINK;
     ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(e3d_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope ps(ctx, PROF_IGEMM_F16, plan.flops_per_patch * N);
     hipLaunchKernelGGL(e3d_bwd_kernel, dim3((unsigned)g), dim3(256), lds, ctx->stream, a);

@@ -346,11 +346,11 @@ class DeviceModel(object):
         check(self.lib.alq_model_create(sess.ctx, arr, len(self.layers), cd, self.max_batch, C.byref(self._m)))
         _track(self)
         self.max_batch = int(self.lib.alq_model_max_batch(self._m))      # may be below the request: 32-bit tensor offsets (alq.h)
-        # second scoring pipeline (fisher_device): created at the first call that has more than one device pass to run.
-        # Default since round 6 (ALQ_LANES=1: one pipeline): outputs are bit-identical, +2.5 % on the 100k-patch pool
-        # (profiles/r05_lanes_ab.txt); it costs a second set of workspaces once a call spans more than one pass
-        self.lanes = max(1, int(os.environ.get('ALQ_LANES', '2')))
-        self._lane2 = None
+        # extra scoring pipelines (fisher_device): created at the first call that has that many device passes to run.  Default
+        # since round 6: two (ALQ_LANES=1: one pipeline; up to 4: three measured no faster than two, four slower): outputs are
+        # bit-identical; each costs a set of workspaces
+        self.lanes = max(1, min(4, int(os.environ.get('ALQ_LANES', '2'))))
+        self._xlanes = []                 # the extra pipelines (lanes - 1 of them once a call spans that many passes)
         self._create_env = {k: v for k, v in os.environ.items() if k.startswith('ALQ_')}     # engine switches are read at creation
         self.L = self.lib.alq_model_num_param_layers(self._m)
         self.nclass = self.layers[-1]['cout']
@@ -671,6 +671,8 @@ class DeviceModel(object):
         feat = self.sess.empty((n, self.feature_dim), torch.float32) if want_feat else None
         if rows is not None:
             assert rows.dtype == torch.int64 and rows.is_contiguous() and int(rows.numel()) == n
+        # one pipeline: forward-only passes leave no gaps a second one could fill (configs[4]'s filter: 0.3625 s per 200k patches
+        # with two pipelines against 0.3601 s with one, same box)
         for a in range(0, n, self.max_batch):
             b = min(n, a + self.max_batch)
             pb = self.sess.empty((self.nclass, b - a), torch.float32)
@@ -733,27 +735,30 @@ class DeviceModel(object):
         # small kernels run beside the next pass's first launches instead of leaving the chip idle.  Each pass is the same
         # launches on the same data whichever pipeline runs it, so every per-patch output is bit-identical to ALQ_LANES=1;
         # the passes' partial sums of A are added in pass order after the join.
-        # Pass sizes: an EVEN number of equal passes, so that two pipelines get the same work (100,000 patches at 2047 per pass are
-        # 49 passes - one pipeline runs 25 of them and the other idles through the last one: 268.0 against 272.7 k patches/s
-        # same-box, three rounds).  Per-patch results do not depend on the cut (tests: any batch cut is bit-identical); the cut itself
-        # does not depend on the number of pipelines, so the pass-ordered sum of A is the same bits with one pipeline or two
+        # Pass sizes: a number of EQUAL passes that divides among the pipelines - a multiple of 6 (1, 2 or 3 pipelines), or an even
+        # number when the call has fewer than 6 - so that all of them get the same work (100,000 patches at 2047 per pass are 49
+        # passes: with two pipelines one ran 25 of them and the other idled through the last one: 268.0 against 272.7 k patches/s
+        # same-box, three rounds).  Per-patch results do not depend on the cut (tests: any batch cut is bit-identical); the cut
+        # itself does not depend on the number of pipelines, so the pass-ordered sum of A is the same bits with one, two or three
         step = self.max_batch
         if n > self.max_batch and not os.environ.get('ALQ_NO_PASS_BALANCE'):
             P = -(-n // self.max_batch)
-            P += P & 1
+            mult = int(os.environ.get('ALQ_PASS_MULT', '6'))          # (tuning experiments)
+            P = -(-P // mult) * mult if P >= mult else P + (P & 1)
             step = -(-n // P)
         starts = list(range(0, n, step))
-        lane2 = self._second_lane() if (self.lanes > 1 and len(starts) > 1) else None
+        nl = min(self.lanes, len(starts))
+        extra = self._extra_lanes(nl - 1) if nl > 1 else []
         part = self.sess.empty((max(len(starts), 1), L, L), torch.float64) if asum is not None else None
         cur = torch.cuda.current_stream(self.sess.device)
-        # with two pipelines whole passes overlap: the per-context side streams (the statistics kernels of a layer beside its
-        # contraction) then only add two more streams competing for the same gaps (274.4 -> 277.8 k patches/s without them, same
-        # box, three rounds); a single pipeline keeps its side stream (+3.4 %, round 4).  Same kernels, same results either way.
-        side_on = 0 if (lane2 is not None and not os.environ.get('ALQ_LANES_SIDE_STREAM')) else 1
+        # with several pipelines whole passes overlap: the per-context side streams (the statistics kernels of a layer beside its
+        # contraction) then only add streams competing for the same gaps (274.4 -> 277.8 k patches/s without them, same box,
+        # three rounds); a single pipeline keeps its side stream (+3.4 %, round 4).  Same kernels, same results either way.
+        side_on = 0 if (extra and not os.environ.get('ALQ_LANES_SIDE_STREAM')) else 1
         check(self.lib.alq_ctx_use_side_stream(self.sess.ctx, side_on))
-        if lane2 is not None:
-            check(self.lib.alq_ctx_use_side_stream(lane2['sess'].ctx, side_on))
-            lane2['stream'].wait_stream(cur)          # inputs, output buffers and the weights are ordered on the caller's stream
+        for ln in extra:
+            check(self.lib.alq_ctx_use_side_stream(ln['sess'].ctx, side_on))
+            ln['stream'].wait_stream(cur)          # inputs, output buffers and the weights are ordered on the caller's stream
         for k, a in enumerate(starts):
             b = min(n, a + step)
             outs = (ptr(p1_in, a, 4), float(diag_load), ptr(out['p1'], a, 4), ptr(out['g0'], a * L, 8),
@@ -765,14 +770,16 @@ class DeviceModel(object):
                     check(self.lib.alq_fisher(m, C.c_void_p(t.data_ptr() + a * self.elems_per_patch * 4), b - a, *outs))
                 else:
                     check(self.lib.alq_fisher_rows(m, C.c_void_p(t.data_ptr()), C.c_void_p(rows.data_ptr() + a * 8), b - a, *outs))
-            if lane2 is not None and (k & 1):
-                with torch.cuda.stream(lane2['stream']):
-                    lane2['sess'].bind_stream()
-                    launch(lane2['m'])
+            which = k % nl
+            if which:
+                ln = extra[which - 1]
+                with torch.cuda.stream(ln['stream']):
+                    ln['sess'].bind_stream()
+                    launch(ln['m'])
             else:
                 launch(self._m)
-        if lane2 is not None:
-            cur.wait_stream(lane2['stream'])
+        for ln in extra:
+            cur.wait_stream(ln['stream'])
         if not side_on:
             check(self.lib.alq_ctx_use_side_stream(self.sess.ctx, 1))
         if asum is not None:
@@ -807,12 +814,16 @@ class DeviceModel(object):
                 os.environ.update(now)
         return cm()
 
-    def _second_lane(self):
-        """The second scoring pipeline of fisher_device: a libalq context on its own torch stream and a model of the same
-        layers on it; its weights follow `set_weights` (the host copies in var_dict are the single state)."""
+    @property
+    def _lane2(self):
+        """The first extra pipeline (None until a call needed one): what the tests of round 5 look at."""
+        return self._xlanes[0] if self._xlanes else None
+
+    def _extra_lanes(self, count):
+        """`count` extra scoring pipelines of fisher_device: each a libalq context on its own torch stream and a model of the same
+        layers on it; their weights follow `set_weights` (the host copies in var_dict are the single state)."""
         torch = self.sess.torch
-        ln = self._lane2
-        if ln is None:
+        while len(self._xlanes) < count:
             stream = torch.cuda.Stream(self.sess.device)
             with torch.cuda.stream(stream):
                 sess2 = DeviceSession(self.sess.device.index)
@@ -822,17 +833,18 @@ class DeviceModel(object):
                 check(self.lib.alq_model_create(sess2.ctx, arr, nl, cd, self.max_batch, C.byref(m)))
             if int(self.lib.alq_model_max_batch(m)) != self.max_batch:
                 self.lib.alq_model_destroy(m)
-                raise _lib.AlqError('second pipeline: the library granted another batch size')
-            ln = self._lane2 = dict(sess=sess2, stream=stream, m=m, version=None)
-        if ln['version'] != self._weights_version:
-            if any(v is None for v in self.var_dict.values()):
-                raise RuntimeError('set_weights() has not been called')
-            with self._creation_env():
-                for ti, name in enumerate(self.var_names):
-                    W, b = self.var_dict[name]
-                    check(self.lib.alq_model_set_weights(ln['m'], ti, W.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)))
-            ln['version'] = self._weights_version
-        return ln
+                raise _lib.AlqError('extra pipeline: the library granted another batch size')
+            self._xlanes.append(dict(sess=sess2, stream=stream, m=m, version=None))
+        for ln in self._xlanes[:count]:
+            if ln['version'] != self._weights_version:
+                if any(v is None for v in self.var_dict.values()):
+                    raise RuntimeError('set_weights() has not been called')
+                with self._creation_env():
+                    for ti, name in enumerate(self.var_names):
+                        W, b = self.var_dict[name]
+                        check(self.lib.alq_model_set_weights(ln['m'], ti, W.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)))
+                ln['version'] = self._weights_version
+        return self._xlanes[:count]
 
     def fisher(self, x, p1=None, diag_load=1e-5):
         t, n = self._as_device_batch(x)
@@ -896,11 +908,10 @@ class DeviceModel(object):
         return buf[:e.value].cpu().numpy()
 
     def close(self):
-        ln = getattr(self, '_lane2', None)
-        if ln is not None:
+        for ln in getattr(self, '_xlanes', []):
             self.lib.alq_model_destroy(ln['m'])
             ln['sess'].close()
-            self._lane2 = None
+        self._xlanes = []
         if self._m:
             self.lib.alq_model_destroy(self._m)
             self._m = C.c_void_p()

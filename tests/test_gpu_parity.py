@@ -1712,6 +1712,35 @@ def test_two_scoring_pipelines_are_bit_identical_to_one(sess):
     m.close()
 
 
+def test_repeated_passes_under_several_pipelines_return_the_same_bits(sess):
+    """Every kernel of a pass must give the same bits whatever else shares the compute units with it.  Regression for the enc1
+    backward kernel (csrc/e3d.hip): the void step that follows an odd-length row stream used to stage zero rows into the ring
+    slots of the stream's last step, which slower waves of the workgroup could still be reading - never seen with one pipeline,
+    one run in ten with a second context's kernels on the same CUs (enc1's score of single patches moved by 1e-7 relative).
+    All default kernels, 320 patches in passes of 33 (odd streams in the last workgroups), 120 runs on two and on three
+    pipelines against one run on a single pipeline."""
+    import ctypes as C
+    from nnal_amd._lib import check
+    torch = sess.torch
+    n = 320
+    ld, sk, in_shape, pars, (m,) = _netc32_models(sess, [{}], max_batch=33, bias_std=0.05)
+    x = sess.empty((n, 32 ** 3), torch.float32)
+    check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, 32 ** 3, C.c_void_p(x.data_ptr())))
+    keys = ('p1', 'g0', 'g1', 'A')
+
+    def run(lanes):
+        m.lanes = lanes
+        r = m.fisher_device(x, n, None, 1e-3, want=keys)
+        return {k: r[k].cpu().numpy() for k in keys}
+    one = run(1)
+    for lanes in (2, 3):
+        for it in range(120):
+            cur = run(lanes)
+            for k in keys:
+                np.testing.assert_array_equal(one[k], cur[k], err_msg='%d pipelines, run %d: %s' % (lanes, it, k))
+    m.close()
+
+
 def test_plane_sweep_dec1_forward_against_the_two_slot_engine(sess):
     """NET-C's `dec1` forward (3x3x3 conv over the concat [up1 | enc2], 32 -> 16 channels at 16^3 + bias + ReLU; reference call site
     NN_extended.py:416-426) on the plane-sweep kernel of csrc/d3d.hip (default since round 5) against the two-slot engine's launch

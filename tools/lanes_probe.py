@@ -34,7 +34,9 @@ def main():
         m.set_weights(pars)
         lanes.append((st, s, m))
     want = ('p1', 'H', 'g0', 'g1', 'A', 'trace', 'Asum')
-    for L in (1, 2, 3, 4, 2, 3):
+    for L in (1, 2, 3, 4, 2, 3, 1):
+        for st, s, m in lanes:
+            check(s.lib.alq_ctx_use_side_stream(s.ctx, 1 if L == 1 else 0))
         P = -(-n // 2047)
         P = -(-P // L) * L
         step = -(-n // P)

@@ -39,6 +39,69 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA p
 PEAK_HBM_TBPS = 8.0                     # MI355X_MICROARCH.md: HBM3E
 SPLIT_PRODUCTS = 6                      # bf16 MFMA MACs issued per fp32-accurate MAC (igemm3.hip)
 B_ALG = 4 * 32 ** 3 + 4 * (1 + 2 * 8 + 64)   # input + outputs per patch, bytes
+BOOST_SCLK_MHZ = 2400.0                 # MI355X_MICROARCH.md: the clock the dense peaks are quoted at
+
+
+class ClockSampler(object):
+    """Engine clock and socket power of the GPU this rank computes on, read from its hwmon files (`freq1_input`, `power1_input`:
+    world-readable, no tool, no GPU call) every 25 ms between start() and stop().  The scoring pass holds the board at its power
+    cap; the clock it sustains there - not the boost clock the datasheet peaks are quoted at - is what its matrix pipes run at."""
+
+    def __init__(self, torch, index):
+        self.dir = None
+        self.samples = []
+        self._stop = None
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            bdf = '%04x:%02x:%02x.0' % (getattr(pr, 'pci_domain_id', 0), pr.pci_bus_id, pr.pci_device_id)
+            import glob
+            for d in glob.glob('/sys/class/drm/card*/device'):
+                if os.path.basename(os.path.realpath(d)) == bdf:
+                    hw = glob.glob(os.path.join(d, 'hwmon', 'hwmon*'))
+                    if hw and os.path.exists(os.path.join(hw[0], 'freq1_input')):
+                        self.dir = hw[0]
+                        self.bdf = bdf
+        except Exception:
+            self.dir = None
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return float(f.read().strip())
+        except Exception:
+            return None
+
+    def start(self):
+        if self.dir is None:
+            return
+        import threading
+        self.samples = []
+        self._stop = threading.Event()
+
+        def run():
+            while not self._stop.is_set():
+                f, w = self._read('freq1_input'), self._read('power1_input')
+                if f is not None:
+                    self.samples.append((f / 1e6, (w or 0.0) / 1e6))
+                self._stop.wait(0.025)
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        if self._stop is None:
+            return None
+        self._stop.set()
+        self._thread.join()
+        self._stop = None
+        if not self.samples:
+            return None
+        f = sorted(s[0] for s in self.samples)
+        w = sorted(s[1] for s in self.samples)
+        cap = self._read('power1_cap')
+        return {'sclk_mhz_mean': sum(f) / len(f), 'sclk_mhz_median': f[len(f) // 2], 'sclk_mhz_min': f[0], 'sclk_mhz_max': f[-1],
+                'power_w_mean': sum(w) / len(w), 'power_w_max': w[-1], 'power_cap_w': cap / 1e6 if cap else None,
+                'boost_sclk_mhz': BOOST_SCLK_MHZ, 'samples': len(f), 'device': self.bdf,
+                'source': 'hwmon freq1_input / power1_input of the device, every 25 ms over the timed region'}
 
 
 def main():
@@ -170,19 +233,23 @@ def main():
     # other pipeline runs beside it - and the roofline pass below instead
     in_region = model.lanes == 1 and not os.environ.get('ALQ_BENCH_NO_EVENTS')
     sess.prof_enable(args.prof_every if in_region else 0)
+    sampler = ClockSampler(torch, local_rank)
     pool_shard.barrier()
     torch.cuda.synchronize()
+    sampler.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
     pool_shard.barrier()
     dt = time.perf_counter() - t0
+    clocks = sampler.stop()
     sess.prof_enable(False)
     prof = sess.prof_read()
     dt = pool_shard.max_over_ranks(dt)
     lanes_timed = int(model.lanes)
     prof_patches = None
+    clocks_roof = clocks if in_region else None
     if not in_region and not os.environ.get('ALQ_BENCH_NO_EVENTS'):
         # the roofline pass: the same launches on the first passes of the pool, ONE pipeline, HIP events on every launch
         # (outside the timed region; what rocprofv3 --kernel-trace shows for `--lanes 1`)
@@ -190,8 +257,10 @@ def main():
         prof_patches = min(n_local, args.roofline_passes * args.batch)
         sess.prof_reset()
         sess.prof_enable(1)
+        sampler.start()
         model.fisher_device(x, prof_patches, None, 1e-3, want=('p1', 'H', 'g0', 'g1', 'A', 'trace', 'Asum'))
         torch.cuda.synchronize()
+        clocks_roof = sampler.stop()
         sess.prof_enable(False)
         prof = sess.prof_read()
         model.lanes = lanes_timed
@@ -292,7 +361,19 @@ def main():
                          'time_share_ms_sampled': {k: v['ms'] for k, v in prof.items()},
                          'time_share_note': 'event spans; the reduce / fc_small kernels of the backward pass run on the side stream '
                                             'BESIDE the igemm launches (their spans overlap those, they do not add up to the step)'},
+            # engine clock / board power while the timed region ran: the pass sits at the board's power cap, below the boost clock
+            # the peaks above are quoted at (`frac` stays against the datasheet peak)
+            'clocks': clocks,
         }
+        if clocks_roof:
+            r = line['roofline']
+            r['clocks'] = clocks_roof
+            r['sclk_ratio'] = clocks_roof['sclk_mhz_mean'] / BOOST_SCLK_MHZ
+            r['frac_at_sustained_sclk'] = r['frac'] / r['sclk_ratio']
+            r['frac_at_sustained_sclk_note'] = ('frac against the 16-bit MFMA peak scaled to the mean engine clock measured while these launches '
+                                                'ran (%.0f of %.0f MHz at %.0f W of a %.0f W cap): what the matrix pipes could deliver at that clock; '
+                                                'not a datasheet figure' % (clocks_roof['sclk_mhz_mean'], BOOST_SCLK_MHZ, clocks_roof['power_w_mean'],
+                                                                            clocks_roof.get('power_cap_w') or 0.0))
         note('GPU: %.1f patches/s' % value)
         # what the LAST pass of the timed region ran on (asked before the accuracy passes below, one of which is the exact-fp32 engine)
         info = sess.lib.alq_model_engine_info

@@ -379,3 +379,42 @@ def test_ref64_host_side_scores_and_flip_records():
     np.testing.assert_allclose(out['A'], A, rtol=1e-12, atol=1e-18)
     assert ref64.Ref64.close(np.array([1.0, 2.0]), np.array([1.0 + 1e-6, 2.0]))
     assert not ref64.Ref64.close(np.array([1.0, 2.0]), np.array([1.001, 2.0]))
+
+
+def test_bench_clock_sampler_reads_the_hwmon_files_of_the_device(tmp_path, monkeypatch):
+    """bench.py's ClockSampler: the device's hwmon directory is found through its PCI address, clock and power are averaged over the
+    samples, and a box without the files (or a torch build without the PCI fields) yields None instead of a number."""
+    import glob as _glob
+    import importlib.util
+    import time
+    import types
+    spec = importlib.util.spec_from_file_location('bench_for_test', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    pci = tmp_path / 'devices' / '0000:f4:00.0'
+    hw = pci / 'hwmon' / 'hwmon7'
+    hw.mkdir(parents=True)
+    (hw / 'freq1_input').write_text('2016000000\n')
+    (hw / 'power1_input').write_text('1355000000\n')
+    (hw / 'power1_cap').write_text('1400000000\n')
+    card = tmp_path / 'card3'
+    card.mkdir()
+    os.symlink(str(pci), str(card / 'device'))
+    real_glob = _glob.glob
+    monkeypatch.setattr(_glob, 'glob', lambda p: real_glob(p.replace('/sys/class/drm', str(tmp_path))))
+    props = types.SimpleNamespace(pci_domain_id=0, pci_bus_id=0xf4, pci_device_id=0)
+    torch_like = types.SimpleNamespace(cuda=types.SimpleNamespace(get_device_properties=lambda i: props))
+    s = bench.ClockSampler(torch_like, 0)
+    assert os.path.realpath(s.dir) == os.path.realpath(str(hw))
+    s.start()
+    time.sleep(0.12)
+    r = s.stop()
+    assert r['samples'] >= 2 and r['sclk_mhz_mean'] == 2016.0 and r['power_w_mean'] == 1355.0 and r['power_cap_w'] == 1400.0
+    assert r['device'] == '0000:f4:00.0'
+    # no such device / no PCI fields: no sampler, no numbers
+    other = types.SimpleNamespace(cuda=types.SimpleNamespace(get_device_properties=lambda i: types.SimpleNamespace(pci_bus_id=1, pci_device_id=0)))
+    s2 = bench.ClockSampler(other, 0)
+    s2.start()
+    assert s2.dir is None and s2.stop() is None
+    s3 = bench.ClockSampler(types.SimpleNamespace(cuda=types.SimpleNamespace(get_device_properties=lambda i: types.SimpleNamespace())), 0)
+    assert s3.dir is None

@@ -114,9 +114,9 @@ def main():
     ap.add_argument('--netb-pool', type=int, default=16384, help='patches of the NET-B side measurement at N = 1 (0 = skip)')
     ap.add_argument('--batch', type=int, default=2047,
                     help='most patches per device pass.  2047 = the most the engines\' unsigned 32-bit tensor offsets address for 32^3 NET-C '
-                         '(the library clamps a larger request to it).  fisher_device cuts a pool into an EVEN number of equal passes of at '
-                         'most this size, so that the two scoring pipelines get the same work (100,000 patches: 50 passes of 2000; '
-                         '+1.75 %% same-box against 48 x 2047 + 1744)')
+                         '(the library clamps a larger request to it).  fisher_device cuts a pool into an EVEN number of equal passes of at most '
+                         'this size, so that the two scoring pipelines get the same work (DeviceModel.pass_cut; 100,000 patches: 50 passes '
+                         'of 2000; +1.75 %% same-box against 48 x 2047 + 1744)')
     ap.add_argument('--topB', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-accuracy', action='store_true', help='skip the accuracy passes behind the timed region (PMC / sweep runs: their fp64 kernels would dominate a short trace)')
@@ -131,7 +131,7 @@ def main():
                          'contexts so that one pass\'s tail runs beside the next one\'s first launches (outputs bit-identical to 1, '
                          'test_two_scoring_pipelines_are_bit_identical_to_one).  Per-launch durations then include co-residency, so the '
                          'roofline object always comes from a SEPARATE single-pipeline pass with HIP events on every launch')
-    ap.add_argument('--roofline-passes', type=int, default=8, help='device passes of the separate single-pipeline roofline pass')
+    ap.add_argument('--roofline-passes', type=int, default=12, help='device passes of the separate single-pipeline roofline pass (an even number: they are then cut like the timed region\'s)')
     ap.add_argument('--cpu-sample', type=int, default=128, help='patches the CPU baseline scores (~15 s on 16 cores)')
     ap.add_argument('--cpu-all-cores', action='store_true',
                     help='also time ONE patch of the CPU baseline with os.cpu_count() threads (BASELINE.md 3 names that thread count; at '
@@ -254,7 +254,9 @@ def main():
         # the roofline pass: the same launches on the first passes of the pool, ONE pipeline, HIP events on every launch
         # (outside the timed region; what rocprofv3 --kernel-trace shows for `--lanes 1`)
         model.lanes = 1
-        prof_patches = min(n_local, args.roofline_passes * args.batch)
+        # ... in passes of the timed region's size: an even number of them is cut into exactly those passes
+        step_timed = model.pass_cut(n_local)[0]
+        prof_patches = min(n_local, max(2, args.roofline_passes // 2 * 2) * step_timed)
         sess.prof_reset()
         sess.prof_enable(1)
         sampler.start()
@@ -281,7 +283,7 @@ def main():
         ig_n = prof['igemm3_fwd']['launches'] + prof['igemm3_bwd']['launches'] + f16['launches']
         # patches behind the sampled launches: 12 igemm4 launches per device pass of `batch` patches (the pool divides evenly
         # at the default sizes; a ragged last pass would be counted at full size, so derive the count from the passes)
-        passes_per_step = -(-n_local // args.batch)
+        passes_per_step = len(model.pass_cut(n_local)[1])
         sampled_passes = ig_n / 12.0
         if prof_patches is None:
             prof_patches = sampled_passes * (n_local / float(passes_per_step))
@@ -297,9 +299,10 @@ def main():
             try:
                 tj = json.load(open(tp))
                 # measured per launch at tj['batch'] patches; a launch moves bytes in proportion to its patches
-                traffic = tj.get('hbm_bytes_per_launch') * args.batch / float(tj.get('batch', args.batch))
-                traffic_note = 'PMC 2*FETCH_SIZE + WRITE_SIZE per igemm4 launch, measured at batch %d (%s), scaled to batch %d' % (
-                    tj.get('batch', args.batch), 'profiles/pmc_traffic.json', args.batch)
+                per_launch = prof_patches / max(ig_n / 12.0, 1.0)      # patches behind one of the launches `avg_launch_ms` averages
+                traffic = tj.get('hbm_bytes_per_launch') * per_launch / float(tj.get('batch', args.batch))
+                traffic_note = ('PMC 2*FETCH_SIZE + WRITE_SIZE per contraction launch, measured at %d patches per launch (%s), scaled to the '
+                                '%.0f patches per launch of the launches timed here' % (tj.get('batch', args.batch), 'profiles/pmc_traffic.json', per_launch))
             except Exception:
                 traffic = None
         line = {
@@ -317,6 +320,7 @@ def main():
                                     '%d synthetic 32^3 2-class patches per GPU, random-init weights seed 14' % n_local),
                        'outputs_per_patch': 'p1, |p1-.5| (top-B keys), H, g0[8], g1[8], A[8x8], tr A stored; sum A over the pool',
                        'pool_global': n_global, 'pool_per_gpu': n_local, 'batch': model.max_batch, 'topB': args.topB,
+                       'passes_per_step': len(model.pass_cut(n_local)[1]), 'patches_per_pass': model.pass_cut(n_local)[0],
                        # integers the driver can check: ranks of the torch.distributed group and of the RCCL communicator the libalq
                        # context owns (0 = none: the Fisher sum goes through torch.distributed or, at world 1, nowhere)
                        'dist_world_size': dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1,

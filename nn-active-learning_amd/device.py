@@ -735,18 +735,13 @@ class DeviceModel(object):
         # small kernels run beside the next pass's first launches instead of leaving the chip idle.  Each pass is the same
         # launches on the same data whichever pipeline runs it, so every per-patch output is bit-identical to ALQ_LANES=1;
         # the passes' partial sums of A are added in pass order after the join.
-        # Pass sizes: a number of EQUAL passes that divides among the pipelines - a multiple of 6 (1, 2 or 3 pipelines), or an even
-        # number when the call has fewer than 6 - so that all of them get the same work (100,000 patches at 2047 per pass are 49
-        # passes: with two pipelines one ran 25 of them and the other idled through the last one: 268.0 against 272.7 k patches/s
-        # same-box, three rounds).  Per-patch results do not depend on the cut (tests: any batch cut is bit-identical); the cut
-        # itself does not depend on the number of pipelines, so the pass-ordered sum of A is the same bits with one, two or three
-        step = self.max_batch
-        if n > self.max_batch and not os.environ.get('ALQ_NO_PASS_BALANCE'):
-            P = -(-n // self.max_batch)
-            mult = int(os.environ.get('ALQ_PASS_MULT', '6'))          # (tuning experiments)
-            P = -(-P // mult) * mult if P >= mult else P + (P & 1)
-            step = -(-n // P)
-        starts = list(range(0, n, step))
+        # Pass sizes: an EVEN number of equal passes, so that two pipelines get the same work (100,000 patches at 2047 per pass are 49
+        # passes: one pipeline ran 25 of them and the other idled through the last one: 268.0 against 272.7 k patches/s same-box,
+        # three rounds).  Per-patch results do not depend on the cut (tests: any batch cut is bit-identical); the cut itself does not
+        # depend on the number of pipelines, so the pass-ordered sum of A is the same bits with one, two or three.  (A multiple of 6
+        # - equal shares for three pipelines as well - was tried: 50 ... 56 passes score the same within noise on NET-C, but NET-B
+        # streams its 168 MB of fc weights once per pass and 16,384 patches became 12 passes instead of 8: ALQ_PASS_MULT=6.)
+        step, starts = self.pass_cut(n)
         nl = min(self.lanes, len(starts))
         extra = self._extra_lanes(nl - 1) if nl > 1 else []
         part = self.sess.empty((max(len(starts), 1), L, L), torch.float64) if asum is not None else None
@@ -813,6 +808,16 @@ class DeviceModel(object):
                     os.environ.pop(k, None)
                 os.environ.update(now)
         return cm()
+
+    def pass_cut(self, n):
+        """How fisher_device cuts n patches into device passes: (patches per pass, first patch of every pass)."""
+        step = self.max_batch
+        if n > self.max_batch and not os.environ.get('ALQ_NO_PASS_BALANCE'):
+            P = -(-n // self.max_batch)
+            mult = int(os.environ.get('ALQ_PASS_MULT', '2'))          # (tuning experiments)
+            P = -(-P // mult) * mult if P >= mult else P + (P & 1)
+            step = -(-n // P)
+        return step, list(range(0, n, step))
 
     @property
     def _lane2(self):

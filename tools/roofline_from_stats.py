@@ -49,7 +49,9 @@ def main():
         'source': {'stats_csv': stats_csv, 'bench_line': bench_json},
         'patches_in_trace': patches, 'igemm4_launches': ig_calls, 'igemm4_total_ms': ig_ns / 1e6,
         'igemm4_avg_launch_ms': ig_ns / 1e6 / max(ig_calls, 1),
-        'igemm4_ms_per_batch_pass': ig_ns / 1e6 / (patches / float(line['config']['batch'])),
+        # per device pass as the run cut them (config.patches_per_pass; older lines: config.batch)
+        'patches_per_pass': line['config'].get('patches_per_pass', line['config']['batch']),
+        'igemm4_ms_per_batch_pass': ig_ns / 1e6 / (patches / float(line['config'].get('patches_per_pass', line['config']['batch']))),
         'igemm4_alg_flops_per_patch': per_patch,
         'algorithmic_tflops': alg / secs / 1e12, 'executed_16bit_tflops': executed / secs / 1e12,
         'frac': executed / secs / 1e12 / PEAK_16BIT_TFLOPS,
@@ -61,7 +63,7 @@ def main():
     out['frac_rel_diff_bench_vs_trace'] = rf['frac'] / out['frac'] - 1.0
     if len(sys.argv) > 3:
         tj = json.load(open(sys.argv[3]))
-        bytes_per_launch = tj['hbm_bytes_per_launch'] * line['config']['batch'] / float(tj.get('batch', line['config']['batch']))
+        bytes_per_launch = tj['hbm_bytes_per_launch'] * out['patches_per_pass'] / float(tj.get('batch', line['config']['batch']))
         out['hbm'] = {'traffic_bytes_per_launch': bytes_per_launch, 'hbm_frac': bytes_per_launch * ig_calls / secs / (PEAK_HBM_TBPS * 1e12),
                       'traffic_bytes_per_patch_all_igemm4': bytes_per_launch * ig_calls / patches, 'source': sys.argv[3]}
     json.dump(out, sys.stdout, indent=1)

@@ -1,7 +1,9 @@
 #!/bin/bash
 # The tracked profile set of round 6 (GPU box):  bash tools/run_r06_profiles.sh r06
 #   1. default bench (two pipelines timed, roofline from the separate single-pipeline pass) plain
-#   2. rocprofv3 --kernel-trace --stats of the default command and of `--lanes 1` (per-launch durations without co-residency)
+#   2. rocprofv3 --kernel-trace --stats of the default command and of `--lanes 1` (per-launch durations without co-residency);
+#      both without the accuracy passes behind the timed region, so that the trace holds the (warmup + steps) x pool patches
+#      tools/roofline_from_stats.py divides by and nothing else
 #   3. the PMC passes of tools/run_pmc.sh (bench pool 8188) and of NET-B (tools/gpu_netb.py 2048)
 #   4. one line per other config (0, 1, 3, 4, 5)
 set -eo pipefail
@@ -10,8 +12,8 @@ ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 OUT="$ROOT/gpurun_out"; mkdir -p "$OUT"; export TMPDIR=/tmp
 cd "$ROOT"
 python3 bench.py > "$OUT/${TAG}_bench_default.json" 2> "$OUT/${TAG}_bench_default.err"; echo "plain bench done"
-rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_default_stats" -o stats --output-format csv -- python3 bench.py --no-cpu-baseline --netb-pool 0 > "$OUT/${TAG}_bench_default_under_rocprof.json" 2> "$OUT/${TAG}_rp1.err"; echo "rocprof default done"
-rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_lanes1_stats" -o stats --output-format csv -- python3 bench.py --lanes 1 --no-cpu-baseline --netb-pool 0 > "$OUT/${TAG}_bench_lanes1_under_rocprof.json" 2> "$OUT/${TAG}_rp2.err"; echo "rocprof lanes 1 done"
+rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_default_stats" -o stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-accuracy --netb-pool 0 > "$OUT/${TAG}_bench_default_under_rocprof.json" 2> "$OUT/${TAG}_rp1.err"; echo "rocprof default done"
+rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_lanes1_stats" -o stats --output-format csv -- python3 bench.py --lanes 1 --no-cpu-baseline --no-accuracy --netb-pool 0 > "$OUT/${TAG}_bench_lanes1_under_rocprof.json" 2> "$OUT/${TAG}_rp2.err"; echo "rocprof lanes 1 done"
 for c in 0 1 3 4 5; do python3 bench.py --config $c > "$OUT/${TAG}_bench_config$c.json" 2> "$OUT/${TAG}_c$c.err"; echo "config $c done"; done
 bash tools/run_pmc.sh ${TAG}pmc 8188
 PMC_ARGS="tools/gpu_netb.py 2048" bash tools/run_pmc.sh ${TAG}netb

@@ -628,6 +628,9 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
             g4.OD = ly.out.D; g4.OH = ly.out.H; g4.OW = ly.out.W; g4.Co = sp.cout;
             for (int q = 0; q < 3; ++q) { g4.k[q] = sp.k[q]; g4.s[q] = sp.s[q]; g4.lo[q] = ly.lo[q]; }
             ALQ_TRY(gemm_build(d, NB, &ly.fwd[0], &g4));
+            // a 2-D window of 25 taps or more: the two-slot engine's tiles re-stage too much halo - NET-B's conv2 (24 -> 32 channels,
+            // 5 x 5 at 32^2) takes 673 us per 2048 patches there and ~390 on igemm3 (round 6; ALQ_NO_WIDE2D_RULE=1 = the other arm)
+            if (ly.fwd[0].p4.ok && ly.fwd[0].p3.ok && d.ID == 1 && d.tz.size() >= 25 && !getenv("ALQ_NO_WIDE2D_RULE")) ly.fwd[0].p4.ok = false;
             if (!ly.fwd[0].p4.ok && !ly.fwd[0].p3.ok && !ly.fwd[0].pd.ok && sp.cout > 32 && !getenv("ALQ_NO_CO_SPLIT")) {
                 for (int w : {32, 48, 16}) {
                     if (sp.cout % w || sp.cout <= w) continue;

@@ -215,6 +215,9 @@ struct Igemm2Args {
     int tpg;                   // tiles per patch group
     int in_bytes;              // bytes of the input tensor for N patches (buffer descriptor range)
     int in_pstride, out_pstride;   // voxels per patch group step: PT*ID*IH*IW, PT*OD*OH*OW
+    // igemm3's fp16-pair instantiation (launches with a host-known bound on their input): x * f16_sc = h + l 2^-11,
+    // result = (c + cl 2^-11) * f16_inv; a bias enters the accumulator as bias * f16_bias_sc
+    float f16_sc = 0.f, f16_inv = 0.f, f16_bias_sc = 0.f;
 };
 
 struct Igemm2Plan {
@@ -293,9 +296,15 @@ struct Igemm3Plan {
     size_t lds_bytes = 0;
     std::vector<unsigned short> h_W;   // [chunk][s][piece][tile][lane][8] bf16 bits
     void *d_W = nullptr;
+    // the fp16-pair twin (round 6): pieces h, l x 2^11 of W x 2^w16_exp, same layout with two pieces; packed on request
+    // (igemm3_pack_weights_f16) for the Gemms whose launches come with a bound on their input (backward launches of a Fisher pass)
+    std::vector<unsigned short> h_W16;
+    void *d_W16 = nullptr;
+    int w16_exp = 0;
 };
 int igemm3_build_plan(const Igemm2Plan &p2, Igemm3Plan *p3);
 void igemm3_pack_weights(const Igemm2Plan &p2, Igemm3Plan *p3, const std::vector<float> &Bmat);
+void igemm3_pack_weights_f16(const Igemm2Plan &p2, Igemm3Plan *p3, const std::vector<float> &Bmat);
 int igemm3_launch(alq_ctx *ctx, const Igemm2Plan &p2, const Igemm3Plan &plan, const View &in, const View &out,
                   const float *bias, int relu, int accumulate, int N, int prof_cls, const Igemm2Fuse *fuse);
 
@@ -563,6 +572,7 @@ struct Gemm {
     Igemm4Plan p4;
     FcGemmPlan pfc;
     bool pfc_f16 = false;      // also pack the fp16-pair twin of pfc's weights (backward launches; forward launches of wide fc layers)
+    bool p3_f16 = false;       // also pack the fp16-pair twin of p3's weights: a backward Gemm that runs on igemm3 (no two-slot plan)
     unsigned *fc_row_amax = nullptr;   // forward launch of a wide fc layer on fp16 pairs: [max_batch] measured input maxima (scratch)
     DirectPlan pd;
 };

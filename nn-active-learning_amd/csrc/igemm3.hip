@@ -27,6 +27,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // In-kernel phase stamps (diagnostic build only, -DALQ_STAMPS; see igemm2.hip)
 #ifdef ALQ_STAMPS
@@ -65,7 +67,11 @@ __device__ inline i32x4 sload4(const int *p) {
     return v;
 }
 
-template <int NTW, bool WRES, bool SUMS>
+// F16 (round 6): the fp16-pair form for launches whose input has a host-known bound (the backward launches of a Fisher pass):
+// x 2^e = h + l 2^-11 (the lo pieces scaled up: the bound is loose by orders of magnitude and true-scale lo pieces of typical
+// values would be fp16 subnormals), weights likewise; three products instead of six - (h, h) in one accumulator, (l, h) + (h, l)
+// at 2^11 in a second one, joined in the epilogue.  LDS rows keep their 48-byte pitch ([h8 | l8 | -]).
+template <int NTW, bool WRES, bool SUMS, bool F16>
 __global__ __launch_bounds__(256, 2) void igemm3_kernel(const Igemm2Args a) {
     extern __shared__ __attribute__((aligned(16))) char lds3[];
     const int tid = threadIdx.x;
@@ -77,11 +83,12 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(const Igemm2Args a) {
     const int S = (a.ntaps + 3) >> 2;
     const int halo = a.HZ * a.HY * a.HX;
     const int nhv = a.PT * halo;
-    const int Wchunk = S * 3 * NTW * 1024;                 // bytes of one 8-channel weight chunk
+    constexpr int NP = F16 ? 2 : 3;                        // operand pieces
+    const int Wchunk = S * NP * NTW * 1024;                // bytes of one 8-channel weight chunk
     const int Wbytes = WRES ? a.nchunks * Wchunk : Wchunk;
     char *Wl = lds3;
     char *Al = lds3 + Wbytes;
-    constexpr int WREGS = WRES ? 1 : (I3_MAXS * 3 * NTW + 3) / 4;    // 16-byte registers per thread per chunk
+    constexpr int WREGS = WRES ? 1 : (I3_MAXS * NP * NTW + 3) / 4;    // 16-byte registers per thread per chunk
     constexpr int NSLOT = I3_MAXSLOT;
     const char *Wg = reinterpret_cast<const char *>(a.W);
 
@@ -242,14 +249,24 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(const Igemm2Args a) {
         for (int it = 0; it < NSLOT; ++it) {
             if (it < nit && tid + it * 256 < nslots) {
                 float v0 = R[it].x, v1 = R[it].y, v2 = R[it].z, v3 = R[it].w;
-                uint2 hi, mid, lo;
-                hi.x = split2(v0, v1);  hi.y = split2(v2, v3);
-                mid.x = split2(v0, v1); mid.y = split2(v2, v3);
-                lo.x = split2(v0, v1);  lo.y = split2(v2, v3);
                 char *dst = Al + sbase + it * (128 * I3_ROWB);
-                *reinterpret_cast<uint2 *>(dst) = hi;
-                *reinterpret_cast<uint2 *>(dst + 16) = mid;
-                *reinterpret_cast<uint2 *>(dst + 32) = lo;
+                if constexpr (F16) {
+                    const float sc = a.f16_sc, sc11 = a.f16_sc * 2048.f;
+                    const f16x2 h01 = __builtin_convertvector(f32x2{v0 * sc, v1 * sc}, f16x2), h23 = __builtin_convertvector(f32x2{v2 * sc, v3 * sc}, f16x2);
+                    // (x 2^e - h) 2^11: exact in fp32 (the remainder of a rounding to 11 bits)
+                    const f16x2 l01 = __builtin_convertvector(f32x2{__builtin_fmaf((float)h01.x, -2048.f, v0 * sc11), __builtin_fmaf((float)h01.y, -2048.f, v1 * sc11)}, f16x2);
+                    const f16x2 l23 = __builtin_convertvector(f32x2{__builtin_fmaf((float)h23.x, -2048.f, v2 * sc11), __builtin_fmaf((float)h23.y, -2048.f, v3 * sc11)}, f16x2);
+                    *reinterpret_cast<uint2 *>(dst) = uint2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+                    *reinterpret_cast<uint2 *>(dst + 16) = uint2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+                } else {
+                    uint2 hi, mid, lo;
+                    hi.x = split2(v0, v1);  hi.y = split2(v2, v3);
+                    mid.x = split2(v0, v1); mid.y = split2(v2, v3);
+                    lo.x = split2(v0, v1);  lo.y = split2(v2, v3);
+                    *reinterpret_cast<uint2 *>(dst) = hi;
+                    *reinterpret_cast<uint2 *>(dst + 16) = mid;
+                    *reinterpret_cast<uint2 *>(dst + 32) = lo;
+                }
             }
         }
         if constexpr (!WRES) {
@@ -263,6 +280,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(const Igemm2Args a) {
 
     // ---------------- deferred epilogue (identical to igemm2.hip) ---------------------------------------
     f32x4 acc[4][NTW];
+    f32x4 accl[F16 ? 4 : 1][F16 ? NTW : 1];      // F16: the (l, h) + (h, l) products at 2^11
     bool have_pend = false;
     char *outb = reinterpret_cast<char *>(a.out);
     const char *maskb = reinterpret_cast<const char *>(a.mask);
@@ -289,6 +307,11 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(const Igemm2Args a) {
             for (int nt = 0; nt < NTW; ++nt) {
                 const int c = nt * 16 + lq * 4;
                 f32x4 val = acc[ms][nt];
+                if constexpr (F16) {
+                    const f32x4 cl = accl[ms][nt];
+                    val.x = __builtin_fmaf(cl.x, 0x1p-11f, val.x) * a.f16_inv; val.y = __builtin_fmaf(cl.y, 0x1p-11f, val.y) * a.f16_inv;
+                    val.z = __builtin_fmaf(cl.z, 0x1p-11f, val.z) * a.f16_inv; val.w = __builtin_fmaf(cl.w, 0x1p-11f, val.w) * a.f16_inv;
+                }
                 const bool on = live && c < a.Co;
                 if (on) {
                     f32x4 *dst = reinterpret_cast<f32x4 *>(outb + (unsigned)((obase_e + eoff[ms] + nt * 16) * 4));
@@ -365,13 +388,48 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(const Igemm2Args a) {
 #pragma unroll
                 for (int ms = 0; ms < 4; ++ms)
 #pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt) acc[ms][nt] = bias4[nt];
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        acc[ms][nt] = bias4[nt];
+                        if constexpr (F16) {
+                            acc[ms][nt] = f32x4{bias4[nt].x * a.f16_bias_sc, bias4[nt].y * a.f16_bias_sc, bias4[nt].z * a.f16_bias_sc, bias4[nt].w * a.f16_bias_sc};
+                            accl[ms][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                    }
             }
             const char *Wc = Wl + (WRES ? chunk * Wchunk : 0) + lane * 16;
             for (int rep = 0; rep <= a.dbg_repeat; ++rep)
 #pragma unroll
             for (int s = 0; s < I3_MAXS; ++s) {
                 if (s < S) {
+                    if constexpr (F16) {
+                        f16x8 Wf[2][NTW];
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+#pragma unroll
+                            for (int nt = 0; nt < NTW; ++nt)
+                                Wf[p][nt] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(Wc + ((s * 2 + p) * NTW + nt) * 1024));
+#pragma unroll
+                        for (int mh = 0; mh < 4; mh += 2) {
+                            f16x8 X[2][2];
+#pragma unroll
+                            for (int m2 = 0; m2 < 2; ++m2) {
+                                const char *row = Al + vbase[mh + m2] + toff[s];
+#pragma unroll
+                                for (int p = 0; p < 2; ++p)
+                                    X[p][m2] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(row + 16 * p));
+                            }
+#pragma unroll
+                            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                                for (int m2 = 0; m2 < 2; ++m2) {
+                                    f32x4 cl = accl[mh + m2][nt];
+                                    cl = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[1][nt], X[0][m2], cl, 0, 0, 0);
+                                    cl = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[0][nt], X[1][m2], cl, 0, 0, 0);
+                                    accl[mh + m2][nt] = cl;
+                                    acc[mh + m2][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[0][nt], X[0][m2], acc[mh + m2][nt], 0, 0, 0);
+                                }
+                        }
+                    } else {
                     bf16x8 Wf[3][NTW];
 #pragma unroll
                     for (int p = 0; p < 3; ++p)
@@ -406,6 +464,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(const Igemm2Args a) {
                                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[0][nt], X[0][m2], c, 0, 0, 0);
                                 acc[mh + m2][nt] = c;
                             }
+                    }
                     }
                 }
             }
@@ -481,9 +540,45 @@ void igemm3_pack_weights(const Igemm2Plan &p2, Igemm3Plan *p3, const std::vector
                     }
 }
 
-template <int NTW, bool WRES, bool SUMS>
+// fp16 bits of x (round to nearest even, host side; |x| < 65504 by the callers' scaling)
+static unsigned short f16_rne(float x) {
+    const _Float16 h = (_Float16)x;
+    unsigned short u;
+    std::memcpy(&u, &h, 2);
+    return u;
+}
+
+// The fp16-pair twin of the packed weights: W 2^e = h + l 2^-11 with max |W| 2^e in [2^13, 2^14); same layout, two pieces
+void igemm3_pack_weights_f16(const Igemm2Plan &p2, Igemm3Plan *p3, const std::vector<float> &Bmat) {
+    const Igemm2Args &a = p2.a;
+    const int NTW = p3->NTW, Ci = a.Ci, Co = a.Co, S = (a.ntaps + 3) / 4;
+    float amax = 0.f;
+    for (float w : Bmat) amax = std::max(amax, std::fabs(w));
+    int ex = 0;
+    (void)std::frexp(amax > 0.f ? amax : 1.f, &ex);       // amax = f 2^ex, f in [.5, 1)
+    p3->w16_exp = 14 - ex;
+    const float sw = std::ldexp(1.f, p3->w16_exp);
+    p3->h_W16.assign((size_t)a.nchunks * S * 2 * NTW * 64 * 8, 0);
+    for (int ch = 0; ch < a.nchunks; ++ch)
+        for (int s = 0; s < S; ++s)
+            for (int nt = 0; nt < NTW; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int tp = 4 * s + (lane >> 4);
+                        const int co = nt * 16 + (lane & 15);
+                        float w = 0.f;
+                        if (tp < a.ntaps && co < Co && ch * 8 + j < Ci) w = Bmat[((size_t)tp * Ci + ch * 8 + j) * Co + co] * sw;
+                        const _Float16 h = (_Float16)w;
+                        const float l = (w - (float)h) * 2048.f;
+                        const size_t base = ((((size_t)ch * S + s) * 2) * NTW + nt) * 64 * 8 + (size_t)lane * 8 + j;
+                        p3->h_W16[base] = f16_rne((float)h);
+                        p3->h_W16[base + (size_t)NTW * 64 * 8] = f16_rne(l);
+                    }
+}
+
+template <int NTW, bool WRES, bool SUMS, bool F16 = false>
 static int launch3_s(alq_ctx *ctx, const Igemm3Plan &plan, const Igemm2Args &a, unsigned grid) {
-    auto kfn = igemm3_kernel<NTW, WRES, SUMS>;
+    auto kfn = igemm3_kernel<NTW, WRES, SUMS, F16>;
     if (plan.lds_bytes > 64 * 1024)
         ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)plan.lds_bytes));
@@ -494,6 +589,9 @@ static int launch3_s(alq_ctx *ctx, const Igemm3Plan &plan, const Igemm2Args &a, 
 
 template <int NTW, bool WRES>
 static int launch3_t(alq_ctx *ctx, const Igemm3Plan &plan, const Igemm2Args &a, unsigned grid) {
+    if (a.f16_sc > 0.f)
+        return (a.osumA || a.osumB) ? launch3_s<NTW, WRES, true, true>(ctx, plan, a, grid)
+                                    : launch3_s<NTW, WRES, false, true>(ctx, plan, a, grid);
     return (a.osumA || a.osumB) ? launch3_s<NTW, WRES, true>(ctx, plan, a, grid)
                                 : launch3_s<NTW, WRES, false>(ctx, plan, a, grid);
 }
@@ -533,10 +631,22 @@ int igemm3_launch(alq_ctx *ctx, const Igemm2Plan &p2, const Igemm3Plan &plan, co
         a.osumA = fuse->osumA; a.osumB = fuse->osumB;
         a.split = fuse->split > 0 ? fuse->split : (1 << 30);
     }
+    // the fp16-pair instantiation: a host-known bound on the input (Igemm2Fuse::in_bound - the cotangent bound of a Fisher pass),
+    // the twin weights packed, nothing accumulated into (those launches keep the exact split)
+    a.f16_sc = a.f16_inv = a.f16_bias_sc = 0.f;
+    const bool f16 = fuse && fuse->in_bound > 0.f && plan.d_W16 && !accumulate && !g_no_f16x2 && !g_dbg_knobs[2];
+    if (f16) {
+        int ex = 0;
+        (void)std::frexp(fuse->in_bound, &ex);            // bound = f 2^ex, f in [.5, 1): |x| 2^(14 - ex) < 2^14
+        a.W = reinterpret_cast<const float *>(plan.d_W16);
+        a.f16_sc = std::ldexp(1.f, 14 - ex);
+        a.f16_inv = std::ldexp(1.f, -(14 - ex) - plan.w16_exp);
+        a.f16_bias_sc = std::ldexp(1.f, (14 - ex) + plan.w16_exp);
+    }
     const int pgroups = (N + a.PT - 1) / a.PT;
     const long long total = (long long)pgroups * a.tpg;
     const unsigned grid = (unsigned)std::min<long long>(total, 256LL * plan.wgs_per_cu);
-    ProfScope ps(ctx, prof_cls, p2.flops_per_patch * N);
+    ProfScope ps(ctx, f16 ? (int)PROF_IGEMM_F16 : prof_cls, p2.flops_per_patch * N);
 #define ALQ_L3(NT) \
     case NT: return plan.wres ? launch3_t<NT, true>(ctx, plan, a, grid) : launch3_t<NT, false>(ctx, plan, a, grid)
     switch (plan.NTW) { ALQ_L3(1); ALQ_L3(2); ALQ_L3(3); }

@@ -348,6 +348,15 @@ static int gemm_set(alq_model *m, Gemm *g, const std::vector<float> &Bmat) {
                                    m->ctx->stream));
             ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
             std::vector<unsigned short>().swap(g->p3.h_W);
+            if (g->p3_f16 && !g->p4.ok) {      // (round 6) the fp16-pair twin for launches with a static input bound
+                igemm3_pack_weights_f16(g->p2, &g->p3, Bmat);
+                unsigned short *dw16 = reinterpret_cast<unsigned short *>(g->p3.d_W16);
+                if (!dw16) ALQ_TRY(m->dalloc(&dw16, g->p3.h_W16.size()));
+                g->p3.d_W16 = dw16;
+                ALQ_HIP(hipMemcpyAsync(dw16, g->p3.h_W16.data(), g->p3.h_W16.size() * sizeof(unsigned short), hipMemcpyHostToDevice, m->ctx->stream));
+                ALQ_HIP(hipStreamSynchronize(m->ctx->stream));
+                std::vector<unsigned short>().swap(g->p3.h_W16);
+            }
         }
         if (!g->p2.d_W) ALQ_TRY(m->dalloc(&g->p2.d_W, g->p2.h_W.size()));
         ALQ_HIP(hipMemcpyAsync(g->p2.d_W, g->p2.h_W.data(), g->p2.h_W.size() * sizeof(float), hipMemcpyHostToDevice,
@@ -669,6 +678,9 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
                 gb.OD = ly.in.D; gb.OH = ly.in.H; gb.OW = ly.in.W; gb.Co = ly.in.C;
                 ALQ_TRY(gemm_build(b, NB, &ly.bwd, &gb));
                 ly.has_bwd = true;
+                // a backward launch that stays on igemm3 (no two-slot plan: NET-B's 5 x 5 and 96-channel convs) takes fp16 pairs under the
+                // cotangent bound of a Fisher pass like the two-slot launches do (round 6; ALQ_NO_V3_F16=1: bf16 triples as before)
+                ly.bwd.p3_f16 = !ly.bwd.p4.ok && ly.bwd.p3.ok && !getenv("ALQ_NO_V3_F16");
             }
         } else if (sp.type == ALQ_CONVT) {
             // y[p] = sum_{q,t: s*q + t - lo = p} x[q] W[t]; output parity class c = p mod s uses the
@@ -1390,6 +1402,12 @@ static int run_backward_main(alq_model *m, const float *d_x, int N) {
                     fz = Igemm2Fuse();
                     fz.in_bound = ly.dout_bound;
                     fuse = &fz;
+                }
+                // the same bound for a launch that runs on igemm3's fp16-pair instantiation (no two-slot plan)
+                if (!ly.bwd.p4.ok && ly.bwd.p3.ok && ly.bwd.p3.d_W16 && !acc && !g_no_f16x2 && ly.dout_bound > 0.f && !m->no_bound16 && !g_dbg_knobs[2] &&
+                    !g_dbg_knobs[4] && !g_dbg_knobs[5] && !ly.bwd.pd.ok && !ly.bwd.pfc.ok) {
+                    if (!fuse) { fz = Igemm2Fuse(); fuse = &fz; }
+                    fz.in_bound = ly.dout_bound;
                 }
                 const unsigned *mine = ly.dout_amax;
                 ly.dout_amax = nullptr;

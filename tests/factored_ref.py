@@ -101,7 +101,9 @@ def factored_unit_scores(model, x, details=None, flips=None):
             recs.append(dict(name=name, type=ltype, a=a_in.detach(), pre=pre, W=W, b=b, spec=spec, relu=relu))
             if relu and flips is not None and name in flips:
                 keep = (pre.detach() > 0) ^ torch.as_tensor(np.asarray(flips[name], dtype=bool))
-                out = pre * keep.to(pre.dtype)
+                # a unit inverted to 'passes' outputs |pre| (derivative 1): the engine that let it pass computed a positive value, and a
+                # max-pool behind the layer compares it with the zeros of its window (csrc/ref64.hip does the same)
+                out = pre * keep.to(pre.dtype) + ((pre.detach().abs() - pre.detach()) * keep.to(pre.dtype))
             else:
                 out = torch.relu(pre) if relu else pre
         elif ltype == 'pool':

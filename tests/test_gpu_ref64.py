@@ -243,3 +243,63 @@ def test_device_fp64_reference_against_the_reference_run_goldens(sess, golden_di
     if '32cube' not in fname:
         assert rep['golden']['flips_needed']['0'] == n, rep          # small nets: no fragile decision within fp32 rounding
     m.close()
+
+
+@pytest.mark.parametrize('shape', [(32, 32, 32), (25, 25, 2)])
+def test_netb_conv_backward_on_igemm3_fp16_pairs(sess, shape):
+    """NET-B's conv backward launches that have no two-slot plan (conv2: 32 -> 24 channels through 25 taps, conv4: 96 -> 48 channels)
+    on igemm3's fp16-pair instantiation under the cotangent bound of a Fisher pass (csrc/igemm3.hip, round 6: three products
+    per MAC instead of six) against bf16 triples (ALQ_NO_V3_F16=1) and against the exact-fp32 engine, judged by the fp64
+    evaluation on the device: same posteriors bit for bit (the forward pass does not change), every layer score within 2e-6 of
+    its maximum + 2e-5 relative of the bf16-triple build, the fp16-pair build disagrees with fp64 on no more patches than
+    1.25 x the exact-fp32 engine + 4, nothing unexplained.  Shapes: the bench's [32, 32, 32] and the reference's 25 x 25 x 2
+    (PW_AL.py:181) with a ragged last workgroup."""
+    import os
+    from nnal_amd import device, ref64
+    from nnal_amd._lib import check
+    torch = sess.torch
+    n = 203
+    ld = netspec.net_b_small(width=256)
+    pars = netspec.he_init(ld, shape, seed=17, bias_std=0.02)
+    x = sess.to_device(np.random.RandomState(22).randn(n, int(np.prod(shape))).astype(np.float32), torch.float32)
+    eng, post, f16 = {}, {}, {}
+    for name, env in (('fp16_pairs', {}), ('bf16_triples', {'ALQ_NO_V3_F16': '1'})):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            m = device.DeviceModel(sess, ld, shape, (), max_batch=n)
+            m.set_weights(pars)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        sess.prof_reset()
+        sess.prof_enable(1)
+        r = m.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1'))
+        torch.cuda.synchronize()
+        sess.prof_enable(False)
+        f16[name] = sess.prof_read()['igemm_f16x2']['launches']
+        eng[name] = (r['g0'].cpu().numpy(), r['g1'].cpu().numpy())
+        post[name] = r['p1'].cpu().numpy()
+        if name == 'fp16_pairs':
+            check(sess.lib.alq_debug_set(4, 1))
+            try:
+                r = m.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1'))
+                eng['exact_fp32'] = (r['g0'].cpu().numpy(), r['g1'].cpu().numpy())
+            finally:
+                check(sess.lib.alq_debug_set(4, 0))
+            r64 = ref64.Ref64(m, max_samples=64)
+            keep = m
+        else:
+            m.close()
+    assert f16['fp16_pairs'] >= f16['bf16_triples'] + 2, f16          # conv2's and conv4's backward launches took the split
+    np.testing.assert_array_equal(post['fp16_pairs'], post['bf16_triples'])
+    for a, b in zip(eng['fp16_pairs'], eng['bf16_triples']):
+        scale = np.abs(b).max(axis=0, keepdims=True)
+        assert (np.abs(a - b) <= 2e-6 * scale + 2e-5 * np.abs(b)).all(), float((np.abs(a - b) / scale).max())
+    rep, base, found = r64.engine_report(x, np.arange(n), eng, eps=ref64.DEFAULT_EPS)
+    print(rep)
+    for k in ('over_2e-6', 'over_1e-4'):
+        assert rep['fp16_pairs'][k] <= 1.25 * rep['exact_fp32'][k] + 4, (k, rep)
+    for k in eng:
+        assert rep[k]['flips_needed']['unexplained'] == 0, (k, rep[k])
+    keep.close()

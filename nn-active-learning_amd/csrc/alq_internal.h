@@ -218,6 +218,10 @@ struct Igemm2Args {
     // igemm3's fp16-pair instantiation (launches with a host-known bound on their input): x * f16_sc = h + l 2^-11,
     // result = (c + cl 2^-11) * f16_inv; a bias enters the accumulator as bias * f16_bias_sc
     float f16_sc = 0.f, f16_inv = 0.f, f16_bias_sc = 0.f;
+    // ... or ONE scale per patch from a bound on max |input| of every patch (float bits; forward launches: measured input maximum
+    // pushed through the layers' L1 norms, k_fwd_bounds): tiles of one patch only (PT = 1); f16_wexp = the weights' exponent
+    const unsigned *f16_bound = nullptr;
+    int f16_wexp = 0;
 };
 
 struct Igemm2Plan {
@@ -618,7 +622,8 @@ int k_rowsum_field(alq_ctx *, const float *field, int64_t len, int N, float *out
 // bound[k][p] = max(bound[k - 1][p], bound[src2[k]][p]) * L[k] + B[k] for k = 1 .. nl - 1, bound[0] = the first layer's measured maximum
 // (float bits, as the producers' epilogues leave them): what a forward launch with the fp16x2 split takes as its input maxima when
 // nothing measured them (model.hip, run_forward)
-struct FwdBoundsArgs { int nl; float L[16]; float B[16]; int src2[16]; };
+struct FwdBoundsArgs { int nl; float L[16]; float B[16]; int src2[16]; int from_input = 0; };
+int k_rowmax_abs(alq_ctx *, const float *x, int N, long long K, unsigned *out);      // out[n] = bits of max |x[n][:]|
 int k_fwd_bounds(alq_ctx *, const unsigned *amax0, int N, int stride, const FwdBoundsArgs &a, unsigned *bound_all);
 int flip_segments(int N);      // scan segments / list slots k_flip_fix needs for N patches
 int flip_list_len(int N);

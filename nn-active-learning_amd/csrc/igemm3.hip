@@ -67,6 +67,12 @@ __device__ inline i32x4 sload4(const int *p) {
     return v;
 }
 
+__device__ inline int sload1(const unsigned *p) {
+    int v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+    return v;
+}
+
 // F16 (round 6): the fp16-pair form for launches whose input has a host-known bound (the backward launches of a Fisher pass):
 // x 2^e = h + l 2^-11 (the lo pieces scaled up: the bound is loose by orders of magnitude and true-scale lo pieces of typical
 // values would be fp16 subnormals), weights likewise; three products instead of six - (h, h) in one accumulator, (l, h) + (h, l)
@@ -191,6 +197,9 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(const Igemm2Args a) {
     };
     int f_out = 0, c_out = 0, p_out = 0;
     int f_cls = 0, c_cls = 0, p_cls = 0;
+    // F16: the scales of the tile being staged / contracted (c_) and of the tile whose epilogue is pending (p_)
+    int f_t = 0;
+    float c_sc = a.f16_sc, c_bsc = a.f16_bias_sc, p_inv = a.f16_inv, c_inv = a.f16_inv;
     int f_l = 0, c_l = 0, p_l = 0, f_g = 0, c_g = 0, p_g = 0;
 
     int goff[NSLOT];
@@ -200,6 +209,13 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(const Igemm2Args a) {
         f_out = td.y + fpg * a.out_pstride;
         f_cls = td.z;
         f_l = fl; f_g = fpg;
+        if constexpr (F16) {
+            if (a.f16_bound) {      // bound = f 2^ex, f in [.5, 1): x 2^(14 - ex) < 2^14; the exponent field E = ex + 126 (clamped: no inf / denormal scale)
+                int E = (sload1(a.f16_bound + (fpg < a.N ? fpg : 0)) >> 23) & 255;
+                E = E < 40 ? 40 : (E > 200 ? 200 : E);
+                f_t = 140 - E;
+            }
+        }
         const int cls = f_cls & 63;
         const unsigned bit = 1u << (cls & 31);
         const bool hi = cls >= 32;
@@ -251,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(const Igemm2Args a) {
                 float v0 = R[it].x, v1 = R[it].y, v2 = R[it].z, v3 = R[it].w;
                 char *dst = Al + sbase + it * (128 * I3_ROWB);
                 if constexpr (F16) {
-                    const float sc = a.f16_sc, sc11 = a.f16_sc * 2048.f;
+                    const float sc = c_sc, sc11 = c_sc * 2048.f;
                     const f16x2 h01 = __builtin_convertvector(f32x2{v0 * sc, v1 * sc}, f16x2), h23 = __builtin_convertvector(f32x2{v2 * sc, v3 * sc}, f16x2);
                     // (x 2^e - h) 2^11: exact in fp32 (the remainder of a rounding to 11 bits)
                     const f16x2 l01 = __builtin_convertvector(f32x2{__builtin_fmaf((float)h01.x, -2048.f, v0 * sc11), __builtin_fmaf((float)h01.y, -2048.f, v1 * sc11)}, f16x2);
@@ -309,8 +325,8 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(const Igemm2Args a) {
                 f32x4 val = acc[ms][nt];
                 if constexpr (F16) {
                     const f32x4 cl = accl[ms][nt];
-                    val.x = __builtin_fmaf(cl.x, 0x1p-11f, val.x) * a.f16_inv; val.y = __builtin_fmaf(cl.y, 0x1p-11f, val.y) * a.f16_inv;
-                    val.z = __builtin_fmaf(cl.z, 0x1p-11f, val.z) * a.f16_inv; val.w = __builtin_fmaf(cl.w, 0x1p-11f, val.w) * a.f16_inv;
+                    val.x = __builtin_fmaf(cl.x, 0x1p-11f, val.x) * p_inv; val.y = __builtin_fmaf(cl.y, 0x1p-11f, val.y) * p_inv;
+                    val.z = __builtin_fmaf(cl.z, 0x1p-11f, val.z) * p_inv; val.w = __builtin_fmaf(cl.w, 0x1p-11f, val.w) * p_inv;
                 }
                 const bool on = live && c < a.Co;
                 if (on) {
@@ -360,7 +376,16 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(const Igemm2Args a) {
         int chunk = 0;
         bool first = true;
         for (;;) {
-            if (chunk == 0) { c_out = f_out; c_cls = f_cls; c_l = f_l; c_g = f_g; }
+            if (chunk == 0) {
+                c_out = f_out; c_cls = f_cls; c_l = f_l; c_g = f_g;
+                if constexpr (F16) {
+                    if (a.f16_bound) {
+                        c_sc = __builtin_bit_cast(float, (unsigned)(127 + f_t) << 23);
+                        c_bsc = __builtin_bit_cast(float, (unsigned)(127 + f_t + a.f16_wexp) << 23);
+                        c_inv = __builtin_bit_cast(float, (unsigned)(127 - f_t - a.f16_wexp) << 23);
+                    }
+                }
+            }
             if (!first) __syncthreads();
             first = false;
             PHASE3_END(1);
@@ -391,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(const Igemm2Args a) {
                     for (int nt = 0; nt < NTW; ++nt) {
                         acc[ms][nt] = bias4[nt];
                         if constexpr (F16) {
-                            acc[ms][nt] = f32x4{bias4[nt].x * a.f16_bias_sc, bias4[nt].y * a.f16_bias_sc, bias4[nt].z * a.f16_bias_sc, bias4[nt].w * a.f16_bias_sc};
+                            acc[ms][nt] = f32x4{bias4[nt].x * c_bsc, bias4[nt].y * c_bsc, bias4[nt].z * c_bsc, bias4[nt].w * c_bsc};
                             accl[ms][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
                         }
                     }
@@ -471,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(const Igemm2Args a) {
             PHASE3_END(6);
             if (tile_done) {
                 have_pend = true;
-                p_out = c_out; p_cls = c_cls; p_l = c_l; p_g = c_g;
+                p_out = c_out; p_cls = c_cls; p_l = c_l; p_g = c_g; p_inv = c_inv;
                 if (!next_valid) break;
             }
             chunk = nchunk;
@@ -634,8 +659,16 @@ int igemm3_launch(alq_ctx *ctx, const Igemm2Plan &p2, const Igemm3Plan &plan, co
     // the fp16-pair instantiation: a host-known bound on the input (Igemm2Fuse::in_bound - the cotangent bound of a Fisher pass),
     // the twin weights packed, nothing accumulated into (those launches keep the exact split)
     a.f16_sc = a.f16_inv = a.f16_bias_sc = 0.f;
-    const bool f16 = fuse && fuse->in_bound > 0.f && plan.d_W16 && !accumulate && !g_no_f16x2 && !g_dbg_knobs[2];
-    if (f16) {
+    a.f16_bound = nullptr; a.f16_wexp = 0;
+    // ... or one scale per patch (forward launches): Igemm2Fuse::in_amax = a bound on max |input| of every patch; tiles of one patch
+    const bool f16p = fuse && fuse->in_amax && !fuse->in_amax2 && plan.d_W16 && a.PT == 1 && !accumulate && !g_no_f16x2;
+    const bool f16 = f16p || (fuse && fuse->in_bound > 0.f && plan.d_W16 && !accumulate && !g_no_f16x2 && !g_dbg_knobs[2]);
+    if (f16p) {
+        a.W = reinterpret_cast<const float *>(plan.d_W16);
+        a.f16_bound = fuse->in_amax;
+        a.f16_wexp = plan.w16_exp;
+        a.f16_sc = a.f16_inv = a.f16_bias_sc = 1.f;       // (selects the instantiation; the kernel derives the scales per tile)
+    } else if (f16) {
         int ex = 0;
         (void)std::frexp(fuse->in_bound, &ex);            // bound = f 2^ex, f in [.5, 1): |x| 2^(14 - ex) < 2^14
         a.W = reinterpret_cast<const float *>(plan.d_W16);

@@ -1283,12 +1283,52 @@ int k_rowmax_u32(alq_ctx *ctx, const unsigned *in, int len, int N, unsigned *out
     return ALQ_OK;
 }
 
+// max |x| of every patch's input as float bits (one wave per patch; any element count)
+__global__ __launch_bounds__(256) void rowmax_abs_kernel(const float *x, int N, long long K, unsigned *out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float *p = x + (size_t)row * K;
+    float m = 0.f;
+    if ((K & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0) {      // rows start 16-byte aligned: four 16-byte loads in flight per lane
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        const v4 *q = reinterpret_cast<const v4 *>(p);
+        const long long K4 = K >> 2;
+        long long k = lane;
+        for (; k + 192 < K4; k += 256) {
+            const v4 a = q[k], b = q[k + 64], c = q[k + 128], d = q[k + 192];
+            const float ma = fmaxf(fmaxf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), fmaxf(__builtin_fabsf(a.z), __builtin_fabsf(a.w)));
+            const float mb = fmaxf(fmaxf(__builtin_fabsf(b.x), __builtin_fabsf(b.y)), fmaxf(__builtin_fabsf(b.z), __builtin_fabsf(b.w)));
+            const float mc = fmaxf(fmaxf(__builtin_fabsf(c.x), __builtin_fabsf(c.y)), fmaxf(__builtin_fabsf(c.z), __builtin_fabsf(c.w)));
+            const float md = fmaxf(fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), fmaxf(__builtin_fabsf(d.z), __builtin_fabsf(d.w)));
+            m = fmaxf(m, fmaxf(fmaxf(ma, mb), fmaxf(mc, md)));
+        }
+        for (; k < K4; k += 64) {
+            const v4 a = q[k];
+            m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), fmaxf(__builtin_fabsf(a.z), __builtin_fabsf(a.w))));
+        }
+    } else {
+        for (long long k = lane; k < K; k += 64) m = fmaxf(m, __builtin_fabsf(p[k]));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) out[row] = __builtin_bit_cast(unsigned, m);
+}
+int k_rowmax_abs(alq_ctx *ctx, const float *x, int N, long long K, unsigned *out) {
+    ProfScope ps(ctx, PROF_REDUCE, 0);
+    ALQ_REQUIRE(x && out && N >= 1 && K >= 1, ALQ_EINVAL, "rowmax_abs: bad argument");
+    hipLaunchKernelGGL(rowmax_abs_kernel, dim3((N + 3) / 4), dim3(256), 0, ctx->stream, x, N, K, out);
+    ALQ_LAUNCH_CHECK();
+    return ALQ_OK;
+}
+
 __global__ void fwd_bounds_kernel(const unsigned *amax0, int N, int stride, FwdBoundsArgs a, unsigned *bound_all) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N) return;
     float b[16];
+    // amax0 = the measured maximum of layer 0's OUTPUT - or (from_input) of the network INPUT, pushed through layer 0 like the others
     b[0] = __builtin_bit_cast(float, amax0[p]);
-    bound_all[p] = amax0[p];
+    if (a.from_input) b[0] = b[0] * a.L[0] + a.B[0];
+    bound_all[p] = __builtin_bit_cast(unsigned, b[0]);
     for (int k = 1; k < a.nl && k < 16; ++k) {
         float in = b[k - 1];
         if (a.src2[k] >= 0) in = fmaxf(in, b[a.src2[k]]);

@@ -124,6 +124,8 @@ struct alq_model {
     unsigned *flip_cnt = nullptr, *flip_list = nullptr;     // candidates of the flip-safe fused head (igemm4 FCF + F16)
     int flip_cap = 0;
     unsigned *bound_all = nullptr;          // [layer][max_batch] derived per-patch output bounds (float bits), k_fwd_bounds
+    unsigned *in_amax = nullptr;            // [max_batch] measured max |x| of every patch of the network input (igemm3's forward fp16 pairs)
+    bool v3_fwd_f16 = false;                // some forward conv launch stays on igemm3 and has the fp16-pair twin packed (set at build)
     unsigned *flip_overflow = nullptr;      // marked groups beyond the scan's lists since the model was created: drained by the sweep path of flip_fix_kernel (kernels.hip), none dropped
     int no_flipfix = 0;                                      // ALQ_NO_FLIPFIX at creation (A/B: the head's sign bits as the fp16x2 contraction leaves them)
     size_t amax_tiles_len = 0;
@@ -640,6 +642,13 @@ static int build_model(alq_model *m, const alq_layer_t *specs, int n_layers) {
             // a 2-D window of 25 taps or more: the two-slot engine's tiles re-stage too much halo - NET-B's conv2 (24 -> 32 channels,
             // 5 x 5 at 32^2) takes 673 us per 2048 patches there and ~390 on igemm3 (round 6; ALQ_NO_WIDE2D_RULE=1 = the other arm)
             if (ly.fwd[0].p4.ok && ly.fwd[0].p3.ok && d.ID == 1 && d.tz.size() >= 25 && !getenv("ALQ_NO_WIDE2D_RULE")) ly.fwd[0].p4.ok = false;
+            // a forward launch that stays on igemm3, tiles of one patch: the fp16-pair twin of its weights for Fisher / forward-only passes
+            // (run_forward, round 6; ALQ_NO_V3_F16_FWD=1: bf16 triples as before)
+            if (!ly.fwd[0].p4.ok && !ly.fwd[0].pd.ok && !ly.fwd[0].pfc.ok && ly.fwd[0].p3.ok && ly.fwd[0].p2.a.PT == 1 && sp.skip_src < 0 &&
+                !getenv("ALQ_NO_V3_F16_FWD") && !getenv("ALQ_NO_V3_F16")) {
+                ly.fwd[0].p3_f16 = true;
+                m->v3_fwd_f16 = true;
+            }
             if (!ly.fwd[0].p4.ok && !ly.fwd[0].p3.ok && !ly.fwd[0].pd.ok && sp.cout > 32 && !getenv("ALQ_NO_CO_SPLIT")) {
                 for (int w : {32, 48, 16}) {
                     if (sp.cout % w || sp.cout <= w) continue;
@@ -926,6 +935,30 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
         ALQ_TRY(m->dalloc(&m->bound_all, (size_t)nl * m->max_batch));
         for (int k = 0; k < nl; ++k) m->layers[k].bound_fwd = m->bound_all + (size_t)k * m->max_batch;
     }
+    // Forward launches that stay on igemm3 (no two-slot plan: NET-B's conv1 .. conv3) on fp16 pairs, one scale per patch: the
+    // measured maximum of every patch of the network input, pushed through the layers' L1 norms, bounds every layer's input.
+    // Fisher passes and forward-only passes; not the passes that keep every activation for training, not under dropout.
+    const bool v3f16 = m->v3_fwd_f16 && (with_sums || light) && !no16 && !drop && !any_derived && !use_dcp(0) && nl <= 16 &&
+                       !g_dbg_knobs[3] && !g_dbg_knobs[4] && !g_dbg_knobs[5] && m->layers[0].in.split == 0 && m->layers[0].in.cs == m->layers[0].in.C;
+    if (v3f16) {
+        if (!m->in_amax) ALQ_TRY(m->dalloc(&m->in_amax, (size_t)m->max_batch));
+        if (!m->bound_all) {
+            ALQ_TRY(m->dalloc(&m->bound_all, (size_t)nl * m->max_batch));
+            for (int k = 0; k < nl; ++k) m->layers[k].bound_fwd = m->bound_all + (size_t)k * m->max_batch;
+        }
+        ALQ_TRY(k_rowmax_abs(ctx, d_x, N, (long long)m->layers[0].in.vox() * m->layers[0].in.C, m->in_amax));
+        FwdBoundsArgs ba;
+        ba.nl = nl;
+        ba.from_input = 1;
+        for (int k = 0; k < nl && k < 16; ++k) {
+            const Layer &lk = m->layers[k];
+            const bool par = lk.pidx >= 0 && lk.spec.type != ALQ_FC;
+            ba.L[k] = par ? lk.out_l1 : 1.f;
+            ba.B[k] = par ? lk.out_bmax : 0.f;
+            ba.src2[k] = lk.spec.skip_src;
+        }
+        ALQ_TRY(k_fwd_bounds(ctx, m->in_amax, N, m->max_batch, ba, m->bound_all));
+    }
     auto take_amax = [&](Igemm2Fuse &fz, int j) {      // the input maxima of consumer j
         if (!cons[j]) return;
         const bool dv = cons[j] == 2;
@@ -1070,7 +1103,22 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                 }
                 const bool sg_here = with_sums && fuse && !m->no_signs && ly.spec.relu && ly.out.sg && v4_fwd(ly.fwd[0], in, ly.out);
                 if (sg_here) fz.sign_out = ly.out.sg;
-                ALQ_TRY(gemm_launch(ctx, ly.fwd[0], in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM_FWD, fuse, &fused));
+                {
+                    // igemm3's fp16-pair instantiation for a forward launch without a two-slot plan (NET-B's conv1 .. conv3): one scale per
+                    // patch from the bound on this layer's input (measured maximum of the network input pushed through the L1 norms)
+                    Igemm2Fuse hz;
+                    const Igemm2Fuse *fu = fuse;
+                    if (v3f16 && !ly.fwd[0].p4.ok && !ly.fwd[0].pd.ok && !ly.fwd[0].pfc.ok && ly.fwd[0].p3.ok && ly.fwd[0].p3.d_W16 && ly.fwd[0].p2.a.PT == 1 &&
+                        in.split == 0 && ly.spec.skip_src < 0) {
+                        if (fuse) hz = *fuse;
+                        hz.in_amax = i == 0 ? m->in_amax : m->layers[i - 1].bound_fwd;
+                        hz.in_amax2 = nullptr;
+                        fu = &hz;
+                    }
+                    bool f2 = false;
+                    ALQ_TRY(gemm_launch(ctx, ly.fwd[0], in, ly.out, ly.d_bias, ly.spec.relu, 0, N, PROF_IGEMM_FWD, fu, &f2));
+                    fused = fuse ? f2 : false;
+                }
                 ly.signs_ready = sg_here;
                 if (fuse && prod[i]) ALQ_TRY(k_rowmax_u32(ctx, m->amax_tiles, ly.fwd[0].p4.a.tpg * 4, N, ly.amax_fwd));
                 break;

@@ -263,7 +263,8 @@ def test_netb_conv_backward_on_igemm3_fp16_pairs(sess, shape):
     pars = netspec.he_init(ld, shape, seed=17, bias_std=0.02)
     x = sess.to_device(np.random.RandomState(22).randn(n, int(np.prod(shape))).astype(np.float32), torch.float32)
     eng, post, f16 = {}, {}, {}
-    for name, env in (('fp16_pairs', {}), ('bf16_triples', {'ALQ_NO_V3_F16': '1'})):
+    # (both arms keep the forward launches on bf16 triples: the posteriors must then be the same bits)
+    for name, env in (('fp16_pairs', {'ALQ_NO_V3_F16_FWD': '1'}), ('bf16_triples', {'ALQ_NO_V3_F16': '1'})):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
@@ -296,6 +297,80 @@ def test_netb_conv_backward_on_igemm3_fp16_pairs(sess, shape):
     for a, b in zip(eng['fp16_pairs'], eng['bf16_triples']):
         scale = np.abs(b).max(axis=0, keepdims=True)
         assert (np.abs(a - b) <= 2e-6 * scale + 2e-5 * np.abs(b)).all(), float((np.abs(a - b) / scale).max())
+    rep, base, found = r64.engine_report(x, np.arange(n), eng, eps=ref64.DEFAULT_EPS)
+    print(rep)
+    for k in ('over_2e-6', 'over_1e-4'):
+        assert rep['fp16_pairs'][k] <= 1.25 * rep['exact_fp32'][k] + 4, (k, rep)
+    for k in eng:
+        assert rep[k]['flips_needed']['unexplained'] == 0, (k, rep[k])
+    keep.close()
+
+
+@pytest.mark.parametrize('shape', [(32, 32, 32), (25, 25, 2)])
+def test_netb_conv_forward_on_igemm3_fp16_pairs(sess, shape):
+    """NET-B's conv FORWARD launches that stay on igemm3 (conv1 .. conv3: no two-slot plan) on fp16 pairs with one scale per patch -
+    the measured maximum of every patch of the network input pushed through the layers' L1 norms (k_rowmax_abs + k_fwd_bounds;
+    csrc/igemm3.hip, round 6) - against bf16 triples (ALQ_NO_V3_F16_FWD=1) and the exact-fp32 engine, judged by the fp64
+    evaluation on the device: posteriors within 2e-6, the fp16-pair build disagrees with fp64 on no more patches than 1.25 x the
+    exact-fp32 engine + 4, nothing unexplained; per-patch scales make the results independent of the batch cut (bit-identical
+    for passes of 203, 64 and 7 patches), forward-only posteriors == the Fisher pass's; an all-zero patch and a patch scaled by 2^20
+    ride along (scales from their own maxima)."""
+    import os
+    from nnal_amd import device, ref64
+    from nnal_amd._lib import check
+    torch = sess.torch
+    n = 203
+    ld = netspec.net_b_small(width=256)
+    pars = netspec.he_init(ld, shape, seed=19, bias_std=0.02)
+    xs = np.random.RandomState(23).randn(n, int(np.prod(shape))).astype(np.float32)
+    xs[5] = 0.0
+    xs[6] *= 2.0 ** 20
+    xs[7] *= 2.0 ** -20
+    x = sess.to_device(xs, torch.float32)
+    eng, post, f16 = {}, {}, {}
+    for name, env in (('fp16_pairs', {}), ('bf16_triples', {'ALQ_NO_V3_F16_FWD': '1'})):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            m = device.DeviceModel(sess, ld, shape, (), max_batch=n)
+            m.set_weights(pars)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        sess.prof_reset()
+        sess.prof_enable(1)
+        r = m.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1'))
+        torch.cuda.synchronize()
+        sess.prof_enable(False)
+        f16[name] = sess.prof_read()['igemm_f16x2']['launches']
+        eng[name] = (r['g0'].cpu().numpy(), r['g1'].cpu().numpy())
+        post[name] = r['p1'].cpu().numpy()
+        if name == 'fp16_pairs':
+            # batch cuts: the same bits whatever shares a pass with a patch
+            for mb in (64, 7):
+                m2 = device.DeviceModel(sess, ld, shape, (), max_batch=mb)
+                m2.set_weights(pars)
+                m2.lanes = 1
+                r2 = m2.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1'))
+                for k in ('p1', 'g0', 'g1'):
+                    np.testing.assert_array_equal(r2[k].cpu().numpy(), r[k].cpu().numpy(), err_msg='batch %d: %s' % (mb, k))
+                m2.close()
+            pf = m.forward_device(x, n)[0].cpu().numpy()
+            np.testing.assert_array_equal(pf[1], post[name])
+            check(sess.lib.alq_debug_set(4, 1))
+            try:
+                r = m.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1'))
+                eng['exact_fp32'] = (r['g0'].cpu().numpy(), r['g1'].cpu().numpy())
+            finally:
+                check(sess.lib.alq_debug_set(4, 0))
+            r64 = ref64.Ref64(m, max_samples=64)
+            keep = m
+        else:
+            m.close()
+    # conv1, conv2 and conv3 took the split (25 x 25 x 2: two of them - a layer whose tiles hold several patches keeps bf16 triples)
+    assert f16['fp16_pairs'] >= f16['bf16_triples'] + (3 if shape[0] == 32 else 2), f16
+    assert np.isfinite(post['fp16_pairs']).all() and np.isfinite(eng['fp16_pairs'][0]).all()
+    np.testing.assert_allclose(post['fp16_pairs'], post['bf16_triples'], rtol=0, atol=2e-6)
     rep, base, found = r64.engine_report(x, np.arange(n), eng, eps=ref64.DEFAULT_EPS)
     print(rep)
     for k in ('over_2e-6', 'over_1e-4'):

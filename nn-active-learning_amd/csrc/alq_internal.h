@@ -559,6 +559,7 @@ struct FcGemmPlan {
     std::vector<unsigned short> h_W16; // the same as fp16 pairs (2 pieces) of w 2^w_exp, for launches with a static input bound
     void *d_W16 = nullptr;
     int w_exp = 0;
+    int form = 0;                      // fp16-pair launches: 0 = 128-wide tiles, tall wave tiles (default), 1 = 64 x 64 wave tiles (ALQ_FC_SQUARE), 2 = 64-wide tiles (ALQ_FC_BN64); read when the plan is built
 };
 int fcgemm_build_plan(int K, int N, FcGemmPlan *plan);
 void fcgemm_pack_weights(FcGemmPlan *plan, const std::vector<float> &Bmat /* [K][N] */);

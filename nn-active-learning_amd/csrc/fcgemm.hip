@@ -87,16 +87,24 @@ __device__ inline int fc_row_exp(unsigned fm) {
 // BN = features per workgroup tile: 64 (the packed weight tile), or 128 = two packed tiles side by side (fp16 pairs only, round 6):
 // a wave then owns 64 x 64 = 4 x 4 MFMA tiles - 16 fragment reads per 48 MFMAs instead of 12 per 24 (the 64-wide kernel is
 // LDS-read bound: 56 % LDS active at 28 % MFMA busy) - and the activation tile is staged and split for half as many workgroups.
-template <bool F16, int BN>
+// TALL (128-wide tiles only): a wave owns all 128 patches x 32 features (8 x 2 MFMA tiles) instead of 64 x 64: every weight
+// fragment is then loaded from global memory by ONE wave (the two 64 x 64 tiles of a column load the same 8 KB per k-step: the
+// vector-memory path of a CU ran at ~62 of its 64 B/clk), at the price of twice the activation fragment reads from LDS
+// (NET-B, 2048 patches, same box: fc launches 1.05 -> 0.93 ms, pass 3.70 -> 3.57 ms; a 256-wide workgroup tile with 128 x 64 wave
+// tiles - half the loads and reads per MFMA again, but one wave per SIMD - scored like the 64 x 64 tiles: 3.69 ms).  Same sums in
+// the same order per output element: bit-identical to the 64 x 64 tiles (ALQ_FC_SQUARE=1 = that arm).
+template <bool F16, int BN, bool TALL = false>
 __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
     static_assert(BN == FC_BN || (F16 && BN == 2 * FC_BN), "128-wide tiles for the fp16-pair form only");
+    static_assert(!TALL || BN == 2 * FC_BN, "tall wave tiles: 128-wide workgroup tiles");
     // WD: the weight fragments come straight from global memory (the packed layout IS the MFMA lane layout: 256 contiguous bytes per
     // 16 lanes), one k-step ahead in registers, instead of through LDS: the 64-wide kernel's LDS was 56 % active - 32 KB of writes
     // at ~80 B/clk and 64 KB of fragment reads per k-step - of which the weights were half
     constexpr bool WD = BN == 2 * FC_BN;
     constexpr int NP = F16 ? 2 : 3;                     // pieces per operand
     constexpr int NC = BN / FC_BN;                      // packed 64-feature weight tiles per workgroup
-    constexpr int NI = BN / 32;                         // MFMA column tiles per wave
+    constexpr int NI = TALL ? 2 : BN / 32;              // MFMA column tiles per wave
+    constexpr int MI = TALL ? 8 : 4;                    // MFMA row tiles per wave
     constexpr int XB = NP * 4 * FC_BM * 16, WB = WD ? 0 : NP * 4 * BN * 16, WB64 = NP * 4 * FC_BN * 16;
     extern __shared__ __attribute__((aligned(16))) char fc_lds[];
     const int tid = threadIdx.x;
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
     f32x4 xa[2][2];
     i32x4 wr[NC][NP];
     // WD: this lane's fragment of MFMA column tile ni = feature row wn + 16 ni + lrow, k-group lq, of packed tile (row >> 6)
-    const int wm = (wave & 1) * 64, wn = (wave >> 1) * (BN / 2);
+    const int wm = TALL ? 0 : (wave & 1) * 64, wn = TALL ? wave * 32 : (wave >> 1) * (BN / 2);
     i32x4 Wn[NP][NI];
     const char *wfrag[NI];
 #pragma unroll
@@ -201,9 +209,9 @@ __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
     };
 
     // wave tile: 64 patches x BN / 2 features = 4 x NI MFMA tiles
-    f32x4 acc[4][NI];
+    f32x4 acc[MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
     __syncthreads();
     for (int ks = 0; ks < nks; ++ks) {
         const int buf = ks & 1;
-        i32x4 Wf[NP][NI], Xf[NP][4];
+        i32x4 Wf[NP][NI], Xf[NP][MI];
         if constexpr (WD) {      // the fragments fetched one k-step ago (fetch(0) in front of the loop)
 #pragma unroll
             for (int p = 0; p < NP; ++p)
@@ -230,12 +238,12 @@ __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
             for (int ni = 0; ni < NI; ++ni)
                 if constexpr (!WD) Wf[p][ni] = *reinterpret_cast<const i32x4 *>(Wbuf(buf) + ((p * 4 + lq) * BN + wn + ni * 16 + lrow) * 16);
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
                 Xf[p][mi] = *reinterpret_cast<const i32x4 *>(Xbuf(buf) + ((p * 4 + lq) * FC_BM + wm + mi * 16 + lrow) * 16);
         }
         // the piece products, smallest first
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 f32x4 c = acc[mi][ni];
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void fcgemm_kernel(const FcGemmArgs a) {
         __syncthreads();
     }
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
         const int m = m0 + wm + mi * 16 + lrow;
         if (m >= a.M) continue;
 #pragma unroll
@@ -286,6 +294,7 @@ int fcgemm_build_plan(int K, int N, FcGemmPlan *plan) {
     plan->ok = false;
     if (K % FC_BK != 0 || N % FC_BN != 0 || K < 256 || N < 256) return ALQ_OK;
     plan->K = K; plan->N = N;
+    plan->form = getenv("ALQ_FC_BN64") ? 2 : (getenv("ALQ_FC_SQUARE") ? 1 : 0);
     plan->ok = true;
     return ALQ_OK;
 }
@@ -355,9 +364,13 @@ void fcgemm_pack_weights_f16(FcGemmPlan *plan, const std::vector<float> &Bmat /*
 
 // the fp16-pair launch: 128-feature tiles where the layer's width allows (ALQ_FC_BN64=1: the 64-wide kernel, A/B)
 static int fc16_go(alq_ctx *ctx, const FcGemmPlan &plan, const FcGemmArgs &a, int M) {
-    static const bool bn64 = getenv("ALQ_FC_BN64") != nullptr;
+    const bool bn64 = plan.form == 2, tall = plan.form == 0;
     ProfScope ps16(ctx, PROF_IGEMM_F16, 2.0 * M * (double)plan.K * plan.N);
-    if (plan.N % (2 * FC_BN) == 0 && !bn64) {
+    if (plan.N % (2 * FC_BN) == 0 && !bn64 && tall) {
+        const size_t lds = 2 * (2 * 4 * FC_BM * 16);
+        ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fcgemm_kernel<true, 2 * FC_BN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((fcgemm_kernel<true, 2 * FC_BN, true>), dim3(plan.N / (2 * FC_BN), (M + FC_BM - 1) / FC_BM), dim3(256), lds, ctx->stream, a);
+    } else if (plan.N % (2 * FC_BN) == 0 && !bn64) {
         const size_t lds = 2 * (2 * 4 * FC_BM * 16);          // activations only: the weight fragments come from global memory
         ALQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fcgemm_kernel<true, 2 * FC_BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((fcgemm_kernel<true, 2 * FC_BN>), dim3(plan.N / (2 * FC_BN), (M + FC_BM - 1) / FC_BM), dim3(256), lds, ctx->stream, a);

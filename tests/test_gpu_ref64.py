@@ -378,3 +378,33 @@ def test_netb_conv_forward_on_igemm3_fp16_pairs(sess, shape):
     for k in eng:
         assert rep[k]['flips_needed']['unexplained'] == 0, (k, rep[k])
     keep.close()
+
+
+def test_fc_gemm_tile_forms_give_the_same_bits(sess):
+    """The fp16-pair fc GEMM (csrc/fcgemm.hip) in its three tile forms - 128-wide workgroup tiles with tall 128 x 32 wave tiles
+    (default since round 6: every weight fragment is loaded by one wave), with 64 x 64 wave tiles (ALQ_FC_SQUARE=1), 64-wide tiles
+    (ALQ_FC_BN64=1) - adds the same products in the same order per output element: NET-B's scores are the same bits."""
+    import os
+    from nnal_amd import device
+    torch = sess.torch
+    n = 200
+    ld = netspec.net_b_small(width=256)
+    shape = (32, 32, 32)
+    pars = netspec.he_init(ld, shape, seed=23, bias_std=0.02)
+    x = sess.to_device(np.random.RandomState(29).randn(n, 32 ** 3).astype(np.float32), torch.float32)
+    got = {}
+    for name, env in (('tall', {}), ('square', {'ALQ_FC_SQUARE': '1'}), ('bn64', {'ALQ_FC_BN64': '1'})):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            m = device.DeviceModel(sess, ld, shape, (), max_batch=n)
+            m.set_weights(pars)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        r = m.fisher_device(x, n, None, 1e-3, want=('p1', 'g0', 'g1'))
+        got[name] = {k: r[k].cpu().numpy() for k in ('p1', 'g0', 'g1')}
+        m.close()
+    for name in ('square', 'bn64'):
+        for k in ('p1', 'g0', 'g1'):
+            np.testing.assert_array_equal(got['tall'][k], got[name][k], err_msg='%s: %s' % (name, k))

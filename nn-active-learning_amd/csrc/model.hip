@@ -1090,12 +1090,17 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                 if (fuse && prod[i]) fz.out_amax = m->amax_tiles;
                 if (!ly.fwd_co.empty() && !prod[i] && !cons[i] && !g_dbg_knobs[4] && !g_dbg_knobs[5]) {
                     // a wide conv as launches over slices of its output channels (no epilogue fusion: channel sums and ReLU masks the plain way)
+                    // (round 6) with per-patch bounds on the input at hand (v3f16: igemm3's forward launches above this layer asked for
+                    // them) the slices take the two-slot engine's fp16-pair form too: one scale per patch, three products
+                    Igemm2Fuse sz;
+                    const bool s16 = v3f16 && i >= 1 && in.split == 0 && ly.spec.skip_src < 0 && !getenv("ALQ_NO_CO_SPLIT_F16");
+                    if (s16) sz.in_amax = m->layers[i - 1].bound_fwd;
                     for (size_t j = 0; j < ly.fwd_co.size(); ++j) {
                         View oj = ly.out;
                         oj.c0 = ly.out.c0 + (int)j * ly.fwd_co_w;
                         oj.C = ly.fwd_co_w;
                         bool f1 = false;
-                        ALQ_TRY(gemm_launch(ctx, ly.fwd_co[j], in, oj, ly.d_bias + j * ly.fwd_co_w, ly.spec.relu, 0, N, PROF_IGEMM_FWD, nullptr, &f1));
+                        ALQ_TRY(gemm_launch(ctx, ly.fwd_co[j], in, oj, ly.d_bias + j * ly.fwd_co_w, ly.spec.relu, 0, N, PROF_IGEMM_FWD, s16 ? &sz : nullptr, &f1));
                     }
                     fused = false;
                     ly.signs_ready = false;

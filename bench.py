@@ -751,9 +751,10 @@ def netb_rate(sess, n, x):
             'tflops_executed': (190.9e6 + 151.5e6) * n / dt / 1e12,
             'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak if peak > 0 else 0.0,
                          'useful_frac': ach / peak_f16, 'traffic': traffic, 'traffic_note': traffic_note, 'launches': nl, 'avg_launch_ms': ms / max(nl, 1),
-                         'kernel': 'the contraction launches of a NET-B pass (4 conv forward + 3 conv backward-data on the two-slot / bf16x3 / fp32 engines, '
-                                   '2 wide fc forward (fp16 pairs under measured per-patch maxima since round 6) + 2 wide fc backward on fcgemm), HIP events '
-                                   'on every launch of a separate pass',
+                         'kernel': 'the contraction launches of a NET-B pass (conv1 - conv3 forward and conv2 / conv4 backward-data on igemm3, conv4 forward '
+                                   'as three 32-channel launches and conv3 backward-data on the two-slot engine, 2 wide fc forward + 2 wide fc backward '
+                                   'on fcgemm; fp16 pairs wherever the launch knows a bound on its input - measured per-patch maxima pushed through the '
+                                   'L1 norms forward, the cotangent bound backward - see alg_flops_per_patch), HIP events on every launch of a separate pass',
                          'peak_note': 'algorithmic fp32 flops; peak = flop-weighted harmonic mean of %.0f / 6 (bf16x3 launches, %.0f %% of the '
                                       'flops) and %.0f / 3 (fp16-pair launches)' % (PEAK_BF16_MFMA_TFLOPS, 100.0 * bf_fl / max(fl, 1.0), PEAK_BF16_MFMA_TFLOPS),
                          'alg_flops_per_patch': {'bf16x3': bf_fl / max(n, 1), 'f16x2': f16['flops'] / max(n, 1)},

@@ -279,6 +279,7 @@ struct Igemm2Fuse {
     unsigned *flip_cnt = nullptr, *flip_list = nullptr;
     int flip_cap = 0;
     float flip_l1 = 0.f;
+    bool flip_bias_nonzero = false;     // igemm4's fused head: with a non-zero bias an exact +0 is marked too (see the kernel)
 };
 
 extern unsigned long long *g_igemm2_dbg;

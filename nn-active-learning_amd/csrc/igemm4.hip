@@ -605,7 +605,11 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Igemm4Args a) {
                         if (AHAS(flip_list)) {
                             const float mn = fminf(fminf(__builtin_fabsf(val.x), __builtin_fabsf(val.y)),
                                                    fminf(__builtin_fabsf(val.z), __builtin_fabsf(val.w)));
-                            unsure = (mn < p_tau && mn > 0.f) ? 16u : 0u;      // (exactly +0: an all-zero window under a zero bias, +0 in the exact evaluation too)
+                            // (exactly +0 under ZERO biases: an all-zero window, +0 in the exact evaluation too - not marked; under non-zero
+                            // biases an exact +0 is acc x inv == -bias or two flushed pieces, and the exact value may be a tiny positive:
+                            // marked.  The host passes the threshold negated for non-zero biases: no further kernel argument.)
+                            const float tau = __builtin_fabsf(p_tau);
+                            unsure = (mn < tau && (mn > 0.f || p_tau < 0.f)) ? 16u : 0u;
                         }
                     }
                     if (FCF || AF(relu)) {
@@ -2016,7 +2020,7 @@ static int igemm4_launch_impl(alq_ctx *ctx, const Igemm4Plan &plan, const View &
                 // rms error 2^-22 sqrt(sum x^2 w^2) of independent roundings, and a threshold there marks ~150 groups per 32^3
                 // patch (the fix-up then costs 160 us per 2000 patches).  The threshold is 1/16 of the worst case = ~160 rms
                 // errors: ~10 groups per patch, 15 us.
-                a.flip_tau = std::ldexp(fuse->flip_l1, -24);
+                a.flip_tau = std::ldexp(fuse->flip_l1, -24) * (fuse->flip_bias_nonzero ? -1.f : 1.f);
                 a.flip_cnt = fuse->flip_cnt; a.flip_list = fuse->flip_list; a.flip_cap = fuse->flip_cap;
             }
         }

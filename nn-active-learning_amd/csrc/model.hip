@@ -1037,7 +1037,7 @@ static int run_forward(alq_model *m, const float *d_x, int N, bool with_sums, bo
                             ALQ_TRY(m->dalloc(&m->flip_overflow, (size_t)1));
                             ALQ_HIP(hipMemsetAsync(m->flip_overflow, 0, sizeof(unsigned), ctx->stream));
                         }
-                        fz.flip_cnt = m->flip_cnt; fz.flip_list = m->flip_list; fz.flip_cap = m->flip_cap; fz.flip_l1 = ly.fwd_l1;
+                        fz.flip_cnt = m->flip_cnt; fz.flip_list = m->flip_list; fz.flip_cap = m->flip_cap; fz.flip_l1 = ly.fwd_l1; fz.flip_bias_nonzero = ly.out_bmax > 0.f;
                     }
                     // the plane-sweep engine (c3d.hip) where its geometry applies and both per-patch input maxima are known
                     c3_head = ly.c3f.ok && ly.c3f.d_W && nx->c3_part && fz.in_amax && fz.in_amax2 && !g_no_f16x2 && !m->no_c3d;

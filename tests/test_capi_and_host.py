@@ -418,3 +418,29 @@ def test_bench_clock_sampler_reads_the_hwmon_files_of_the_device(tmp_path, monke
     assert s2.dir is None and s2.stop() is None
     s3 = bench.ClockSampler(types.SimpleNamespace(cuda=types.SimpleNamespace(get_device_properties=lambda i: types.SimpleNamespace())), 0)
     assert s3.dir is None
+
+
+def test_pass_cut_is_even_equal_and_independent_of_the_pipelines(monkeypatch):
+    """DeviceModel.pass_cut (what fisher_device and bench.py's bookkeeping share): an even number of equal passes of at most max_batch
+    patches once a call spans several; one pass otherwise; ALQ_NO_PASS_BALANCE restores max_batch-sized passes with a ragged last one;
+    the cut never depends on the number of scoring pipelines (the pass-ordered sum of A is then the same bits with one or two)."""
+    m = device.DeviceModel.__new__(device.DeviceModel)
+    m.max_batch = 2047
+    for lanes in (1, 2, 3):
+        m.lanes = lanes
+        step, starts = m.pass_cut(100000)
+        assert (step, len(starts)) == (2000, 50) and starts[-1] + step >= 100000
+    assert m.pass_cut(2047) == (2047, [0]) and m.pass_cut(5) == (2047, [0])
+    step, starts = m.pass_cut(2048)
+    assert (step, starts) == (1024, [0, 1024])
+    step, starts = m.pass_cut(3 * 2047)              # three full passes -> four equal ones
+    assert len(starts) == 4 and step == -(-3 * 2047 // 4) and all(b - a == step for a, b in zip(starts, starts[1:]))
+    for n in (4095, 10000, 16384, 99999, 1000000):
+        step, starts = m.pass_cut(n)
+        assert len(starts) % 2 == 0 and step <= m.max_batch and (len(starts) - 1) * step < n <= len(starts) * step
+    monkeypatch.setenv('ALQ_NO_PASS_BALANCE', '1')
+    step, starts = m.pass_cut(100000)
+    assert step == 2047 and len(starts) == 49
+    monkeypatch.delenv('ALQ_NO_PASS_BALANCE')
+    monkeypatch.setenv('ALQ_PASS_MULT', '6')
+    assert len(m.pass_cut(100000)[1]) == 54

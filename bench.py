@@ -392,7 +392,7 @@ def main():
         if ws == 1 and not args.no_accuracy:
             line['accuracy'] = accuracy_vs_exact_fp32(sess, model, x, min(args.batch, n_local), n64=min(args.batch, n_local))
         if ws == 1 and args.netb_pool > 0:
-            line['netb'] = netb_rate(sess, args.netb_pool, x)
+            line['netb'] = netb_rate(sess, args.netb_pool, x, accuracy=not args.no_accuracy)
         if not args.no_cpu_baseline and ws == 1:      # reported at N = 1 only (the other ranks would sit in the barrier)
             note('timing the CPU baseline')
             line['cpu_baseline'] = cpu_baseline(x[:args.cpu_sample].cpu().numpy(), ld, sk, in_shape, pars, args.cpu_all_cores)
@@ -698,7 +698,7 @@ def volume_config(args, sess, rank, ws):
 NETB_BATCH = 2048      # same-box sweep over 8192 patches: 186 k patches/s at 256, 278 k at 512, 330 k at 1024, 350 k at 2048
 
 
-def netb_rate(sess, n, x):
+def netb_rate(sess, n, x, accuracy=True):
     """"NET-B at [n,32,32,32] reported alongside" - the reference's literal patch net
     (NN.create_PW1: 42.05 M parameters, the 32 slices of a patch as channels) Fisher-scored on the first n pool
     patches, same outputs per patch; one warm-up pass, then one timed pass.  Not part of `value`."""
@@ -728,6 +728,14 @@ def netb_rate(sess, n, x):
     torch.cuda.synchronize()
     sess.prof_enable(False)
     prof = sess.prof_read()
+    # the same accuracy statement as for NET-C, on the first 512 / 256 of these patches: every contraction launch of NET-B runs on
+    # fp16 pairs (three products) - how far from the fp64 evaluation, next to the exact-fp32 engine on the same patches
+    acc = None
+    if accuracy:
+        try:
+            acc = accuracy_vs_exact_fp32(sess, model, x, min(n, 512), n64=min(n, 256))
+        except Exception as e:      # an accuracy report must not take the throughput line with it
+            acc = {'error': str(e)}
     model.close()
     bf = ('igemm_fwd', 'igemm_bwd', 'igemm3_fwd', 'igemm3_bwd', 'direct_conv')
     bf_ms, bf_fl = sum(prof[k]['ms'] for k in bf if k in prof), sum(prof[k]['flops'] for k in bf if k in prof)
@@ -748,7 +756,7 @@ def netb_rate(sess, n, x):
             traffic = None
     return {'value': n / dt, 'unit': 'patches/s', 'net': 'NET-B = NN.create_PW1 (NN.py:1328-1336), input [N,32,32,32], 7 parameterised layers',
             'patches': n, 'batch': NETB_BATCH, 'scoring_pipelines': lanes_timed, 'flops_per_patch_executed': 190.9e6 + 151.5e6,
-            'tflops_executed': (190.9e6 + 151.5e6) * n / dt / 1e12,
+            'tflops_executed': (190.9e6 + 151.5e6) * n / dt / 1e12, 'accuracy': acc,
             'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak if peak > 0 else 0.0,
                          'useful_frac': ach / peak_f16, 'traffic': traffic, 'traffic_note': traffic_note, 'launches': nl, 'avg_launch_ms': ms / max(nl, 1),
                          'kernel': 'the contraction launches of a NET-B pass (conv1 - conv3 forward and conv2 / conv4 backward-data on igemm3, conv4 forward '

@@ -25,10 +25,7 @@ def main():
     x = sess.empty((n, 32 ** 3), torch.float32)
     check(sess.lib.alq_synth_patches(sess.ctx, 1004, 0, n, 32 ** 3, C.c_void_p(x.data_ptr())))
     # the cut fisher_device will make: the main model's last pass
-    P = -(-n // B)
-    P = -(-P // 6) * 6 if P >= 6 else P + (P & 1)
-    step = -(-n // P)
-    starts = list(range(0, n, step))
+    step, starts = m.pass_cut(n)
     last_main = [a for k, a in enumerate(starts) if k % 2 == 0][-1]
     nlast = min(n, last_main + step) - last_main
     ref = None
